@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""Benchmark of the link-prediction hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full ``LinkPredictionEvaluator.evaluate`` over the test split of
+the workload (default: BASELINE.json configs[1] = TransE dim=200 L2 on an
+FB15k-237-shaped synthetic KG: 14,541 entities, 237 relations, 20,466 test
+triples => 20,466 x 2 sides x 14,541 = 5.95e8 scored triples per step), with
+the model tables, the test triples and the filter index already resident in HBM.
+Metric = link-prediction triples scored / second (whole job, all ranks).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
+  --scaling weak   (default) every rank evaluates its own FB15k-237-sized test
+                   split against its replica of the tables: the units are
+                   independent, there is no data-path collective; ranks are
+                   all-gathered once at the end of the timed region.
+  --scaling strong one test split, --shard queries | entities (entity-sharded
+                   candidate ranges with --exchange counts | scores over RCCL).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: "roofline" (dominant kernel timed live with HIP events on the launch
+stream) and "cpu_baseline" (the oracle = reference CPU algorithm, timed on the
+host cores of this box on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (kind, dataset shape, dim, p)
+    'transe_fb15k237': ('transe', 'fb15k237', 200, 2),
+    'complex_wn18rr': ('complex', 'wn18rr', 200, 2),
+    'distmult_fb15k': ('distmult', 'fb15k', 400, 2),
+    'transe_nations': ('transe', 'nations', 50, 2),
+}
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='transe_fb15k237', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=32768, help='evaluate() b_size')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--shard', default='queries', choices=['queries', 'entities'])
+    ap.add_argument('--exchange', default='counts', choices=['counts', 'scores'])
+    ap.add_argument('--materialize', action='store_true', help='fused=False: write the (B,N) scores')
+    ap.add_argument('--l2-mode', default='expand', choices=['expand', 'direct'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
+    return ap.parse_args()
+
+
+def make_model(kind, p, tables, n_ent, n_rel):
+    import torchkge_amd as tk
+    d = tables[0].shape[1]
+    if kind == 'transe':
+        m, names = tk.TransEModel(d, n_ent, n_rel, 'L%d' % p), ['ent_emb', 'rel_emb']
+    elif kind == 'distmult':
+        m, names = tk.DistMultModel(d, n_ent, n_rel), ['ent_emb', 'rel_emb']
+    elif kind == 'complex':
+        m, names = tk.ComplExModel(d, n_ent, n_rel), ['re_ent_emb', 'im_ent_emb', 're_rel_emb', 'im_rel_emb']
+    else:
+        raise ValueError(kind)
+    m.load_state_dict({n + '.weight': t for n, t in zip(names, tables)})
+    return m
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    import torchkge_amd as tk
+    from torchkge_amd import _hip
+    from oracle import kge_oracle as orc     # synthetic-KG generator + the cpu_baseline leg only
+
+    kind, shape, d, p = WORKLOADS[args.workload]
+    n_ent, n_rel, n_train, n_valid, n_test = orc.DATASET_SHAPES[shape]
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=0)
+    model = make_model(kind, p, tables, n_ent, n_rel).to(device)
+    if kind == 'transe':
+        model.l2_mode = args.l2_mode
+
+    # synthetic KG of the dataset's shape; filters span the full graph (train+valid+test)
+    cfg_seed = 1000 + sorted(WORKLOADS).index(args.workload)
+    heads, tails, rels = orc.synthetic_triples(n_ent, n_rel, n_train + n_valid + n_test, cfg_seed)
+    ident_e = {i: i for i in range(n_ent)}
+    ident_r = {i: i for i in range(n_rel)}
+    kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels}, ent2ix=ident_e,
+                           rel2ix=ident_r)
+    _, _, kg_test = kg.split_kg(sizes=(n_train, n_valid, n_test))
+    if world > 1 and args.scaling == 'weak':
+        # every rank gets its own test split of the same size (facts of the same graph)
+        g = torch.Generator().manual_seed(7 + rank)
+        sel = torch.randperm(kg.n_facts, generator=g)[:n_test]
+        kg_test = tk.KnowledgeGraph(kg={'heads': heads[sel], 'tails': tails[sel], 'relations': rels[sel]},
+                                    ent2ix=ident_e, rel2ix=ident_r, _filter_src=kg._lazy)
+    # test triples resident in HBM before the timed region
+    kg_test.head_idx = kg_test.head_idx.to(device)
+    kg_test.tail_idx = kg_test.tail_idx.to(device)
+    kg_test.relations = kg_test.relations.to(device)
+
+    shard = None
+    if world > 1 and args.scaling == 'strong':
+        shard = args.shard
+    ev = tk.LinkPredictionEvaluator(model, kg_test, fused=not args.materialize, shard=shard,
+                                    exchange=args.exchange)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        ev.evaluate(args.batch, verbose=False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev.evaluate(args.batch, verbose=False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    units_per_rank_step = n_test * 2 * n_ent
+    total_units = units_per_rank_step * (world if (world > 1 and args.scaling == 'weak') else 1)
+    value = total_units * args.steps / elapsed
+    hit10, mrr = ev.hit_at_k(10), ev.mrr()
+
+    # ---- roofline of the dominant kernel (the all-candidates count kernel) ----
+    roof = None
+    if rank == 0:
+        B = min(args.batch, n_test)
+        h, t, r = kg_test.head_idx[:B], kg_test.tail_idx[:B], kg_test.relations[:B]
+        with model.lp_session():
+            prob = model.lp_problem(h, t, r, 'tail')
+            s_true = prob.pair_scores(t)
+            raw = torch.zeros(B, dtype=torch.int32, device=device)
+            scores_buf = torch.empty(B, n_ent, device=device) if args.materialize else None
+            run = (lambda: prob.scores(scores_buf)) if args.materialize else (lambda: prob.count_ge(s_true, raw))
+            for _ in range(3):
+                run()
+            reps = 20
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            e0.record()                     # events on torch's current stream = the launch stream
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize(device)
+            kern_s = e0.elapsed_time(e1) / 1e3 / reps
+        K = d * (2 if kind == 'complex' else 1)
+        mode = prob.desc.mode
+        if mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND):
+            flops_per_pair = 2 * K           # one fp32 MFMA FMA per (pair, k)
+            kname = 'lp_gemm_kernel (fp32 MFMA 32x32x2)'
+        else:
+            flops_per_pair = 3 * K           # sub, mul, add on the VALU
+            kname = 'lp_direct_kernel (fp32 VALU)'
+        achieved = flops_per_pair * B * n_ent / kern_s / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload)
+            except Exception:
+                traffic = None
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_TFLOPS, 4), 'traffic': traffic,
+                'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4),
+                'pairs_per_launch': B * n_ent, 'flops_per_pair': flops_per_pair}
+
+    # ---- reference CPU path (oracle) on a bounded sample, rank 0, N = 1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.set_num_threads(os.cpu_count())
+        th, tt_, tr = kg_test.head_idx.cpu(), kg_test.tail_idx.cpu(), kg_test.relations.cpu()
+        dh, dtl = kg.dict_of_heads, kg.dict_of_tails
+        bs = 128
+
+        def run_cpu(ns):
+            c0 = time.perf_counter()
+            out = orc.lp_evaluate(kind, tables, th[:ns], tt_[:ns], tr[:ns], dh, dtl, bs, p)
+            return time.perf_counter() - c0, out
+        probe_t, _ = run_cpu(bs)                       # also warms the allocator / threads
+        probe_t, _ = run_cpu(bs)
+        ns = int(max(bs, min(n_test, (args.cpu_seconds / max(probe_t, 1e-6)) * bs)) // bs * bs)
+        cpu_t, (rh, rt, frh, frt) = run_cpu(ns)
+        same = (torch.equal(rh, ev.rank_true_heads[:ns]) and torch.equal(rt, ev.rank_true_tails[:ns]) and
+                torch.equal(frh, ev.filt_rank_true_heads[:ns]) and torch.equal(frt, ev.filt_rank_true_tails[:ns]))
+        n_diff = int((rh != ev.rank_true_heads[:ns]).sum() + (rt != ev.rank_true_tails[:ns]).sum() +
+                     (frh != ev.filt_rank_true_heads[:ns]).sum() + (frt != ev.filt_rank_true_tails[:ns]).sum())
+        mo = orc.lp_metrics(rh, rt, frh, frt, 10)
+        mg = orc.lp_metrics(ev.rank_true_heads[:ns], ev.rank_true_tails[:ns], ev.filt_rank_true_heads[:ns],
+                            ev.filt_rank_true_tails[:ns], 10)
+        cpu = {'value': round(ns * 2 * n_ent / cpu_t, 1), 'unit': 'triples_scored/s',
+               'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '%d of %d test triples, b_size=%d, oracle.lp_evaluate (reference algorithm on '
+                         'torch CPU ops), %.1f s' % (ns, n_test, bs, cpu_t),
+               'ranks_equal_to_gpu': bool(same), 'ranks_differing': n_diff, 'ranks_compared': 4 * ns,
+               'filt_hits10_cpu_gpu': [mo['hit_at_k'][1], mg['hit_at_k'][1]],
+               'filt_mrr_cpu_gpu': [mo['mrr'][1], mg['mrr'][1]]}
+
+    if rank == 0:
+        par = 'single' if world == 1 else ('%s-%d' % ('queries-weak' if args.scaling == 'weak'
+                                                      else args.shard + '-' + (args.exchange if args.shard == 'entities' else 'strong'), world))
+        line = {
+            'metric': 'link-prediction triples scored/sec (filtered LP eval, both sides)',
+            'value': round(value, 1), 'unit': 'triples_scored/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
+                                   'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
+                                       kind, d, p, shape, n_ent, n_rel, n_test, args.batch),
+                       'parallelism': par, 'fused_rank': not args.materialize,
+                       'scored_triples_per_step': total_units},
+            'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,243 @@
+/*
+ * kge_hip.h -- C ABI of libkge_hip.so, the MI355X (gfx950) engine behind the
+ * torchkge link-prediction / scoring hot path.
+ *
+ * The reference (torchkge v0.17.7) is pure Python and has no FFI; its drop-in
+ * boundary is the Python class API.  This header is the
+ * C-ABI a binding for that API sits on: plain pointers and sizes, no torch
+ * types.  Every entry point
+ *   - takes DEVICE pointers (fp32 row-major tables, int64 index vectors),
+ *   - launches on the given hipStream_t (passed as void*) and returns without
+ *     synchronising,
+ *   - never allocates, frees or retains caller memory,
+ *   - returns 0 on success, a negative KGE_E* code for argument errors, or a
+ *     positive hipError_t if a launch failed.
+ *
+ * Reference interface each entry replaces (paths relative to the reference):
+ *   kge_score_triples            Model.scoring_function
+ *                                  models/translation.py:69-81 (TransE), :183-206 (TransH),
+ *                                  :538-568 (TransD); models/bilinear.py:188-199 (DistMult),
+ *                                  :460-473 (ComplEx)
+ *   kge_score_triples_bwd        autograd of the above (Model.forward under Trainer,
+ *                                  models/interfaces.py:65-82, utils/training.py:156-167)
+ *   kge_lp_prep                  Model.inference_prepare_candidates
+ *                                  translation.py:105-125, :234-258, :603-627;
+ *                                  bilinear.py:247-267, :530-556
+ *   kge_row_sqnorm/kge_row_dot/  the per-entity part of evaluate_projections
+ *   kge_lp_scores (as a GEMM)      translation.py:260-284, :629-652 (never builds (R,N,d))
+ *   kge_lp_scores                Model.inference_scoring_function (entity candidates)
+ *                                  models/interfaces.py:240-260; bilinear.py:224-240, :501-522
+ *   kge_lp_scores_batched        same, for an arbitrary materialised (B,N,d) candidate tensor
+ *   kge_get_rank                 utils/operations.py:37-61
+ *   kge_filter_lookup +          utils/modeling.py:53-102 (get_true_targets / filter_scores)
+ *   kge_filter_scores
+ *   kge_filtered_rank_from_scores  get_rank(scores) + get_rank(filter_scores(scores))
+ *                                  evaluation.py:292-300
+ *   kge_lp_pair_scores,          the fused form of evaluation.py:290-300 that never
+ *   kge_lp_count_ge,               materialises the (B,N) score matrix
+ *   kge_lp_filter_sub,
+ *   kge_rank_finalize
+ *   kge_corrupt_scatter          BernoulliNegativeSampler.corrupt_batch / Uniform...
+ *                                  sampling.py:313-325 and :206-221 (the integer scatter)
+ *   kge_gather_rows              nn.Embedding lookups of the above
+ *   kge_normalize_rows           Model.normalize_parameters (translation.py:83-90 etc.)
+ */
+#ifndef KGE_HIP_H
+#define KGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *kge_stream_t; /* hipStream_t */
+
+#define KGE_EINVAL (-1)   /* bad argument (null pointer, bad size / kind) */
+#define KGE_EALIGN (-2)   /* pointer or leading dimension not aligned as required */
+
+/* model kinds (kge_score_triples, kge_lp_prep) */
+enum {
+    KGE_TRANSE_L1 = 0,
+    KGE_TRANSE_L2 = 1,
+    KGE_TRANSH = 2,
+    KGE_TRANSD = 3,
+    KGE_DISTMULT = 4,
+    KGE_COMPLEX = 5
+};
+
+/* which entity is replaced by the candidates */
+enum {
+    KGE_SIDE_TAIL = 0,   /* candidates replace the tail: query = f(h, r)            */
+    KGE_SIDE_HEAD = 1,   /* candidates replace the head: query = f(t, r)            */
+    KGE_SIDE_PROJ_H = 2, /* kge_lp_prep only: Q0 = projected head, no relation term */
+    KGE_SIDE_PROJ_T = 3  /* kge_lp_prep only: Q0 = projected tail, no relation term */
+};
+
+/* kge_ewise ops (query-side elementwise algebra of inference_scoring_function) */
+enum {
+    KGE_EW_ADD = 0,      /* a + b         */
+    KGE_EW_SUB = 1,      /* a - b         */
+    KGE_EW_MUL = 2,      /* a * b         */
+    KGE_EW_MULSUB = 3,   /* a*b - c*d     */
+    KGE_EW_MULADD = 4    /* a*b + c*d     */
+};
+
+/* all-candidates scorer modes (kge_lp_desc.mode) */
+enum {
+    KGE_LP_DOT = 0,        /* s = A0.T0 (+ A1.T1)              bilinear, fp32 MFMA            */
+    KGE_LP_L2_EXPAND = 1,  /* s = -max(qn+en-2*A0.T0, 0)       TransE L2 as fp32 MFMA GEMM     */
+    KGE_LP_L1_DIRECT = 2,  /* s = -sum_k |A0 - T0 (+a*Wq)|     broadcast-subtract, fp32 VALU   */
+    KGE_LP_L2_DIRECT = 3   /* s = -sum_k (A0 - T0 (+a*Wq))^2   broadcast-subtract, fp32 VALU   */
+};
+
+/*
+ * Descriptor of one all-candidates scoring problem: B queries against the N
+ * table rows [c_base, c_base+N) of the (possibly sharded) entity table.
+ *   score(i, c) for local candidate c in [0,N):
+ *     DOT        : chain(A0[i], T0[c], K0) then chain(A1[i], T1[c], K1)
+ *     L2_EXPAND  : -fmaxf(fmaf(-2, chain(A0[i],T0[c],K0), qn[i] + en[c]), 0)
+ *     L1/L2_DIRECT: diff_k = A0[i,k] - T0[c,k]; if Wq: diff_k = fmaf(a, Wq[i,k], diff_k)
+ *                   with a = scal[c*scal_ld + (scal_ld > 1 ? r_idx[i] : 0)];
+ *                   acc += |diff_k|  or  acc = fmaf(diff_k, diff_k, acc);  s = -acc
+ *   chain(x, y, K): acc = fmaf(x[k], y[k], acc) for k = 0..K-1 in order, one
+ *   accumulator -- the arithmetic v_mfma_f32_32x32x2_f32 performs -- so every
+ *   kernel that scores a pair (tile kernels, pair kernel, filter kernel)
+ *   produces bit-identical scores.
+ */
+typedef struct kge_lp_desc {
+    int32_t mode;
+    int32_t K0, K1;            /* inner dims of segment 0 / 1 (K1 = 0: unused) */
+    int32_t reserved;
+    int64_t B, N;              /* queries, local candidates */
+    int64_t c_base;            /* global id of local candidate 0 */
+    const float *A0; int64_t lda0;   /* (B,K0) query matrix */
+    const float *T0; int64_t ldt0;   /* (N,K0) candidate table shard */
+    const float *A1; int64_t lda1;   /* (B,K1) or NULL */
+    const float *T1; int64_t ldt1;   /* (N,K1) or NULL */
+    const float *qn;           /* (B) ||A0[i]||^2   (L2_EXPAND) */
+    const float *en;           /* (N) ||T0[c]||^2   (L2_EXPAND) */
+    const float *Wq; int64_t ldw;    /* (B,K0) per-query direction or NULL (DIRECT) */
+    const float *scal; int64_t scal_ld; /* (N,scal_ld) per-candidate scalars (DIRECT + Wq) */
+    const int64_t *r_idx;      /* (B) column of scal used by query i (when scal_ld > 1) */
+} kge_lp_desc;
+
+/* ---- K1: fused gather + normalise + score (scoring_function) ------------- */
+/* tables: TransE/DistMult {E,R}; TransH {E,R,W}; TransD {E,R,Ep,Rp}; ComplEx {Ere,Eim,Rre,Rim}.
+ * d_ent = row length of entity tables, d_rel = row length of relation tables
+ * (equal except TransD, which needs d_ent >= d_rel).  Tables are contiguous. */
+int kge_score_triples(int kind, const float *t0, const float *t1, const float *t2, const float *t3,
+                      int d_ent, int d_rel, const int64_t *h, const int64_t *t, const int64_t *r,
+                      int64_t B, float *out, kge_stream_t stream);
+
+/* backward: adds d(sum_i go[i]*score_i)/d(table) into g0..g3 (same shapes as
+ * t0..t3, caller-zeroed or accumulating) with fp32 atomics. */
+int kge_score_triples_bwd(int kind, const float *t0, const float *t1, const float *t2,
+                          const float *t3, int d_ent, int d_rel, const int64_t *h,
+                          const int64_t *t, const int64_t *r, int64_t B, const float *go,
+                          float *g0, float *g1, float *g2, float *g3, kge_stream_t stream);
+
+/* ---- link-prediction query preparation ----------------------------------- */
+/* Fills the query-side operands of a kge_lp_desc for one side:
+ *   TransE   Q0 = E[h]+R[r] | E[t]-R[r];  qn = chain ||Q0||^2 (optional)
+ *   TransH   Q0 = p_r(h)+R[r] | p_r(t)-R[r], p_r(e) = E[e]-(E[e].W[r])W[r];  Wq = W[r]
+ *   TransD   Q0 = (s_h Rp[r]+E[h,:dr])+R[r] | (s_t Rp[r]+E[t,:dr])-R[r], s_e = Ep[e].E[e]; Wq = Rp[r]
+ *   DistMult Q0 = E[h]*R[r] | R[r]*E[t]
+ *   ComplEx  Q0 = re_h re_r - im_h im_r | re_r re_t + im_r im_t
+ *            Q1 = re_h im_r + im_h re_r | re_r im_t - im_r re_t
+ * side KGE_SIDE_PROJ_H / _PROJ_T: Q0 = the (projected) head / tail embedding alone
+ * (E[e]; p_r(e) for TransH/TransD; ComplEx: Q0 = re, Q1 = im), Wq still filled.
+ * Q0/Q1/Wq are (B, d_rel) contiguous. */
+int kge_lp_prep(int kind, int side, const float *t0, const float *t1, const float *t2,
+                const float *t3, int d_ent, int d_rel, const int64_t *h, const int64_t *t,
+                const int64_t *r, int64_t B, float *Q0, float *Q1, float *qn, float *Wq,
+                kge_stream_t stream);
+
+/* out = op(a, b[, c, d]) elementwise over n floats (separate mul / add roundings,
+ * as the reference's (re_h * re_r - im_h * im_r) etc., bilinear.py:514-522). */
+int kge_ewise(int op, const float *a, const float *b, const float *c, const float *d, int64_t n,
+              float *out, kge_stream_t stream);
+
+/* out[i] = chain_k X[i,k]^2 */
+int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, kge_stream_t stream);
+/* out[i] = scale * chain_k X[i,k]*Y[i,k] */
+int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t rows, int K, float scale,
+                float *out, kge_stream_t stream);
+/* out[i,:] = X[idx[i],:]  (rows of length K, table ld) */
+int kge_gather_rows(const float *X, int64_t ld, const int64_t *idx, int64_t rows, int K,
+                    float *out, kge_stream_t stream);
+/* X[i,:] /= max(||X[i,:]||_2, 1e-12)   (torch.nn.functional.normalize, p=2, dim=1) */
+int kge_normalize_rows(float *X, int64_t ld, int64_t rows, int K, kge_stream_t stream);
+
+/* ---- all-candidates scoring ----------------------------------------------- */
+/* out[i*ldo + c] = score(i,c), i<B, c<N (local candidates). */
+int kge_lp_scores(const kge_lp_desc *d, float *out, int64_t ldo, kge_stream_t stream);
+
+/* out[p] = score(qi[p], ci[p] - c_base) or 0 if ci[p] outside the shard.
+ * qi == NULL means qi[p] = p.  ci holds GLOBAL candidate ids. */
+int kge_lp_pair_scores(const kge_lp_desc *d, const int64_t *qi, const int64_t *ci, int64_t P,
+                       float *out, kge_stream_t stream);
+
+/* raw_count[i] += #{c in shard : score(i,c) >= s_true[i]}  (int32 atomics; the
+ * caller zeroes raw_count).  No score is written to memory. */
+int kge_lp_count_ge(const kge_lp_desc *d, const float *s_true, int32_t *raw_count,
+                    kge_stream_t stream);
+
+/* per query i with filter segment targets[seg_lo[i]:seg_hi[i]) (GLOBAL ids):
+ *   sub[i]   = sum over c in segment, c != true_idx[i], c in shard of
+ *              [score(i,c) >= s_true[i]] - [-inf >= s_true[i]]
+ *   found[i] = 1 if true_idx[i] occurs in the segment AND lies in this shard. */
+int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
+                      const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                      int32_t *sub, int32_t *found, kge_stream_t stream);
+
+/* rank[i] = raw[i]; filt_rank[i] = found[i] ? raw[i] - sub[i] : raw[i]  (int64 out) */
+int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
+                      int64_t *rank, int64_t *filt_rank, kge_stream_t stream);
+
+/* generic: every query has its own candidate matrix cand[i] (N,K) at
+ * cand + i*stride_b (stride_b = 0: shared), rows at stride_n.
+ * mode DOT / L1_DIRECT / L2_DIRECT; score = f(q[i], cand[i,c]). */
+int kge_lp_scores_batched(int mode, const float *q, int64_t ldq, const float *cand,
+                          int64_t stride_b, int64_t stride_n, int64_t B, int64_t N, int K,
+                          float *out, int64_t ldo, kge_stream_t stream);
+
+/* ---- rank / filter on a materialised score matrix ------------------------- */
+int kge_get_rank(const float *scores, int64_t ld, const int64_t *true_idx, int64_t B, int64_t N,
+                 int low_values, int64_t *rank, kge_stream_t stream);
+
+/* binary-search key1[i]*n_key2 + key2[i] in the sorted key array of a filter
+ * index; seg_lo/seg_hi = its target segment, or 0/0 if the key is absent. */
+int kge_filter_lookup(const int64_t *keys, int64_t n_keys, const int64_t *offsets,
+                      const int64_t *key1, const int64_t *key2, int64_t n_key2, int64_t B,
+                      int64_t *seg_lo, int64_t *seg_hi, kge_stream_t stream);
+
+/* in place: scores[i, c] = -inf for c in segment i, c != true_idx[i]; rows whose
+ * segment is empty or does not contain true_idx[i] are left untouched. */
+int kge_filter_scores(float *scores, int64_t ld, const int64_t *true_idx, const int64_t *seg_lo,
+                      const int64_t *seg_hi, const int32_t *targets, int64_t B, int64_t N,
+                      kge_stream_t stream);
+
+/* rank and filtered rank from a materialised (B,N) matrix in one pass. */
+int kge_filtered_rank_from_scores(const float *scores, int64_t ld, const int64_t *true_idx,
+                                  const int64_t *seg_lo, const int64_t *seg_hi,
+                                  const int32_t *targets, int64_t B, int64_t N, int64_t *rank,
+                                  int64_t *filt_rank, kge_stream_t stream);
+
+/* ---- negative sampling ----------------------------------------------------- */
+/* neg_heads/neg_tails (B*n_neg): position j (batch element j % B): mask[j] != 0
+ * -> head := draws_h[#ones before j], tail kept; else tail := draws_t[#zeros
+ * before j], head kept.  ws: int32 workspace of kge_corrupt_ws_elems(B*n_neg). */
+int64_t kge_corrupt_ws_elems(int64_t n);
+int kge_corrupt_scatter(const int64_t *heads, const int64_t *tails, const uint8_t *mask,
+                        const int64_t *draws_h, const int64_t *draws_t, int64_t B, int64_t n_neg,
+                        int64_t *neg_heads, int64_t *neg_tails, int32_t *ws, kge_stream_t stream);
+
+/* library / build info */
+int kge_abi_version(void);
+const char *kge_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGE_HIP_H */

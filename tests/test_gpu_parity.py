@@ -1,0 +1,492 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C-ABI (ctypes binding torchkge_amd/_hip.py), against
+  * the C oracle's fmaf-chain contract            -> BIT-EXACT fp32,
+  * the integer semantics of the reference         -> BIT-EXACT int64,
+  * the golden fixtures generated from the reference (tests/golden) -> 1e-5.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as orc
+from tests.helpers import load_golden, oracle_clib, fptr, dict_to_csr, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5     # north-star floating-point tolerance on scores
+CASES = [('transe', 2), ('transe', 1), ('transh', 2), ('transd', 2), ('distmult', 2), ('complex', 2)]
+i64 = ctypes.c_int64
+
+
+@pytest.fixture(scope='module')
+def hip():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from torchkge_amd import _hip
+    _hip.load_library()
+    return _hip
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda()
+
+
+def build_model(kind, p, tables, n_ent, n_rel):
+    import torchkge_amd as tk
+    d = tables[0].shape[1]
+    if kind == 'transe':
+        m = tk.TransEModel(d, n_ent, n_rel, dissimilarity_type='L%d' % p)
+        names = ['ent_emb', 'rel_emb']
+    elif kind == 'transh':
+        m = tk.TransHModel(d, n_ent, n_rel)
+        names = ['ent_emb', 'rel_emb', 'norm_vect']
+    elif kind == 'transd':
+        m = tk.TransDModel(d, tables[1].shape[1], n_ent, n_rel)
+        names = ['ent_emb', 'rel_emb', 'ent_proj_vect', 'rel_proj_vect']
+    elif kind == 'distmult':
+        m = tk.DistMultModel(d, n_ent, n_rel)
+        names = ['ent_emb', 'rel_emb']
+    else:
+        m = tk.ComplExModel(d, n_ent, n_rel)
+        names = ['re_ent_emb', 'im_ent_emb', 're_rel_emb', 'im_rel_emb']
+    sd = {n + '.weight': t.clone() for n, t in zip(names, tables)}
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def golden_batch(z):
+    B = int(z['b_size']); n = len(z['heads']); nt = int(z['n_test'])
+    h = torch.from_numpy(z['heads'][n - nt:][:B]); t = torch.from_numpy(z['tails'][n - nt:][:B])
+    r = torch.from_numpy(z['rels'][n - nt:][:B])
+    return h, t, r
+
+
+# ---------------------------------------------------------------------------
+# fp32 arithmetic contract: MFMA / VALU tile kernels == CPU fmaf chains, bitwise
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('B,N,K', [(70, 300, 32), (130, 515, 200), (5, 129, 50), (257, 1000, 8), (1, 1, 3)])
+def test_mfma_gemm_bit_exact_vs_chain(hip, B, N, K):
+    lib = oracle_clib()
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    A = (torch.rand(B, K, generator=g) * 2 - 1)
+    T = (torch.rand(N, K, generator=g) * 2 - 1)
+    A1 = (torch.rand(B, K, generator=g) * 2 - 1)
+    T1 = (torch.rand(N, K, generator=g) * 2 - 1)
+    ref = np.empty((B, N), dtype=np.float32)
+    # DOT, one segment
+    lib.orc_lp_gemm_chain(fptr(A.numpy()), i64(K), fptr(T.numpy()), i64(K), i64(K), None, i64(0), None, i64(0),
+                          i64(0), i64(B), i64(N), 0, None, None, fptr(ref))
+    prob = hip.LpProblem(hip.LP_DOT, dev(A), dev(T))
+    out = prob.scores().cpu().numpy()
+    assert np.array_equal(out, ref)
+    # pair kernel == tile kernel
+    ci = torch.randint(0, N, (B,), generator=g)
+    ps = prob.pair_scores(dev(ci)).cpu().numpy()
+    assert np.array_equal(ps, ref[np.arange(B), ci.numpy()])
+    # DOT, two segments (ComplEx)
+    lib.orc_lp_gemm_chain(fptr(A.numpy()), i64(K), fptr(T.numpy()), i64(K), i64(K), fptr(A1.numpy()), i64(K),
+                          fptr(T1.numpy()), i64(K), i64(K), i64(B), i64(N), 0, None, None, fptr(ref))
+    prob2 = hip.LpProblem(hip.LP_DOT, dev(A), dev(T), A1=dev(A1), T1=dev(T1))
+    assert np.array_equal(prob2.scores().cpu().numpy(), ref)
+    # L2 via norm expansion
+    qn = np.empty(B, dtype=np.float32); en = np.empty(N, dtype=np.float32)
+    lib.orc_row_sqnorm_chain(fptr(A.numpy()), i64(K), i64(B), i64(K), fptr(qn))
+    lib.orc_row_sqnorm_chain(fptr(T.numpy()), i64(K), i64(N), i64(K), fptr(en))
+    dA, dT = dev(A), dev(T)
+    qn_d, en_d = hip.row_sqnorm(dA), hip.row_sqnorm(dT)
+    assert np.array_equal(qn_d.cpu().numpy(), qn) and np.array_equal(en_d.cpu().numpy(), en)
+    lib.orc_lp_gemm_chain(fptr(A.numpy()), i64(K), fptr(T.numpy()), i64(K), i64(K), None, i64(0), None, i64(0),
+                          i64(0), i64(B), i64(N), 1, fptr(qn), fptr(en), fptr(ref))
+    prob3 = hip.LpProblem(hip.LP_L2_EXPAND, dA, dT, qn=qn_d, en=en_d)
+    assert np.array_equal(prob3.scores().cpu().numpy(), ref)
+    # fused count == count on the materialised matrix
+    s_true = prob3.pair_scores(dev(ci))
+    raw = prob3.count_ge(s_true).cpu().numpy()
+    assert np.array_equal(raw, (ref >= ref[np.arange(B), ci.numpy()][:, None]).sum(1))
+
+
+@pytest.mark.parametrize('B,N,K,p,axpy', [(70, 300, 32, 2, False), (33, 515, 200, 1, False),
+                                          (130, 260, 50, 2, False), (65, 300, 24, 2, True),
+                                          (20, 131, 200, 1, True), (3, 7, 5, 2, True)])
+def test_direct_kernels_bit_exact_vs_chain(hip, B, N, K, p, axpy):
+    lib = oracle_clib()
+    g = torch.Generator().manual_seed(B + N + K)
+    Q = torch.rand(B, K, generator=g) * 2 - 1
+    T = torch.rand(N, K + 3, generator=g)[:, :K] * 2 - 1         # ld != K (TransD-style slice)
+    Tn = np.ascontiguousarray(T.numpy())
+    R = 5
+    W = torch.rand(B, K, generator=g) - 0.5
+    scal = torch.rand(N, R, generator=g) - 0.5
+    ridx = torch.randint(0, R, (B,), generator=g)
+    ref = np.empty((B, N), dtype=np.float32)
+    lib.orc_lp_direct_chain(fptr(Q.numpy()), i64(K), fptr(Tn), i64(K), i64(K),
+                            fptr(W.numpy()) if axpy else None, i64(K),
+                            fptr(scal.numpy()) if axpy else None, i64(R),
+                            fptr(ridx.numpy()) if axpy else None, i64(B), i64(N), p, fptr(ref))
+    Td = dev(torch.rand(N, K + 3))  # device table with ld = K+3
+    Td[:, :K] = dev(T)
+    mode = hip.LP_L1_DIRECT if p == 1 else hip.LP_L2_DIRECT
+    prob = hip.LpProblem(mode, dev(Q), Td, Wq=dev(W) if axpy else None, scal=dev(scal) if axpy else None,
+                         r_idx=dev(ridx) if axpy else None, K0=K)
+    out = prob.scores().cpu().numpy()
+    assert np.array_equal(out, ref)
+    ci = torch.randint(0, N, (B,), generator=g)
+    st = prob.pair_scores(dev(ci))
+    assert np.array_equal(st.cpu().numpy(), ref[np.arange(B), ci.numpy()])
+    raw = prob.count_ge(st).cpu().numpy()
+    assert np.array_equal(raw, (ref >= ref[np.arange(B), ci.numpy()][:, None]).sum(1))
+
+
+# ---------------------------------------------------------------------------
+# golden fixtures generated from the reference
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('kind,p', CASES)
+def test_scoring_function_and_forward_vs_reference(hip, kind, p):
+    z, tables = load_golden(kind, p)
+    m = build_model(kind, p, tables, int(z['n_ent']), int(z['n_rel']))
+    h, t, r = (x.cuda() for x in golden_batch(z))
+    with torch.no_grad():
+        sf = m.scoring_function(h, t, r)
+        pos, neg = m(h, t, r, dev(z['neg_heads']), dev(z['neg_tails']))
+    assert np.abs(sf.cpu().numpy() - z['sf']).max() < TOL
+    assert np.abs(pos.cpu().numpy() - z['fwd_pos']).max() < TOL
+    assert np.abs(neg.cpu().numpy() - z['fwd_neg']).max() < TOL
+
+
+@pytest.mark.parametrize('kind,p', CASES)
+def test_inference_api_vs_reference(hip, kind, p):
+    """Drop-in API: inference_prepare_candidates + inference_scoring_function
+    (and the lp_* aliases) give the reference's (b, N) score matrices."""
+    z, tables = load_golden(kind, p)
+    m = build_model(kind, p, tables, int(z['n_ent']), int(z['n_rel']))
+    h, t, r = (x.cuda() for x in golden_batch(z))
+    h_e, t_e, r_e, cand = m.inference_prepare_candidates(h, t, r, entities=True)
+    s_tail = m.inference_scoring_function(h_e, cand, r_e)
+    s_head = m.lp_scoring_function(cand, t_e, r_e)
+    assert s_tail.shape == z['s_tail'].shape
+    assert np.abs(s_tail.cpu().numpy() - z['s_tail']).max() < TOL
+    assert np.abs(s_head.cpu().numpy() - z['s_head']).max() < TOL
+    if kind == 'transe' and p == 2:
+        m.l2_mode = 'direct'     # broadcast-subtract path gives the same matrix within tolerance
+        s2 = m.inference_scoring_function(h_e, cand, r_e)
+        assert np.abs(s2.cpu().numpy() - z['s_tail']).max() < TOL
+        # a materialised (non-broadcast) candidate tensor takes the generic batched kernel
+        s3 = m.inference_scoring_function(h_e, cand.contiguous(), r_e)
+        assert np.abs(s3.cpu().numpy() - z['s_tail']).max() < TOL
+
+
+@pytest.mark.parametrize('kind,p', [('transe', 2), ('complex', 2), ('transh', 2)])
+def test_rank_and_filter_bit_exact_on_reference_scores(hip, kind, p):
+    """get_rank / filter_scores are integer functions of a score matrix: fed the
+    reference's own matrix they must reproduce the reference exactly."""
+    import torchkge_amd as tk
+    from torchkge_amd.utils import get_rank, filter_scores
+    z, _ = load_golden(kind, p)
+    h, t, r = golden_batch(z)
+    heads, tails, rels = (torch.from_numpy(z[k]) for k in ('heads', 'tails', 'rels'))
+    _, dict_of_tails, _ = orc.build_filter_dicts(heads, tails, rels)
+    s = dev(z['s_tail'])
+    rk = get_rank(s, t.cuda())
+    assert rk.dtype == torch.int64 and np.array_equal(rk.cpu().numpy(), z['rk_tail'])
+    f = filter_scores(s, dict_of_tails, h.cuda(), r.cuda(), t.cuda())
+    assert np.array_equal(f.cpu().numpy(), z['f_tail'])
+    assert np.array_equal(get_rank(f, t.cuda()).cpu().numpy(), z['frk_tail'])
+    # fused rank+filter on the materialised matrix
+    from torchkge_amd.filter_index import filter_index_for
+    idx = filter_index_for(dict_of_tails, 'cuda')
+    lo, hi = idx.lookup(h.cuda(), r.cuda())
+    rk2, frk2 = hip.filtered_rank_from_scores(s, t.cuda(), lo, hi, idx.targets)
+    assert np.array_equal(rk2.cpu().numpy(), z['rk_tail']) and np.array_equal(frk2.cpu().numpy(), z['frk_tail'])
+    # low_values and the reference's known-answer vector (tests/test_utils.py:156-163)
+    data = dev(np.array([[1, 2, 3, 4, 0], [1, 2, 1, 3, 0]], dtype=np.float32))
+    true = dev(np.array([4, 2]))
+    assert get_rank(data, true).tolist() == [5, 4]
+    assert get_rank(data, true, low_values=True).tolist() == [1, 3]
+
+
+def test_filter_edge_cases_bit_exact(hip):
+    """missing key, key whose set lacks the true entity (row untouched), -inf
+    true score, NaN entries -- against the C oracle."""
+    lib = oracle_clib()
+    B, N = 6, 40
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(B, N, generator=g)
+    true = torch.tensor([3, 5, 7, 9, 11, 13])
+    s[2, 7] = -float('inf')          # -inf true score: filtered -inf entries still count
+    s[3, 1] = float('nan')
+    s[4, 11] = float('nan')          # NaN true score: nothing counts
+    dictionary = {(0, 0): {3, 4, 5}, (1, 0): {1, 2}, (2, 0): {7, 8, 30}, (3, 0): {9, 1, 2},
+                  (4, 0): {11, 0}}
+    key1 = torch.arange(B); key2 = torch.zeros(B, dtype=torch.long)
+    has, off, tgt = dict_to_csr(dictionary, key1, key2)
+    sn = np.ascontiguousarray(s.numpy())
+    rk = np.empty(B, dtype=np.int64); frk = np.empty(B, dtype=np.int64)
+    lib.orc_filtered_rank(fptr(sn), i64(B), i64(N), fptr(true.numpy()), fptr(has), fptr(off), fptr(tgt),
+                          fptr(rk), fptr(frk))
+    fs = sn.copy()
+    lib.orc_filter_scores(fptr(fs), i64(B), i64(N), fptr(true.numpy()), fptr(has), fptr(off), fptr(tgt))
+    # python oracle agrees with the C oracle
+    fo = orc.filter_scores(s, dictionary, key1, key2, true)
+    assert np.array_equal(fo.numpy(), fs, equal_nan=True)
+    assert np.array_equal(orc.get_rank(fo, true).numpy(), frk)
+    from torchkge_amd.utils import filter_scores, get_rank
+    f = filter_scores(s.cuda(), dictionary, key1.cuda(), key2.cuda(), true.cuda())
+    assert np.array_equal(f.cpu().numpy(), fs, equal_nan=True)
+    assert np.array_equal(get_rank(s.cuda(), true.cuda()).cpu().numpy(), rk)
+    assert np.array_equal(get_rank(f, true.cuda()).cpu().numpy(), frk)
+    from torchkge_amd.filter_index import FilterIndex
+    idx = FilterIndex.from_dict(dictionary, 'cuda')
+    lo, hi = idx.lookup(key1.cuda(), key2.cuda())
+    rk2, frk2 = hip.filtered_rank_from_scores(s.cuda(), true.cuda(), lo, hi, idx.targets)
+    assert np.array_equal(rk2.cpu().numpy(), rk) and np.array_equal(frk2.cpu().numpy(), frk)
+
+
+def _rank_bounds(scores, true_idx, tol):
+    st = scores.gather(1, true_idx.view(-1, 1))
+    return (scores >= st + tol).sum(1), (scores >= st - tol).sum(1)
+
+
+@pytest.mark.parametrize('kind,p', CASES)
+def test_evaluator_vs_reference(hip, kind, p):
+    """LinkPredictionEvaluator: fused == materialised == composed drop-in path
+    bit for bit; vs the reference's ranks: equal, except where the reference's
+    own scores tie within 2*TOL (then inside the tie interval); metrics 1e-5."""
+    import torchkge_amd as tk
+    z, tables = load_golden(kind, p)
+    n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
+    m = build_model(kind, p, tables, n_ent, n_rel)
+    heads, tails, rels = (torch.from_numpy(z[k]) for k in ('heads', 'tails', 'rels'))
+    kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    nt = int(z['n_test']); n = len(heads)
+    _, kg_test = kg.split_kg(sizes=(n - nt, nt))
+    B = int(z['b_size'])
+    ev = tk.LinkPredictionEvaluator(m, kg_test)
+    with pytest.raises(tk.NotYetEvaluatedError):
+        ev.mrr()
+    ev.evaluate(b_size=B, verbose=False)
+    ev2 = tk.LinkPredictionEvaluator(m, kg_test, fused=False)
+    ev2.evaluate(b_size=7, verbose=False)           # different batch size, short last batch
+    names = ['rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails']
+    for nm in names:
+        a = getattr(ev, nm)
+        assert a.dtype == torch.int64 and a.shape[0] == nt and not a.is_cuda
+        assert torch.equal(a, getattr(ev2, nm))
+    # composed public API path (what a user-defined Model subclass gets)
+    ev3 = tk.LinkPredictionEvaluator(m, kg_test)
+    import types
+
+    def generic_side(self, h, t, r, side, index, lo, hi, sharded):
+        key1, true_idx = (h, t) if side == 'tail' else (t, h)
+        return self._rank_side_generic(h, t, r, side, index, true_idx, key1)
+    ev3._rank_side = types.MethodType(generic_side, ev3)
+    ev3.evaluate(b_size=B, verbose=False)
+    for nm in names:
+        assert torch.equal(getattr(ev, nm), getattr(ev3, nm))
+    # vs the reference
+    dh, dt, _ = orc.build_filter_dicts(heads, tails, rels)
+    th, tt, tr = heads[n - nt:], tails[n - nt:], rels[n - nt:]
+    for side, nm_raw, nm_f, true_idx, dic, k1 in [('tail', 'rank_true_tails', 'filt_rank_true_tails', tt, dt, th),
+                                                   ('head', 'rank_true_heads', 'filt_rank_true_heads', th, dh, tt)]:
+        s = orc.lp_scores(kind, tables, th, tt, tr, side, p)
+        lo, hi = _rank_bounds(s, true_idx, 2 * TOL)
+        got = getattr(ev, nm_raw)
+        assert ((got >= lo) & (got <= hi)).all()
+        f = orc.filter_scores(s, dic, k1, tr, true_idx)
+        lo, hi = _rank_bounds(f, true_idx, 2 * TOL)
+        got = getattr(ev, nm_f)
+        assert ((got >= lo) & (got <= hi)).all()
+    for nm in names:   # on these fixtures there are no near-ties: exact equality with the reference
+        assert np.array_equal(getattr(ev, nm).numpy(), z[nm])
+    assert abs(ev.hit_at_k(10)[1] - z['hit10'][1]) < TOL and abs(ev.hit_at_k(10)[0] - z['hit10'][0]) < TOL
+    assert abs(ev.mrr()[1] - z['mrr'][1]) < TOL and abs(ev.mrr()[0] - z['mrr'][0]) < TOL
+    assert abs(ev.mean_rank()[1] - z['mean_rank'][1]) < 1e-3
+    ev.print_results(k=[1, 10])
+
+
+# ---------------------------------------------------------------------------
+# negative sampling: integer scatter bit-exact
+# ---------------------------------------------------------------------------
+def test_sampler_same_seed_same_samples(hip):
+    import torchkge_amd as tk
+    z = np.load(GOLDEN + '/ref_sampler.npz')
+    heads, tails, rels = (torch.from_numpy(z[k]) for k in ('heads', 'tails', 'rels'))
+    n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
+    kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    samp = tk.BernoulliNegativeSampler(kg, n_neg=3)
+    assert np.array_equal(samp.bern_probs.numpy(), z['bern_probs'])       # host precompute: exact
+    h, t, r = heads[:200].cuda(), tails[:200].cuda(), rels[:200].cuda()
+    for n_neg in (1, 3):
+        torch.manual_seed(99)
+        nh, nt = samp.corrupt_batch(h, t, r, n_neg=n_neg)
+        torch.manual_seed(99)     # reference op sequence on the same device RNG
+        oh, ot, mask, dh, dt = orc.corrupt_batch(h, t, r, n_neg, samp.bern_probs, n_ent)
+        assert nh.dtype == torch.int64 and nh.is_cuda
+        assert torch.equal(nh, oh) and torch.equal(nt, ot)
+    usamp = tk.UniformNegativeSampler(kg, n_neg=2)
+    torch.manual_seed(5)
+    nh, nt = usamp.corrupt_batch(h, t, r)
+    torch.manual_seed(5)
+    oh, ot, *_ = orc.corrupt_batch(h, t, r, 2, None, n_ent, uniform=True)
+    assert torch.equal(nh, oh) and torch.equal(nt, ot)
+    # corrupt_kg driver
+    torch.manual_seed(1)
+    ch, ct = samp.corrupt_kg(batch_size=128, use_cuda=True)
+    assert ch.shape[0] == kg.n_facts and not ch.is_cuda
+    # sync-free variant: valid corruption (exactly one side changed per mask)
+    samp.sync_free = True
+    nh, nt = samp.corrupt_batch(h, t, r, n_neg=2)
+    changed_h = nh != h.repeat(2); changed_t = nt != t.repeat(2)
+    assert not (changed_h & changed_t).any()
+    assert int(nh.min()) >= 0 and int(nh.max()) < n_ent
+
+
+@pytest.mark.parametrize('B,n_neg,pr', [(1, 1, 0.5), (1000, 1, 0.0), (1000, 2, 1.0), (4097, 3, 0.3),
+                                        (32768, 1, 0.57), (300000, 4, 0.5)])
+def test_corrupt_scatter_bit_exact(hip, B, n_neg, pr):
+    lib = oracle_clib()
+    g = torch.Generator().manual_seed(B + n_neg)
+    n = B * n_neg
+    heads = torch.randint(0, 10000, (B,), generator=g); tails = torch.randint(0, 10000, (B,), generator=g)
+    mask = (torch.rand(n, generator=g) < pr).to(torch.uint8)
+    k = int(mask.sum())
+    dh = torch.randint(1, 10000, (k,), generator=g); dt = torch.randint(1, 10000, (n - k,), generator=g)
+    oh = np.empty(n, dtype=np.int64); ot = np.empty(n, dtype=np.int64)
+    lib.orc_corrupt_scatter(fptr(heads.numpy()), fptr(tails.numpy()), fptr(mask.numpy()), fptr(dh.numpy()),
+                            fptr(dt.numpy()), i64(B), i64(n_neg), fptr(oh), fptr(ot))
+    nh, nt = hip.corrupt_scatter(heads.cuda(), tails.cuda(), mask.cuda(), dh.cuda(), dt.cuda(), n_neg)
+    assert np.array_equal(nh.cpu().numpy(), oh) and np.array_equal(nt.cpu().numpy(), ot)
+
+
+# ---------------------------------------------------------------------------
+# backward of scoring_function (training path)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('kind,p', CASES)
+def test_scoring_function_backward_vs_autograd(hip, kind, p):
+    z, tables = load_golden(kind, p)
+    m = build_model(kind, p, tables, int(z['n_ent']), int(z['n_rel']))
+    g = torch.Generator().manual_seed(11)
+    B = 257
+    h = torch.randint(0, int(z['n_ent']), (B,), generator=g).cuda()
+    t = torch.randint(0, int(z['n_ent']), (B,), generator=g).cuda()
+    r = torch.randint(0, int(z['n_rel']), (B,), generator=g).cuda()
+    w = torch.rand(B, generator=g).cuda()
+    m.zero_grad()
+    (m.scoring_function(h, t, r) * w).sum().backward()
+    got = [prm.grad.clone() for prm in m._tables()]
+    ref_tabs = [x.clone().cuda().requires_grad_(True) for x in tables]
+    (orc.score_triples(kind, ref_tabs, h, t, r, p=p) * w).sum().backward()
+    for a, b in zip(got, ref_tabs):
+        scale = max(1.0, float(b.grad.abs().max()))
+        assert (a - b.grad).abs().max().item() < 1e-4 * scale
+    # one training step through Model.forward + MarginLoss changes the tables
+    import torchkge_amd as tk
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    nh = torch.randint(0, int(z['n_ent']), (B,), generator=g).cuda()
+    pos, neg = m(h, t, r, nh, t)
+    loss = tk.MarginLoss(0.5)(pos, neg)
+    opt.zero_grad(); loss.backward(); opt.step()
+    m.normalize_parameters()
+    assert torch.isfinite(m._tables()[0]).all()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('kind,shape,d', [('transe', 'fb15k237', 200), ('complex', 'wn18rr', 200),
+                                          ('distmult', 'fb15k', 400), ('transh', 'fb15k237', 100),
+                                          ('transd', 'fb15k237', 100)])
+def test_full_size_properties(hip, kind, shape, d):
+    import torchkge_amd as tk
+    n_ent, n_rel = orc.DATASET_SHAPES[shape][:2]
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=0)
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    B = 384
+    h, t, r = orc.synthetic_triples(n_ent, n_rel, B, seed=1, device='cuda')
+    t[0], h[1], t[2] = 0, n_ent - 1, n_ent - 1            # boundary candidates
+    # build a small filter index: every query filters a few random entities + its true one
+    g = torch.Generator().manual_seed(2)
+    extra = torch.randint(0, n_ent, (B, 5), generator=g)
+    dic = {}
+    for i in range(B):
+        dic.setdefault((int(h[i]), int(r[i])), set()).update([int(t[i])] + extra[i].tolist())
+    from torchkge_amd.filter_index import FilterIndex
+    idx = FilterIndex.from_dict(dic, 'cuda')
+    seg_lo, seg_hi = idx.lookup(h, r)
+    prob = m.lp_problem(h, t, r, 'tail')
+    scores = prob.scores()
+    s_true = prob.pair_scores(t)
+    assert torch.equal(s_true, scores.gather(1, t.view(-1, 1)).view(-1))       # pair == tile, bitwise
+    raw = prob.count_ge(s_true)
+    rk, frk = hip.filtered_rank_from_scores(scores, t, seg_lo, seg_hi, idx.targets)
+    assert torch.equal(raw.long(), rk)                                         # fused == materialised
+    sub, found = prob.filter_sub(s_true, t, seg_lo, seg_hi, idx.targets)
+    rk2, frk2 = hip.rank_finalize(raw, sub, found)
+    assert torch.equal(rk2, rk) and torch.equal(frk2, frk)
+    assert int(rk.min()) >= 1 and (frk <= rk).all() and (frk >= 1).all()
+    # agreement with the drop-in composition get_rank(filter_scores())
+    from torchkge_amd.utils import filter_scores, get_rank
+    assert torch.equal(get_rank(filter_scores(scores, idx, h, r, t), t), frk)
+    # sharding: 3 virtual shards concatenate to the full matrix, counts add up (bitwise)
+    parts, cnt = [], torch.zeros(3, B, dtype=torch.int32, device='cuda')
+    from torchkge_amd import distributed as kd
+    for pidx in range(3):
+        lo, hi = kd.shard_range(n_ent, 3, pidx)
+        pp = m.lp_problem(h, t, r, 'tail', ent_lo=lo, ent_hi=hi)
+        parts.append(pp.scores())
+        st = pp.pair_scores(t)
+        own = (t >= lo) & (t < hi)
+        assert torch.equal(st[own], s_true[own]) and (st[~own] == 0).all()
+        cnt[0] += pp.count_ge(s_true)
+        s_, f_ = pp.filter_sub(s_true, t, seg_lo, seg_hi, idx.targets)
+        cnt[1] += s_; cnt[2] += f_
+    assert torch.equal(torch.cat(parts, 1), scores)
+    assert torch.equal(cnt[0], raw) and torch.equal(cnt[1], sub) and torch.equal(cnt[2], found)
+    if kind in ('distmult', 'complex'):
+        # linearity of the bilinear scorer: exact under power-of-two scaling
+        Q2 = hip.LpProblem(hip.LP_DOT, prob.keep[0] * 2.0, prob.keep[1],
+                           A1=None if prob.keep[2] is None else prob.keep[2] * 2.0, T1=prob.keep[3])
+        assert torch.equal(Q2.scores(), scores * 2.0)
+    else:
+        assert (scores <= 0).all()
+        if kind == 'transe':
+            # a query equal to a table row scores ~0 against it, and is the row's best candidate
+            E = m.ent_emb.weight.data
+            pz = m._translational_problem(E[:B].contiguous(), E)
+            sz = pz.scores()
+            assert (sz[torch.arange(B), torch.arange(B)].abs() < TOL).all()
+            assert (sz.argmax(1).cpu() == torch.arange(B)).all()
+    # against the oracle on a slice the CPU finishes in seconds
+    hs, ts, rs = h[:8].cpu(), t[:8].cpu(), r[:8].cpu()
+    so = orc.lp_scores(kind, tables, hs, ts, rs, 'tail', 2)
+    assert (scores[:8].cpu() - so).abs().max().item() < TOL
+    so = orc.lp_scores(kind, tables, hs, ts, rs, 'head', 2)
+    assert (m.lp_problem(h[:8], t[:8], r[:8], 'head').scores().cpu() - so).abs().max().item() < TOL
+
+
+def test_empty_and_tiny_batches(hip):
+    import torchkge_amd as tk
+    tables = orc.init_tables('transe', 14, 55, 50, seed=0)       # Nations shape, d = 50 (scalar-load path)
+    m = build_model('transe', 2, tables, 14, 55)
+    e = torch.zeros(0, dtype=torch.long, device='cuda')
+    assert m.scoring_function(e, e, e).shape == (0,)
+    prob = m.lp_problem(e, e, e, 'tail')
+    assert prob.scores().shape == (0, 14)
+    h, t, r = orc.synthetic_triples(14, 55, 5, seed=3, device='cuda')
+    s = m.lp_problem(h, t, r, 'tail').scores().cpu()
+    so = orc.lp_scores('transe', tables, h.cpu(), t.cpu(), r.cpu(), 'tail', 2)
+    assert (s - so).abs().max().item() < TOL
+    sf = m.scoring_function(h, t, r).cpu()
+    assert (sf - orc.score_triples('transe', tables, h.cpu(), t.cpu(), r.cpu(), p=2)).abs().max().item() < TOL
+    with pytest.raises(RuntimeError):
+        m.scoring_function(h.cpu(), t.cpu(), r.cpu())            # no CPU fallback
+
+
+def test_dissimilarities_known_answers(hip):
+    from torchkge_amd.utils import l1_dissimilarity, l2_dissimilarity
+    a = dev(np.array([[1.4, 2, 3, 4], [5.4, 6, 7, 8]], dtype=np.float32))
+    b = dev(np.array([[1.3, 4, 2, 10], [5.9, 8, 6, 7]], dtype=np.float32))
+    assert (l1_dissimilarity(a, b).cpu() - torch.tensor([9.1, 4.5])).abs().max() < 1e-5
+    assert (l2_dissimilarity(a, b).cpu() - torch.tensor([41.01, 6.25])).abs().max() < 1e-4

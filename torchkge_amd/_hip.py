@@ -1,0 +1,410 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libkge_hip.so (include/kge_hip.h) and thin tensor-level
+wrappers.  PyTorch is plumbing here: it owns device memory and the stream; all
+arithmetic of the hot path happens inside the HIP library.
+
+There is NO CPU fallback: every wrapper raises if the library is missing or a
+tensor is not a HIP (``cuda``) tensor.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libkge_hip.so')
+
+# enums of include/kge_hip.h
+TRANSE_L1, TRANSE_L2, TRANSH, TRANSD, DISTMULT, COMPLEX = range(6)
+SIDE_TAIL, SIDE_HEAD, SIDE_PROJ_H, SIDE_PROJ_T = range(4)
+EW_ADD, EW_SUB, EW_MUL, EW_MULSUB, EW_MULADD = range(5)
+LP_DOT, LP_L2_EXPAND, LP_L1_DIRECT, LP_L2_DIRECT = range(4)
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+
+class LpDesc(ctypes.Structure):
+    """struct kge_lp_desc (include/kge_hip.h)."""
+    _fields_ = [
+        ('mode', ctypes.c_int32), ('K0', ctypes.c_int32), ('K1', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
+        ('B', _i64), ('N', _i64), ('c_base', _i64),
+        ('A0', _vp), ('lda0', _i64), ('T0', _vp), ('ldt0', _i64),
+        ('A1', _vp), ('lda1', _i64), ('T1', _vp), ('ldt1', _i64),
+        ('qn', _vp), ('en', _vp),
+        ('Wq', _vp), ('ldw', _i64), ('scal', _vp), ('scal_ld', _i64),
+        ('r_idx', _vp),
+    ]
+
+
+_SIGNATURES = {
+    'kge_score_triples': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp],
+    'kge_score_triples_bwd': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp,
+                              _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_prep': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp,
+                    _vp, _vp, _vp],
+    'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp],
+    'kge_row_dot': [_vp, _vp, _i64, _i64, _int, ctypes.c_float, _vp, _vp],
+    'kge_gather_rows': [_vp, _i64, _vp, _i64, _int, _vp, _vp],
+    'kge_normalize_rows': [_vp, _i64, _i64, _int, _vp],
+    'kge_lp_scores': [ctypes.POINTER(LpDesc), _vp, _i64, _vp],
+    'kge_lp_pair_scores': [ctypes.POINTER(LpDesc), _vp, _vp, _i64, _vp, _vp],
+    'kge_lp_count_ge': [ctypes.POINTER(LpDesc), _vp, _vp, _vp],
+    'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
+    'kge_get_rank': [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
+    'kge_filter_lookup': [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    'kge_filter_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    'kge_filtered_rank_from_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    'kge_corrupt_scatter': [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+}
+# every symbol include/kge_hip.h declares
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version',
+                                               'kge_build_arch'])
+
+_lib = None
+
+
+def load_library():
+    """dlopen libkge_hip.so (built in-tree by torchkge_amd/csrc/build.py).
+    Fails loudly: the HIP extension IS the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'torchkge_amd: %s not found -- build it with `python -m torchkge_amd.csrc.build` '
+            '(or __graft_entry__.build()); there is no CPU / PyTorch fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _int
+    lib.kge_corrupt_ws_elems.argtypes = [_i64]
+    lib.kge_corrupt_ws_elems.restype = _i64
+    lib.kge_abi_version.argtypes = []
+    lib.kge_abi_version.restype = _int
+    lib.kge_build_arch.argtypes = []
+    lib.kge_build_arch.restype = ctypes.c_char_p
+    if lib.kge_abi_version() != 1:
+        raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        if rc < 0:
+            raise RuntimeError('torchkge_amd: %s rejected its arguments (code %d)' % (name, rc))
+        raise RuntimeError('torchkge_amd: %s failed with hipError_t %d' % (name, rc))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                'torchkge_amd runs only on MI355X (HIP) tensors; got a %s tensor. There is no '
+                'CPU fallback -- move the model / indices to `cuda`.' % t.device)
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def f32c(t):
+    """fp32 contiguous view/copy (precondition of every table / matrix argument)."""
+    if t.dtype != torch.float32:
+        raise RuntimeError('torchkge_amd: expected a float32 tensor, got %s' % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def i64c(t):
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------
+# tensor-level wrappers
+# ---------------------------------------------------------------------------
+def score_triples(kind, tables, d_ent, d_rel, h, t, r):
+    lib = load_library()
+    require_cuda(h, t, r, *tables)
+    tabs = [f32c(x) for x in tables] + [None] * (4 - len(tables))
+    h, t, r = i64c(h), i64c(t), i64c(r)
+    B = h.shape[0]
+    out = torch.empty(B, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        _check(lib.kge_score_triples(kind, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
+                                     d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(out), _stream()),
+               'kge_score_triples')
+    return out
+
+
+def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
+    """Returns a list of gradient tensors (or None) matching ``tables``."""
+    lib = load_library()
+    tabs = [f32c(x) for x in tables] + [None] * (4 - len(tables))
+    grads = [torch.zeros_like(x) for x in tabs[:len(tables)]] + [None] * (4 - len(tables))
+    go = f32c(grad_out)
+    B = h.shape[0]
+    with torch.cuda.device(h.device):
+        _check(lib.kge_score_triples_bwd(kind, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
+                                         d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(go),
+                                         _p(grads[0]), _p(grads[1]), _p(grads[2]), _p(grads[3]),
+                                         _stream()), 'kge_score_triples_bwd')
+    return [g if n else None for g, n in zip(grads[:len(tables)], needs)]
+
+
+def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=False,
+            want_q1=False):
+    lib = load_library()
+    require_cuda(h, t, r, *tables)
+    tabs = [f32c(x) for x in tables] + [None] * (4 - len(tables))
+    h, t, r = i64c(h), i64c(t), i64c(r)
+    B = h.shape[0]
+    dev = h.device
+    Q0 = torch.empty(B, d_rel, dtype=torch.float32, device=dev)
+    Q1 = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_q1 else None
+    qn = torch.empty(B, dtype=torch.float32, device=dev) if want_qn else None
+    Wq = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_w else None
+    with torch.cuda.device(dev):
+        _check(lib.kge_lp_prep(kind, side, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
+                               d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(Q0), _p(Q1), _p(qn),
+                               _p(Wq), _stream()), 'kge_lp_prep')
+    return Q0, Q1, qn, Wq
+
+
+def ewise(op, a, b, c=None, d=None):
+    """Elementwise query-side algebra (kge_ewise); all operands same shape."""
+    lib = load_library()
+    require_cuda(a, b, c, d)
+    a, b = f32c(a), f32c(b)
+    c = None if c is None else f32c(c)
+    d = None if d is None else f32c(d)
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _check(lib.kge_ewise(op, _p(a), _p(b), _p(c), _p(d), a.numel(), _p(out), _stream()), 'kge_ewise')
+    return out
+
+
+def row_sqnorm(X, K=None):
+    lib = load_library()
+    require_cuda(X)
+    X = f32c(X)
+    rows, ld = X.shape[0], X.stride(0)
+    K = X.shape[1] if K is None else K
+    out = torch.empty(rows, dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(lib.kge_row_sqnorm(_p(X), ld, rows, K, _p(out), _stream()), 'kge_row_sqnorm')
+    return out
+
+
+def row_dot(X, Y, scale=1.0):
+    lib = load_library()
+    require_cuda(X, Y)
+    X, Y = f32c(X), f32c(Y)
+    assert X.shape == Y.shape
+    rows, K = X.shape
+    out = torch.empty(rows, dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(lib.kge_row_dot(_p(X), _p(Y), K, rows, K, ctypes.c_float(scale), _p(out), _stream()),
+               'kge_row_dot')
+    return out
+
+
+def gather_rows(X, idx):
+    lib = load_library()
+    require_cuda(X, idx)
+    X, idx = f32c(X), i64c(idx)
+    rows, K = idx.shape[0], X.shape[1]
+    out = torch.empty(rows, K, dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(lib.kge_gather_rows(_p(X), X.stride(0), _p(idx), rows, K, _p(out), _stream()),
+               'kge_gather_rows')
+    return out
+
+
+def normalize_rows_(X):
+    """In-place F.normalize(X, p=2, dim=1)."""
+    lib = load_library()
+    require_cuda(X)
+    if not X.is_contiguous() or X.dtype != torch.float32:
+        raise RuntimeError('normalize_rows_: need a contiguous float32 matrix')
+    with torch.cuda.device(X.device):
+        _check(lib.kge_normalize_rows(_p(X), X.stride(0), X.shape[0], X.shape[1], _stream()),
+               'kge_normalize_rows')
+    return X
+
+
+class LpProblem(object):
+    """Python owner of a kge_lp_desc: keeps the tensors alive and exposes the
+    descriptor entry points."""
+
+    def __init__(self, mode, A0, T0, A1=None, T1=None, qn=None, en=None, Wq=None, scal=None,
+                 r_idx=None, c_base=0, K0=None):
+        require_cuda(A0, T0, A1, T1, qn, en, Wq, scal, r_idx)
+        self.keep = [A0, T0, A1, T1, qn, en, Wq, scal, r_idx]
+        self.device = A0.device
+        d = LpDesc()
+        d.mode = mode
+        d.K0 = A0.shape[1] if K0 is None else K0
+        d.K1 = 0 if A1 is None else A1.shape[1]
+        d.B, d.N, d.c_base = A0.shape[0], T0.shape[0], c_base
+        d.A0, d.lda0 = A0.data_ptr(), A0.stride(0)
+        d.T0, d.ldt0 = T0.data_ptr(), T0.stride(0)
+        if A1 is not None:
+            d.A1, d.lda1 = A1.data_ptr(), A1.stride(0)
+            d.T1, d.ldt1 = T1.data_ptr(), T1.stride(0)
+        if qn is not None:
+            d.qn, d.en = qn.data_ptr(), en.data_ptr()
+        if Wq is not None:
+            d.Wq, d.ldw = Wq.data_ptr(), Wq.stride(0)
+            d.scal = scal.data_ptr()
+            d.scal_ld = 1 if scal.dim() == 1 else scal.stride(0)
+            if r_idx is not None:
+                d.r_idx = r_idx.data_ptr()
+        self.desc = d
+        self.B, self.N = int(d.B), int(d.N)
+
+    def scores(self, out=None):
+        lib = load_library()
+        if out is None:
+            out = torch.empty(self.B, self.N, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib.kge_lp_scores(ctypes.byref(self.desc), _p(out), out.stride(0), _stream()),
+                   'kge_lp_scores')
+        return out
+
+    def pair_scores(self, ci, qi=None):
+        lib = load_library()
+        ci = i64c(ci)
+        P = ci.shape[0]
+        out = torch.empty(P, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib.kge_lp_pair_scores(ctypes.byref(self.desc), _p(qi), _p(ci), P, _p(out),
+                                          _stream()), 'kge_lp_pair_scores')
+        return out
+
+    def count_ge(self, s_true, raw=None):
+        lib = load_library()
+        if raw is None:
+            raw = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib.kge_lp_count_ge(ctypes.byref(self.desc), _p(s_true), _p(raw), _stream()),
+                   'kge_lp_count_ge')
+        return raw
+
+    def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets):
+        lib = load_library()
+        sub = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        found = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib.kge_lp_filter_sub(ctypes.byref(self.desc), _p(s_true), _p(true_idx),
+                                         _p(seg_lo), _p(seg_hi), _p(targets), _p(sub), _p(found),
+                                         _stream()), 'kge_lp_filter_sub')
+        return sub, found
+
+
+def rank_finalize(raw, sub, found):
+    lib = load_library()
+    B = raw.shape[0]
+    rank = torch.empty(B, dtype=torch.int64, device=raw.device)
+    filt = torch.empty(B, dtype=torch.int64, device=raw.device)
+    with torch.cuda.device(raw.device):
+        _check(lib.kge_rank_finalize(_p(raw), _p(sub), _p(found), B, _p(rank), _p(filt), _stream()),
+               'kge_rank_finalize')
+    return rank, filt
+
+
+def lp_scores_batched(mode, q, cand):
+    """q (B,K); cand (B,N,K) with arbitrary batch / row strides (inner stride 1)."""
+    lib = load_library()
+    require_cuda(q, cand)
+    q = f32c(q)
+    if cand.dtype != torch.float32:
+        raise RuntimeError('expected float32 candidates')
+    if cand.stride(2) != 1:
+        cand = cand.contiguous()
+    B, N, K = cand.shape
+    out = torch.empty(B, N, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _check(lib.kge_lp_scores_batched(mode, _p(q), q.stride(0), _p(cand), cand.stride(0),
+                                         cand.stride(1), B, N, K, _p(out), out.stride(0), _stream()),
+               'kge_lp_scores_batched')
+    return out
+
+
+def get_rank(scores, true_idx, low_values=False):
+    lib = load_library()
+    require_cuda(scores, true_idx)
+    scores = f32c(scores)
+    true_idx = i64c(true_idx)
+    B, N = scores.shape
+    rank = torch.empty(B, dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _check(lib.kge_get_rank(_p(scores), scores.stride(0), _p(true_idx), B, N,
+                                1 if low_values else 0, _p(rank), _stream()), 'kge_get_rank')
+    return rank
+
+
+def filter_lookup(keys, offsets, key1, key2, n_key2):
+    lib = load_library()
+    key1, key2 = i64c(key1), i64c(key2)
+    B = key1.shape[0]
+    lo = torch.empty(B, dtype=torch.int64, device=key1.device)
+    hi = torch.empty(B, dtype=torch.int64, device=key1.device)
+    with torch.cuda.device(key1.device):
+        _check(lib.kge_filter_lookup(_p(keys), keys.shape[0], _p(offsets), _p(key1), _p(key2),
+                                     n_key2, B, _p(lo), _p(hi), _stream()), 'kge_filter_lookup')
+    return lo, hi
+
+
+def filter_scores_(scores, true_idx, seg_lo, seg_hi, targets):
+    lib = load_library()
+    B, N = scores.shape
+    with torch.cuda.device(scores.device):
+        _check(lib.kge_filter_scores(_p(scores), scores.stride(0), _p(true_idx), _p(seg_lo),
+                                     _p(seg_hi), _p(targets), B, N, _stream()), 'kge_filter_scores')
+    return scores
+
+
+def filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
+    lib = load_library()
+    scores = f32c(scores)
+    B, N = scores.shape
+    rank = torch.empty(B, dtype=torch.int64, device=scores.device)
+    filt = torch.empty(B, dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _check(lib.kge_filtered_rank_from_scores(_p(scores), scores.stride(0), _p(true_idx),
+                                                 _p(seg_lo), _p(seg_hi), _p(targets), B, N,
+                                                 _p(rank), _p(filt), _stream()),
+               'kge_filtered_rank_from_scores')
+    return rank, filt
+
+
+def corrupt_scatter(heads, tails, mask_u8, draws_h, draws_t, n_neg):
+    lib = load_library()
+    require_cuda(heads, tails, mask_u8, draws_h, draws_t)
+    heads, tails = i64c(heads), i64c(tails)
+    draws_h, draws_t = i64c(draws_h), i64c(draws_t)
+    B = heads.shape[0]
+    n = B * n_neg
+    dev = heads.device
+    nh = torch.empty(n, dtype=torch.int64, device=dev)
+    nt = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = torch.empty(int(lib.kge_corrupt_ws_elems(n)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.kge_corrupt_scatter(_p(heads), _p(tails), _p(mask_u8), _p(draws_h), _p(draws_t),
+                                       B, n_neg, _p(nh), _p(nt), _p(ws), _stream()),
+               'kge_corrupt_scatter')
+    return nh, nt

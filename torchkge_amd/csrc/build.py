@@ -1,0 +1,75 @@
+# -*- coding: utf-8 -*-
+"""Build libkge_hip.so (gfx950) in-tree with hipcc.
+
+    python -m torchkge_amd.csrc.build          # or __graft_entry__.build()
+
+hipcc cross-compiles for gfx950 without a GPU.  The shared object lands next to
+the sources (torchkge_amd/csrc/libkge_hip.so): git-ignored, but it travels to
+the GPU box with the gpurun snapshot.  -ffp-contract=off is part of the
+numerical contract (see kge_common.h): fused multiply-adds are explicit fmaf().
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ['score_triples.hip', 'lp_prep.hip', 'lp_gemm_mfma.hip', 'lp_direct.hip',
+           'rank_filter.hip', 'corrupt.hip']
+HEADERS = ['kge_common.h', os.path.join('..', '..', 'include', 'kge_hip.h')]
+LIB = os.path.join(HERE, 'libkge_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+         '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libkge_hip.so.  Returns the path."""
+    bdir = os.path.join(HERE, '_build')
+    os.makedirs(bdir, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(bdir, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs + [os.path.abspath(__file__)]):
+            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), r.stdout))
+        return r.stdout
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            outs = list(ex.map(run, jobs))
+        if verbose:
+            for o in outs:
+                if o.strip():
+                    print(o)
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

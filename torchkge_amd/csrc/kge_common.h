@@ -1,0 +1,94 @@
+// Shared device helpers for libkge_hip.so (gfx950 only).
+// Compiled with -ffp-contract=off: every fused multiply-add in this library is
+// an explicit fmaf(), so the fp32 arithmetic is exactly what the source says
+// (and what oracle/kge_oracle.c restates on the CPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/kge_hip.h"
+
+#define KGE_WAVE 64
+
+#define KGE_CHECK_LAUNCH()                          \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+static inline hipStream_t kge_s(kge_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool kge_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- the scoring contract of kge_lp_desc (see include/kge_hip.h) ----------
+__device__ __forceinline__ float lp_chain_dot(const float *__restrict__ a, const float *__restrict__ t,
+                                              int K, float acc)
+{
+    for (int k = 0; k < K; ++k) acc = fmaf(a[k], t[k], acc);
+    return acc;
+}
+
+__device__ __forceinline__ float lp_epilogue(int mode, float dot, float qn, float en)
+{
+    if (mode == KGE_LP_L2_EXPAND) {
+        float d2 = fmaf(-2.0f, dot, qn + en);
+        return -fmaxf(d2, 0.0f);
+    }
+    return dot;
+}
+
+// score of query i against LOCAL candidate c, any mode (scalar reference path
+// used by the pair / filter kernels; bit-identical to the tile kernels).
+__device__ __forceinline__ float lp_pair_score(const kge_lp_desc &d, int64_t i, int64_t c)
+{
+    if (d.mode == KGE_LP_DOT || d.mode == KGE_LP_L2_EXPAND) {
+        float acc = lp_chain_dot(d.A0 + i * d.lda0, d.T0 + c * d.ldt0, d.K0, 0.0f);
+        if (d.K1 > 0) acc = lp_chain_dot(d.A1 + i * d.lda1, d.T1 + c * d.ldt1, d.K1, acc);
+        float qn = 0.f, en = 0.f;
+        if (d.mode == KGE_LP_L2_EXPAND) { qn = d.qn[i]; en = d.en[c]; }
+        return lp_epilogue(d.mode, acc, qn, en);
+    }
+    const float *q = d.A0 + i * d.lda0;
+    const float *t = d.T0 + c * d.ldt0;
+    float acc = 0.0f;
+    if (d.Wq) {
+        const float a = d.scal[c * d.scal_ld + (d.scal_ld > 1 ? d.r_idx[i] : 0)];
+        const float *w = d.Wq + i * d.ldw;
+        for (int k = 0; k < d.K0; ++k) {
+            float diff = fmaf(a, w[k], q[k] - t[k]);
+            acc = (d.mode == KGE_LP_L1_DIRECT) ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+        }
+    } else {
+        for (int k = 0; k < d.K0; ++k) {
+            float diff = q[k] - t[k];
+            acc = (d.mode == KGE_LP_L1_DIRECT) ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+        }
+    }
+    return -acc;
+}
+
+static inline int kge_lp_desc_check(const kge_lp_desc *d)
+{
+    if (!d) return KGE_EINVAL;
+    if (d->mode < KGE_LP_DOT || d->mode > KGE_LP_L2_DIRECT) return KGE_EINVAL;
+    if (d->B < 0 || d->N < 0 || d->K0 <= 0 || d->K1 < 0) return KGE_EINVAL;
+    if (!d->A0 || !d->T0) return KGE_EINVAL;
+    if (d->K1 > 0 && (!d->A1 || !d->T1)) return KGE_EINVAL;
+    if (d->K1 > 0 && d->mode != KGE_LP_DOT) return KGE_EINVAL;
+    if (d->mode == KGE_LP_L2_EXPAND && (!d->qn || !d->en)) return KGE_EINVAL;
+    if (d->Wq && (!d->scal || d->scal_ld < 1 || (d->scal_ld > 1 && !d->r_idx))) return KGE_EINVAL;
+    if (d->Wq && d->mode < KGE_LP_L1_DIRECT) return KGE_EINVAL;
+    return 0;
+}

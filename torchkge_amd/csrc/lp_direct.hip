@@ -1,0 +1,293 @@
+// Translational all-candidates scores by broadcast-subtract + L_p reduction
+// (fp32 VALU), gfx950.
+//
+//   S[i,c] = - sum_k | q_i[k] - e_c[k] (+ a(i,c) * w_i[k]) |^p ,  p in {1,2}
+//
+// Replaces TranslationModel.inference_scoring_function (interfaces.py:240-260)
+// for TransE-L1/L2 (translation.py:105-125) and, with the rank-1 term, for
+// TransH (cand = E[c] - a[c,r_i] W[r_i], translation.py:234-284) and TransD
+// (cand = s_c Rp[r_i] + E[c,:dr], translation.py:603-652) WITHOUT the reference's
+// (R,N,d) projection cache or its (b,N,d) intermediates.
+//
+// Register-tiled: 256 threads as 16(query) x 16(candidate); each thread owns a
+// TM x 8 micro-tile with one fp32 accumulator per pair (ascending-k order =
+// the contract of lp_pair_score), q / e / w tiles staged through
+// double-buffered LDS in BK = 32 slices (row stride 36: conflict-free b128).
+#include "kge_common.h"
+
+namespace {
+
+constexpr int BK = 32, LDS_LD = BK + 4, NTHREADS = 256, TN = 8, BN = 16 * TN;
+
+struct DirectParams {
+    kge_lp_desc d;
+    float *out;
+    int64_t ldo;
+    const float *s_true;
+    int *raw_count;
+    int row_panels, col_tiles, tiles_per_block, col_chunks;
+};
+
+template <bool VEC4>
+__device__ __forceinline__ void g_load8(const float *__restrict__ base, int64_t ld, int64_t row,
+                                        bool row_ok, int k, int K, float (&v)[8])
+{
+    if (VEC4) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (row_ok) {
+            const float *p = base + row * ld + k;
+            if (k + 4 <= K) a = *reinterpret_cast<const float4 *>(p);
+            if (k + 8 <= K) b = *reinterpret_cast<const float4 *>(p + 4);
+        }
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (row_ok && k + j < K) ? base[row * ld + k + j] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void lds_store8(float *dst, const float (&v)[8])
+{
+    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <bool L1>
+__device__ __forceinline__ float acc_step(float acc, float diff)
+{
+    return L1 ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+}
+
+// TM = 8 (plain) or 4 (AXPY: the per-pair scalar a(i,c) also lives in registers)
+template <bool VEC4, bool L1, bool AXPY, bool COUNT, int TM>
+__global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectParams p)
+{
+    constexpr int BM = 16 * TM;
+    constexpr int QCH = BM * 4 / NTHREADS; // 8-float chunks of the q tile per thread (2 or 1)
+    constexpr int Q_FLOATS = BM * LDS_LD, T_FLOATS = BN * LDS_LD;
+    constexpr int BUF_FLOATS = Q_FLOATS * (AXPY ? 2 : 1) + T_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const kge_lp_desc &d = p.d;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+
+    const int nblk_grid = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk_grid >> 3, xr = nblk_grid & 7, xcd = bid & 7, loc = bid >> 3;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    const int rp = lid % p.row_panels, cc = lid / p.row_panels;
+    const int64_t row0 = (int64_t)rp * BM;
+    const int tile_begin = cc * p.tiles_per_block;
+    const int tile_end = min(tile_begin + p.tiles_per_block, p.col_tiles);
+    const int ntiles = tile_end - tile_begin;
+    if (ntiles <= 0) return;
+
+    const int K = d.K0;
+    const int S = (K + BK - 1) / BK;
+    const int G = ntiles * S;
+
+    float stQ[QCH][8], stW[AXPY ? QCH : 1][8], stT[2][8];
+    const int srow = tid >> 2, skc = tid & 3;
+
+    auto prefetch = [&](int g) {
+        const int ti = g / S, s = g - ti * S;
+        const int k = s * BK + skc * 8;
+        const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
+#pragma unroll
+        for (int j = 0; j < QCH; ++j) {
+            const int64_t r = row0 + srow + 64 * j;
+            g_load8<VEC4>(d.A0, d.lda0, r, r < d.B, k, K, stQ[j]);
+            if (AXPY) g_load8<VEC4>(d.Wq, d.ldw, r, r < d.B, k, K, stW[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t r = col0 + srow + 64 * j;
+            g_load8<VEC4>(d.T0, d.ldt0, r, r < d.N, k, K, stT[j]);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float *Qs = smem + buf * BUF_FLOATS;
+        float *Ts = Qs + Q_FLOATS;
+        float *Ws = Ts + T_FLOATS;
+#pragma unroll
+        for (int j = 0; j < QCH; ++j) {
+            lds_store8(Qs + (srow + 64 * j) * LDS_LD + skc * 8, stQ[j]);
+            if (AXPY) lds_store8(Ws + (srow + 64 * j) * LDS_LD + skc * 8, stW[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) lds_store8(Ts + (srow + 64 * j) * LDS_LD + skc * 8, stT[j]);
+    };
+
+    float acc[TM][TN];
+    float av[AXPY ? TM : 1][AXPY ? TN : 1];
+    int cnt[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        cnt[i] = 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
+    }
+
+    int *rc = reinterpret_cast<int *>(smem + 2 * BUF_FLOATS);
+    float *st_s = smem + 2 * BUF_FLOATS + BM;
+    if (tid < BM) {
+        const int64_t row = row0 + tid;
+        rc[tid] = 0;
+        st_s[tid] = (COUNT && row < d.B) ? p.s_true[row] : 0.f;
+    }
+
+    auto load_av = [&](int ti) {
+        if (AXPY) {
+            const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int64_t row = row0 + ty + 16 * i;
+                const int64_t rsel = (d.scal_ld > 1 && row < d.B) ? d.r_idx[row] : 0;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int64_t col = col0 + tx + 16 * j;
+                    av[AXPY ? i : 0][AXPY ? j : 0] =
+                        (col < d.N && row < d.B) ? d.scal[col * d.scal_ld + rsel] : 0.f;
+                }
+            }
+        }
+    };
+
+    prefetch(0);
+    stage_store(0);
+    load_av(0);
+    __syncthreads();
+
+    for (int g = 0; g < G; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < G) prefetch(g + 1);
+        const int ti = g / S, s = g - ti * S;
+        const int nk4 = min(BK / 4, (K - s * BK + 3) >> 2);
+
+        const float *Qb = smem + buf * BUF_FLOATS + ty * LDS_LD;
+        const float *Tb = smem + buf * BUF_FLOATS + Q_FLOATS + tx * LDS_LD;
+        const float *Wb = smem + buf * BUF_FLOATS + Q_FLOATS + T_FLOATS + ty * LDS_LD;
+#pragma unroll 2
+        for (int k4 = 0; k4 < nk4; ++k4) {
+            float4 q[TM], t[TN], w[AXPY ? TM : 1];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                q[i] = *reinterpret_cast<const float4 *>(Qb + 16 * i * LDS_LD + k4 * 4);
+                if (AXPY) w[AXPY ? i : 0] = *reinterpret_cast<const float4 *>(Wb + 16 * i * LDS_LD + k4 * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) t[j] = *reinterpret_cast<const float4 *>(Tb + 16 * j * LDS_LD + k4 * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float dx = q[i].x - t[j].x, dy = q[i].y - t[j].y, dz = q[i].z - t[j].z, dw = q[i].w - t[j].w;
+                    if (AXPY) {
+                        const float a = av[AXPY ? i : 0][AXPY ? j : 0];
+                        const float4 wv = w[AXPY ? i : 0];
+                        dx = fmaf(a, wv.x, dx); dy = fmaf(a, wv.y, dy);
+                        dz = fmaf(a, wv.z, dz); dw = fmaf(a, wv.w, dw);
+                    }
+                    float v = acc[i][j];
+                    v = acc_step<L1>(v, dx); v = acc_step<L1>(v, dy);
+                    v = acc_step<L1>(v, dz); v = acc_step<L1>(v, dw);
+                    acc[i][j] = v;
+                }
+        }
+
+        if (s == S - 1) {
+            const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int lrow = ty + 16 * i;
+                const int64_t row = row0 + lrow;
+                const float stv = COUNT ? st_s[lrow] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int64_t col = col0 + tx + 16 * j;
+                    const float sc = -acc[i][j];
+                    if (COUNT) cnt[i] += (col < d.N && sc >= stv) ? 1 : 0;
+                    else if (col < d.N && row < d.B) p.out[row * p.ldo + col] = sc;
+                    acc[i][j] = 0.f;
+                }
+            }
+            if (ti + 1 < ntiles) load_av(ti + 1);
+        }
+
+        if (g + 1 < G) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (COUNT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            if (cnt[i]) atomicAdd(&rc[ty + 16 * i], cnt[i]);
+        __syncthreads();
+        if (tid < BM) {
+            const int64_t row = row0 + tid;
+            const int v = rc[tid];
+            if (row < d.B && v) atomicAdd(&p.raw_count[row], v);
+        }
+    }
+}
+
+template <bool VEC4, bool L1, bool AXPY, bool COUNT>
+int launch(DirectParams &p, hipStream_t s)
+{
+    constexpr int TM = AXPY ? 4 : 8;
+    constexpr int BM = 16 * TM;
+    constexpr int BUF_FLOATS = BM * LDS_LD * (AXPY ? 2 : 1) + BN * LDS_LD;
+    constexpr int SMEM_BYTES = 2 * BUF_FLOATS * 4 + 2 * BM * 4;
+    const kge_lp_desc &d = p.d;
+    p.row_panels = (int)((d.B + BM - 1) / BM);
+    p.col_tiles = (int)((d.N + BN - 1) / BN);
+    const int target_blocks = 2048;
+    int chunks = (target_blocks + p.row_panels - 1) / p.row_panels;
+    if (chunks > p.col_tiles) chunks = p.col_tiles;
+    if (chunks < 1) chunks = 1;
+    p.tiles_per_block = (p.col_tiles + chunks - 1) / chunks;
+    p.col_chunks = (p.col_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
+    const int grid = p.row_panels * p.col_chunks;
+
+    auto k = lp_direct_kernel<VEC4, L1, AXPY, COUNT, TM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), SMEM_BYTES, s, p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool VEC4, bool L1>
+int dispatch2(DirectParams &p, bool axpy, bool count, hipStream_t s)
+{
+    if (axpy) return count ? launch<VEC4, L1, true, true>(p, s) : launch<VEC4, L1, true, false>(p, s);
+    return count ? launch<VEC4, L1, false, true>(p, s) : launch<VEC4, L1, false, false>(p, s);
+}
+
+} // namespace
+
+int kge_lp_direct_run(const kge_lp_desc *d, float *out, int64_t ldo, const float *s_true,
+                      int32_t *raw_count, hipStream_t s)
+{
+    if (d->B == 0 || d->N == 0) return 0;
+    if ((out != nullptr) == (raw_count != nullptr)) return KGE_EINVAL;
+    DirectParams p;
+    p.d = *d;
+    p.out = out;
+    p.ldo = ldo;
+    p.s_true = s_true;
+    p.raw_count = raw_count;
+    const bool axpy = d->Wq != nullptr;
+    bool vec4 = (d->K0 % 4 == 0) && (d->lda0 % 4 == 0) && (d->ldt0 % 4 == 0) &&
+                kge_aligned16(d->A0) && kge_aligned16(d->T0);
+    if (axpy) vec4 = vec4 && (d->ldw % 4 == 0) && kge_aligned16(d->Wq);
+    const bool l1 = d->mode == KGE_LP_L1_DIRECT;
+    const bool count = raw_count != nullptr;
+    if (vec4) return l1 ? dispatch2<true, true>(p, axpy, count, s) : dispatch2<true, false>(p, axpy, count, s);
+    return l1 ? dispatch2<false, true>(p, axpy, count, s) : dispatch2<false, false>(p, axpy, count, s);
+}

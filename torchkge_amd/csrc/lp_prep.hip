@@ -1,0 +1,252 @@
+// Query-side preparation for all-candidates link prediction (gfx950):
+// the device equivalent of Model.inference_prepare_candidates
+//   TransE   models/translation.py:105-125       DistMult models/bilinear.py:247-267
+//   TransH   models/translation.py:234-258       ComplEx  models/bilinear.py:530-556
+//   TransD   models/translation.py:603-627
+// plus the per-entity reductions that stand in for evaluate_projections
+// (translation.py:260-284, :629-652): instead of caching P[r,e,:] (R x N x d
+// floats) the engine keeps one scalar per (entity[,relation]).
+// One wavefront per row; all HBM-bound and tiny next to the scoring kernels.
+#include "kge_common.h"
+
+namespace {
+
+constexpr int WPB = 4;
+
+inline int grid_rows(int64_t rows)
+{
+    int64_t b = (rows + WPB - 1) / WPB;
+    const int64_t cap = 256 * 8;
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+inline int grid_threads(int64_t n, int bs)
+{
+    int64_t b = (n + bs - 1) / bs;
+    const int64_t cap = 256 * 8;
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+struct PrepParams {
+    int kind, side;
+    const float *t0, *t1, *t2, *t3;
+    int d_ent, d_rel;
+    const int64_t *h, *t, *r;
+    int64_t B;
+    float *Q0, *Q1, *Wq;
+};
+
+__global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    const int de = p.d_ent, dr = p.d_rel;
+    const bool tail = p.side == KGE_SIDE_TAIL;
+    const bool proj = p.side >= KGE_SIDE_PROJ_H; // projection only, no relation term
+    const bool use_h = tail || p.side == KGE_SIDE_PROJ_H;
+    for (int64_t i = wave; i < p.B; i += nwaves) {
+        const int64_t ei = use_h ? p.h[i] : p.t[i]; // the entity that stays in the query
+        const int64_t ri = p.r[i];
+        float *q0 = p.Q0 + i * dr;
+        switch (p.kind) {
+        case KGE_TRANSE_L1:
+        case KGE_TRANSE_L2: {
+            const float *e = p.t0 + ei * de, *r = p.t1 + ri * dr;
+            for (int k = lane; k < dr; k += 64) q0[k] = proj ? e[k] : (tail ? e[k] + r[k] : e[k] - r[k]);
+            break;
+        }
+        case KGE_DISTMULT: {
+            const float *e = p.t0 + ei * de, *r = p.t1 + ri * dr;
+            for (int k = lane; k < dr; k += 64) q0[k] = proj ? e[k] : (tail ? e[k] * r[k] : r[k] * e[k]);
+            break;
+        }
+        case KGE_COMPLEX: {
+            const float *re = p.t0 + ei * de, *im = p.t1 + ei * de;
+            const float *rr = p.t2 + ri * dr, *ir = p.t3 + ri * dr;
+            float *q1 = p.Q1 + i * dr;
+            for (int k = lane; k < dr; k += 64) {
+                if (proj) {
+                    q0[k] = re[k];
+                    q1[k] = im[k];
+                } else if (tail) { // bilinear.py:514-515
+                    q0[k] = re[k] * rr[k] - im[k] * ir[k];
+                    q1[k] = re[k] * ir[k] + im[k] * rr[k];
+                } else {    // bilinear.py:521-522 (re = re_t, im = im_t)
+                    q0[k] = rr[k] * re[k] + ir[k] * im[k];
+                    q1[k] = rr[k] * im[k] - ir[k] * re[k];
+                }
+            }
+            break;
+        }
+        case KGE_TRANSH: {
+            const float *e = p.t0 + ei * de, *r = p.t1 + ri * dr, *w = p.t2 + ri * dr;
+            float a = 0.f;
+            for (int k = lane; k < dr; k += 64) a = fmaf(e[k], w[k], a);
+            a = wave_sum(a);
+            float *wq = p.Wq + i * dr;
+            for (int k = lane; k < dr; k += 64) {
+                const float pe = e[k] - a * w[k]; // translation.py:281
+                q0[k] = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
+                wq[k] = w[k];
+            }
+            break;
+        }
+        case KGE_TRANSD: {
+            const float *e = p.t0 + ei * de, *ep = p.t2 + ei * de;
+            const float *r = p.t1 + ri * dr, *rp = p.t3 + ri * dr;
+            float sc = 0.f;
+            for (int k = lane; k < de; k += 64) sc = fmaf(ep[k], e[k], sc);
+            sc = wave_sum(sc);
+            float *wq = p.Wq + i * dr;
+            for (int k = lane; k < dr; k += 64) {
+                const float pe = sc * rp[k] + e[k]; // translation.py:646
+                q0[k] = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
+                wq[k] = rp[k];
+            }
+            break;
+        }
+        }
+    }
+}
+
+// serial single-accumulator chains (one thread per row): these feed
+// L2_EXPAND's qn / en and must match oracle orc_row_sqnorm_chain bit for bit.
+__global__ void row_sqnorm_kernel(const float *__restrict__ X, int64_t ld, int64_t rows, int K, float *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        const float *x = X + i * ld;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(x[k], x[k], acc);
+        out[i] = acc;
+    }
+}
+__global__ void row_dot_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t ld,
+                               int64_t rows, int K, float scale, float *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        const float *x = X + i * ld, *y = Y + i * ld;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(x[k], y[k], acc);
+        out[i] = scale * acc;
+    }
+}
+
+__global__ void ewise_kernel(int op, const float *__restrict__ a, const float *__restrict__ b,
+                             const float *__restrict__ c, const float *__restrict__ d, int64_t n, float *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        switch (op) {
+        case KGE_EW_ADD: v = a[i] + b[i]; break;
+        case KGE_EW_SUB: v = a[i] - b[i]; break;
+        case KGE_EW_MUL: v = a[i] * b[i]; break;
+        case KGE_EW_MULSUB: v = a[i] * b[i] - c[i] * d[i]; break;
+        default: v = a[i] * b[i] + c[i] * d[i]; break;
+        }
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(WPB * 64) void gather_rows_kernel(const float *__restrict__ X, int64_t ld,
+                                                               const int64_t *__restrict__ idx,
+                                                               int64_t rows, int K, float *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    for (int64_t i = wave; i < rows; i += (int64_t)gridDim.x * WPB) {
+        const float *x = X + idx[i] * ld;
+        float *o = out + i * K;
+        for (int k = lane; k < K; k += 64) o[k] = x[k];
+    }
+}
+
+__global__ __launch_bounds__(WPB * 64) void normalize_rows_kernel(float *X, int64_t ld, int64_t rows, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    for (int64_t i = wave; i < rows; i += (int64_t)gridDim.x * WPB) {
+        float *x = X + i * ld;
+        float ss = 0.f;
+        for (int k = lane; k < K; k += 64) ss = fmaf(x[k], x[k], ss);
+        ss = wave_sum(ss);
+        const float n = fmaxf(sqrtf(ss), 1e-12f);
+        for (int k = lane; k < K; k += 64) x[k] = x[k] / n;
+    }
+}
+
+} // namespace
+
+extern "C" int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!X || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, ld, rows, K, out);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t rows, int K, float scale,
+                           float *out, kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!X || !Y || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(row_dot_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, Y, ld, rows, K, scale, out);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_ewise(int op, const float *a, const float *b, const float *c, const float *d, int64_t n,
+                         float *out, kge_stream_t stream)
+{
+    if (op < KGE_EW_ADD || op > KGE_EW_MULADD || n < 0) return KGE_EINVAL;
+    if (n == 0) return 0;
+    if (!a || !b || !out) return KGE_EINVAL;
+    if (op >= KGE_EW_MULSUB && (!c || !d)) return KGE_EINVAL;
+    hipLaunchKernelGGL(ewise_kernel, dim3(grid_threads(n, 256)), dim3(256), 0, kge_s(stream), op, a, b, c, d, n, out);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_gather_rows(const float *X, int64_t ld, const int64_t *idx, int64_t rows, int K,
+                               float *out, kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!X || !idx || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_rows(rows)), dim3(WPB * 64), 0, kge_s(stream), X, ld, idx, rows, K, out);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_normalize_rows(float *X, int64_t ld, int64_t rows, int K, kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!X) return KGE_EINVAL;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid_rows(rows)), dim3(WPB * 64), 0, kge_s(stream), X, ld, rows, K);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_lp_prep(int kind, int side, const float *t0, const float *t1, const float *t2,
+                           const float *t3, int d_ent, int d_rel, const int64_t *h, const int64_t *t,
+                           const int64_t *r, int64_t B, float *Q0, float *Q1, float *qn, float *Wq,
+                           kge_stream_t stream)
+{
+    if (kind < KGE_TRANSE_L1 || kind > KGE_COMPLEX) return KGE_EINVAL;
+    if (side < KGE_SIDE_TAIL || side > KGE_SIDE_PROJ_T) return KGE_EINVAL;
+    if (!t0 || !t1 || d_ent <= 0 || d_rel <= 0 || B < 0) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!h || !t || !r || !Q0) return KGE_EINVAL;
+    if (kind == KGE_COMPLEX && (!t2 || !t3 || !Q1)) return KGE_EINVAL;
+    if (kind == KGE_TRANSH && (!t2 || !Wq)) return KGE_EINVAL;
+    if (kind == KGE_TRANSD && (!t2 || !t3 || !Wq || d_ent < d_rel)) return KGE_EINVAL;
+    if (kind != KGE_TRANSD && d_ent != d_rel) return KGE_EINVAL;
+    PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq};
+    hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(B)), dim3(WPB * 64), 0, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    if (qn) return kge_row_sqnorm(Q0, d_rel, B, d_rel, qn, stream);
+    return 0;
+}

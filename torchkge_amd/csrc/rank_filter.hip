@@ -1,0 +1,340 @@
+// K4: rank / filter kernels (integer results, bit-exact to the reference) and
+// the entry points that dispatch the all-candidates scorers (gfx950).
+//   get_rank                      utils/operations.py:37-61
+//   get_true_targets/filter_scores utils/modeling.py:53-102
+//   the rank/filter half of LinkPredictionEvaluator.evaluate  evaluation.py:290-300
+// HBM-bound streaming over the (B,N) matrix when it is materialised; the fused
+// path (pair scores + count_ge + filter_sub + finalize) never materialises it.
+#include "kge_common.h"
+
+int kge_lp_gemm_run(const kge_lp_desc *d, float *out, int64_t ldo, const float *s_true,
+                    int32_t *raw_count, hipStream_t s);
+int kge_lp_direct_run(const kge_lp_desc *d, float *out, int64_t ldo, const float *s_true,
+                      int32_t *raw_count, hipStream_t s);
+
+namespace {
+
+constexpr int RB = 256; // threads per row-block
+
+__device__ __forceinline__ int block_sum_i(int v, int *sh)
+{
+    v = wave_sum_i(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    int t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}
+
+__device__ __forceinline__ int count_row(const float *__restrict__ row, int64_t N, float tv, bool low)
+{
+    int c = 0;
+    const int64_t head = ((16 - (reinterpret_cast<uintptr_t>(row) & 15)) & 15) >> 2; // floats to 16B
+    const int64_t nh = head < N ? head : N;
+    for (int64_t j = threadIdx.x; j < nh; j += blockDim.x) c += low ? (row[j] <= tv) : (row[j] >= tv);
+    const int64_t n4 = (N - nh) >> 2;
+    const float4 *r4 = reinterpret_cast<const float4 *>(row + nh);
+    for (int64_t j = threadIdx.x; j < n4; j += blockDim.x) {
+        const float4 v = r4[j];
+        if (low) c += (v.x <= tv) + (v.y <= tv) + (v.z <= tv) + (v.w <= tv);
+        else c += (v.x >= tv) + (v.y >= tv) + (v.z >= tv) + (v.w >= tv);
+    }
+    for (int64_t j = nh + (n4 << 2) + threadIdx.x; j < N; j += blockDim.x)
+        c += low ? (row[j] <= tv) : (row[j] >= tv);
+    return c;
+}
+
+__global__ __launch_bounds__(RB) void get_rank_kernel(const float *__restrict__ scores, int64_t ld,
+                                                      const int64_t *__restrict__ true_idx, int64_t B,
+                                                      int64_t N, int low, int64_t *rank)
+{
+    __shared__ int sh[RB / 64];
+    for (int64_t i = blockIdx.x; i < B; i += gridDim.x) {
+        const float *row = scores + i * ld;
+        const float tv = row[true_idx[i]];
+        const int c = block_sum_i(count_row(row, N, tv, low != 0), sh);
+        if (threadIdx.x == 0) rank[i] = c;
+    }
+}
+
+__global__ __launch_bounds__(RB) void filtered_rank_kernel(const float *__restrict__ scores, int64_t ld,
+                                                           const int64_t *__restrict__ true_idx,
+                                                           const int64_t *__restrict__ seg_lo,
+                                                           const int64_t *__restrict__ seg_hi,
+                                                           const int32_t *__restrict__ targets, int64_t B,
+                                                           int64_t N, int64_t *rank, int64_t *filt)
+{
+    __shared__ int sh[RB / 64];
+    for (int64_t i = blockIdx.x; i < B; i += gridDim.x) {
+        const float *row = scores + i * ld;
+        const int64_t ti = true_idx[i];
+        const float tv = row[ti];
+        const int raw = block_sum_i(count_row(row, N, tv, false), sh);
+        int sub = 0, found = 0;
+        const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+        for (int64_t j = seg_lo[i] + threadIdx.x; j < seg_hi[i]; j += blockDim.x) {
+            const int64_t c = targets[j];
+            if (c == ti) { found = 1; continue; }
+            if (c >= 0 && c < N) sub += ((row[c] >= tv) ? 1 : 0) - neg_inf_counts;
+        }
+        sub = block_sum_i(sub, sh);
+        found = block_sum_i(found, sh);
+        if (threadIdx.x == 0) {
+            rank[i] = raw;
+            filt[i] = found ? raw - sub : raw;
+        }
+    }
+}
+
+__global__ __launch_bounds__(RB) void filter_scores_kernel(float *scores, int64_t ld,
+                                                           const int64_t *__restrict__ true_idx,
+                                                           const int64_t *__restrict__ seg_lo,
+                                                           const int64_t *__restrict__ seg_hi,
+                                                           const int32_t *__restrict__ targets, int64_t B,
+                                                           int64_t N)
+{
+    __shared__ int sh[RB / 64];
+    for (int64_t i = blockIdx.x; i < B; i += gridDim.x) {
+        const int64_t lo = seg_lo[i], hi = seg_hi[i], ti = true_idx[i];
+        int found = 0;
+        for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) found |= (targets[j] == ti);
+        found = block_sum_i(found, sh);
+        if (!found) continue; // KeyError / set.remove KeyError: row untouched (modeling.py:87-88)
+        float *row = scores + i * ld;
+        for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+            const int64_t c = targets[j];
+            if (c != ti && c >= 0 && c < N) row[c] = -INFINITY;
+        }
+    }
+}
+
+__global__ void filter_lookup_kernel(const int64_t *__restrict__ keys, int64_t n_keys,
+                                     const int64_t *__restrict__ offsets, const int64_t *__restrict__ key1,
+                                     const int64_t *__restrict__ key2, int64_t n_key2, int64_t B,
+                                     int64_t *seg_lo, int64_t *seg_hi)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t key = key1[i] * n_key2 + key2[i];
+        int64_t lo = 0, hi = n_keys;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n_keys && keys[lo] == key) { seg_lo[i] = offsets[lo]; seg_hi[i] = offsets[lo + 1]; }
+        else { seg_lo[i] = 0; seg_hi[i] = 0; }
+    }
+}
+
+__global__ void pair_scores_kernel(const kge_lp_desc d, const int64_t *__restrict__ qi,
+                                   const int64_t *__restrict__ ci, int64_t P, float *out)
+{
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = qi ? qi[p] : p;
+        const int64_t c = ci[p] - d.c_base;
+        out[p] = (c >= 0 && c < d.N) ? lp_pair_score(d, i, c) : 0.f;
+    }
+}
+
+// one wavefront per query; lanes stride over the query's filter segment and
+// score each listed candidate with the same arithmetic as the tile kernels.
+__global__ __launch_bounds__(256) void filter_sub_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                         const int64_t *__restrict__ true_idx,
+                                                         const int64_t *__restrict__ seg_lo,
+                                                         const int64_t *__restrict__ seg_hi,
+                                                         const int32_t *__restrict__ targets,
+                                                         int32_t *sub_out, int32_t *found_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t i = wave; i < d.B; i += (int64_t)gridDim.x * 4) {
+        const float tv = s_true[i];
+        const int64_t ti = true_idx[i];
+        const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+        int sub = 0, found = 0;
+        for (int64_t j = seg_lo[i] + lane; j < seg_hi[i]; j += 64) {
+            const int64_t cg = targets[j];
+            const int64_t c = cg - d.c_base;
+            if (c < 0 || c >= d.N) continue;
+            if (cg == ti) { found = 1; continue; }
+            sub += ((lp_pair_score(d, i, c) >= tv) ? 1 : 0) - neg_inf_counts;
+        }
+        sub = wave_sum_i(sub);
+        found = wave_sum_i(found);
+        if (lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
+    }
+}
+
+__global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
+                                     const int32_t *__restrict__ found, int64_t B, int64_t *rank, int64_t *filt)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = raw[i];
+        rank[i] = r;
+        filt[i] = found[i] ? r - sub[i] : r;
+    }
+}
+
+// generic per-query candidate matrices: one wavefront per (query, candidate)
+__global__ __launch_bounds__(256) void lp_batched_kernel(int mode, const float *__restrict__ q, int64_t ldq,
+                                                         const float *__restrict__ cand, int64_t stride_b,
+                                                         int64_t stride_n, int64_t B, int64_t N, int K,
+                                                         float *out, int64_t ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t total = B * N;
+    for (int64_t pidx = wave; pidx < total; pidx += (int64_t)gridDim.x * 4) {
+        const int64_t i = pidx / N, c = pidx - i * N;
+        const float *qq = q + i * ldq;
+        const float *cc = cand + i * stride_b + c * stride_n;
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            if (mode == KGE_LP_DOT) acc = fmaf(qq[k], cc[k], acc);
+            else {
+                const float diff = qq[k] - cc[k];
+                acc = (mode == KGE_LP_L1_DIRECT) ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[i * ldo + c] = (mode == KGE_LP_DOT) ? acc : -acc;
+    }
+}
+
+inline int grid1d(int64_t n, int per_block)
+{
+    int64_t b = (n + per_block - 1) / per_block;
+    const int64_t cap = 256 * 16;
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+} // namespace
+
+extern "C" int kge_get_rank(const float *scores, int64_t ld, const int64_t *true_idx, int64_t B, int64_t N,
+                            int low_values, int64_t *rank, kge_stream_t stream)
+{
+    if (B < 0 || N <= 0 || ld < N) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!scores || !true_idx || !rank) return KGE_EINVAL;
+    hipLaunchKernelGGL(get_rank_kernel, dim3(grid1d(B, 1)), dim3(RB), 0, kge_s(stream), scores, ld, true_idx, B, N,
+                       low_values, rank);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_filter_lookup(const int64_t *keys, int64_t n_keys, const int64_t *offsets,
+                                 const int64_t *key1, const int64_t *key2, int64_t n_key2, int64_t B,
+                                 int64_t *seg_lo, int64_t *seg_hi, kge_stream_t stream)
+{
+    if (B < 0 || n_keys < 0 || n_key2 <= 0) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!key1 || !key2 || !seg_lo || !seg_hi || (n_keys > 0 && (!keys || !offsets))) return KGE_EINVAL;
+    hipLaunchKernelGGL(filter_lookup_kernel, dim3(grid1d(B, 256)), dim3(256), 0, kge_s(stream), keys, n_keys,
+                       offsets, key1, key2, n_key2, B, seg_lo, seg_hi);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_filter_scores(float *scores, int64_t ld, const int64_t *true_idx, const int64_t *seg_lo,
+                                 const int64_t *seg_hi, const int32_t *targets, int64_t B, int64_t N,
+                                 kge_stream_t stream)
+{
+    if (B < 0 || N <= 0 || ld < N) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!scores || !true_idx || !seg_lo || !seg_hi) return KGE_EINVAL;
+    hipLaunchKernelGGL(filter_scores_kernel, dim3(grid1d(B, 1)), dim3(RB), 0, kge_s(stream), scores, ld, true_idx,
+                       seg_lo, seg_hi, targets, B, N);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_filtered_rank_from_scores(const float *scores, int64_t ld, const int64_t *true_idx,
+                                             const int64_t *seg_lo, const int64_t *seg_hi,
+                                             const int32_t *targets, int64_t B, int64_t N, int64_t *rank,
+                                             int64_t *filt_rank, kge_stream_t stream)
+{
+    if (B < 0 || N <= 0 || ld < N) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!scores || !true_idx || !seg_lo || !seg_hi || !rank || !filt_rank) return KGE_EINVAL;
+    hipLaunchKernelGGL(filtered_rank_kernel, dim3(grid1d(B, 1)), dim3(RB), 0, kge_s(stream), scores, ld, true_idx,
+                       seg_lo, seg_hi, targets, B, N, rank, filt_rank);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_lp_scores(const kge_lp_desc *d, float *out, int64_t ldo, kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0 || d->N == 0) return 0;
+    if (!out || ldo < d->N) return KGE_EINVAL;
+    if (d->mode <= KGE_LP_L2_EXPAND) return kge_lp_gemm_run(d, out, ldo, nullptr, nullptr, kge_s(stream));
+    return kge_lp_direct_run(d, out, ldo, nullptr, nullptr, kge_s(stream));
+}
+
+extern "C" int kge_lp_count_ge(const kge_lp_desc *d, const float *s_true, int32_t *raw_count, kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0 || d->N == 0) return 0;
+    if (!s_true || !raw_count) return KGE_EINVAL;
+    if (d->mode <= KGE_LP_L2_EXPAND) return kge_lp_gemm_run(d, nullptr, 0, s_true, raw_count, kge_s(stream));
+    return kge_lp_direct_run(d, nullptr, 0, s_true, raw_count, kge_s(stream));
+}
+
+extern "C" int kge_lp_pair_scores(const kge_lp_desc *d, const int64_t *qi, const int64_t *ci, int64_t P,
+                                  float *out, kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (P < 0) return KGE_EINVAL;
+    if (P == 0) return 0;
+    if (!ci || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(pair_scores_kernel, dim3(grid1d(P, 64)), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
+                                 const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                                 int32_t *sub, int32_t *found, kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0) return 0;
+    if (!s_true || !true_idx || !seg_lo || !seg_hi || !sub || !found) return KGE_EINVAL;
+    hipLaunchKernelGGL(filter_sub_kernel, dim3(grid1d(d->B, 4)), dim3(256), 0, kge_s(stream), *d, s_true, true_idx,
+                       seg_lo, seg_hi, targets, sub, found);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
+                                 int64_t *rank, int64_t *filt_rank, kge_stream_t stream)
+{
+    if (B < 0) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!raw || !sub || !found || !rank || !filt_rank) return KGE_EINVAL;
+    hipLaunchKernelGGL(rank_finalize_kernel, dim3(grid1d(B, 256)), dim3(256), 0, kge_s(stream), raw, sub, found, B,
+                       rank, filt_rank);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_lp_scores_batched(int mode, const float *q, int64_t ldq, const float *cand,
+                                     int64_t stride_b, int64_t stride_n, int64_t B, int64_t N, int K,
+                                     float *out, int64_t ldo, kge_stream_t stream)
+{
+    if (mode != KGE_LP_DOT && mode != KGE_LP_L1_DIRECT && mode != KGE_LP_L2_DIRECT) return KGE_EINVAL;
+    if (B < 0 || N < 0 || K <= 0 || ldo < N) return KGE_EINVAL;
+    if (B == 0 || N == 0) return 0;
+    if (!q || !cand || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(lp_batched_kernel, dim3(grid1d(B * N, 4)), dim3(256), 0, kge_s(stream), mode, q, ldq, cand,
+                       stride_b, stride_n, B, N, K, out, ldo);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_abi_version(void) { return 1; }
+extern "C" const char *kge_build_arch(void) { return "gfx950"; }

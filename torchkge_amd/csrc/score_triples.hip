@@ -1,0 +1,452 @@
+// K1: fused embedding gather + on-the-fly L2 normalisation + score, one
+// wavefront per triple (gfx950).  HBM-bound: every table row is read exactly
+// once (16 B per lane, coalesced within the row), nothing but the fp32 score is
+// written.  Replaces the 6-10 ATen kernels of Model.scoring_function:
+//   TransE   models/translation.py:69-81      -|| h^ + r - t^ ||_p (p=1) or squared L2
+//   TransH   models/translation.py:183-206    -|| p_w(h^) + r - p_w(t^) ||^2
+//   TransD   models/translation.py:538-568    -|| (h^.hp^) rp^ + h^[:dr] + r^ - ... ||^2
+//   DistMult models/bilinear.py:188-199       sum h^ r t^
+//   ComplEx  models/bilinear.py:460-473       Re<h, r, conj t>   (no normalisation)
+// (x^ = x / max(||x||_2, 1e-12), torch.nn.functional.normalize).
+// The backward kernel recomputes the forward intermediates from the same
+// gathered rows and scatters gradients with fp32 atomics.
+#include <type_traits>
+#include "kge_common.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+template <bool VEC4, int NE>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, int d, int lane, float (&x)[NE])
+{
+    if (VEC4) {
+#pragma unroll
+        for (int c = 0; c < NE / 4; ++c) {
+            const int k = (c * 64 + lane) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < d) v = *reinterpret_cast<const float4 *>(p + k);
+            x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int k = e * 64 + lane;
+            x[e] = (k < d) ? p[k] : 0.f;
+        }
+    }
+}
+
+template <bool VEC4, int NE>
+__device__ __forceinline__ int elem_index(int e, int lane)
+{
+    return VEC4 ? ((e >> 2) * 64 + lane) * 4 + (e & 3) : e * 64 + lane;
+}
+
+template <int NE>
+__device__ __forceinline__ float sumsq(const float (&x)[NE])
+{
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s = fmaf(x[e], x[e], s);
+    return wave_sum(s);
+}
+template <int NE>
+__device__ __forceinline__ float dotp(const float (&x)[NE], const float (&y)[NE])
+{
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s = fmaf(x[e], y[e], s);
+    return wave_sum(s);
+}
+// F.normalize: x / max(||x||, eps)
+template <int NE>
+__device__ __forceinline__ float normalize_inplace(float (&x)[NE])
+{
+    const float n = fmaxf(sqrtf(sumsq<NE>(x)), 1e-12f);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) x[e] = x[e] / n;
+    return n;
+}
+
+struct ScoreParams {
+    int kind;
+    const float *t0, *t1, *t2, *t3;
+    int d_ent, d_rel;
+    const int64_t *h, *t, *r;
+    int64_t B;
+    float *out;
+};
+
+template <bool VEC4, int NE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const ScoreParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int de = p.d_ent, dr = p.d_rel;
+
+    for (int64_t i = wave; i < p.B; i += nwaves) {
+        const int64_t hi = p.h[i], ti = p.t[i], ri = p.r[i];
+        float score;
+        if (p.kind == KGE_TRANSE_L1 || p.kind == KGE_TRANSE_L2) {
+            float h[NE], t[NE], r[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            normalize_inplace<NE>(h);
+            normalize_inplace<NE>(t);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float diff = (h[e] + r[e]) - t[e];
+                s = (p.kind == KGE_TRANSE_L1) ? s + fabsf(diff) : fmaf(diff, diff, s);
+            }
+            s = wave_sum(s);
+            if (p.kind == KGE_TRANSE_L2) { const float n = sqrtf(s); s = n * n; } // norm(p=2)**2
+            score = -s;
+        } else if (p.kind == KGE_DISTMULT) {
+            float h[NE], t[NE], r[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            normalize_inplace<NE>(h);
+            normalize_inplace<NE>(t);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) s += (h[e] * r[e]) * t[e];
+            score = wave_sum(s);
+        } else if (p.kind == KGE_COMPLEX) {
+            float reh[NE], imh[NE], ret[NE], imt[NE], rer[NE], imr[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, reh);
+            load_row<VEC4, NE>(p.t1 + hi * de, de, lane, imh);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, ret);
+            load_row<VEC4, NE>(p.t1 + ti * de, de, lane, imt);
+            load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, rer);
+            load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, imr);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                s += reh[e] * (rer[e] * ret[e] + imr[e] * imt[e]) + imh[e] * (rer[e] * imt[e] - imr[e] * ret[e]);
+            score = wave_sum(s);
+        } else if (p.kind == KGE_TRANSH) {
+            float h[NE], t[NE], r[NE], w[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, w);
+            normalize_inplace<NE>(h);
+            normalize_inplace<NE>(t);
+            normalize_inplace<NE>(w);
+            const float hw = dotp<NE>(h, w), tw = dotp<NE>(t, w);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float ph = h[e] - hw * w[e];
+                const float pt = t[e] - tw * w[e];
+                const float diff = (ph + r[e]) - pt;
+                s = fmaf(diff, diff, s);
+            }
+            s = wave_sum(s);
+            const float n = sqrtf(s);
+            score = -(n * n);
+        } else { // KGE_TRANSD
+            float h[NE], t[NE], hp[NE], tp[NE], r[NE], rp[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t2 + hi * de, de, lane, hp);
+            load_row<VEC4, NE>(p.t2 + ti * de, de, lane, tp);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, rp);
+            normalize_inplace<NE>(h);
+            normalize_inplace<NE>(t);
+            normalize_inplace<NE>(hp);
+            normalize_inplace<NE>(tp);
+            normalize_inplace<NE>(r);
+            normalize_inplace<NE>(rp);
+            const float sh = dotp<NE>(h, hp), st = dotp<NE>(t, tp);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const bool in = elem_index<VEC4, NE>(e, lane) < dr; // ent[:, :rel_emb_dim]
+                const float ph = rp[e] * sh + (in ? h[e] : 0.f);
+                const float pt = rp[e] * st + (in ? t[e] : 0.f);
+                const float diff = (ph + r[e]) - pt;
+                s = fmaf(diff, diff, s);
+            }
+            s = wave_sum(s);
+            const float n = sqrtf(s);
+            score = -(n * n);
+        }
+        if (lane == 0) p.out[i] = score;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: d(sum_i go_i * score_i) / d tables, scattered with fp32 atomics.
+// With x^ = x/n, n = max(||x||, eps): d/dx = (g - x^ (x^.g)) / n   (n > eps)
+// ---------------------------------------------------------------------------
+struct BwdParams {
+    ScoreParams f;
+    const float *go;
+    float *g0, *g1, *g2, *g3;
+};
+
+template <bool VEC4, int NE>
+__device__ __forceinline__ void scatter_row(float *__restrict__ g, int d, int lane, const float (&x)[NE])
+{
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int k = elem_index<VEC4, NE>(e, lane);
+        if (k < d && x[e] != 0.f) atomicAdd(g + k, x[e]);
+    }
+}
+
+// gradient wrt the un-normalised row given gradient wrt the normalised row
+template <int NE>
+__device__ __forceinline__ void normalize_bwd(const float (&xn)[NE], float n, float (&g)[NE])
+{
+    const float xg = dotp<NE>(xn, g);
+    const bool clamped = n <= 1e-12f; // x/eps: plain scaling
+#pragma unroll
+    for (int e = 0; e < NE; ++e) g[e] = clamped ? g[e] / n : (g[e] - xn[e] * xg) / n;
+}
+
+template <bool VEC4, int NE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const BwdParams q)
+{
+    const ScoreParams &p = q.f;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int de = p.d_ent, dr = p.d_rel;
+
+    for (int64_t i = wave; i < p.B; i += nwaves) {
+        const int64_t hi = p.h[i], ti = p.t[i], ri = p.r[i];
+        const float go = q.go[i];
+        if (go == 0.f) continue;
+        if (p.kind == KGE_TRANSE_L1 || p.kind == KGE_TRANSE_L2) {
+            float h[NE], t[NE], r[NE], gd[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            const float nh = normalize_inplace<NE>(h), nt = normalize_inplace<NE>(t);
+            // score = -sum f(diff); dscore/ddiff = -sign(diff) (L1) or -2 diff (L2)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float diff = (h[e] + r[e]) - t[e];
+                const float sg = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+                gd[e] = go * ((p.kind == KGE_TRANSE_L1) ? -sg : -2.f * diff);
+            }
+            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gd);       // d/dr = gd
+            float gh[NE], gt[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { gh[e] = gd[e]; gt[e] = -gd[e]; }
+            normalize_bwd<NE>(h, nh, gh);
+            normalize_bwd<NE>(t, nt, gt);
+            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
+            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
+        } else if (p.kind == KGE_DISTMULT) {
+            float h[NE], t[NE], r[NE], gh[NE], gt[NE], gr[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            const float nh = normalize_inplace<NE>(h), nt = normalize_inplace<NE>(t);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                gh[e] = go * r[e] * t[e];
+                gt[e] = go * h[e] * r[e];
+                gr[e] = go * h[e] * t[e];
+            }
+            normalize_bwd<NE>(h, nh, gh);
+            normalize_bwd<NE>(t, nt, gt);
+            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
+            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
+            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gr);
+        } else if (p.kind == KGE_COMPLEX) {
+            float reh[NE], imh[NE], ret[NE], imt[NE], rer[NE], imr[NE], g[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, reh);
+            load_row<VEC4, NE>(p.t1 + hi * de, de, lane, imh);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, ret);
+            load_row<VEC4, NE>(p.t1 + ti * de, de, lane, imt);
+            load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, rer);
+            load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, imr);
+            // s = reh(rer ret + imr imt) + imh(rer imt - imr ret)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] = go * (rer[e] * ret[e] + imr[e] * imt[e]);
+            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, g); // d/d reh
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] = go * (rer[e] * imt[e] - imr[e] * ret[e]);
+            scatter_row<VEC4, NE>(q.g1 + hi * de, de, lane, g); // d/d imh
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * rer[e] - imh[e] * imr[e]);
+            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, g); // d/d ret
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * imr[e] + imh[e] * rer[e]);
+            scatter_row<VEC4, NE>(q.g1 + ti * de, de, lane, g); // d/d imt
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * ret[e] + imh[e] * imt[e]);
+            scatter_row<VEC4, NE>(q.g2 + ri * dr, dr, lane, g); // d/d rer
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * imt[e] - imh[e] * ret[e]);
+            scatter_row<VEC4, NE>(q.g3 + ri * dr, dr, lane, g); // d/d imr
+        } else if (p.kind == KGE_TRANSH) {
+            float h[NE], t[NE], r[NE], w[NE], gd[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, w);
+            const float nh = normalize_inplace<NE>(h), nt = normalize_inplace<NE>(t);
+            const float nw = normalize_inplace<NE>(w);
+            const float hw = dotp<NE>(h, w), tw = dotp<NE>(t, w);
+            // diff = (h - t) - (hw - tw) w + r ; score = -|diff|^2
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float diff = ((h[e] - hw * w[e]) + r[e]) - (t[e] - tw * w[e]);
+                gd[e] = go * (-2.f * diff);
+            }
+            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gd); // d/dr
+            const float gdw = dotp<NE>(gd, w);
+            float gh[NE], gt[NE], gw[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                gh[e] = gd[e] - gdw * w[e];         // d/dh^ = gd - (gd.w) w
+                gt[e] = -gh[e];
+                // d/dw^ = -(hw - tw) gd - (gd.w)(h - t)
+                gw[e] = -(hw - tw) * gd[e] - gdw * (h[e] - t[e]);
+            }
+            normalize_bwd<NE>(h, nh, gh);
+            normalize_bwd<NE>(t, nt, gt);
+            normalize_bwd<NE>(w, nw, gw);
+            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
+            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
+            scatter_row<VEC4, NE>(q.g2 + ri * dr, dr, lane, gw);
+        } else { // KGE_TRANSD
+            float h[NE], t[NE], hp[NE], tp[NE], r[NE], rp[NE], gd[NE];
+            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
+            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
+            load_row<VEC4, NE>(p.t2 + hi * de, de, lane, hp);
+            load_row<VEC4, NE>(p.t2 + ti * de, de, lane, tp);
+            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
+            load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, rp);
+            const float nh = normalize_inplace<NE>(h), nt = normalize_inplace<NE>(t);
+            const float nhp = normalize_inplace<NE>(hp), ntp = normalize_inplace<NE>(tp);
+            const float nr = normalize_inplace<NE>(r), nrp = normalize_inplace<NE>(rp);
+            const float sh = dotp<NE>(h, hp), st = dotp<NE>(t, tp);
+            // diff_k = (sh - st) rp_k + [k<dr](h_k - t_k) + r_k   (k < dr; zero beyond)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const bool in = elem_index<VEC4, NE>(e, lane) < dr;
+                const float diff = ((rp[e] * sh + (in ? h[e] : 0.f)) + r[e]) - (rp[e] * st + (in ? t[e] : 0.f));
+                gd[e] = in ? go * (-2.f * diff) : 0.f;
+            }
+            const float gdrp = dotp<NE>(gd, rp);
+            float gr[NE], grp[NE], gh[NE], gt[NE], ghp[NE], gtp[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                gr[e] = gd[e];
+                grp[e] = (sh - st) * gd[e];
+                gh[e] = gd[e] + gdrp * hp[e];   // via [:dr] slice and via sh = h.hp
+                gt[e] = -gd[e] - gdrp * tp[e];
+                ghp[e] = gdrp * h[e];
+                gtp[e] = -gdrp * t[e];
+            }
+            normalize_bwd<NE>(r, nr, gr);
+            normalize_bwd<NE>(rp, nrp, grp);
+            normalize_bwd<NE>(h, nh, gh);
+            normalize_bwd<NE>(t, nt, gt);
+            normalize_bwd<NE>(hp, nhp, ghp);
+            normalize_bwd<NE>(tp, ntp, gtp);
+            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gr);
+            scatter_row<VEC4, NE>(q.g3 + ri * dr, dr, lane, grp);
+            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
+            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
+            scatter_row<VEC4, NE>(q.g2 + hi * de, de, lane, ghp);
+            scatter_row<VEC4, NE>(q.g2 + ti * de, de, lane, gtp);
+        }
+    }
+}
+
+inline int grid_for(int64_t B)
+{
+    int64_t blocks = (B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const int64_t cap = 256 * 8; // 256 CUs x 8 blocks, grid-stride beyond
+    return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
+}
+
+template <typename P, typename KernelSel>
+int dispatch_ne(const P &p, int dmax, bool vec4, int64_t B, hipStream_t s, KernelSel sel)
+{
+    const int per_lane = vec4 ? ((dmax + 255) / 256) * 4 : (dmax + 63) / 64;
+    if (per_lane <= 4) return sel(p, std::integral_constant<int, 4>{}, vec4, B, s);
+    if (per_lane <= 8) return sel(p, std::integral_constant<int, 8>{}, vec4, B, s);
+    if (per_lane <= 16) return sel(p, std::integral_constant<int, 16>{}, vec4, B, s);
+    return KGE_EINVAL; // d > 1024 (vec4) / 1024 (scalar) not supported by the register-resident kernel
+}
+
+int check_common(int kind, const float *t0, const float *t1, const float *t2, const float *t3,
+                 int d_ent, int d_rel, const int64_t *h, const int64_t *t, const int64_t *r, int64_t B)
+{
+    if (kind < KGE_TRANSE_L1 || kind > KGE_COMPLEX) return KGE_EINVAL;
+    if (!t0 || !t1 || d_ent <= 0 || d_rel <= 0 || B < 0) return KGE_EINVAL;
+    if (B > 0 && (!h || !t || !r)) return KGE_EINVAL;
+    if ((kind == KGE_TRANSH || kind == KGE_TRANSD || kind == KGE_COMPLEX) && !t2) return KGE_EINVAL;
+    if ((kind == KGE_TRANSD || kind == KGE_COMPLEX) && !t3) return KGE_EINVAL;
+    if (kind != KGE_TRANSD && d_ent != d_rel) return KGE_EINVAL;
+    if (kind == KGE_TRANSD && d_ent < d_rel) return KGE_EINVAL;
+    return 0;
+}
+
+bool tables_vec4(const float *t0, const float *t1, const float *t2, const float *t3, int d_ent, int d_rel)
+{
+    bool v = (d_ent % 4 == 0) && (d_rel % 4 == 0) && kge_aligned16(t0) && kge_aligned16(t1);
+    if (t2) v = v && kge_aligned16(t2);
+    if (t3) v = v && kge_aligned16(t3);
+    return v;
+}
+
+} // namespace
+
+extern "C" int kge_score_triples(int kind, const float *t0, const float *t1, const float *t2,
+                                 const float *t3, int d_ent, int d_rel, const int64_t *h,
+                                 const int64_t *t, const int64_t *r, int64_t B, float *out,
+                                 kge_stream_t stream)
+{
+    int rc = check_common(kind, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B);
+    if (rc) return rc;
+    if (B == 0) return 0;
+    if (!out) return KGE_EINVAL;
+    ScoreParams p{kind, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, out};
+    const bool vec4 = tables_vec4(t0, t1, t2, t3, d_ent, d_rel);
+    auto sel = [](const ScoreParams &pp, auto ne, bool v4, int64_t b, hipStream_t s) -> int {
+        constexpr int NE = decltype(ne)::value;
+        if (v4) hipLaunchKernelGGL((score_fwd_kernel<true, NE>), dim3(grid_for(b)), dim3(WAVES_PER_BLOCK * 64), 0, s, pp);
+        else hipLaunchKernelGGL((score_fwd_kernel<false, NE>), dim3(grid_for(b)), dim3(WAVES_PER_BLOCK * 64), 0, s, pp);
+        KGE_CHECK_LAUNCH();
+        return 0;
+    };
+    return dispatch_ne(p, d_ent, vec4, B, kge_s(stream), sel);
+}
+
+extern "C" int kge_score_triples_bwd(int kind, const float *t0, const float *t1, const float *t2,
+                                     const float *t3, int d_ent, int d_rel, const int64_t *h,
+                                     const int64_t *t, const int64_t *r, int64_t B, const float *go,
+                                     float *g0, float *g1, float *g2, float *g3, kge_stream_t stream)
+{
+    int rc = check_common(kind, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B);
+    if (rc) return rc;
+    if (B == 0) return 0;
+    if (!go || !g0 || !g1) return KGE_EINVAL;
+    if ((kind == KGE_TRANSH || kind == KGE_TRANSD || kind == KGE_COMPLEX) && !g2) return KGE_EINVAL;
+    if ((kind == KGE_TRANSD || kind == KGE_COMPLEX) && !g3) return KGE_EINVAL;
+    BwdParams q{{kind, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, nullptr}, go, g0, g1, g2, g3};
+    const bool vec4 = tables_vec4(t0, t1, t2, t3, d_ent, d_rel);
+    auto sel = [](const BwdParams &qq, auto ne, bool v4, int64_t b, hipStream_t s) -> int {
+        constexpr int NE = decltype(ne)::value;
+        if (v4) hipLaunchKernelGGL((score_bwd_kernel<true, NE>), dim3(grid_for(b)), dim3(WAVES_PER_BLOCK * 64), 0, s, qq);
+        else hipLaunchKernelGGL((score_bwd_kernel<false, NE>), dim3(grid_for(b)), dim3(WAVES_PER_BLOCK * 64), 0, s, qq);
+        KGE_CHECK_LAUNCH();
+        return 0;
+    };
+    return dispatch_ne(q, d_ent, vec4, B, kge_s(stream), sel);
+}

@@ -1,0 +1,78 @@
+# -*- coding: utf-8 -*-
+"""Multi-GPU plumbing of the link-prediction path: one process per GPU,
+torch.distributed (backend 'nccl' = RCCL over xGMI on MI355X; 'gloo' in the CPU
+tests).  The reference has no distributed code at all; the
+partitioning below is the one BASELINE.json's north star names:
+
+  * the entity table is row-sharded: rank p scores candidates
+    [p*ceil(N/P), min(N, (p+1)*ceil(N/P)));
+  * exchange='scores': every rank all-gathers the partial score tiles
+    S_p (B, N/P) into S (B, N) and ranks on the full matrix;
+  * exchange='counts': ranks are sums over candidates, so each rank counts
+    `>=` on its shard and ONE all-reduce of 3*B int32 (raw, filter correction,
+    found flag) gives bit-identical ranks -- B*12 bytes instead of B*N*4;
+  * the true-candidate score is computed by the shard that owns the true
+    entity and summed with zeros from the others (x + 0 is exact).
+Pure functions of (N, P, p) so P virtual shards can be checked on one device.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_and_rank(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def shard_size(n, world):
+    return (n + world - 1) // world
+
+
+def shard_range(n, world, rank):
+    """Contiguous block partition: [lo, hi) of `n` items owned by `rank`."""
+    per = shard_size(n, world)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def all_reduce_sum(t, group=None):
+    """In-place SUM all-reduce (no-op when not distributed)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_columns(local, n_total, group=None):
+    """Partial score tiles (B, n_p) of every rank -> (B, n_total): ONE
+    all-gather of equal-size (padded) tiles, then a strided copy."""
+    world, rank = world_and_rank(group)
+    if world == 1:
+        return local
+    B = local.shape[0]
+    per = shard_size(n_total, world)
+    send = local
+    if local.shape[1] != per:                      # last shard may be short: pad
+        send = local.new_zeros(B, per)
+        send[:, :local.shape[1]] = local
+    send = send.contiguous()
+    gathered = local.new_empty(world, B, per)
+    dist.all_gather_into_tensor(gathered.view(world * B, per), send, group=group)
+    full = gathered.permute(1, 0, 2).reshape(B, world * per)
+    return full[:, :n_total].contiguous()
+
+
+def all_gather_facts(local, n_total, group=None):
+    """(4, n_p) rank rows of every query shard -> (4, n_total)."""
+    world, rank = world_and_rank(group)
+    if world == 1:
+        return local
+    per = shard_size(n_total, world)
+    send = local
+    if local.shape[1] != per:
+        send = local.new_zeros(local.shape[0], per)
+        send[:, :local.shape[1]] = local
+    send = send.contiguous()
+    gathered = local.new_empty(world, local.shape[0], per)
+    dist.all_gather_into_tensor(gathered.view(world * local.shape[0], per), send, group=group)
+    return gathered.permute(1, 0, 2).reshape(local.shape[0], world * per)[:, :n_total].contiguous()

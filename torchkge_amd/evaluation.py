@@ -1,0 +1,260 @@
+# -*- coding: utf-8 -*-
+"""LinkPredictionEvaluator with the reference's interface
+(torchkge/evaluation.py:207-425): ``LinkPredictionEvaluator(model, kg)``,
+``.evaluate(b_size, verbose)``, ``.mean_rank() / .hit_at_k(k) / .hit_at_k_heads
+/ .hit_at_k_tails / .mrr() / .print_results()``, the four int64 rank vectors and
+``NotYetEvaluatedError`` before ``evaluate``.
+
+What differs is how a batch is ranked.  The reference materialises
+scores (b, N) [through (b, N, d) temporaries], clones them, filters row by row
+in Python and counts twice (evaluation.py:290-300).  Here, per side:
+
+    problem  = model.lp_problem(h, t, r, side)          # query prep kernel
+    s_true   = problem.pair_scores(true_idx)            # B scores
+    raw      = problem.count_ge(s_true)                 # tiled scorer, counts only
+    sub,fnd  = problem.filter_sub(...)                  # scores only the filter lists
+    rank, filt_rank = rank_finalize(raw, sub, fnd)
+
+so the (B, N) matrix never reaches HBM; every kernel scores a pair with the
+same fp32 arithmetic, so the ranks equal get_rank / filter_scores applied to
+the materialised matrix bit for bit (``fused=False`` runs exactly that).
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL): ``shard='entities'``
+row-shards the candidate range; partial results are exchanged either as the
+score tiles themselves (``exchange='scores'``: all-gather, the collective the
+north star names) or as rank counts (``exchange='counts'``: one int32
+all-reduce of 3*B values, bit-identical ranks).  ``shard='queries'`` splits the
+facts instead (no data-path collective, ranks all-gathered once at the end).
+"""
+import torch
+from tqdm.autonotebook import tqdm
+
+from . import _hip
+from . import distributed as kdist
+from .exceptions import NotYetEvaluatedError
+from .filter_index import filter_index_for
+from .utils.data import get_n_batches
+from .utils.modeling import filter_scores
+from .utils.operations import get_rank
+
+
+class HipRankEngine(object):
+    """Per-batch, per-side ranking on the HIP library (the product path)."""
+
+    name = 'hip'
+
+    @staticmethod
+    def check_device(device):
+        if device.type != 'cuda':
+            raise RuntimeError('torchkge_amd.LinkPredictionEvaluator runs on MI355X (HIP) only: '
+                               'move the model to `cuda` (there is no CPU fallback).')
+
+    @staticmethod
+    def lookup(index, key1, key2):
+        return index.lookup(key1, key2)
+
+    @staticmethod
+    def problem(model, h, t, r, side, lo, hi):
+        return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi)
+
+    @staticmethod
+    def true_scores(prob, true_idx):
+        return prob.pair_scores(true_idx)
+
+    @staticmethod
+    def partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets):
+        """int32 (3, B): raw >= counts, filter correction, found-true flag for this shard."""
+        out = torch.zeros(3, prob.B, dtype=torch.int32, device=s_true.device)
+        prob.count_ge(s_true, out[0])
+        lib = _hip.load_library()
+        import ctypes
+        with torch.cuda.device(s_true.device):
+            _hip._check(lib.kge_lp_filter_sub(ctypes.byref(prob.desc), _hip._p(s_true), _hip._p(true_idx),
+                                              _hip._p(seg_lo), _hip._p(seg_hi), _hip._p(targets),
+                                              _hip._p(out[1]), _hip._p(out[2]), _hip._stream()),
+                        'kge_lp_filter_sub')
+        return out
+
+    @staticmethod
+    def finalize(counts):
+        return _hip.rank_finalize(counts[0], counts[1], counts[2])
+
+    @staticmethod
+    def local_scores(prob):
+        return prob.scores()
+
+    @staticmethod
+    def ranks_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
+        return _hip.filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets)
+
+
+class LinkPredictionEvaluator(object):
+    """Evaluate a model by link prediction (evaluation.py:207-425).
+
+    Parameters (beyond the reference's ``model, knowledge_graph``)
+    ----------
+    fused: bool -- rank without materialising the score matrix (default).
+    shard: None | 'entities' | 'queries' -- multi-GPU partitioning (needs an
+        initialised torch.distributed process group, one rank per GPU).
+    exchange: 'counts' | 'scores' -- what entity shards exchange.
+    group: torch.distributed process group (default: WORLD).
+    """
+
+    def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
+                 group=None, engine=None):
+        self.model = model
+        self.kg = knowledge_graph
+        n = knowledge_graph.n_facts
+        self.rank_true_heads = torch.empty(size=(n,)).long()
+        self.rank_true_tails = torch.empty(size=(n,)).long()
+        self.filt_rank_true_heads = torch.empty(size=(n,)).long()
+        self.filt_rank_true_tails = torch.empty(size=(n,)).long()
+        self.evaluated = False
+        assert shard in (None, 'entities', 'queries')
+        assert exchange in ('counts', 'scores')
+        self.fused, self.shard, self.exchange, self.group = fused, shard, exchange, group
+        self.engine = engine if engine is not None else HipRankEngine()
+
+    # -- filter indices ------------------------------------------------------
+    def _filter_indices(self, device):
+        kg = self.kg
+        if hasattr(kg, 'filter_index'):
+            return kg.filter_index('heads', device), kg.filter_index('tails', device)
+        return (filter_index_for(kg.dict_of_heads, device), filter_index_for(kg.dict_of_tails, device))
+
+    # -- one side of one batch ------------------------------------------------
+    def _rank_side(self, h, t, r, side, index, lo, hi, sharded):
+        eng = self.engine
+        key1, true_idx = (h, t) if side == 'tail' else (t, h)
+        seg_lo, seg_hi = eng.lookup(index, key1, r)
+        if self._generic_model:
+            return self._rank_side_generic(h, t, r, side, index, true_idx, key1)
+        prob = eng.problem(self.model, h, t, r, side, lo, hi)
+        if self.fused and not (sharded and self.exchange == 'scores'):
+            s_true = eng.true_scores(prob, true_idx)
+            if sharded:
+                kdist.all_reduce_sum(s_true, self.group)    # owner shard holds the value, others 0
+            counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, index.targets)
+            if sharded:
+                kdist.all_reduce_sum(counts, self.group)
+            return eng.finalize(counts)
+        scores = eng.local_scores(prob)
+        if sharded:
+            scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
+        return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
+
+    def _rank_side_generic(self, h, t, r, side, index, true_idx, key1):
+        """Reference composition (evaluation.py:290-300) for models that only
+        implement the public inference_* API."""
+        h_emb, t_emb, r_emb, cand = self.model.inference_prepare_candidates(h, t, r, entities=True)
+        if side == 'tail':
+            scores = self.model.inference_scoring_function(h_emb, cand, r_emb)
+        else:
+            scores = self.model.inference_scoring_function(cand, t_emb, r_emb)
+        filt = filter_scores(scores, index, key1, r, true_idx)
+        return get_rank(scores, true_idx).detach(), get_rank(filt, true_idx).detach()
+
+    def evaluate(self, b_size, verbose=True):
+        """Rank the true head and tail of every fact of ``kg`` among all
+        entities, raw and filtered (evaluation.py:263-308)."""
+        device = next(self.model.parameters()).device
+        self.engine.check_device(device)
+        kg = self.kg
+        from .models.interfaces import Model as _BaseModel
+        impl = getattr(type(self.model), 'lp_problem', None)
+        self._generic_model = impl is None or impl is _BaseModel.lp_problem
+
+        world, rank = kdist.world_and_rank(self.group) if self.shard else (1, 0)
+        sharded = self.shard == 'entities' and world > 1
+        lo, hi = kdist.shard_range(self.model.n_ent, world, rank) if sharded else (0, self.model.n_ent)
+        if self.shard == 'queries' and world > 1:
+            f_lo, f_hi = kdist.shard_range(kg.n_facts, world, rank)
+        else:
+            f_lo, f_hi = 0, kg.n_facts
+
+        heads = kg.head_idx[f_lo:f_hi].to(device)
+        tails = kg.tail_idx[f_lo:f_hi].to(device)
+        rels = kg.relations[f_lo:f_hi].to(device)
+        n_local = f_hi - f_lo
+        index_h, index_t = self._filter_indices(device)
+        out = torch.empty(4, n_local, dtype=torch.int64, device=device)
+
+        session = self.model.lp_session() if hasattr(self.model, 'lp_session') else _NullCtx()
+        with session, torch.no_grad():
+            n_batches = get_n_batches(n_local, b_size)
+            for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
+                          desc='Link prediction evaluation'):
+                sl = slice(i * b_size, (i + 1) * b_size)
+                h, t, r = heads[sl], tails[sl], rels[sl]
+                out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
+                out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
+
+        if self.shard == 'queries' and world > 1:
+            out = kdist.all_gather_facts(out, kg.n_facts, self.group)
+        res = out.cpu()
+        self.rank_true_heads, self.rank_true_tails = res[0], res[1]
+        self.filt_rank_true_heads, self.filt_rank_true_tails = res[2], res[3]
+        self.evaluated = True
+
+    # -- metrics (evaluation.py:310-425) --------------------------------------
+    def _check(self):
+        if not self.evaluated:
+            raise NotYetEvaluatedError('Evaluator not evaluated call LinkPredictionEvaluator.evaluate')
+
+    def mean_rank(self):
+        """(mean rank, filtered mean rank), each the mean of the head-side and
+        tail-side means (evaluation.py:310-331)."""
+        self._check()
+        sum_ = (self.rank_true_heads.float().mean() + self.rank_true_tails.float().mean()).item()
+        filt_sum = (self.filt_rank_true_heads.float().mean() +
+                    self.filt_rank_true_tails.float().mean()).item()
+        return sum_ / 2, filt_sum / 2
+
+    def hit_at_k_heads(self, k=10):
+        self._check()
+        return ((self.rank_true_heads <= k).float().mean().item(),
+                (self.filt_rank_true_heads <= k).float().mean().item())
+
+    def hit_at_k_tails(self, k=10):
+        self._check()
+        return ((self.rank_true_tails <= k).float().mean().item(),
+                (self.filt_rank_true_tails <= k).float().mean().item())
+
+    def hit_at_k(self, k=10):
+        """(Hit@k, filtered Hit@k) averaged over head and tail replacement
+        (evaluation.py:352-374)."""
+        self._check()
+        head_hit, filt_head_hit = self.hit_at_k_heads(k=k)
+        tail_hit, filt_tail_hit = self.hit_at_k_tails(k=k)
+        return (head_hit + tail_hit) / 2, (filt_head_hit + filt_tail_hit) / 2
+
+    def mrr(self):
+        """(MRR, filtered MRR) averaged over head and tail replacement
+        (evaluation.py:376-397)."""
+        self._check()
+        head_mrr = (self.rank_true_heads.float() ** (-1)).mean()
+        tail_mrr = (self.rank_true_tails.float() ** (-1)).mean()
+        filt_head_mrr = (self.filt_rank_true_heads.float() ** (-1)).mean()
+        filt_tail_mrr = (self.filt_rank_true_tails.float() ** (-1)).mean()
+        return ((head_mrr + tail_mrr).item() / 2, (filt_head_mrr + filt_tail_mrr).item() / 2)
+
+    def print_results(self, k=None, n_digits=3):
+        """Same report as the reference (evaluation.py:399-425)."""
+        if k is None:
+            k = 10
+        ks = [k] if type(k) == int else list(k)
+        for i in ks:
+            print('Hit@{} : {} \t\t Filt. Hit@{} : {}'.format(
+                i, round(self.hit_at_k(k=i)[0], n_digits), i, round(self.hit_at_k(k=i)[1], n_digits)))
+        print('Mean Rank : {} \t Filt. Mean Rank : {}'.format(
+            int(self.mean_rank()[0]), int(self.mean_rank()[1])))
+        print('MRR : {} \t\t Filt. MRR : {}'.format(
+            round(self.mrr()[0], n_digits), round(self.mrr()[1], n_digits)))
+
+
+class _NullCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

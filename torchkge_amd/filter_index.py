@@ -1,0 +1,94 @@
+# -*- coding: utf-8 -*-
+"""Device-resident index of the link-prediction filter sets.
+
+The reference keeps ``dict_of_heads[(t, r)] -> set(h)`` and
+``dict_of_tails[(h, r)] -> set(t)`` as Python dict-of-sets
+(data_structures.py:386-397) and walks them row by row in ``filter_scores``
+(utils/modeling.py:91-102).  Here the same mapping lives in HBM as a sorted-key
+CSR: ``keys`` (int64, sorted, key = k1 * 2**31 + k2), ``offsets`` (int64) and
+``targets`` (int32); a batch looks its segments up with one kernel
+(kge_filter_lookup).  Built once per (dictionary | knowledge graph, device).
+"""
+import itertools
+
+import numpy as np
+import torch
+
+from . import _hip
+
+KEY2_SPAN = 1 << 31   # k2 (relation id) < 2**31, k1 (entity id) < 2**32
+
+
+class FilterIndex(object):
+    def __init__(self, keys, offsets, targets, device):
+        self.keys = torch.as_tensor(keys, dtype=torch.int64).to(device)
+        self.offsets = torch.as_tensor(offsets, dtype=torch.int64).to(device)
+        self.targets = torch.as_tensor(targets, dtype=torch.int32).to(device)
+        if self.targets.numel() == 0:   # keep a valid pointer for the kernels
+            self.targets = torch.zeros(1, dtype=torch.int32, device=device)
+        self.device = torch.device(device)
+        self.n_keys = int(self.keys.shape[0])
+
+    # -- constructors --------------------------------------------------------
+    @classmethod
+    def from_dict(cls, dictionary, device):
+        """From a torchkge-style ``{(k1, k2): set(int)}`` mapping."""
+        n = len(dictionary)
+        if n == 0:
+            return cls(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int32), device)
+        keys = np.fromiter((k1 * KEY2_SPAN + k2 for (k1, k2) in dictionary.keys()), dtype=np.int64, count=n)
+        counts = np.fromiter((len(v) for v in dictionary.values()), dtype=np.int64, count=n)
+        flat = np.fromiter(itertools.chain.from_iterable(dictionary.values()), dtype=np.int64,
+                           count=int(counts.sum()))
+        order = np.argsort(keys, kind='stable')
+        start = np.concatenate([[0], np.cumsum(counts)])
+        new_counts = counts[order]
+        offsets = np.concatenate([[0], np.cumsum(new_counts)])
+        # permutation that moves each segment to its sorted-key position
+        seg_of = np.repeat(np.arange(n), new_counts)
+        within = np.arange(int(new_counts.sum())) - offsets[seg_of]
+        src = start[order][seg_of] + within
+        return cls(keys[order], offsets, flat[src].astype(np.int32), device)
+
+    @classmethod
+    def from_triples(cls, key1, key2, values, device):
+        """From parallel id arrays: index[(key1_j, key2_j)] ∋ values_j (duplicates
+        collapse, like set.add).  numpy sort/unique -- no Python loop over facts."""
+        key1 = np.asarray(key1, dtype=np.int64)
+        key2 = np.asarray(key2, dtype=np.int64)
+        values = np.asarray(values, dtype=np.int64)
+        if key1.size == 0:
+            return cls(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int32), device)
+        k = key1 * KEY2_SPAN + key2
+        order = np.lexsort((values, k))
+        k, v = k[order], values[order]
+        keep = np.ones(k.shape[0], dtype=bool)
+        keep[1:] = (k[1:] != k[:-1]) | (v[1:] != v[:-1])
+        k, v = k[keep], v[keep]
+        ukeys, first = np.unique(k, return_index=True)
+        offsets = np.concatenate([first, [k.shape[0]]])
+        return cls(ukeys, offsets, v.astype(np.int32), device)
+
+    # -- queries -------------------------------------------------------------
+    def lookup(self, key1, key2):
+        """(seg_lo, seg_hi) int64 device vectors; empty segment = key absent."""
+        _hip.require_cuda(key1, key2)
+        return _hip.filter_lookup(self.keys, self.offsets, key1, key2, KEY2_SPAN)
+
+
+_CACHE = []          # [(dictionary, len, device, FilterIndex)] -- small LRU
+_CACHE_MAX = 8
+
+
+def filter_index_for(dictionary, device):
+    """Cached FilterIndex of a dict-of-sets (identity + size keyed)."""
+    device = torch.device(device)
+    for k, (d, n, dev, idx) in enumerate(_CACHE):
+        if d is dictionary and n == len(dictionary) and dev == device:
+            _CACHE.append(_CACHE.pop(k))
+            return idx
+    idx = FilterIndex.from_dict(dictionary, device)
+    _CACHE.append((dictionary, len(dictionary), device, idx))
+    if len(_CACHE) > _CACHE_MAX:
+        _CACHE.pop(0)
+    return idx

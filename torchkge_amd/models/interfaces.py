@@ -1,0 +1,266 @@
+# -*- coding: utf-8 -*-
+"""Model interfaces with the reference's public surface
+(torchkge/models/interfaces.py:13-330) on top of the HIP engine.
+
+Kept from the reference: ``forward`` (incl. the n_neg tiling),
+``scoring_function``, ``normalize_parameters``, ``get_embeddings``,
+``inference_prepare_candidates`` / ``inference_scoring_function`` with the
+rank-based dispatch (the 3-D argument is the candidate set), and the pre-0.17
+aliases ``lp_prep_cands`` / ``lp_scoring_function`` (docs/history.rst:153-157).
+
+Added for the engine: ``lp_problem`` -- the descriptor of one all-candidates
+scoring problem straight from index vectors, which is what
+LinkPredictionEvaluator uses so that the (B, N) score matrix is never written.
+"""
+import torch
+from torch.nn import Module
+
+from .. import _hip
+from ..exceptions import NotYetImplementedError
+
+
+class _ScoreTriples(torch.autograd.Function):
+    """scoring_function as one fused HIP kernel, differentiable wrt the tables
+    (kge_score_triples / kge_score_triples_bwd)."""
+
+    @staticmethod
+    def forward(ctx, kind, d_ent, d_rel, h, t, r, *tables):
+        tabs = [x.detach() for x in tables]
+        ctx.kind, ctx.d_ent, ctx.d_rel = kind, d_ent, d_rel
+        ctx.save_for_backward(h, t, r, *tabs)
+        return _hip.score_triples(kind, tabs, d_ent, d_rel, h, t, r)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h, t, r = ctx.saved_tensors[:3]
+        tabs = list(ctx.saved_tensors[3:])
+        needs = ctx.needs_input_grad[6:]
+        grads = _hip.score_triples_bwd(ctx.kind, tabs, ctx.d_ent, ctx.d_rel, _hip.i64c(h),
+                                       _hip.i64c(t), _hip.i64c(r), grad_out, needs)
+        return (None,) * 6 + tuple(grads)
+
+
+class _SessionCache(object):
+    """Cache of per-entity precomputes (||E[c]||^2, E.W^T, Ep.E ...).  Only
+    active inside ``with model.lp_session():`` (the evaluator opens one per
+    ``evaluate`` call, during which the tables cannot change); outside a session
+    every lookup rebuilds, so stale values are impossible."""
+
+    def __init__(self):
+        self.store = {}
+        self.depth = 0
+
+    def get(self, name, sources, build):
+        if self.depth == 0:
+            return build()
+        sig = tuple((s.data_ptr(), tuple(s.shape), str(s.device)) for s in sources)
+        hit = self.store.get(name)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        val = build()
+        self.store[name] = (sig, val)
+        return val
+
+    def __enter__(self):
+        self.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        self.depth -= 1
+        if self.depth == 0:
+            self.store.clear()
+        return False
+
+
+class EntityCandidates(object):
+    """Light handle standing for the reference's (b, N, d) ``candidates`` tensor
+    when candidates are *projected* entities (TransH / TransD,
+    translation.py:251, :620): it names the table and the per-query relation
+    instead of materialising 4*b*N*d bytes."""
+
+    def __init__(self, model, r_idx, b_size):
+        self.model = model
+        self.r_idx = r_idx
+        self.shape = (b_size, model.n_ent, model._d_rel)
+
+    def dim(self):
+        return 3
+
+
+def _is_cand(x):
+    if isinstance(x, EntityCandidates):
+        return True
+    if isinstance(x, (tuple, list)):
+        return _is_cand(x[0])
+    return torch.is_tensor(x) and x.dim() == 3
+
+
+def _table_of(cand):
+    """(N, d) table if ``cand`` is a batch-broadcast (stride-0) view of one
+    matrix -- what inference_prepare_candidates returns -- else None."""
+    if torch.is_tensor(cand) and cand.dim() == 3 and cand.stride(2) == 1 and \
+            (cand.stride(0) == 0 or cand.shape[0] == 1):
+        return cand[0]
+    return None
+
+
+class Model(Module):
+    """Base interface (interfaces.py:13-174)."""
+
+    _kind = None          # kge_hip.h model kind
+
+    def __init__(self, n_entities, n_relations):
+        super().__init__()
+        self.n_ent = n_entities
+        self.n_rel = n_relations
+        self._cache = _SessionCache()
+
+    # ---- engine hooks (overridden by concrete models) ---------------------
+    def _tables(self):
+        raise NotImplementedError
+
+    def lp_session(self):
+        """Context inside which per-entity precomputes are cached (tables must
+        not change while it is open)."""
+        return self._cache
+
+    @property
+    def _d_ent(self):
+        return self._tables()[0].shape[1]
+
+    @property
+    def _d_rel(self):
+        return self._tables()[1].shape[1]
+
+    def _hip_kind(self):
+        return self._kind
+
+    # ---- reference API ----------------------------------------------------
+    def forward(self, heads, tails, relations, negative_heads, negative_tails,
+                negative_relations=None):
+        """(pos, neg) scores; several negatives per fact tile the positives
+        (interfaces.py:39-82)."""
+        pos = self.scoring_function(heads, tails, relations)
+        if negative_relations is None:
+            negative_relations = relations
+        if negative_heads.shape[0] > negative_relations.shape[0]:
+            n_neg = int(negative_heads.shape[0] / negative_relations.shape[0])
+            pos = pos.repeat(n_neg)
+            neg = self.scoring_function(negative_heads, negative_tails,
+                                        negative_relations.repeat(n_neg))
+        else:
+            neg = self.scoring_function(negative_heads, negative_tails, negative_relations)
+        return pos, neg
+
+    def scoring_function(self, h_idx, t_idx, r_idx):
+        """Score of each triplet, one fused HIP kernel (K1), differentiable."""
+        tables = self._tables()
+        _hip.require_cuda(h_idx, t_idx, r_idx, *tables)
+        return _ScoreTriples.apply(self._hip_kind(), self._d_ent, self._d_rel, h_idx, t_idx,
+                                   r_idx, *tables)
+
+    def normalize_parameters(self):
+        raise NotImplementedError
+
+    def get_embeddings(self):
+        raise NotImplementedError
+
+    def inference_scoring_function(self, h, t, r):
+        raise NotImplementedError
+
+    def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
+        raise NotImplementedError
+
+    # pre-0.17 names used by BASELINE.json's north_star (docs/history.rst:153-157)
+    def lp_scoring_function(self, h, t, r):
+        return self.inference_scoring_function(h, t, r)
+
+    def lp_prep_cands(self, h_idx, t_idx, r_idx, entities=True):
+        return self.inference_prepare_candidates(h_idx, t_idx, r_idx, entities=entities)
+
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
+        """kge_lp_desc owner for scoring every entity in [ent_lo, ent_hi) as the
+        tail (side='tail') or head (side='head') of each (h, r, t)."""
+        raise NotImplementedError
+
+    @staticmethod
+    def _normalize_weight_(emb):
+        w = emb.weight.data
+        _hip.require_cuda(w)
+        if not w.is_contiguous():
+            w = w.contiguous()
+            emb.weight.data = w
+        _hip.normalize_rows_(w)
+
+
+class TranslationModel(Model):
+    """Translational models: score = -dissimilarity(p(h) + r, p(t))
+    (interfaces.py:177-272)."""
+
+    def __init__(self, n_entities, n_relations, dissimilarity_type):
+        super().__init__(n_entities, n_relations)
+        assert dissimilarity_type in ['L1', 'L2', 'torus_L1', 'torus_L2', 'torus_eL2']
+        if dissimilarity_type not in ('L1', 'L2'):
+            raise NotYetImplementedError('torus dissimilarities (TorusE) are outside the MI355X '
+                                         'hot path (SURVEY.md section 2, row 5).')
+        self.dissimilarity_type = dissimilarity_type
+        from ..utils.dissimilarities import l1_dissimilarity, l2_dissimilarity
+        self.dissimilarity = l1_dissimilarity if dissimilarity_type == 'L1' else l2_dissimilarity
+        # 'expand': ||q-e||^2 as an fp32 MFMA GEMM; 'direct': broadcast-subtract on the VALU
+        self.l2_mode = 'expand'
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # reference TransH/TransD state_dicts carry the (n_rel, n_ent, d)
+        # `projected_entities` cache (translation.py:178-181); the engine has none.
+        state_dict.pop(prefix + 'projected_entities', None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _direct_mode(self):
+        return _hip.LP_L1_DIRECT if self.dissimilarity_type == 'L1' else _hip.LP_L2_DIRECT
+
+    def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
+        """Problem for s[i,c] = -diss(q_i, table[c] (- a w_i))."""
+        if self.dissimilarity_type == 'L2' and self.l2_mode == 'expand' and Wq is None:
+            en = self._cache.get('en_%d_%d' % (c_base, table.shape[0]), [table],
+                                 lambda: _hip.row_sqnorm(table))
+            return _hip.LpProblem(_hip.LP_L2_EXPAND, q, table, qn=_hip.row_sqnorm(q), en=en,
+                                  c_base=c_base, K0=K0)
+        return _hip.LpProblem(self._direct_mode(), q, table, Wq=Wq, scal=scal, r_idx=r_idx,
+                              c_base=c_base, K0=K0)
+
+    def inference_scoring_function(self, proj_h, proj_t, r):
+        """-dissimilarity(proj_h + r, proj_t) against every candidate; the 3-D
+        argument (or EntityCandidates handle) is the candidate set
+        (interfaces.py:240-272)."""
+        if torch.is_tensor(r) and r.dim() == 3:
+            # relation prediction: -diss(h + r_c, t) = -diss(r_c, t - h)
+            if not (torch.is_tensor(proj_h) and proj_h.dim() == 2 and proj_t.dim() == 2):
+                raise NotYetImplementedError('relation candidates with relation-specific '
+                                             'projections (TransH/TransD) are not on the hot path')
+            return self._score_against(_hip.ewise(_hip.EW_SUB, proj_t, proj_h), r)
+        assert r.dim() == 2
+        if _is_cand(proj_t):
+            assert torch.is_tensor(proj_h) and proj_h.dim() == 2   # tail completion
+            return self._score_against(_hip.ewise(_hip.EW_ADD, proj_h, r), proj_t)
+        assert _is_cand(proj_h) and proj_t.dim() == 2              # head completion
+        return self._score_against(_hip.ewise(_hip.EW_SUB, proj_t, r), proj_h)
+
+    def _score_against(self, q, cand):
+        """s[i,c] = -diss(q_i, cand[i,c])."""
+        if isinstance(cand, EntityCandidates):
+            return self._handle_problem(q, cand).scores()
+        table = _table_of(cand)
+        if table is not None:
+            return self._translational_problem(q, _hip.f32c(table)).scores()
+        return _hip.lp_scores_batched(self._direct_mode(), q, cand)
+
+    def _handle_problem(self, q, cand):
+        raise NotImplementedError
+
+
+class BilinearModel(Model):
+    """Bilinear models (interfaces.py:275-330)."""
+
+    def __init__(self, emb_dim, n_entities, n_relations):
+        super().__init__(n_entities, n_relations)
+        self.emb_dim = emb_dim

@@ -1,0 +1,236 @@
+# -*- coding: utf-8 -*-
+"""TransE / TransH / TransD with the reference's constructors, attributes and
+state_dict keys (torchkge/models/translation.py:18-652) on the HIP engine.
+
+TransH / TransD never build the reference's (n_rel, n_ent, d) projection cache
+(`projected_entities`, filled by an n_ent-iteration Python loop,
+translation.py:260-284 / :629-652): one scalar per (entity, relation) [TransH:
+a = E.W^T] or per entity [TransD: s = Ep.E] is enough, and the rank-1
+correction is applied inside the all-candidates kernel.
+"""
+import torch
+
+from .. import _hip
+from ..exceptions import NotYetImplementedError
+from ..utils.modeling import init_embedding
+from .interfaces import TranslationModel, EntityCandidates
+
+
+def _shard(table, lo, hi):
+    return table if (lo == 0 and hi == table.shape[0]) else table[lo:hi]
+
+
+class TransEModel(TranslationModel):
+    """TransE (translation.py:18-125).  ``TransEModel(emb_dim, n_entities,
+    n_relations, dissimilarity_type='L2')``; parameters ``ent_emb``, ``rel_emb``."""
+
+    def __init__(self, emb_dim, n_entities, n_relations, dissimilarity_type='L2'):
+        super().__init__(n_entities, n_relations, dissimilarity_type)
+        self.emb_dim = emb_dim
+        self.ent_emb = init_embedding(self.n_ent, self.emb_dim)
+        self.rel_emb = init_embedding(self.n_rel, self.emb_dim)
+        # translation.py:66-67: entities and (once) relations L2-normalised
+        self.ent_emb.weight.data = torch.nn.functional.normalize(self.ent_emb.weight.data, p=2, dim=1)
+        self.rel_emb.weight.data = torch.nn.functional.normalize(self.rel_emb.weight.data, p=2, dim=1)
+
+    def _tables(self):
+        return [self.ent_emb.weight, self.rel_emb.weight]
+
+    def _hip_kind(self):
+        return _hip.TRANSE_L1 if self.dissimilarity_type == 'L1' else _hip.TRANSE_L2
+
+    def normalize_parameters(self):
+        """L2-normalise entity embeddings (translation.py:83-90)."""
+        self._normalize_weight_(self.ent_emb)
+
+    def get_embeddings(self):
+        self.normalize_parameters()
+        return self.ent_emb.weight.data, self.rel_emb.weight.data
+
+    def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
+        """(h, t, r, candidates); candidates is a stride-0 (b, N, d) view of the
+        table, as in the reference (translation.py:105-125)."""
+        b_size = h_idx.shape[0]
+        E, R = self.ent_emb.weight.data, self.rel_emb.weight.data
+        h, t, r = _hip.gather_rows(E, h_idx), _hip.gather_rows(E, t_idx), _hip.gather_rows(R, r_idx)
+        if entities:
+            candidates = E.view(1, self.n_ent, self.emb_dim).expand(b_size, self.n_ent, self.emb_dim)
+        else:
+            candidates = R.view(1, self.n_rel, self.emb_dim).expand(b_size, self.n_rel, self.emb_dim)
+        return h, t, r, candidates
+
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
+        ent_hi = self.n_ent if ent_hi is None else ent_hi
+        tabs = [x.data for x in self._tables()]
+        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        Q0, _, _, _ = _hip.lp_prep(self._hip_kind(), sd, tabs, self.emb_dim, self.emb_dim,
+                                   h_idx, t_idx, r_idx)
+        return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi),
+                                           c_base=ent_lo)
+
+
+class TransHModel(TranslationModel):
+    """TransH (translation.py:128-284).  ``TransHModel(emb_dim, n_entities,
+    n_relations)``; parameters ``ent_emb``, ``rel_emb``, ``norm_vect``."""
+
+    def __init__(self, emb_dim, n_entities, n_relations):
+        super().__init__(n_entities, n_relations, dissimilarity_type='L2')
+        self.emb_dim = emb_dim
+        self.ent_emb = init_embedding(self.n_ent, self.emb_dim)
+        self.rel_emb = init_embedding(self.n_rel, self.emb_dim)
+        self.norm_vect = init_embedding(self.n_rel, self.emb_dim)
+        self._host_normalize()
+        self.evaluated_projections = False
+
+    _kind = _hip.TRANSH
+
+    def _tables(self):
+        return [self.ent_emb.weight, self.rel_emb.weight, self.norm_vect.weight]
+
+    @staticmethod
+    def project(ent, norm_vect):
+        return ent - (ent * norm_vect).sum(dim=1).view(-1, 1) * norm_vect
+
+    def _host_normalize(self):
+        F = torch.nn.functional
+        self.ent_emb.weight.data = F.normalize(self.ent_emb.weight.data, p=2, dim=1)
+        self.norm_vect.weight.data = F.normalize(self.norm_vect.weight.data, p=2, dim=1)
+        self.rel_emb.weight.data = self.project(self.rel_emb.weight.data, self.norm_vect.weight.data)
+
+    def normalize_parameters(self):
+        """Normalise entities and normal vectors, re-project relations onto
+        their hyperplanes (translation.py:208-219)."""
+        self._normalize_weight_(self.ent_emb)
+        self._normalize_weight_(self.norm_vect)
+        R, W = self.rel_emb.weight.data, self.norm_vect.weight.data
+        a = _hip.row_dot(R, W)                                   # (R.W) per relation
+        # r - (r.w) w   via the ewise kernel: a*w then r - that
+        aw = _hip.ewise(_hip.EW_MUL, a.view(-1, 1).expand_as(W).contiguous(), W)
+        self.rel_emb.weight.data = _hip.ewise(_hip.EW_SUB, R, aw)
+
+    def get_embeddings(self):
+        self.normalize_parameters()
+        return self.ent_emb.weight.data, self.rel_emb.weight.data, self.norm_vect.weight.data
+
+    def _a_matrix(self, lo, hi):
+        """a[c, r] = E[c].W[r] for c in [lo, hi): the only thing the
+        reference's projected_entities cache is needed for (translation.py:272-281)."""
+        E, W = _hip.f32c(self.ent_emb.weight.data), _hip.f32c(self.norm_vect.weight.data)
+        Es = _shard(E, lo, hi)
+        return self._cache.get('transh_a_%d_%d' % (lo, hi), [E, W],
+                               lambda: _hip.LpProblem(_hip.LP_DOT, Es, W).scores())
+
+    def evaluate_projections(self):
+        """Kept for API compatibility (translation.py:260-284); the engine needs
+        no (n_rel, n_ent, d) cache, so this only marks the projections valid."""
+        self.evaluated_projections = True
+
+    def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
+        """(proj_h, proj_t, r, candidates) (translation.py:234-258); candidates
+        is an EntityCandidates handle, not a (b, N, d) copy."""
+        if not entities:
+            raise NotYetImplementedError('TransH relation candidates are not on the hot path')
+        tabs = [x.data for x in self._tables()]
+        d = self.emb_dim
+        proj_h = _hip.lp_prep(_hip.TRANSH, _hip.SIDE_PROJ_H, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)[0]
+        proj_t = _hip.lp_prep(_hip.TRANSH, _hip.SIDE_PROJ_T, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)[0]
+        r = _hip.gather_rows(tabs[1], r_idx)
+        return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), h_idx.shape[0])
+
+    def _handle_problem(self, q, cand, ent_lo=0, ent_hi=None):
+        ent_hi = self.n_ent if ent_hi is None else ent_hi
+        E, W = _hip.f32c(self.ent_emb.weight.data), self.norm_vect.weight.data
+        Wq = _hip.gather_rows(W, cand.r_idx)
+        return self._translational_problem(q, _shard(E, ent_lo, ent_hi), Wq=Wq,
+                                           scal=self._a_matrix(ent_lo, ent_hi), r_idx=cand.r_idx,
+                                           c_base=ent_lo)
+
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
+        ent_hi = self.n_ent if ent_hi is None else ent_hi
+        tabs = [x.data for x in self._tables()]
+        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        d = self.emb_dim
+        Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSH, sd, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)
+        return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
+                                           scal=self._a_matrix(ent_lo, ent_hi),
+                                           r_idx=_hip.i64c(r_idx), c_base=ent_lo)
+
+
+class TransDModel(TranslationModel):
+    """TransD (translation.py:461-652).  ``TransDModel(ent_emb_dim, rel_emb_dim,
+    n_entities, n_relations)``; parameters ``ent_emb``, ``rel_emb``,
+    ``ent_proj_vect``, ``rel_proj_vect``.  Needs ent_emb_dim >= rel_emb_dim
+    (the reference's ``ent[:, :rel_emb_dim]`` slice, :568)."""
+
+    _kind = _hip.TRANSD
+
+    def __init__(self, ent_emb_dim, rel_emb_dim, n_entities, n_relations):
+        super().__init__(n_entities, n_relations, 'L2')
+        self.ent_emb_dim = ent_emb_dim
+        self.rel_emb_dim = rel_emb_dim
+        self.ent_emb = init_embedding(self.n_ent, self.ent_emb_dim)
+        self.rel_emb = init_embedding(self.n_rel, self.rel_emb_dim)
+        self.ent_proj_vect = init_embedding(self.n_ent, self.ent_emb_dim)
+        self.rel_proj_vect = init_embedding(self.n_rel, self.rel_emb_dim)
+        F = torch.nn.functional
+        for emb in (self.ent_emb, self.rel_emb, self.ent_proj_vect, self.rel_proj_vect):
+            emb.weight.data = F.normalize(emb.weight.data, p=2, dim=1)
+        self.evaluated_projections = False
+
+    def _tables(self):
+        return [self.ent_emb.weight, self.rel_emb.weight, self.ent_proj_vect.weight,
+                self.rel_proj_vect.weight]
+
+    def normalize_parameters(self):
+        """L2-normalise all four tables (translation.py:570-579)."""
+        for emb in (self.ent_emb, self.rel_emb, self.ent_proj_vect, self.rel_proj_vect):
+            self._normalize_weight_(emb)
+
+    def get_embeddings(self):
+        self.normalize_parameters()
+        return (self.ent_emb.weight.data, self.rel_emb.weight.data,
+                self.ent_proj_vect.weight.data, self.rel_proj_vect.weight.data)
+
+    def _neg_sigma(self, lo, hi):
+        """-s[c], s[c] = Ep[c].E[c]: all the reference's projected_entities
+        cache depends on per entity (translation.py:641-646)."""
+        E, Ep = _hip.f32c(self.ent_emb.weight.data), _hip.f32c(self.ent_proj_vect.weight.data)
+        return self._cache.get('transd_s_%d_%d' % (lo, hi), [E, Ep],
+                               lambda: _hip.row_dot(_shard(Ep, lo, hi), _shard(E, lo, hi), scale=-1.0))
+
+    def evaluate_projectionss(self):
+        """Kept for API compatibility (translation.py:629-652, reference spelling)."""
+        self.evaluated_projections = True
+
+    evaluate_projections = evaluate_projectionss
+
+    def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
+        """(proj_h, proj_t, r, candidates) (translation.py:603-627)."""
+        if not entities:
+            raise NotYetImplementedError('TransD relation candidates are not on the hot path')
+        tabs = [x.data for x in self._tables()]
+        de, dr = self.ent_emb_dim, self.rel_emb_dim
+        proj_h = _hip.lp_prep(_hip.TRANSD, _hip.SIDE_PROJ_H, tabs, de, dr, h_idx, t_idx, r_idx, want_w=True)[0]
+        proj_t = _hip.lp_prep(_hip.TRANSD, _hip.SIDE_PROJ_T, tabs, de, dr, h_idx, t_idx, r_idx, want_w=True)[0]
+        r = _hip.gather_rows(tabs[1], r_idx)
+        return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), h_idx.shape[0])
+
+    def _problem(self, q, Wq, ent_lo, ent_hi):
+        E = _hip.f32c(self.ent_emb.weight.data)
+        # candidates use E[c, :d_r]: same rows, inner dim K0 = d_r, leading dim d_e
+        return self._translational_problem(q, _shard(E, ent_lo, ent_hi), Wq=Wq,
+                                           scal=self._neg_sigma(ent_lo, ent_hi), c_base=ent_lo,
+                                           K0=self.rel_emb_dim)
+
+    def _handle_problem(self, q, cand, ent_lo=0, ent_hi=None):
+        ent_hi = self.n_ent if ent_hi is None else ent_hi
+        Wq = _hip.gather_rows(self.rel_proj_vect.weight.data, cand.r_idx)
+        return self._problem(q, Wq, ent_lo, ent_hi)
+
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
+        ent_hi = self.n_ent if ent_hi is None else ent_hi
+        tabs = [x.data for x in self._tables()]
+        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSD, sd, tabs, self.ent_emb_dim, self.rel_emb_dim,
+                                    h_idx, t_idx, r_idx, want_w=True)
+        return self._problem(Q0, Wq, ent_lo, ent_hi)
