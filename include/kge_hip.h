@@ -100,10 +100,14 @@ enum {
  *     L1/L2_DIRECT: diff_k = A0[i,k] - T0[c,k]; if Wq: diff_k = fmaf(a, Wq[i,k], diff_k)
  *                   with a = scal[c*scal_ld + (scal_ld > 1 ? r_idx[i] : 0)];
  *                   acc += |diff_k|  or  acc = fmaf(diff_k, diff_k, acc);  s = -acc
- *   chain(x, y, K): acc = fmaf(x[k], y[k], acc) for k = 0..K-1 in order, one
- *   accumulator -- the arithmetic v_mfma_f32_32x32x2_f32 performs -- so every
- *   kernel that scores a pair (tile kernels, pair kernel, filter kernel)
- *   produces bit-identical scores.
+ *   chain(x, y, K): ONE accumulator, acc = fmaf(x[k], y[k], acc), k visiting
+ *   the 8-blocks of [0,K) in ascending order and, inside each 8-block, the
+ *   offsets 0,4,1,5,2,6,3,7 (absent k >= K skipped) -- exactly the sequence in
+ *   which the tile kernel feeds v_mfma_f32_32x32x2_f32 (an fp32 fmaf chain) --
+ *   so every kernel that scores a pair (tile kernels, pair kernel, filter
+ *   kernel) produces bit-identical scores, and oracle/kge_oracle.c reproduces
+ *   them bit for bit on the CPU.  The DIRECT modes accumulate in plain
+ *   ascending k.
  */
 typedef struct kge_lp_desc {
     int32_t mode;

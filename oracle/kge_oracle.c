@@ -99,13 +99,25 @@ void orc_corrupt_scatter(const int64_t *heads, const int64_t *tails, const uint8
 
 /* ---- (2) fp32 arithmetic contract of the HIP all-candidates kernels ------- */
 
-/* dot chain: acc = fmaf(a[k], t[k], acc), k ascending, segment 0 then 1. */
+/* dot chain: one accumulator, acc = fmaf(a[k], t[k], acc), segment 0 then 1;
+ * k runs over 8-blocks in ascending order and, inside an 8-block, in the order
+ * 0,4,1,5,2,6,3,7 -- the order in which the gfx950 kernel feeds
+ * v_mfma_f32_32x32x2_f32 (include/kge_hip.h, kge_lp_desc). */
+static float chain_seg(const float *a, const float *t, int64_t K, float acc)
+{
+    for (int64_t kb = 0; kb < K; kb += 8)
+        for (int j = 0; j < 4; ++j) {
+            const int64_t k0 = kb + j, k1 = kb + 4 + j;
+            if (k0 < K) acc = fmaf(a[k0], t[k0], acc);
+            if (k1 < K) acc = fmaf(a[k1], t[k1], acc);
+        }
+    return acc;
+}
 static float chain_dot(const float *a0, const float *t0, int64_t K0,
                        const float *a1, const float *t1, int64_t K1)
 {
-    float acc = 0.0f;
-    for (int64_t k = 0; k < K0; ++k) acc = fmaf(a0[k], t0[k], acc);
-    for (int64_t k = 0; k < K1; ++k) acc = fmaf(a1[k], t1[k], acc);
+    float acc = chain_seg(a0, t0, K0, 0.0f);
+    if (K1 > 0) acc = chain_seg(a1, t1, K1, acc);
     return acc;
 }
 

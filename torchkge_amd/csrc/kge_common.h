@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/kge_hip.h"
 
 #define KGE_WAVE 64
@@ -36,7 +37,17 @@ __device__ __forceinline__ int wave_sum_i(int v)
 __device__ __forceinline__ float lp_chain_dot(const float *__restrict__ a, const float *__restrict__ t,
                                               int K, float acc)
 {
-    for (int k = 0; k < K; ++k) acc = fmaf(a[k], t[k], acc);
+    // the MFMA kernel's accumulation order: 8-blocks ascending, and inside an
+    // 8-block k = 0,4,1,5,2,6,3,7 (lane-half h of the wave supplies k = 4h + j
+    // to MFMA j, and v_mfma_f32_32x32x2_f32 adds half 0's product first)
+    for (int kb = 0; kb < K; kb += 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k0 = kb + j, k1 = kb + 4 + j;
+            if (k0 < K) acc = fmaf(a[k0], t[k0], acc);
+            if (k1 < K) acc = fmaf(a[k1], t[k1], acc);
+        }
+    }
     return acc;
 }
 
@@ -79,11 +90,19 @@ __device__ __forceinline__ float lp_pair_score(const kge_lp_desc &d, int64_t i, 
     return -acc;
 }
 
+// tuning knob for experiments (env KGE_LP_TARGET_BLOCKS), default `dflt`
+static inline int kge_env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 static inline int kge_lp_desc_check(const kge_lp_desc *d)
 {
     if (!d) return KGE_EINVAL;
     if (d->mode < KGE_LP_DOT || d->mode > KGE_LP_L2_DIRECT) return KGE_EINVAL;
     if (d->B < 0 || d->N < 0 || d->K0 <= 0 || d->K1 < 0) return KGE_EINVAL;
+    if (d->B == 0 || d->N == 0) return 0; // empty problem: nothing is dereferenced
     if (!d->A0 || !d->T0) return KGE_EINVAL;
     if (d->K1 > 0 && (!d->A1 || !d->T1)) return KGE_EINVAL;
     if (d->K1 > 0 && d->mode != KGE_LP_DOT) return KGE_EINVAL;

@@ -89,6 +89,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectPara
     float stQ[QCH][8], stW[AXPY ? QCH : 1][8], stT[2][8];
     const int srow = tid >> 2, skc = tid & 3;
 
+    // unconditional loads from clamped addresses (all in flight together);
+    // out-of-range rows / k are zeroed when staged into LDS (see lp_gemm_mfma.hip)
+    auto ld8 = [&](const float *base, int64_t ld, int64_t r, int64_t rmax, int k, float (&v)[8]) {
+        if (VEC4) {
+            const int k0 = (k < K) ? k : 0, k1 = (k + 4 < K) ? k + 4 : 0;
+            const float *pr = base + min(r, rmax) * ld;
+            const float4 a = *reinterpret_cast<const float4 *>(pr + k0);
+            const float4 b = *reinterpret_cast<const float4 *>(pr + k1);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+            g_load8<false>(base, ld, r, r <= rmax, k, K, v);
+        }
+    };
+    auto zero8 = [&](bool r_ok, int k, float (&v)[8]) {
+        if (VEC4) {
+            const bool k0_ok = k < K, k1_ok = k + 4 < K;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (r_ok && (e < 4 ? k0_ok : k1_ok)) ? v[e] : 0.f;
+        }
+    };
     auto prefetch = [&](int g) {
         const int ti = g / S, s = g - ti * S;
         const int k = s * BK + skc * 8;
@@ -96,19 +117,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectPara
 #pragma unroll
         for (int j = 0; j < QCH; ++j) {
             const int64_t r = row0 + srow + 64 * j;
-            g_load8<VEC4>(d.A0, d.lda0, r, r < d.B, k, K, stQ[j]);
-            if (AXPY) g_load8<VEC4>(d.Wq, d.ldw, r, r < d.B, k, K, stW[j]);
+            ld8(d.A0, d.lda0, r, d.B - 1, k, stQ[j]);
+            if (AXPY) ld8(d.Wq, d.ldw, r, d.B - 1, k, stW[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t r = col0 + srow + 64 * j;
-            g_load8<VEC4>(d.T0, d.ldt0, r, r < d.N, k, K, stT[j]);
-        }
+        for (int j = 0; j < 2; ++j) ld8(d.T0, d.ldt0, col0 + srow + 64 * j, d.N - 1, k, stT[j]);
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, int g) {
         float *Qs = smem + buf * BUF_FLOATS;
         float *Ts = Qs + Q_FLOATS;
         float *Ws = Ts + T_FLOATS;
+        {
+            const int ti = g / S, s = g - ti * S;
+            const int k = s * BK + skc * 8;
+            const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
+#pragma unroll
+            for (int j = 0; j < QCH; ++j) {
+                const bool ok = row0 + srow + 64 * j < d.B;
+                zero8(ok, k, stQ[j]);
+                if (AXPY) zero8(ok, k, stW[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) zero8(col0 + srow + 64 * j < d.N, k, stT[j]);
+        }
 #pragma unroll
         for (int j = 0; j < QCH; ++j) {
             lds_store8(Qs + (srow + 64 * j) * LDS_LD + skc * 8, stQ[j]);
@@ -142,19 +173,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectPara
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int64_t row = row0 + ty + 16 * i;
-                const int64_t rsel = (d.scal_ld > 1 && row < d.B) ? d.r_idx[row] : 0;
+                const int64_t rsel = (d.scal_ld > 1) ? d.r_idx[min(row, d.B - 1)] : 0;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int64_t col = col0 + tx + 16 * j;
-                    av[AXPY ? i : 0][AXPY ? j : 0] =
-                        (col < d.N && row < d.B) ? d.scal[col * d.scal_ld + rsel] : 0.f;
+                for (int j = 0; j < TN; ++j) { // clamped, unconditional (values of padded rows/cols are unused)
+                    const int64_t col = min(col0 + tx + 16 * j, d.N - 1);
+                    av[AXPY ? i : 0][AXPY ? j : 0] = d.scal[col * d.scal_ld + rsel];
                 }
             }
         }
     };
 
     prefetch(0);
-    stage_store(0);
+    stage_store(0, 0);
     load_av(0);
     __syncthreads();
 
@@ -206,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectPara
                 for (int j = 0; j < TN; ++j) {
                     const int64_t col = col0 + tx + 16 * j;
                     const float sc = -acc[i][j];
-                    if (COUNT) cnt[i] += (col < d.N && sc >= stv) ? 1 : 0;
+                    if (COUNT) cnt[i] += (sc >= stv) ? (col < d.N ? 1 : 0) : 0;
                     else if (col < d.N && row < d.B) p.out[row * p.ldo + col] = sc;
                     acc[i][j] = 0.f;
                 }
@@ -214,7 +244,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectPara
             if (ti + 1 < ntiles) load_av(ti + 1);
         }
 
-        if (g + 1 < G) stage_store(buf ^ 1);
+        if (g + 1 < G) stage_store(buf ^ 1, g + 1);
         __syncthreads();
     }
 
@@ -241,7 +271,7 @@ int launch(DirectParams &p, hipStream_t s)
     const kge_lp_desc &d = p.d;
     p.row_panels = (int)((d.B + BM - 1) / BM);
     p.col_tiles = (int)((d.N + BN - 1) / BN);
-    const int target_blocks = 2048;
+    const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 2048);
     int chunks = (target_blocks + p.row_panels - 1) / p.row_panels;
     if (chunks > p.col_tiles) chunks = p.col_tiles;
     if (chunks < 1) chunks = 1;
