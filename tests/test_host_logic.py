@@ -1,0 +1,252 @@
+"""CPU-only tests of the host logic: C-ABI exports, KnowledgeGraph / filter
+index construction, metrics, sampler probabilities, no-CPU-fallback behaviour,
+sharding math, and the multi-process (gloo, world_size 2) exchange paths."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as orc
+from tests.helpers import ROOT, GOLDEN, load_golden, OracleRankEngine
+
+import torchkge_amd as tk
+from torchkge_amd import _hip
+from torchkge_amd import distributed as kd
+from torchkge_amd.exceptions import (NotYetEvaluatedError, WrongArgumentsError, SizeMismatchError,
+                                     SanityError)
+from torchkge_amd.filter_index import FilterIndex, KEY2_SPAN
+
+
+def toy_df():
+    import pandas as pd
+    return pd.DataFrame([[0, 1, 0], [0, 2, 0], [0, 3, 0], [0, 4, 0], [1, 2, 1], [1, 3, 2], [2, 4, 0],
+                         [3, 4, 4], [5, 4, 0]], columns=['from', 'to', 'rel'])
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _hip.load_library()          # no GPU needed to dlopen and resolve symbols
+    hdr = open(os.path.join(ROOT, 'include', 'kge_hip.h')).read()
+    declared = set(re.findall(r'\b(kge_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_hip.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _hip.LIB_PATH], text=True)
+    assert declared <= set(re.findall(r' T (kge_[a-z0-9_]+)', out))
+    assert lib.kge_abi_version() == 1 and lib.kge_build_arch() == b'gfx950'
+    # the descriptor struct mirrors the header field for field
+    fields = re.search(r'typedef struct kge_lp_desc \{(.*?)\} kge_lp_desc;', hdr, re.S).group(1)
+    names = re.findall(r'\b(\w+)\s*(?:;|,)', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
+    assert names == [f[0] for f in _hip.LpDesc._fields_]
+
+
+def test_no_cpu_fallback():
+    m = tk.TransEModel(8, 10, 3)
+    i = torch.tensor([0, 1])
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m.scoring_function(i, i, i)
+    with pytest.raises(RuntimeError):
+        m.inference_prepare_candidates(i, i, i)
+    with pytest.raises(RuntimeError):
+        tk.utils.get_rank(torch.zeros(2, 3), i)
+    kg = tk.KnowledgeGraph(df=toy_df())
+    with pytest.raises(RuntimeError, match='MI355X'):
+        tk.LinkPredictionEvaluator(m, kg).evaluate(4, verbose=False)
+    with pytest.raises(RuntimeError):
+        tk.BernoulliNegativeSampler(kg).corrupt_batch(kg.head_idx, kg.tail_idx, kg.relations)
+    # the oracle is never imported by the product package
+    res = subprocess.run(['grep', '-rlE', r'^\s*(from|import)\s+\.*oracle', os.path.join(ROOT, 'torchkge_amd'),
+                          '--include=*.py'], stdout=subprocess.PIPE, text=True)
+    assert res.stdout.strip() == ''
+
+
+def test_knowledge_graph_constructor_and_split():
+    # reference tests/test_data.py: argument validation
+    df = toy_df()
+    kg = tk.KnowledgeGraph(df=df)
+    assert (kg.n_ent, kg.n_rel, kg.n_facts) == (6, 4, 9)
+    with pytest.raises(WrongArgumentsError):
+        tk.KnowledgeGraph()
+    with pytest.raises(WrongArgumentsError):
+        tk.KnowledgeGraph(df=df, kg={'heads': kg.head_idx, 'tails': kg.tail_idx, 'relations': kg.relations})
+    with pytest.raises(WrongArgumentsError):
+        tk.KnowledgeGraph(kg={'heads': kg.head_idx, 'tails': kg.tail_idx})
+    with pytest.raises(WrongArgumentsError):
+        tk.KnowledgeGraph(kg={'heads': kg.head_idx, 'tails': kg.tail_idx, 'relations': kg.relations})
+    with pytest.raises(SanityError):
+        tk.KnowledgeGraph(kg={'heads': kg.head_idx.int(), 'tails': kg.tail_idx, 'relations': kg.relations},
+                          ent2ix=kg.ent2ix, rel2ix=kg.rel2ix)
+    with pytest.raises(WrongArgumentsError):
+        kg.split_kg(sizes=(3, 3))
+    with pytest.raises(SizeMismatchError):
+        kg.split_kg(sizes=(3, 3, 2, 1))
+    tr, te = kg.split_kg(sizes=(6, 3))
+    assert (tr.n_facts, te.n_facts) == (6, 3)
+    tr, va, te = kg.split_kg(sizes=(5, 2, 2))
+    assert torch.equal(te.head_idx, kg.head_idx[7:])
+    # children share the FULL graph's filter sets (data_structures.py:236-238)
+    dh, dt, dr = orc.build_filter_dicts(kg.head_idx, kg.tail_idx, kg.relations)
+    assert dict(te.dict_of_heads) == dict(dh) and dict(te.dict_of_tails) == dict(dt)
+    assert dict(te.dict_of_rels) == dict(dr)
+    torch.manual_seed(0)
+    tr, te = kg.split_kg(share=0.7)
+    assert tr.n_facts + te.n_facts == 9
+    assert set(torch.cat([tr.head_idx, tr.tail_idx]).tolist()) == set(range(6))   # every entity in train
+    tr, va, te = kg.split_kg(share=0.6, validation=True)
+    assert tr.n_facts + va.n_facts + te.n_facts == 9
+    assert kg[0] == (0, 1, 0) and len(kg) == 9
+    assert list(kg.get_df().columns) == ['from', 'to', 'rel']
+
+
+def test_filter_index_matches_dicts():
+    z = np.load(GOLDEN + '/ref_sampler.npz')
+    heads, tails, rels = z['heads'], z['tails'], z['rels']
+    dh, dt, _ = orc.build_filter_dicts(heads, tails, rels)
+    for d, (k1, k2, v) in ((dh, (tails, rels, heads)), (dt, (heads, rels, tails))):
+        a = FilterIndex.from_dict(d, 'cpu')
+        b = FilterIndex.from_triples(k1, k2, v, 'cpu')
+        assert torch.equal(a.keys, b.keys) and torch.equal(a.offsets, b.offsets)
+        assert (a.keys[1:] > a.keys[:-1]).all()
+        for j in range(0, a.n_keys, 37):
+            key = int(a.keys[j])
+            want = d[(key // KEY2_SPAN, key % KEY2_SPAN)]
+            got_a = set(a.targets[int(a.offsets[j]):int(a.offsets[j + 1])].tolist())
+            got_b = set(b.targets[int(b.offsets[j]):int(b.offsets[j + 1])].tolist())
+            assert got_a == want and got_b == want
+    assert FilterIndex.from_dict({}, 'cpu').n_keys == 0
+
+
+def test_bernoulli_probabilities_known_answers():
+    # reference tests/test_utils.py:77-95
+    kg = tk.KnowledgeGraph(df=toy_df())
+    t = torch.cat((kg.head_idx.view(-1, 1), kg.tail_idx.view(-1, 1), kg.relations.view(-1, 1)), dim=1)
+    assert tk.utils.get_tph(t) == {0: 2., 1: 1., 2: 1., 3: 1.}
+    assert tk.utils.get_hpt(t) == {0: 1.5, 1: 1., 2: 1., 3: 1.}
+    probs = tk.utils.get_bernoulli_probs(kg)
+    for k, v in {0: 0.5714, 1: 0.5, 2: 0.5, 3: 0.5}.items():
+        assert abs(probs[k] - v) < 1e-3
+    z = np.load(GOLDEN + '/ref_sampler.npz')
+    n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
+    kg = tk.KnowledgeGraph(kg={'heads': torch.from_numpy(z['heads']), 'tails': torch.from_numpy(z['tails']),
+                               'relations': torch.from_numpy(z['rels'])},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    samp = tk.BernoulliNegativeSampler(kg)
+    assert np.array_equal(samp.bern_probs.numpy(), z['bern_probs'])
+    assert tk.utils.get_mask(10, 1, 3).tolist() == [False, True, True] + [False] * 7
+
+
+def test_metrics_from_ranks_equal_reference():
+    z, _ = load_golden('transe', 2)
+    m = tk.TransEModel(4, 5, 2)
+    kg = tk.KnowledgeGraph(df=toy_df())
+    ev = tk.LinkPredictionEvaluator(m, kg)
+    for f in (ev.mrr, ev.mean_rank, ev.hit_at_k, ev.hit_at_k_heads, ev.hit_at_k_tails):
+        with pytest.raises(NotYetEvaluatedError):
+            f()
+    ev.rank_true_heads = torch.from_numpy(z['rank_true_heads'])
+    ev.rank_true_tails = torch.from_numpy(z['rank_true_tails'])
+    ev.filt_rank_true_heads = torch.from_numpy(z['filt_rank_true_heads'])
+    ev.filt_rank_true_tails = torch.from_numpy(z['filt_rank_true_tails'])
+    ev.evaluated = True
+    assert np.allclose(ev.hit_at_k(10), z['hit10'], atol=0)
+    assert np.allclose(ev.mrr(), z['mrr'], atol=0)
+    assert np.allclose(ev.mean_rank(), z['mean_rank'], atol=0)
+    ev.print_results(k=[1, 3])
+
+
+def test_model_surface_matches_reference_names():
+    m = tk.TransHModel(8, 10, 3)
+    assert sorted(m.state_dict()) == ['ent_emb.weight', 'norm_vect.weight', 'rel_emb.weight']
+    sd = dict(m.state_dict())
+    sd['projected_entities'] = torch.zeros(3, 10, 8)      # present in reference state_dicts
+    m.load_state_dict(sd)
+    m = tk.TransDModel(8, 6, 10, 3)
+    assert sorted(m.state_dict()) == ['ent_emb.weight', 'ent_proj_vect.weight', 'rel_emb.weight',
+                                      'rel_proj_vect.weight']
+    m = tk.ComplExModel(8, 10, 3)
+    assert sorted(m.state_dict()) == ['im_ent_emb.weight', 'im_rel_emb.weight', 're_ent_emb.weight',
+                                      're_rel_emb.weight']
+    for cls in (tk.TransEModel, tk.DistMultModel):
+        m = cls(8, 10, 3)
+        assert (m.ent_emb.weight.norm(dim=1) - 1).abs().max() < 1e-5
+        assert m.lp_scoring_function.__func__ is not None and m.lp_prep_cands.__func__ is not None
+
+
+def test_shard_ranges_partition():
+    for n, w in [(14541, 8), (10, 3), (7, 8), (4594485, 8), (0, 2)]:
+        parts = [kd.shard_range(n, w, r) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert all(hi - lo <= kd.shard_size(n, w) for lo, hi in parts)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import torchkge_amd as tk
+from oracle import kge_oracle as orc
+from tests.helpers import load_golden, OracleRankEngine
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[3]
+dist.init_process_group('gloo', rank=rank, world_size=world)
+kind = sys.argv[4]
+z, tables = load_golden(kind, 2)
+n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
+heads, tails, rels = (torch.from_numpy(z[k]) for k in ('heads', 'tails', 'rels'))
+kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels},
+                       ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+nt = int(z['n_test'])
+_, kg_test = kg.split_kg(sizes=(len(heads) - nt, nt))
+if kind == 'transe':
+    m = tk.TransEModel(tables[0].shape[1], n_ent, n_rel)
+else:
+    m = tk.ComplExModel(tables[0].shape[1], n_ent, n_rel)
+ok = True
+for shard, exchange, fused in [('entities', 'counts', True), ('entities', 'scores', True),
+                               ('entities', 'scores', False), ('queries', 'counts', True)]:
+    ev = tk.LinkPredictionEvaluator(m, kg_test, fused=fused, shard=shard, exchange=exchange,
+                                    engine=OracleRankEngine(kind, tables))
+    ev.evaluate(b_size=13, verbose=False)
+    for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
+        same = np.array_equal(getattr(ev, nm).numpy(), z[nm])
+        ok = ok and same
+        if not same:
+            print('MISMATCH', rank, shard, exchange, fused, nm, flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+@pytest.mark.parametrize('kind', ['transe', 'complex'])
+def test_multiprocess_sharded_evaluation_gloo(kind, tmp_path):
+    """world_size 2 on CPU/gloo: entity-sharded (count all-reduce and score
+    all-gather) and query-sharded evaluation give the reference's ranks."""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'root': ROOT})
+    port = str(29500 + (os.getpid() % 2000) + (0 if kind == 'transe' else 1))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', port, kind]) for r in range(2)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0, 0]
+
+
+def test_single_process_engine_hook_equals_reference():
+    """world_size 1 through the same evaluator code path (oracle engine)."""
+    z, tables = load_golden('distmult', 2)
+    n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
+    heads, tails, rels = (torch.from_numpy(z[k]) for k in ('heads', 'tails', 'rels'))
+    kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    nt = int(z['n_test'])
+    _, kg_test = kg.split_kg(sizes=(len(heads) - nt, nt))
+    m = tk.DistMultModel(tables[0].shape[1], n_ent, n_rel)
+    for fused in (True, False):
+        ev = tk.LinkPredictionEvaluator(m, kg_test, fused=fused, engine=OracleRankEngine('distmult', tables))
+        ev.evaluate(b_size=16, verbose=False)
+        for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
+            assert np.array_equal(getattr(ev, nm).numpy(), z[nm])
+    assert abs(ev.mrr()[1] - z['mrr'][1]) < 1e-7
