@@ -188,13 +188,43 @@ def main():
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload)
+                # measured off-line with rocprofv3 --pmc (see profiles/), bytes per launch
+                traffic = (json.load(open(tfile)).get(args.workload) or {}).get('bytes_per_launch')
             except Exception:
                 traffic = None
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_TFLOPS, 4), 'traffic': traffic,
                 'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4),
                 'pairs_per_launch': B * n_ent, 'flops_per_pair': flops_per_pair}
+
+    # ---- secondary numbers of the same hot path: scoring_function (K1) and corrupt_batch (K5) ----
+    sec = None
+    if rank == 0:
+        Bt = 32768                                     # training batch of docs/tutorials/transe.rst:25
+        h2, t2, r2 = orc.synthetic_triples(n_ent, n_rel, Bt, seed=3, device=device)
+
+        def ev_time(fn, reps=20):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1) / 1e3 / reps
+        with torch.no_grad():
+            t_sf = ev_time(lambda: model.scoring_function(h2, t2, r2))
+        bytes_per_triple = (24 * d + 28) if kind == 'complex' else (12 * d + 28)
+        samp = tk.BernoulliNegativeSampler(kg)
+        t_cb = ev_time(lambda: samp.corrupt_batch(h2, t2, r2), reps=10)
+        sec = {'scoring_function': {'triples_per_s': round(Bt / t_sf, 1), 'batch': Bt, 'ms': round(t_sf * 1e3, 4),
+                                    'algorithmic_bytes_per_triple': bytes_per_triple,
+                                    'achieved_GBps': round(Bt * bytes_per_triple / t_sf / 1e9, 1),
+                                    'frac_of_8TBps': round(Bt * bytes_per_triple / t_sf / 1e9 / PEAK_HBM_GBS, 4)},
+               'corrupt_batch': {'samples_per_s': round(Bt / t_cb, 1), 'batch': Bt, 'ms': round(t_cb * 1e3, 4),
+                                 'note': 'includes the reference-compatible mask.sum().item() host sync'}}
 
     # ---- reference CPU path (oracle) on a bounded sample, rank 0, N = 1 only ----
     cpu = None
@@ -206,16 +236,19 @@ def main():
 
         def run_cpu(ns):
             c0 = time.perf_counter()
-            out = orc.lp_evaluate(kind, tables, th[:ns], tt_[:ns], tr[:ns], dh, dtl, bs, p)
+            out = orc.lp_evaluate(kind, tables, th[:ns], tt_[:ns], tr[:ns], dh, dtl, bs, p, tie_tol=2e-5)
             return time.perf_counter() - c0, out
         probe_t, _ = run_cpu(bs)                       # also warms the allocator / threads
         probe_t, _ = run_cpu(bs)
         ns = int(max(bs, min(n_test, (args.cpu_seconds / max(probe_t, 1e-6)) * bs)) // bs * bs)
-        cpu_t, (rh, rt, frh, frt) = run_cpu(ns)
-        same = (torch.equal(rh, ev.rank_true_heads[:ns]) and torch.equal(rt, ev.rank_true_tails[:ns]) and
-                torch.equal(frh, ev.filt_rank_true_heads[:ns]) and torch.equal(frt, ev.filt_rank_true_tails[:ns]))
-        n_diff = int((rh != ev.rank_true_heads[:ns]).sum() + (rt != ev.rank_true_tails[:ns]).sum() +
-                     (frh != ev.filt_rank_true_heads[:ns]).sum() + (frt != ev.filt_rank_true_tails[:ns]).sum())
+        cpu_t, (rh, rt, frh, frt, ties) = run_cpu(ns)
+        gpu_r = torch.stack([ev.rank_true_heads[:ns], ev.rank_true_tails[:ns],
+                             ev.filt_rank_true_heads[:ns], ev.filt_rank_true_tails[:ns]])
+        cpu_r = torch.stack([rh, rt, frh, frt])
+        n_diff = int((gpu_r != cpu_r).sum())
+        same = n_diff == 0
+        # every GPU rank must lie in the interval the reference's own scores allow within 2e-5
+        in_tie = bool(((gpu_r >= ties[..., 0]) & (gpu_r <= ties[..., 1])).all())
         mo = orc.lp_metrics(rh, rt, frh, frt, 10)
         mg = orc.lp_metrics(ev.rank_true_heads[:ns], ev.rank_true_tails[:ns], ev.filt_rank_true_heads[:ns],
                             ev.filt_rank_true_tails[:ns], 10)
@@ -224,6 +257,7 @@ def main():
                'sample': '%d of %d test triples, b_size=%d, oracle.lp_evaluate (reference algorithm on '
                          'torch CPU ops), %.1f s' % (ns, n_test, bs, cpu_t),
                'ranks_equal_to_gpu': bool(same), 'ranks_differing': n_diff, 'ranks_compared': 4 * ns,
+               'gpu_ranks_within_reference_tie_interval_2e-5': in_tie,
                'filt_hits10_cpu_gpu': [mo['hit_at_k'][1], mg['hit_at_k'][1]],
                'filt_mrr_cpu_gpu': [mo['mrr'][1], mg['mrr'][1]]}
 
@@ -242,7 +276,7 @@ def main():
                        'parallelism': par, 'fused_rank': not args.materialize,
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'secondary': sec,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Summarise a tools/profile_round.sh output directory into markdown."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    name = name.replace('(anonymous namespace)::', '')
+    return name.split('(')[0][:70]
+
+
+def main(out):
+    print('# rocprofv3 summary (%s)\n' % os.path.basename(out))
+    for f in sorted(glob.glob(os.path.join(out, 'bench_*.json'))):
+        try:
+            j = json.loads(open(f).read().strip().splitlines()[-1])
+        except Exception as e:  # noqa
+            print('* %s: unreadable (%s)' % (os.path.basename(f), e))
+            continue
+        r = j.get('roofline') or {}
+        print('* `%s`: value **%.4g %s**, %.3f ms/step, filt Hits@10 %.5f, filt MRR %.6f; dominant kernel %s: '
+              '%.1f %s = %.1f%% of peak (%.4f ms/launch)' % (
+                  os.path.basename(f), j['value'], j['unit'], j['ms_per_step'], j['filtered_hits_at_10'],
+                  j['filtered_mrr'], r.get('kernel'), r.get('achieved', 0), r.get('unit'), 100 * r.get('frac', 0),
+                  r.get('kernel_ms', 0)))
+        if j.get('cpu_baseline'):
+            print('  * cpu_baseline: %s' % json.dumps(j['cpu_baseline']))
+        if j.get('secondary'):
+            print('  * secondary: %s' % json.dumps(j['secondary']))
+    stats = glob.glob(os.path.join(out, 'trace', '*kernel_stats.csv')) + glob.glob(os.path.join(out, 'trace', '*', '*kernel_stats.csv'))
+    if stats:
+        print('\n## kernel-trace --stats (bench.py --steps 10 --warmup 3)\n')
+        print('| kernel | calls | total ms | avg us | % |')
+        print('|---|---|---|---|---|')
+        for r in csv.DictReader(open(stats[0])):
+            print('| %s | %s | %.3f | %.2f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                                      float(r['AverageNs']) / 1e3, r['Percentage']))
+    print('\n## PMC counters, mean per launch of the dominant kernels\n')
+    print('| counter | kernel | launches | mean per launch |')
+    print('|---|---|---|---|')
+    for d in sorted(glob.glob(os.path.join(out, 'pmc_*'))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, '*counter_collection.csv')) + glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                k = short(r['Kernel_Name'])
+                if 'lp_gemm' in k or 'lp_direct' in k or 'score_fwd' in k:
+                    agg[(r['Counter_Name'], k)].append(float(r['Counter_Value']))
+            for (c, k), v in sorted(agg.items()):
+                print('| %s | %s | %d | %.6g |' % (c, k, len(v), sum(v) / len(v)))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
