@@ -60,6 +60,9 @@ def parse():
     ap.add_argument('--materialize', action='store_true', help='fused=False: write the (B,N) scores')
     ap.add_argument('--l2-mode', default='expand', choices=['expand', 'direct'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend; 'gloo' only to dry-run the N>1 logic on one GPU")
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
     return ap.parse_args()
 
@@ -87,11 +90,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)   # (>1 rank per GPU only in --backend gloo dry runs)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
+        else:
+            dist.init_process_group('gloo')                        # logic dry-run (several ranks on one GPU)
 
     import torchkge_amd as tk
     from torchkge_amd import _hip
@@ -127,7 +134,7 @@ def main():
     if world > 1 and args.scaling == 'strong':
         shard = args.shard
     ev = tk.LinkPredictionEvaluator(model, kg_test, fused=not args.materialize, shard=shard,
-                                    exchange=args.exchange)
+                                    exchange=args.exchange, graph=not args.no_graph)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -144,7 +151,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -273,7 +280,7 @@ def main():
             'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
                                    'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
                                        kind, d, p, shape, n_ent, n_rel, n_test, args.batch),
-                       'parallelism': par, 'fused_rank': not args.materialize,
+                       'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': not args.no_graph,
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
             'roofline': roof, 'cpu_baseline': cpu, 'secondary': sec,

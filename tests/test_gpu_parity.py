@@ -284,6 +284,28 @@ def test_evaluator_vs_reference(hip, kind, p):
     ev3.evaluate(b_size=B, verbose=False)
     for nm in names:
         assert torch.equal(getattr(ev, nm), getattr(ev3, nm))
+    # single-stream (no two-stream overlap of the short kernels) gives the same ranks
+    ev6 = tk.LinkPredictionEvaluator(m, kg_test, overlap=False)
+    ev6.evaluate(b_size=B, verbose=False)
+    for nm in names:
+        assert torch.equal(getattr(ev, nm), getattr(ev6, nm))
+    # hipGraph replay of the whole evaluate(): capture call and two replays, tables changed in between
+    ev4 = tk.LinkPredictionEvaluator(m, kg_test, graph=True)
+    ev4.evaluate(b_size=B, verbose=False)
+    for nm in names:
+        assert torch.equal(getattr(ev, nm), getattr(ev4, nm))
+    prm = next(m.parameters())
+    saved = prm.data.clone()
+    prm.data.mul_(1.37)
+    ev4.evaluate(b_size=B, verbose=False)
+    ev5 = tk.LinkPredictionEvaluator(m, kg_test)
+    ev5.evaluate(b_size=B, verbose=False)
+    for nm in names:
+        assert torch.equal(getattr(ev5, nm), getattr(ev4, nm))     # replay sees the new table values
+    prm.data.copy_(saved)
+    ev4.evaluate(b_size=B, verbose=False)
+    for nm in names:
+        assert torch.equal(getattr(ev, nm), getattr(ev4, nm))
     # vs the reference
     dh, dt, _ = orc.build_filter_dicts(heads, tails, rels)
     th, tt, tr = heads[n - nt:], tails[n - nt:], rels[n - nt:]

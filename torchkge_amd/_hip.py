@@ -304,10 +304,12 @@ class LpProblem(object):
                    'kge_lp_count_ge')
         return raw
 
-    def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets):
+    def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None):
         lib = load_library()
-        sub = torch.empty(self.B, dtype=torch.int32, device=self.device)
-        found = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        if sub is None:
+            sub = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        if found is None:
+            found = torch.empty(self.B, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _check(lib.kge_lp_filter_sub(ctypes.byref(self.desc), _p(s_true), _p(true_idx),
                                          _p(seg_lo), _p(seg_hi), _p(targets), _p(sub), _p(found),

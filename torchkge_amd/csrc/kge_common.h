@@ -40,7 +40,18 @@ __device__ __forceinline__ float lp_chain_dot(const float *__restrict__ a, const
     // the MFMA kernel's accumulation order: 8-blocks ascending, and inside an
     // 8-block k = 0,4,1,5,2,6,3,7 (lane-half h of the wave supplies k = 4h + j
     // to MFMA j, and v_mfma_f32_32x32x2_f32 adds half 0's product first)
-    for (int kb = 0; kb < K; kb += 8) {
+    int kb = 0;
+    for (; kb + 8 <= K; kb += 8) { // full 8-blocks: 16 independent loads, then the dependent chain
+        float av[8], tv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { av[j] = a[kb + j]; tv[j] = t[kb + j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = fmaf(av[j], tv[j], acc);
+            acc = fmaf(av[4 + j], tv[4 + j], acc);
+        }
+    }
+    if (kb < K) { // partial last block
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k0 = kb + j, k1 = kb + 4 + j;

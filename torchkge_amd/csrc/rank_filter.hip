@@ -137,8 +137,9 @@ __global__ void pair_scores_kernel(const kge_lp_desc d, const int64_t *__restric
     }
 }
 
-// one wavefront per query; lanes stride over the query's filter segment and
-// score each listed candidate with the same arithmetic as the tile kernels.
+// 8 lanes per query (8 queries per wavefront); the lanes of a group stride over
+// the query's filter segment and score each listed candidate with the same
+// arithmetic as the tile kernels.  Most segments hold a handful of entities.
 __global__ __launch_bounds__(256) void filter_sub_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
                                                          const int64_t *__restrict__ true_idx,
                                                          const int64_t *__restrict__ seg_lo,
@@ -146,23 +147,32 @@ __global__ __launch_bounds__(256) void filter_sub_kernel(const kge_lp_desc d, co
                                                          const int32_t *__restrict__ targets,
                                                          int32_t *sub_out, int32_t *found_out)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int64_t i = wave; i < d.B; i += (int64_t)gridDim.x * 4) {
-        const float tv = s_true[i];
-        const int64_t ti = true_idx[i];
-        const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+    constexpr int LPQ = 8;
+    const int sub_lane = threadIdx.x & (LPQ - 1);
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPQ;
+    const int64_t ngroups = (int64_t)gridDim.x * 256 / LPQ;
+    const int64_t rounds = (d.B + ngroups - 1) / ngroups;   // uniform trip count: shuffles need all lanes
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t i = group + rd * ngroups;
         int sub = 0, found = 0;
-        for (int64_t j = seg_lo[i] + lane; j < seg_hi[i]; j += 64) {
-            const int64_t cg = targets[j];
-            const int64_t c = cg - d.c_base;
-            if (c < 0 || c >= d.N) continue;
-            if (cg == ti) { found = 1; continue; }
-            sub += ((lp_pair_score(d, i, c) >= tv) ? 1 : 0) - neg_inf_counts;
+        if (i < d.B) {
+            const float tv = s_true[i];
+            const int64_t ti = true_idx[i];
+            const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+            for (int64_t j = seg_lo[i] + sub_lane; j < seg_hi[i]; j += LPQ) {
+                const int64_t cg = targets[j];
+                const int64_t c = cg - d.c_base;
+                if (c < 0 || c >= d.N) continue;
+                if (cg == ti) { found = 1; continue; }
+                sub += ((lp_pair_score(d, i, c) >= tv) ? 1 : 0) - neg_inf_counts;
+            }
         }
-        sub = wave_sum_i(sub);
-        found = wave_sum_i(found);
-        if (lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
+#pragma unroll
+        for (int o = LPQ / 2; o > 0; o >>= 1) {
+            sub += __shfl_xor(sub, o, 64);
+            found += __shfl_xor(found, o, 64);
+        }
+        if (i < d.B && sub_lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
     }
 }
 
@@ -304,7 +314,7 @@ extern "C" int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, cons
     if (rc) return rc;
     if (d->B == 0) return 0;
     if (!s_true || !true_idx || !seg_lo || !seg_hi || !sub || !found) return KGE_EINVAL;
-    hipLaunchKernelGGL(filter_sub_kernel, dim3(grid1d(d->B, 4)), dim3(256), 0, kge_s(stream), *d, s_true, true_idx,
+    hipLaunchKernelGGL(filter_sub_kernel, dim3(grid1d(d->B, 32)), dim3(256), 0, kge_s(stream), *d, s_true, true_idx,
                        seg_lo, seg_hi, targets, sub, found);
     KGE_CHECK_LAUNCH();
     return 0;

@@ -66,13 +66,7 @@ class HipRankEngine(object):
         """int32 (3, B): raw >= counts, filter correction, found-true flag for this shard."""
         out = torch.zeros(3, prob.B, dtype=torch.int32, device=s_true.device)
         prob.count_ge(s_true, out[0])
-        lib = _hip.load_library()
-        import ctypes
-        with torch.cuda.device(s_true.device):
-            _hip._check(lib.kge_lp_filter_sub(ctypes.byref(prob.desc), _hip._p(s_true), _hip._p(true_idx),
-                                              _hip._p(seg_lo), _hip._p(seg_hi), _hip._p(targets),
-                                              _hip._p(out[1]), _hip._p(out[2]), _hip._stream()),
-                        'kge_lp_filter_sub')
+        prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2])
         return out
 
     @staticmethod
@@ -97,11 +91,14 @@ class LinkPredictionEvaluator(object):
     shard: None | 'entities' | 'queries' -- multi-GPU partitioning (needs an
         initialised torch.distributed process group, one rank per GPU).
     exchange: 'counts' | 'scores' -- what entity shards exchange.
+    graph: bool -- capture one evaluate() into a hipGraph and replay it on later
+        calls with the same shapes (removes the host launch gaps between the
+        ~20 short kernels of a batch).
     group: torch.distributed process group (default: WORLD).
     """
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
-                 group=None, engine=None):
+                 group=None, engine=None, graph=False, overlap=True):
         self.model = model
         self.kg = knowledge_graph
         n = knowledge_graph.n_facts
@@ -114,6 +111,10 @@ class LinkPredictionEvaluator(object):
         assert exchange in ('counts', 'scores')
         self.fused, self.shard, self.exchange, self.group = fused, shard, exchange, group
         self.engine = engine if engine is not None else HipRankEngine()
+        self.graph = graph and engine is None       # replay evaluate() as one hipGraph (single GPU)
+        self._graph = self._graph_static = self._graph_key = None
+        self.overlap = overlap                      # two-stream overlap of the short kernels (single GPU, fused)
+        self._aux_stream = None
 
     # -- filter indices ------------------------------------------------------
     def _filter_indices(self, device):
@@ -142,6 +143,50 @@ class LinkPredictionEvaluator(object):
         if sharded:
             scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
         return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
+
+    def _rank_batch_overlapped(self, h, t, r, index_t, index_h):
+        """Both sides of one batch on two HIP streams: the short kernels (filter
+        lookup, query prep, true scores, filter correction) of one side run on an
+        auxiliary stream underneath the other side's long all-candidates count
+        kernel instead of in front of it.  Same kernels, same results."""
+        dev = h.device
+        main = torch.cuda.current_stream(dev)
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(dev)
+        aux = self._aux_stream
+        B = h.shape[0]
+        m = self.model
+        # tail side prepared on the main stream
+        lo_t, hi_t = index_t.lookup(h, r)
+        prob_t = m.lp_problem(h, t, r, 'tail')
+        st_t = prob_t.pair_scores(t)
+        cnt_t = torch.zeros(3, B, dtype=torch.int32, device=dev)
+        cnt_h = torch.zeros(3, B, dtype=torch.int32, device=dev)
+        e_t = torch.cuda.Event()
+        e_t.record(main)
+        aux.wait_event(e_t)
+        with torch.cuda.stream(aux):     # head-side prep + tail filter correction, under the tail GEMM
+            lo_h, hi_h = index_h.lookup(t, r)
+            prob_h = m.lp_problem(h, t, r, 'head')
+            st_h = prob_h.pair_scores(h)
+            e_h = torch.cuda.Event()
+            e_h.record(aux)
+            prob_t.filter_sub(st_t, t, lo_t, hi_t, index_t.targets, cnt_t[1], cnt_t[2])
+        prob_t.count_ge(st_t, cnt_t[0])
+        main.wait_event(e_h)
+        prob_h.count_ge(st_h, cnt_h[0])
+        with torch.cuda.stream(aux):     # head filter correction, under the head GEMM
+            prob_h.filter_sub(st_h, h, lo_h, hi_h, index_h.targets, cnt_h[1], cnt_h[2])
+            e_done = torch.cuda.Event()
+            e_done.record(aux)
+        main.wait_event(e_done)
+        for x in [lo_h, hi_h, st_h] + [k for k in prob_h.keep if k is not None]:
+            x.record_stream(main)        # allocated on aux, consumed on main
+        for x in [lo_t, hi_t, st_t, cnt_t, cnt_h] + [k for k in prob_t.keep if k is not None]:
+            x.record_stream(aux)         # allocated on main, consumed on aux
+        rk_t, frk_t = _hip.rank_finalize(cnt_t[0], cnt_t[1], cnt_t[2])
+        rk_h, frk_h = _hip.rank_finalize(cnt_h[0], cnt_h[1], cnt_h[2])
+        return rk_t, frk_t, rk_h, frk_h
 
     def _rank_side_generic(self, h, t, r, side, index, true_idx, key1):
         """Reference composition (evaluation.py:290-300) for models that only
@@ -172,22 +217,59 @@ class LinkPredictionEvaluator(object):
         else:
             f_lo, f_hi = 0, kg.n_facts
 
-        heads = kg.head_idx[f_lo:f_hi].to(device)
-        tails = kg.tail_idx[f_lo:f_hi].to(device)
-        rels = kg.relations[f_lo:f_hi].to(device)
         n_local = f_hi - f_lo
         index_h, index_t = self._filter_indices(device)
-        out = torch.empty(4, n_local, dtype=torch.int64, device=device)
-
         session = self.model.lp_session() if hasattr(self.model, 'lp_session') else _NullCtx()
-        with session, torch.no_grad():
-            n_batches = get_n_batches(n_local, b_size)
-            for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
-                          desc='Link prediction evaluation'):
-                sl = slice(i * b_size, (i + 1) * b_size)
-                h, t, r = heads[sl], tails[sl], rels[sl]
-                out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
-                out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
+
+        overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
+                   isinstance(self.engine, HipRankEngine) and device.type == 'cuda')
+
+        def run(heads, tails, rels, out):
+            with session, torch.no_grad():
+                n_batches = get_n_batches(n_local, b_size)
+                for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
+                              desc='Link prediction evaluation'):
+                    sl = slice(i * b_size, (i + 1) * b_size)
+                    h, t, r = heads[sl], tails[sl], rels[sl]
+                    if overlap:
+                        out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
+                            self._rank_batch_overlapped(h, t, r, index_t, index_h)
+                        continue
+                    out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
+                    out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
+
+        use_graph = self.graph and world == 1 and device.type == 'cuda' and n_local > 0
+        if not use_graph:
+            heads = kg.head_idx[f_lo:f_hi].to(device)
+            tails = kg.tail_idx[f_lo:f_hi].to(device)
+            rels = kg.relations[f_lo:f_hi].to(device)
+            out = torch.empty(4, n_local, dtype=torch.int64, device=device)
+            run(heads, tails, rels, out)
+        else:
+            # the whole evaluate() as ONE hipGraph: ~20 short launches per batch
+            # replayed without host launch gaps (capture is keyed on everything
+            # that fixes shapes and addresses; table VALUES may change freely)
+            key = (b_size, n_local, str(device), self.fused, overlap,
+                   tuple(p_.data_ptr() for p_ in self.model.parameters()))
+            if self._graph_key != key:
+                st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
+                      'r': kg.relations[f_lo:f_hi].to(device).clone(),
+                      'out': torch.empty(4, n_local, dtype=torch.int64, device=device)}
+                side = torch.cuda.Stream(device)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):            # warm-up outside capture (lazy inits, attribute sets)
+                    run(st['h'], st['t'], st['r'], st['out'])
+                torch.cuda.current_stream(device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run(st['h'], st['t'], st['r'], st['out'])
+                self._graph, self._graph_static, self._graph_key = g, st, key
+            st = self._graph_static
+            st['h'].copy_(kg.head_idx[f_lo:f_hi], non_blocking=True)
+            st['t'].copy_(kg.tail_idx[f_lo:f_hi], non_blocking=True)
+            st['r'].copy_(kg.relations[f_lo:f_hi], non_blocking=True)
+            self._graph.replay()
+            out = st['out']
 
         if self.shard == 'queries' and world > 1:
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
