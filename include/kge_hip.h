@@ -37,6 +37,7 @@
  *   kge_lp_count_ge,               materialises the (B,N) score matrix
  *   kge_lp_filter_sub,
  *   kge_rank_finalize
+ *   kge_topk                     the sort + top_k slice of inference.py:148-150, :243-245
  *   kge_corrupt_scatter          BernoulliNegativeSampler.corrupt_batch / Uniform...
  *                                  sampling.py:313-325 and :206-221 (the integer scatter)
  *   kge_gather_rows              nn.Embedding lookups of the above
@@ -217,7 +218,9 @@ int kge_filter_lookup(const int64_t *keys, int64_t n_keys, const int64_t *offset
                       int64_t *seg_lo, int64_t *seg_hi, kge_stream_t stream);
 
 /* in place: scores[i, c] = -inf for c in segment i, c != true_idx[i]; rows whose
- * segment is empty or does not contain true_idx[i] are left untouched. */
+ * segment is empty or does not contain true_idx[i] are left untouched.
+ * true_idx == NULL: every listed target is masked (get_true_targets with
+ * true_idx=None, utils/modeling.py:83-84, used by inference.py:146, :241). */
 int kge_filter_scores(float *scores, int64_t ld, const int64_t *true_idx, const int64_t *seg_lo,
                       const int64_t *seg_hi, const int32_t *targets, int64_t B, int64_t N,
                       kge_stream_t stream);
@@ -227,6 +230,12 @@ int kge_filtered_rank_from_scores(const float *scores, int64_t ld, const int64_t
                                   const int64_t *seg_lo, const int64_t *seg_hi,
                                   const int32_t *targets, int64_t B, int64_t N, int64_t *rank,
                                   int64_t *filt_rank, kge_stream_t stream);
+
+/* top-k per row in the order (score descending, index ascending); replaces the
+ * full `scores.sort(descending=True)` + slice of EntityInference /
+ * RelationInference (inference.py:148-150, :243-245).  out_idx/out_val: (B,k). */
+int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, int k, int64_t *out_idx,
+             float *out_val, kge_stream_t stream);
 
 /* ---- negative sampling ----------------------------------------------------- */
 /* neg_heads/neg_tails (B*n_neg): position j (batch element j % B): mask[j] != 0

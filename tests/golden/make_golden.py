@@ -20,7 +20,7 @@ sys.path.insert(0, '/root/reference')
 import pandas as pd  # noqa: E402
 import torchkge  # noqa: E402
 from torchkge.data_structures import KnowledgeGraph  # noqa: E402
-from torchkge.evaluation import LinkPredictionEvaluator  # noqa: E402
+from torchkge.evaluation import LinkPredictionEvaluator, RelationPredictionEvaluator  # noqa: E402
 from torchkge.models import (TransEModel, TransHModel, TransDModel,  # noqa: E402
                              DistMultModel, ComplExModel)
 from torchkge.sampling import BernoulliNegativeSampler, UniformNegativeSampler  # noqa: E402
@@ -139,6 +139,27 @@ def main():
         name = 'ref_%s%s.npz' % (kind, '_l1' if (kind == 'transe' and p == 1) else '')
         np.savez_compressed(os.path.join(HERE, name), **out)
         print(name, 'hit10', ev.hit_at_k(10), 'mrr', ev.mrr())
+
+    # ---- relation prediction (evaluation.py:16-204) + relation-candidate scores ----
+    rp = dict(common)
+    for kind in ('transe', 'distmult', 'complex'):
+        m = build_model(kind, 2)
+        tabs = tables_of(kind, m)
+        for i, tb in enumerate(tabs):
+            rp['%s_table%d' % (kind, i)] = tb
+        h, t, r = kg_test.head_idx[:B], kg_test.tail_idx[:B], kg_test.relations[:B]
+        with torch.no_grad():
+            h_e, t_e, r_e, cand = m.inference_prepare_candidates(h, t, r, entities=False)
+            rp['%s_s_rel' % kind] = m.inference_scoring_function(h_e, t_e, cand).numpy()
+            for directed in (True, False):
+                ev = RelationPredictionEvaluator(m, kg_test, directed=directed)
+                ev.evaluate(b_size=B, verbose=False)
+                tag = '%s_%s' % (kind, 'dir' if directed else 'undir')
+                rp[tag + '_rank'] = ev.rank_true_rels.numpy()
+                rp[tag + '_frank'] = ev.filt_rank_true_rels.numpy()
+                rp[tag + '_mrr'] = np.array(ev.mrr())
+                rp[tag + '_hit3'] = np.array(ev.hit_at_k(3))
+    np.savez_compressed(os.path.join(HERE, 'ref_relpred.npz'), **rp)
 
     # ---- sampler ---------------------------------------------------------
     samp = BernoulliNegativeSampler(kg, n_neg=3)

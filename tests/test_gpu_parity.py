@@ -512,3 +512,117 @@ def test_dissimilarities_known_answers(hip):
     b = dev(np.array([[1.3, 4, 2, 10], [5.9, 8, 6, 7]], dtype=np.float32))
     assert (l1_dissimilarity(a, b).cpu() - torch.tensor([9.1, 4.5])).abs().max() < 1e-5
     assert (l2_dissimilarity(a, b).cpu() - torch.tensor([41.01, 6.25])).abs().max() < 1e-4
+
+
+# ---------------------------------------------------------------------------
+# "next" rows of SURVEY section 8f: relation prediction, top-k inference
+# ---------------------------------------------------------------------------
+def _relpred_setup(kind):
+    import torchkge_amd as tk
+    z = np.load(GOLDEN + '/ref_relpred.npz')
+    ntab = 4 if kind == 'complex' else 2
+    tables = [torch.from_numpy(z['%s_table%d' % (kind, i)]) for i in range(ntab)]
+    n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    heads, tails, rels = (torch.from_numpy(z[k]) for k in ('heads', 'tails', 'rels'))
+    kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    nt = int(z['n_test'])
+    _, kg_test = kg.split_kg(sizes=(len(heads) - nt, nt))
+    return z, tables, m, kg, kg_test
+
+
+@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex'])
+def test_relation_prediction_vs_reference(hip, kind):
+    import torchkge_amd as tk
+    z, tables, m, kg, kg_test = _relpred_setup(kind)
+    B = int(z['b_size'])
+    h, t, r = kg_test.head_idx[:B].cuda(), kg_test.tail_idx[:B].cuda(), kg_test.relations[:B].cuda()
+    h_e, t_e, r_e, cand = m.inference_prepare_candidates(h, t, r, entities=False)
+    s = m.inference_scoring_function(h_e, t_e, cand)
+    assert np.abs(s.cpu().numpy() - z['%s_s_rel' % kind]).max() < TOL
+    for directed, tag in ((True, 'dir'), (False, 'undir')):
+        ev = tk.RelationPredictionEvaluator(m, kg_test, directed=directed)
+        with pytest.raises(tk.NotYetEvaluatedError):
+            ev.mrr()
+        ev.evaluate(b_size=B, verbose=False)
+        if directed:
+            assert np.array_equal(ev.rank_true_rels.numpy(), z['%s_%s_rank' % (kind, tag)])
+            assert np.array_equal(ev.filt_rank_true_rels.numpy(), z['%s_%s_frank' % (kind, tag)])
+            assert abs(ev.mrr()[1] - z['%s_%s_mrr' % (kind, tag)][1]) < TOL
+            assert abs(ev.hit_at_k(3)[1] - z['%s_%s_hit3' % (kind, tag)][1]) < TOL
+        else:
+            # (h,?,t) and (t,?,h) scores tie up to rounding (exactly for DistMult, whose
+            # score is symmetric): ranks must lie in the reference's own tie interval
+            heads, tails, rels = kg_test.head_idx, kg_test.tail_idx, kg_test.relations
+            so = torch.cat((orc.rp_scores(kind, tables, heads, tails), orc.rp_scores(kind, tables, heads, tails, swap=True)), 1)
+            lo, hi = _rank_bounds(so, rels, 2 * TOL)
+            assert ((ev.rank_true_rels >= lo) & (ev.rank_true_rels <= hi)).all()
+            fo = torch.cat((orc.filter_scores(so[:, :so.shape[1] // 2], kg.dict_of_rels, heads, tails, rels),
+                            orc.filter_scores(so[:, so.shape[1] // 2:], kg.dict_of_rels, heads, tails, rels)), 1)
+            lo, hi = _rank_bounds(fo, rels, 2 * TOL)
+            assert ((ev.filt_rank_true_rels >= lo) & (ev.filt_rank_true_rels <= hi)).all()
+    ev.print_results(k=3)
+
+
+@pytest.mark.parametrize('B,N,k', [(7, 300, 5), (3, 14541, 10), (2, 5, 5), (4, 1000, 1)])
+def test_topk_kernel_exact(hip, B, N, k):
+    g = torch.Generator().manual_seed(B * N + k)
+    s = torch.randn(B, N, generator=g)
+    s[0, min(3, N - 1)] = s[0, 0]                       # a tie: lower index first
+    if k < N:
+        s[B - 1, N - 1] = float('nan')                  # NaN is never selected
+    v, ix = hip.topk(s.cuda(), k)
+    sn = torch.where(torch.isnan(s), torch.full_like(s, -float('inf')), s)
+    order = np.lexsort((np.arange(N)[None, :].repeat(B, 0), -sn.numpy()), axis=1)[:, :k]
+    assert np.array_equal(ix.cpu().numpy(), order)
+    assert np.array_equal(v.cpu().numpy(), np.take_along_axis(sn.numpy(), order, 1))
+    # exhausted rows (fewer selectable entries than k) yield (-inf, -1)
+    s2 = torch.tensor([[1.0, float('nan'), 3.0]])
+    v2, i2 = hip.topk(s2.cuda(), 3)
+    assert i2.cpu().tolist() == [[2, 0, -1]] and v2.cpu()[0, 2].item() == -float('inf')
+
+
+@pytest.mark.parametrize('kind,p', [('transe', 2), ('transh', 2), ('complex', 2)])
+def test_entity_and_relation_inference(hip, kind, p):
+    import torchkge_amd as tk
+    z, tables = load_golden(kind, p)
+    n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
+    m = build_model(kind, p, tables, n_ent, n_rel)
+    h, t, r = golden_batch(z)
+    heads, tails, rels = (torch.from_numpy(z[k]) for k in ('heads', 'tails', 'rels'))
+    dh, dt, dr = orc.build_filter_dicts(heads, tails, rels)
+    K = 5
+
+    def expect(scores, dictionary, k1, k2):
+        s = scores.clone()
+        if dictionary is not None:
+            s = orc.filter_scores(s, dictionary, k1, k2, None)
+        v, ix = s.sort(descending=True)
+        return v[:, :K], ix[:, :K]
+
+    for missing, dic, side in (('tails', dt, 'tail'), ('heads', dh, 'head'), ('tails', None, 'tail')):
+        known = h if missing == 'tails' else t
+        inf = tk.EntityInference(m, known, r, top_k=K, missing=missing, dictionary=dic)
+        inf.evaluate(b_size=7, verbose=False)
+        so = orc.lp_scores(kind, tables, h, t, r, side, p)
+        ev, eix = expect(so, dic, known, r)
+        assert inf.predictions.shape == (len(known), K) and inf.predictions.dtype == torch.int64
+        assert (inf.scores - ev).abs().max().item() < TOL
+        gap_ok = (ev[:, :-1] - ev[:, 1:]).min(dim=1).values > 4 * TOL     # unambiguous order only
+        assert torch.equal(inf.predictions[gap_ok], eix[gap_ok])
+    with pytest.raises(tk.exceptions.WrongArgumentsError):
+        tk.EntityInference(m, h, r, missing='both')
+    if kind != 'transh':
+        rinf = tk.RelationInference(m, h, t, top_k=3, dictionary=dr)
+        rinf.evaluate(b_size=16, verbose=False)
+        so = orc.filter_scores(orc.rp_scores(kind, tables, h, t, p), dr, h, t, None)
+        v, ix = so.sort(descending=True)
+        assert (rinf.scores - v[:, :3]).abs().max().item() < TOL or torch.isinf(v[:, :3]).any()
+        fin = torch.isfinite(v[:, :3]).all(dim=1) & ((v[:, :2] - v[:, 1:3]).min(dim=1).values > 4 * TOL)
+        assert torch.equal(rinf.predictions[fin], ix[:, :3][fin])
+    # filter_scores with true_idx=None masks every known target
+    from torchkge_amd.utils import filter_scores
+    s_ref = torch.from_numpy(z['s_tail'])
+    f = filter_scores(s_ref.cuda(), dt, h.cuda(), r.cuda(), None)
+    assert np.array_equal(f.cpu().numpy(), orc.filter_scores(s_ref, dt, h, r, None).numpy())

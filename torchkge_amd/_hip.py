@@ -61,6 +61,7 @@ _SIGNATURES = {
     'kge_filter_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
     'kge_filtered_rank_from_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     'kge_corrupt_scatter': [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    'kge_topk': [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp],
 }
 # every symbol include/kge_hip.h declares
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version',
@@ -392,6 +393,19 @@ def filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
                                                  _p(rank), _p(filt), _stream()),
                'kge_filtered_rank_from_scores')
     return rank, filt
+
+
+def topk(scores, k):
+    """(values (B,k), indices (B,k)) in the order (score desc, index asc)."""
+    lib = load_library()
+    require_cuda(scores)
+    scores = f32c(scores)
+    B, N = scores.shape
+    idx = torch.empty(B, k, dtype=torch.int64, device=scores.device)
+    val = torch.empty(B, k, dtype=torch.float32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _check(lib.kge_topk(_p(scores), scores.stride(0), B, N, k, _p(idx), _p(val), _stream()), 'kge_topk')
+    return val, idx
 
 
 def corrupt_scatter(heads, tails, mask_u8, draws_h, draws_t, n_neg):

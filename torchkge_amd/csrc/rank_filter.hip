@@ -97,11 +97,15 @@ __global__ __launch_bounds__(RB) void filter_scores_kernel(float *scores, int64_
 {
     __shared__ int sh[RB / 64];
     for (int64_t i = blockIdx.x; i < B; i += gridDim.x) {
-        const int64_t lo = seg_lo[i], hi = seg_hi[i], ti = true_idx[i];
-        int found = 0;
-        for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) found |= (targets[j] == ti);
-        found = block_sum_i(found, sh);
-        if (!found) continue; // KeyError / set.remove KeyError: row untouched (modeling.py:87-88)
+        const int64_t lo = seg_lo[i], hi = seg_hi[i];
+        // true_idx == NULL (get_true_targets(..., true_idx=None), modeling.py:83-84): mask every known target
+        const int64_t ti = true_idx ? true_idx[i] : -1;
+        if (true_idx) {
+            int found = 0;
+            for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) found |= (targets[j] == ti);
+            found = block_sum_i(found, sh);
+            if (!found) continue; // KeyError / set.remove KeyError: row untouched (modeling.py:87-88)
+        }
         float *row = scores + i * ld;
         for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
             const int64_t c = targets[j];
@@ -212,6 +216,46 @@ __global__ __launch_bounds__(256) void lp_batched_kernel(int mode, const float *
     }
 }
 
+// top-k of each row in the strict order (score descending, index ascending):
+// pass j finds the largest element that is strictly after the (j-1)-th pick, so
+// nothing is marked or copied; k passes over a row that stays in L2.  NaNs are
+// never selected (as with `>`-based comparison); exhausted rows yield (-inf, -1).
+__global__ __launch_bounds__(RB) void topk_kernel(const float *__restrict__ scores, int64_t ld, int64_t B,
+                                                  int64_t N, int k, int64_t *out_idx, float *out_val)
+{
+    __shared__ float sv[RB / 64];
+    __shared__ int64_t si[RB / 64];
+    for (int64_t i = blockIdx.x; i < B; i += gridDim.x) {
+        const float *row = scores + i * ld;
+        float last_v = INFINITY;
+        int64_t last_i = -1;
+        for (int j = 0; j < k; ++j) {
+            float bv = -INFINITY;
+            int64_t bi = -1;
+            for (int64_t c = threadIdx.x; c < N; c += blockDim.x) {
+                const float v = row[c];
+                const bool after = (v < last_v) || (v == last_v && c > last_i);   // not picked yet
+                const bool better = (v > bv) || (v == bv && (bi < 0 || c < bi));
+                if (after && better && v == v) { bv = v; bi = c; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int64_t oi = __shfl_xor(bi, o, 64);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+            __syncthreads();
+            bv = sv[0]; bi = si[0];
+            for (int w = 1; w < RB / 64; ++w)
+                if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] < bi))) { bv = sv[w]; bi = si[w]; }
+            if (threadIdx.x == 0) { out_idx[i * k + j] = bi; out_val[i * k + j] = bi >= 0 ? bv : -INFINITY; }
+            if (bi < 0) { last_v = -INFINITY; last_i = N; } else { last_v = bv; last_i = bi; }
+        }
+    }
+}
+
 inline int grid1d(int64_t n, int per_block)
 {
     int64_t b = (n + per_block - 1) / per_block;
@@ -252,7 +296,7 @@ extern "C" int kge_filter_scores(float *scores, int64_t ld, const int64_t *true_
 {
     if (B < 0 || N <= 0 || ld < N) return KGE_EINVAL;
     if (B == 0) return 0;
-    if (!scores || !true_idx || !seg_lo || !seg_hi) return KGE_EINVAL;
+    if (!scores || !seg_lo || !seg_hi) return KGE_EINVAL; // true_idx may be NULL: filter all known targets
     hipLaunchKernelGGL(filter_scores_kernel, dim3(grid1d(B, 1)), dim3(RB), 0, kge_s(stream), scores, ld, true_idx,
                        seg_lo, seg_hi, targets, B, N);
     KGE_CHECK_LAUNCH();
@@ -342,6 +386,17 @@ extern "C" int kge_lp_scores_batched(int mode, const float *q, int64_t ldq, cons
     if (!q || !cand || !out) return KGE_EINVAL;
     hipLaunchKernelGGL(lp_batched_kernel, dim3(grid1d(B * N, 4)), dim3(256), 0, kge_s(stream), mode, q, ldq, cand,
                        stride_b, stride_n, B, N, K, out, ldo);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, int k, int64_t *out_idx,
+                        float *out_val, kge_stream_t stream)
+{
+    if (B < 0 || N <= 0 || ld < N || k <= 0) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!scores || !out_idx || !out_val) return KGE_EINVAL;
+    hipLaunchKernelGGL(topk_kernel, dim3(grid1d(B, 1)), dim3(RB), 0, kge_s(stream), scores, ld, B, N, k, out_idx, out_val);
     KGE_CHECK_LAUNCH();
     return 0;
 }

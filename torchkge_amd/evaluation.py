@@ -340,3 +340,76 @@ class _NullCtx(object):
 
     def __exit__(self, *exc):
         return False
+
+
+class RelationPredictionEvaluator(object):
+    """Rank the true relation of every fact among all relations, raw and
+    filtered, with the reference's interface (torchkge/evaluation.py:16-204):
+    ``RelationPredictionEvaluator(model, kg, directed=True)``, ``.evaluate``,
+    ``.mean_rank / .hit_at_k / .mrr / .print_results``, ``rank_true_rels`` and
+    ``filt_rank_true_rels``.  Candidates are the relation table (at most a few
+    thousand rows), so the drop-in composition prepare -> score -> filter_scores
+    -> get_rank is used as is, every step on the HIP kernels."""
+
+    def __init__(self, model, knowledge_graph, directed=True):
+        self.model = model
+        self.kg = knowledge_graph
+        self.directed = directed
+        self.rank_true_rels = torch.empty(size=(knowledge_graph.n_facts,)).long()
+        self.filt_rank_true_rels = torch.empty(size=(knowledge_graph.n_facts,)).long()
+        self.evaluated = False
+
+    def evaluate(self, b_size, verbose=True):
+        device = next(self.model.parameters()).device
+        HipRankEngine.check_device(device)
+        kg = self.kg
+        heads, tails, rels = kg.head_idx.to(device), kg.tail_idx.to(device), kg.relations.to(device)
+        index = filter_index_for(kg.dict_of_rels, device)
+        ranks = torch.empty(2, kg.n_facts, dtype=torch.int64, device=device)
+        n_batches = get_n_batches(kg.n_facts, b_size)
+        with torch.no_grad():
+            for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
+                          desc='Relation prediction evaluation'):
+                sl = slice(i * b_size, (i + 1) * b_size)
+                h_idx, t_idx, r_idx = heads[sl], tails[sl], rels[sl]
+                h_emb, t_emb, r_emb, candidates = self.model.inference_prepare_candidates(
+                    h_idx, t_idx, r_idx, entities=False)
+                scores = self.model.inference_scoring_function(h_emb, t_emb, candidates)
+                filt_scores = filter_scores(scores, index, h_idx, t_idx, r_idx)
+                if not self.directed:      # evaluation.py:99-104: also score (t, _, h)
+                    scores_bis = self.model.inference_scoring_function(t_emb, h_emb, candidates)
+                    filt_scores_bis = filter_scores(scores_bis, index, h_idx, t_idx, r_idx)
+                    scores = torch.cat((scores, scores_bis), dim=1)
+                    filt_scores = torch.cat((filt_scores, filt_scores_bis), dim=1)
+                ranks[0, sl] = get_rank(scores, r_idx)
+                ranks[1, sl] = get_rank(filt_scores, r_idx)
+        res = ranks.cpu()
+        self.rank_true_rels, self.filt_rank_true_rels = res[0], res[1]
+        self.evaluated = True
+
+    def _check(self):
+        if not self.evaluated:
+            raise NotYetEvaluatedError('Evaluator not evaluated call LinkPredictionEvaluator.evaluate')
+
+    def mean_rank(self):
+        self._check()
+        return self.rank_true_rels.float().mean().item(), self.filt_rank_true_rels.float().mean().item()
+
+    def hit_at_k(self, k=10):
+        self._check()
+        return ((self.rank_true_rels <= k).float().mean().item(),
+                (self.filt_rank_true_rels <= k).float().mean().item())
+
+    def mrr(self):
+        self._check()
+        return ((self.rank_true_rels.float() ** (-1)).mean().item(),
+                (self.filt_rank_true_rels.float() ** (-1)).mean().item())
+
+    def print_results(self, k=None, n_digits=3):
+        if k is None:
+            k = 10
+        for i in ([k] if type(k) == int else list(k)):
+            print('Hit@{} : {} \t\t Filt. Hit@{} : {}'.format(
+                i, round(self.hit_at_k(k=i)[0], n_digits), i, round(self.hit_at_k(k=i)[1], n_digits)))
+        print('Mean Rank : {} \t Filt. Mean Rank : {}'.format(int(self.mean_rank()[0]), int(self.mean_rank()[1])))
+        print('MRR : {} \t\t Filt. MRR : {}'.format(round(self.mrr()[0], n_digits), round(self.mrr()[1], n_digits)))

@@ -54,7 +54,7 @@ class DistMultModel(BilinearModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(h, t, r, candidates) with a stride-0 (b, N, d) candidates view
         (bilinear.py:247-267)."""
-        b_size = h_idx.shape[0]
+        b_size = max(h_idx.shape[0], t_idx.shape[0], r_idx.shape[0])   # inference passes one empty index
         E, R = self.ent_emb.weight.data, self.rel_emb.weight.data
         h, t, r = _hip.gather_rows(E, h_idx), _hip.gather_rows(E, t_idx), _hip.gather_rows(R, r_idx)
         if entities:
@@ -132,7 +132,7 @@ class ComplExModel(BilinearModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """((re_h, im_h), (re_t, im_t), (re_r, im_r), (re_cand, im_cand))
         (bilinear.py:530-556)."""
-        b_size = h_idx.shape[0]
+        b_size = max(h_idx.shape[0], t_idx.shape[0], r_idx.shape[0])   # inference passes one empty index
         Ere, Eim, Rre, Rim = [x.data for x in self._tables()]
         g = _hip.gather_rows
         h = (g(Ere, h_idx), g(Eim, h_idx))

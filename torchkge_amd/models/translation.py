@@ -16,6 +16,18 @@ from ..utils.modeling import init_embedding
 from .interfaces import TranslationModel, EntityCandidates
 
 
+def _projections(kind, tabs, d_ent, d_rel, h_idx, t_idx, r_idx):
+    """p_r(h), p_r(t) for the index vectors that are present (top-k inference
+    passes an empty tensor for the missing side, inference.py:230-238)."""
+    empty = torch.zeros(0, d_rel, dtype=torch.float32, device=r_idx.device)
+    any_idx = h_idx if h_idx.shape[0] else t_idx
+    proj_h = _hip.lp_prep(kind, _hip.SIDE_PROJ_H, tabs, d_ent, d_rel, h_idx, any_idx, r_idx, want_w=True)[0] \
+        if h_idx.shape[0] else empty
+    proj_t = _hip.lp_prep(kind, _hip.SIDE_PROJ_T, tabs, d_ent, d_rel, any_idx, t_idx, r_idx, want_w=True)[0] \
+        if t_idx.shape[0] else empty
+    return proj_h, proj_t
+
+
 def _shard(table, lo, hi):
     return table if (lo == 0 and hi == table.shape[0]) else table[lo:hi]
 
@@ -50,7 +62,7 @@ class TransEModel(TranslationModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(h, t, r, candidates); candidates is a stride-0 (b, N, d) view of the
         table, as in the reference (translation.py:105-125)."""
-        b_size = h_idx.shape[0]
+        b_size = max(h_idx.shape[0], t_idx.shape[0], r_idx.shape[0])   # inference passes one empty index
         E, R = self.ent_emb.weight.data, self.rel_emb.weight.data
         h, t, r = _hip.gather_rows(E, h_idx), _hip.gather_rows(E, t_idx), _hip.gather_rows(R, r_idx)
         if entities:
@@ -132,10 +144,9 @@ class TransHModel(TranslationModel):
             raise NotYetImplementedError('TransH relation candidates are not on the hot path')
         tabs = [x.data for x in self._tables()]
         d = self.emb_dim
-        proj_h = _hip.lp_prep(_hip.TRANSH, _hip.SIDE_PROJ_H, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)[0]
-        proj_t = _hip.lp_prep(_hip.TRANSH, _hip.SIDE_PROJ_T, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)[0]
+        proj_h, proj_t = _projections(_hip.TRANSH, tabs, d, d, h_idx, t_idx, r_idx)
         r = _hip.gather_rows(tabs[1], r_idx)
-        return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), h_idx.shape[0])
+        return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), max(h_idx.shape[0], t_idx.shape[0]))
 
     def _handle_problem(self, q, cand, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
@@ -210,10 +221,9 @@ class TransDModel(TranslationModel):
             raise NotYetImplementedError('TransD relation candidates are not on the hot path')
         tabs = [x.data for x in self._tables()]
         de, dr = self.ent_emb_dim, self.rel_emb_dim
-        proj_h = _hip.lp_prep(_hip.TRANSD, _hip.SIDE_PROJ_H, tabs, de, dr, h_idx, t_idx, r_idx, want_w=True)[0]
-        proj_t = _hip.lp_prep(_hip.TRANSD, _hip.SIDE_PROJ_T, tabs, de, dr, h_idx, t_idx, r_idx, want_w=True)[0]
+        proj_h, proj_t = _projections(_hip.TRANSD, tabs, de, dr, h_idx, t_idx, r_idx)
         r = _hip.gather_rows(tabs[1], r_idx)
-        return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), h_idx.shape[0])
+        return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), max(h_idx.shape[0], t_idx.shape[0]))
 
     def _problem(self, q, Wq, ent_lo, ent_hi):
         E = _hip.f32c(self.ent_emb.weight.data)

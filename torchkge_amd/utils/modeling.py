@@ -36,8 +36,9 @@ def filter_scores(scores, dictionary, key1, key2, true_idx):
     """Copy of `scores` with -inf at every known true target other than
     true_idx[i] (modeling.py:91-102).  `dictionary` is a torchkge dict-of-sets
     (converted once to a device FilterIndex and cached) or a FilterIndex."""
-    _hip.require_cuda(scores, key1, key2, true_idx)
+    _hip.require_cuda(scores, key1, key2, true_idx)     # true_idx None: mask every known target
     index = dictionary if hasattr(dictionary, 'lookup') else filter_index_for(dictionary, scores.device)
     seg_lo, seg_hi = index.lookup(key1, key2)
     filt = _hip.f32c(scores).clone()
-    return _hip.filter_scores_(filt, _hip.i64c(true_idx), seg_lo, seg_hi, index.targets)
+    return _hip.filter_scores_(filt, None if true_idx is None else _hip.i64c(true_idx), seg_lo, seg_hi,
+                               index.targets)
