@@ -268,6 +268,22 @@ def main():
                'filt_hits10_cpu_gpu': [mo['hit_at_k'][1], mg['hit_at_k'][1]],
                'filt_mrr_cpu_gpu': [mo['mrr'][1], mg['mrr'][1]]}
 
+    # ---- training step through the same kernels (last: it changes the tables) ----
+    if rank == 0 and sec is not None:
+        crit = tk.MarginLoss(0.5)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+
+        def train_step():
+            nh, nt = samp.corrupt_batch(h2, t2, r2)            # K5 (+ torch RNG draws)
+            pos, neg = model(h2, t2, r2, nh, nt)               # K1 forward x2
+            loss = crit(pos, neg)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()                                     # K1 backward x2 (atomic scatter)
+            opt.step()
+        t_tr = ev_time(train_step, reps=10)
+        sec['train_step'] = {'triples_per_s': round(Bt / t_tr, 1), 'batch': Bt, 'ms': round(t_tr * 1e3, 4),
+                             'what': 'corrupt_batch + Model.forward(pos,neg) + MarginLoss + backward + SGD step'}
+
     if rank == 0:
         par = 'single' if world == 1 else ('%s-%d' % ('queries-weak' if args.scaling == 'weak'
                                                       else args.shard + '-' + (args.exchange if args.shard == 'entities' else 'strong'), world))

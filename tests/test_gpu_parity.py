@@ -667,3 +667,40 @@ def test_wikidata5m_scale_properties(hip):
     i = torch.arange(0, nq, 7, device='cuda')
     ref = (A[i].double() * Tre[true[i]].double()).sum(1) + (Bq[i].double() * Tim[true[i]].double()).sum(1)
     assert (s_true[i].double() - ref).abs().max().item() < 1e-6
+
+
+def test_random_shape_sweep_bit_exact(hip):
+    """Ragged shapes (B, N, K not multiples of the 128x128x32 tile, K % 4 != 0 ->
+    scalar-load path, B or N smaller than one tile): MFMA and VALU tile kernels,
+    pair kernel and fused counts vs the C oracle, bit for bit."""
+    lib = oracle_clib()
+    rng = np.random.RandomState(7)
+    shapes = [(1, 2, 1), (2, 129, 7), (127, 127, 9), (129, 257, 33), (300, 40, 64), (31, 1000, 201)]
+    shapes += [(int(rng.randint(1, 400)), int(rng.randint(1, 700)), int(rng.randint(1, 260))) for _ in range(10)]
+    for B, N, K in shapes:
+        g = torch.Generator().manual_seed(B * 7919 + N * 31 + K)
+        A = torch.rand(B, K, generator=g) * 2 - 1
+        T = torch.rand(N, K, generator=g) * 2 - 1
+        ci = torch.randint(0, N, (B,), generator=g)
+        ref = np.empty((B, N), dtype=np.float32)
+        for mode in ('dot', 'expand', 'l1', 'l2'):
+            if mode in ('dot', 'expand'):
+                qn = np.empty(B, dtype=np.float32); en = np.empty(N, dtype=np.float32)
+                lib.orc_row_sqnorm_chain(fptr(A.numpy()), i64(K), i64(B), i64(K), fptr(qn))
+                lib.orc_row_sqnorm_chain(fptr(T.numpy()), i64(K), i64(N), i64(K), fptr(en))
+                lib.orc_lp_gemm_chain(fptr(A.numpy()), i64(K), fptr(T.numpy()), i64(K), i64(K), None, i64(0), None,
+                                      i64(0), i64(0), i64(B), i64(N), 1 if mode == 'expand' else 0, fptr(qn), fptr(en),
+                                      fptr(ref))
+                dA, dT = dev(A), dev(T)
+                prob = (hip.LpProblem(hip.LP_L2_EXPAND, dA, dT, qn=hip.row_sqnorm(dA), en=hip.row_sqnorm(dT))
+                        if mode == 'expand' else hip.LpProblem(hip.LP_DOT, dA, dT))
+            else:
+                lib.orc_lp_direct_chain(fptr(A.numpy()), i64(K), fptr(T.numpy()), i64(K), i64(K), None, i64(0), None,
+                                        i64(0), None, i64(B), i64(N), 1 if mode == 'l1' else 2, fptr(ref))
+                prob = hip.LpProblem(hip.LP_L1_DIRECT if mode == 'l1' else hip.LP_L2_DIRECT, dev(A), dev(T))
+            tag = (B, N, K, mode)
+            assert np.array_equal(prob.scores().cpu().numpy(), ref), tag
+            st = prob.pair_scores(dev(ci))
+            assert np.array_equal(st.cpu().numpy(), ref[np.arange(B), ci.numpy()]), tag
+            assert np.array_equal(prob.count_ge(st).cpu().numpy(),
+                                  (ref >= ref[np.arange(B), ci.numpy()][:, None]).sum(1)), tag

@@ -237,6 +237,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
         KGE_MMA(af, bf)                                                                             \
     }
 
+    float en_pref[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) en_pref[nt] = 0.f;
     int it = 0, s = 0;
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
@@ -246,6 +249,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
         const bool seg1 = s >= steps0;
         const int kb0 = (seg1 ? s - steps0 : s) << 2;
         const int nblk = min(4, (seg1 ? nb1 : nb0) - kb0);
+        if (MODE == KGE_LP_L2_EXPAND && s == S - 1) { // ||e_c||^2 of this tile's columns: issued a whole
+            const int item = (int)item_begin + it;    // step ahead of the epilogue that consumes them
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int64_t col = (int64_t)(item % p.col_tiles) * BN + wc * NT * 32 + nt * 32 + l31;
+                en_pref[nt] = d.en[min(col, d.N - 1)]; // clamped, unconditional
+            }
+        }
 
         const float *Ab = smem + buf * 2 * TILE_FLOATS + (wr * MT * 32 + l31) * LDS_LD + half * 4;
         const float *Bb = smem + buf * 2 * TILE_FLOATS + TILE_FLOATS + (wc * NT * 32 + l31) * LDS_LD + half * 4;
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
             for (int nt = 0; nt < NT; ++nt) {
                 const int64_t col = colb + nt * 32 + l31;
                 cmask[nt] = col < d.N ? 1 : 0;
-                enr[nt] = (MODE == KGE_LP_L2_EXPAND) ? d.en[min(col, d.N - 1)] : 0.f; // clamped, unconditional
+                enr[nt] = (MODE == KGE_LP_L2_EXPAND) ? en_pref[nt] : 0.f;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
