@@ -12,12 +12,14 @@ the model tables, the test triples and the filter index already resident in HBM.
 Metric = link-prediction triples scored / second (whole job, all ranks).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
-  --scaling weak   (default) every rank evaluates its own FB15k-237-sized test
-                   split against its replica of the tables: the units are
-                   independent, there is no data-path collective; ranks are
-                   all-gathered once at the end of the timed region.
-  --scaling strong one test split, --shard queries | entities (entity-sharded
-                   candidate ranges with --exchange counts | scores over RCCL).
+  --scaling weak --shard entities  (default) the entity table grows to N dataset-sized
+                   shards; every rank scores ITS entity shard for all test triples and the
+                   ranks exchange over RCCL: the owner's true scores (all-reduce of B floats)
+                   and the partial rank counts (all-reduce of 3*B int32), or with
+                   --exchange scores the partial score tiles themselves (all-gather).
+  --scaling weak --shard queries   independent replicas: every rank evaluates its own
+                   dataset-sized test split against its replica of the tables (no collective).
+  --scaling strong --shard entities | queries   one dataset-sized job split across ranks.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
 objects: "roofline" (dominant kernel timed live with HIP events on the launch
@@ -55,7 +57,8 @@ def parse():
     ap.add_argument('--workload', default='transe_fb15k237', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32768, help='evaluate() b_size')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--shard', default='queries', choices=['queries', 'entities'])
+    ap.add_argument('--shard', default='entities', choices=['entities', 'queries'],
+                    help='N>1: what is partitioned across ranks (weak+queries = independent replicas)')
     ap.add_argument('--exchange', default='counts', choices=['counts', 'scores'])
     ap.add_argument('--materialize', action='store_true', help='fused=False: write the (B,N) scores')
     ap.add_argument('--l2-mode', default='expand', choices=['expand', 'direct'])
@@ -105,7 +108,13 @@ def main():
     from oracle import kge_oracle as orc     # synthetic-KG generator + the cpu_baseline leg only
 
     kind, shape, d, p = WORKLOADS[args.workload]
-    n_ent, n_rel, n_train, n_valid, n_test = orc.DATASET_SHAPES[shape]
+    n_ent1, n_rel, n_train, n_valid, n_test = orc.DATASET_SHAPES[shape]
+    multi = world > 1
+    # weak scaling over entity shards (default for N > 1): the entity table grows to N
+    # dataset-sized shards, each GPU scores ITS shard for every test triple and the ranks
+    # exchange partial results over RCCL -- per-GPU work is fixed as N grows.
+    ent_weak = multi and args.scaling == 'weak' and args.shard == 'entities'
+    n_ent = n_ent1 * (world if ent_weak else 1)
     tables = orc.init_tables(kind, n_ent, n_rel, d, seed=0)
     model = make_model(kind, p, tables, n_ent, n_rel).to(device)
     if kind == 'transe':
@@ -119,8 +128,9 @@ def main():
     kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels}, ent2ix=ident_e,
                            rel2ix=ident_r)
     _, _, kg_test = kg.split_kg(sizes=(n_train, n_valid, n_test))
-    if world > 1 and args.scaling == 'weak':
-        # every rank gets its own test split of the same size (facts of the same graph)
+    replicas = multi and args.scaling == 'weak' and args.shard != 'entities'
+    if replicas:
+        # every rank evaluates its own test split of the same size (facts of the same graph)
         g = torch.Generator().manual_seed(7 + rank)
         sel = torch.randperm(kg.n_facts, generator=g)[:n_test]
         kg_test = tk.KnowledgeGraph(kg={'heads': heads[sel], 'tails': tails[sel], 'relations': rels[sel]},
@@ -131,8 +141,8 @@ def main():
     kg_test.relations = kg_test.relations.to(device)
 
     shard = None
-    if world > 1 and args.scaling == 'strong':
-        shard = args.shard
+    if multi and not replicas:
+        shard = 'entities' if args.shard == 'entities' else 'queries'
     ev = tk.LinkPredictionEvaluator(model, kg_test, fused=not args.materialize, shard=shard,
                                     exchange=args.exchange, graph=not args.no_graph)
 
@@ -155,10 +165,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    units_per_rank_step = n_test * 2 * n_ent
-    total_units = units_per_rank_step * (world if (world > 1 and args.scaling == 'weak') else 1)
+    # scored triples of the whole job per step
+    total_units = n_test * 2 * n_ent * (world if replicas else 1)
     value = total_units * args.steps / elapsed
     hit10, mrr = ev.hit_at_k(10), ev.mrr()
+    n_ent_full = n_ent
+    if shard == 'entities':            # per-rank candidate range: what one launch of the dominant kernel covers
+        from torchkge_amd import distributed as kd
+        lo_r, hi_r = kd.shard_range(n_ent, world, rank)
+    else:
+        lo_r, hi_r = 0, n_ent
+    n_ent = hi_r - lo_r
 
     # ---- roofline of the dominant kernel (the all-candidates count kernel) ----
     roof = None
@@ -166,7 +183,7 @@ def main():
         B = min(args.batch, n_test)
         h, t, r = kg_test.head_idx[:B], kg_test.tail_idx[:B], kg_test.relations[:B]
         with model.lp_session():
-            prob = model.lp_problem(h, t, r, 'tail')
+            prob = model.lp_problem(h, t, r, 'tail', ent_lo=lo_r, ent_hi=hi_r)
             s_true = prob.pair_scores(t)
             raw = torch.zeros(B, dtype=torch.int32, device=device)
             scores_buf = torch.empty(B, n_ent, device=device) if args.materialize else None
@@ -208,7 +225,7 @@ def main():
     sec = None
     if rank == 0:
         Bt = 32768                                     # training batch of docs/tutorials/transe.rst:25
-        h2, t2, r2 = orc.synthetic_triples(n_ent, n_rel, Bt, seed=3, device=device)
+        h2, t2, r2 = orc.synthetic_triples(n_ent_full, n_rel, Bt, seed=3, device=device)
 
         def ev_time(fn, reps=20):
             for _ in range(3):
@@ -285,8 +302,15 @@ def main():
                              'what': 'corrupt_batch + Model.forward(pos,neg) + MarginLoss + backward + SGD step'}
 
     if rank == 0:
-        par = 'single' if world == 1 else ('%s-%d' % ('queries-weak' if args.scaling == 'weak'
-                                                      else args.shard + '-' + (args.exchange if args.shard == 'entities' else 'strong'), world))
+        if world == 1:
+            par = 'single'
+        elif replicas:
+            par = 'independent-replicas-%d' % world
+        elif shard == 'entities':
+            par = 'entity-shards-%d, RCCL %s of %s' % (world, 'all-reduce' if args.exchange == 'counts' else 'all-gather',
+                                                       'rank counts' if args.exchange == 'counts' else 'score tiles')
+        else:
+            par = 'query-shards-%d' % world
         line = {
             'metric': 'link-prediction triples scored/sec (filtered LP eval, both sides)',
             'value': round(value, 1), 'unit': 'triples_scored/s', 'n_gpus': world, 'steps': args.steps,
@@ -295,7 +319,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
                                    'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
-                                       kind, d, p, shape, n_ent, n_rel, n_test, args.batch),
+                                       kind, d, p, shape + (' x%d entity shards' % world if ent_weak else ''), n_ent_full, n_rel, n_test, args.batch),
                        'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': not args.no_graph,
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
