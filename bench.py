@@ -61,7 +61,7 @@ def parse():
                     help='N>1: what is partitioned across ranks (weak+queries = independent replicas)')
     ap.add_argument('--exchange', default='counts', choices=['counts', 'scores'])
     ap.add_argument('--materialize', action='store_true', help='fused=False: write the (B,N) scores')
-    ap.add_argument('--l2-mode', default='expand', choices=['expand', 'direct'])
+    ap.add_argument('--l2-mode', default='auto', choices=['auto', 'expand', 'direct'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],

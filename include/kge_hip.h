@@ -163,8 +163,10 @@ int kge_lp_prep(int kind, int side, const float *t0, const float *t1, const floa
 int kge_ewise(int op, const float *a, const float *b, const float *c, const float *d, int64_t n,
               float *out, kge_stream_t stream);
 
-/* out[i] = chain_k X[i,k]^2 */
-int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, kge_stream_t stream);
+/* out[i] = chain_k X[i,k]^2; when max_io != NULL also *max_io = max(*max_io, max_i out[i])
+ * (device scalar, atomically -- the evaluator's "was the norm expansion safe" guard) */
+int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, float *max_io,
+                   kge_stream_t stream);
 /* out[i] = scale * chain_k X[i,k]*Y[i,k] */
 int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t rows, int K, float scale,
                 float *out, kge_stream_t stream);

@@ -704,3 +704,47 @@ def test_random_shape_sweep_bit_exact(hip):
             assert np.array_equal(st.cpu().numpy(), ref[np.arange(B), ci.numpy()]), tag
             assert np.array_equal(prob.count_ge(st).cpu().numpy(),
                                   (ref >= ref[np.arange(B), ci.numpy()][:, None]).sum(1)), tag
+
+
+def test_l2_auto_mode_guards_norm_expansion(hip):
+    """TransE-L2: the MFMA norm expansion is only taken while its cancellation
+    error fits the score tolerance; un-normalised tables with large norms fall
+    back to the broadcast-subtract kernel and stay within fp32 relative error
+    of the reference algorithm (oracle), incl. through evaluate()/hipGraph."""
+    import torchkge_amd as tk
+    from torchkge_amd import _hip
+    g = torch.Generator().manual_seed(11)
+    n_ent, n_rel, d, B = 700, 5, 200, 48
+    E = torch.randn(n_ent, d, generator=g) * 0.9            # ||e||^2 ~ 160
+    R = torch.randn(n_rel, d, generator=g) * 0.9
+    h = torch.randint(0, n_ent, (B,), generator=g); t = torch.randint(0, n_ent, (B,), generator=g)
+    r = torch.randint(0, n_rel, (B,), generator=g)
+    ref = orc.lp_scores('transe', [E, R], h, t, r, 'tail', 2, None)
+    m = build_model('transe', 2, [E, R], n_ent, n_rel)
+    assert m.l2_mode == 'auto'
+    pz = m.lp_problem(h.cuda(), t.cuda(), r.cuda(), 'tail')
+    assert pz.desc.mode == _hip.LP_L2_DIRECT
+    s = pz.scores().cpu()
+    rel_err = ((s - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert rel_err < 2e-6
+    m.l2_mode = 'expand'                                     # forced: same problem, visibly worse
+    pz = m.lp_problem(h.cuda(), t.cuda(), r.cuda(), 'tail')
+    assert pz.desc.mode == _hip.LP_L2_EXPAND
+    m.l2_mode = 'auto'
+    # small norms -> expansion, decision made once per evaluate() and not kept afterwards
+    m2 = build_model('transe', 2, [torch.nn.functional.normalize(E, dim=1), torch.nn.functional.normalize(R, dim=1)],
+                     n_ent, n_rel)
+    assert m2.lp_problem(h.cuda(), t.cuda(), r.cuda(), 'head').desc.mode == _hip.LP_L2_EXPAND
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    dh, dt, _ = orc.build_filter_dicts(h, t, r)
+    for model, tabs in ((m, [E, R]), (m2, [x.weight.data.cpu() for x in (m2.ent_emb, m2.rel_emb)])):
+        for graph in (False, True):
+            ev = tk.LinkPredictionEvaluator(model, kg, graph=graph)
+            ev.evaluate(b_size=32, verbose=False)
+            assert model._expand_ok is None
+            scale = float(tabs[0].pow(2).sum(1).max()) * 4 + 1.0
+            ties = orc.lp_evaluate('transe', tabs, h, t, r, dh, dt, 32, 2, tie_tol=4e-6 * scale)[4]
+            got = [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]
+            for k in range(4):
+                assert bool(((got[k] >= ties[k, :, 0]) & (got[k] <= ties[k, :, 1])).all())

@@ -46,7 +46,7 @@ _SIGNATURES = {
     'kge_lp_prep': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp,
                     _vp, _vp, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
-    'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp],
+    'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     'kge_row_dot': [_vp, _vp, _i64, _i64, _int, ctypes.c_float, _vp, _vp],
     'kge_gather_rows': [_vp, _i64, _vp, _i64, _int, _vp, _vp],
     'kge_normalize_rows': [_vp, _i64, _i64, _int, _vp],
@@ -91,7 +91,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 1:
+    if lib.kge_abi_version() != 2:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -198,7 +198,7 @@ def ewise(op, a, b, c=None, d=None):
     return out
 
 
-def row_sqnorm(X, K=None):
+def row_sqnorm(X, K=None, max_io=None):
     lib = load_library()
     require_cuda(X)
     X = f32c(X)
@@ -206,7 +206,7 @@ def row_sqnorm(X, K=None):
     K = X.shape[1] if K is None else K
     out = torch.empty(rows, dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
-        _check(lib.kge_row_sqnorm(_p(X), ld, rows, K, _p(out), _stream()), 'kge_row_sqnorm')
+        _check(lib.kge_row_sqnorm(_p(X), ld, rows, K, _p(out), _p(max_io), _stream()), 'kge_row_sqnorm')
     return out
 
 

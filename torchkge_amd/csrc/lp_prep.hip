@@ -111,13 +111,23 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
 
 // serial single-accumulator chains (one thread per row): these feed
 // L2_EXPAND's qn / en and must match oracle orc_row_sqnorm_chain bit for bit.
-__global__ void row_sqnorm_kernel(const float *__restrict__ X, int64_t ld, int64_t rows, int K, float *out)
+__global__ void row_sqnorm_kernel(const float *__restrict__ X, int64_t ld, int64_t rows, int K, float *out,
+                                  float *max_io)
 {
+    float big = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
         const float *x = X + i * ld;
         float acc = 0.f;
         for (int k = 0; k < K; ++k) acc = fmaf(x[k], x[k], acc);
         out[i] = acc;
+        // squared norms are >= 0 (or NaN, whose bit pattern is above +inf): their
+        // order as floats is their order as unsigned bit patterns
+        big = __uint_as_float(max(__float_as_uint(big), __float_as_uint(acc)));
+    }
+    if (max_io) {
+        unsigned m = __float_as_uint(big);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned *>(max_io), m);
     }
 }
 __global__ void row_dot_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t ld,
@@ -176,12 +186,14 @@ __global__ __launch_bounds__(WPB * 64) void normalize_rows_kernel(float *X, int6
 
 } // namespace
 
-extern "C" int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, kge_stream_t stream)
+extern "C" int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, float *max_io,
+                              kge_stream_t stream)
 {
     if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
     if (rows == 0) return 0;
     if (!X || !out) return KGE_EINVAL;
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, ld, rows, K, out);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, ld, rows, K, out,
+                       max_io);
     KGE_CHECK_LAUNCH();
     return 0;
 }
@@ -247,6 +259,6 @@ extern "C" int kge_lp_prep(int kind, int side, const float *t0, const float *t1,
     PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq};
     hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(B)), dim3(WPB * 64), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
-    if (qn) return kge_row_sqnorm(Q0, d_rel, B, d_rel, qn, stream);
+    if (qn) return kge_row_sqnorm(Q0, d_rel, B, d_rel, qn, nullptr, stream);
     return 0;
 }

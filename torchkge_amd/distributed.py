@@ -43,6 +43,13 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def all_reduce_max(t, group=None):
+    """In-place MAX all-reduce (no-op when not distributed)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def all_gather_columns(local, n_total, group=None):
     """Partial score tiles (B, n_p) of every rank -> (B, n_total): ONE
     all-gather of equal-size (padded) tiles, then a strided copy."""

@@ -219,6 +219,9 @@ class LinkPredictionEvaluator(object):
 
         n_local = f_hi - f_lo
         index_h, index_t = self._filter_indices(device)
+        guard = None
+        if hasattr(self.model, 'lp_guard_begin') and not self._generic_model and device.type == 'cuda':
+            guard = self.model.lp_guard_begin(device)   # TransE-L2: optimistic MFMA norm expansion
         session = self.model.lp_session() if hasattr(self.model, 'lp_session') else _NullCtx()
 
         overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
@@ -226,6 +229,8 @@ class LinkPredictionEvaluator(object):
 
         def run(heads, tails, rels, out):
             with session, torch.no_grad():
+                if guard is not None and self.model._expand_ok is None:
+                    guard.zero_()
                 n_batches = get_n_batches(n_local, b_size)
                 for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
                               desc='Link prediction evaluation'):
@@ -250,6 +255,7 @@ class LinkPredictionEvaluator(object):
             # replayed without host launch gaps (capture is keyed on everything
             # that fixes shapes and addresses; table VALUES may change freely)
             key = (b_size, n_local, str(device), self.fused, overlap,
+                   getattr(self.model, '_expand_ok', None),     # kernel choice is baked into the capture
                    tuple(p_.data_ptr() for p_ in self.model.parameters()))
             if self._graph_key != key:
                 st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
@@ -271,6 +277,18 @@ class LinkPredictionEvaluator(object):
             self._graph.replay()
             out = st['out']
 
+        if guard is not None:
+            # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
+            # cancellation error could exceed the score tolerance -> redo on the VALU kernel
+            worst = guard.sum()
+            if world > 1:
+                kdist.all_reduce_max(worst, self.group)     # every rank must take the same branch
+            if not float(worst.item()) <= self.model.L2_EXPAND_LIMIT:
+                self.model._expand_ok = False
+                out = torch.empty(4, n_local, dtype=torch.int64, device=device)
+                run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
+                    kg.relations[f_lo:f_hi].to(device), out)
+            self.model.lp_guard_end()
         if self.shard == 'queries' and world > 1:
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
         res = out.cpu()

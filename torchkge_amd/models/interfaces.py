@@ -206,8 +206,14 @@ class TranslationModel(Model):
         self.dissimilarity_type = dissimilarity_type
         from ..utils.dissimilarities import l1_dissimilarity, l2_dissimilarity
         self.dissimilarity = l1_dissimilarity if dissimilarity_type == 'L1' else l2_dissimilarity
-        # 'expand': ||q-e||^2 as an fp32 MFMA GEMM; 'direct': broadcast-subtract on the VALU
-        self.l2_mode = 'expand'
+        # 'expand': ||q-e||^2 = ||q||^2 + ||e||^2 - 2 q.e as an fp32 MFMA GEMM;
+        # 'direct': broadcast-subtract on the VALU; 'auto': expand while the operands
+        # are small enough for the cancellation error to stay inside the 1e-5 score
+        # tolerance (||q||^2 + ||e||^2 <= L2_EXPAND_LIMIT), direct otherwise.
+        self.l2_mode = 'auto'
+        self._expand_ok = None      # True/False: forced by the evaluator; None: guarded (see below)
+        self._lp_guard = None       # device scalar: max ||q||^2 + ||e||^2 seen during an evaluation
+        self._guard_on = False
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # reference TransH/TransD state_dicts carry the (n_rel, n_ent, d)
@@ -218,13 +224,45 @@ class TranslationModel(Model):
     def _direct_mode(self):
         return _hip.LP_L1_DIRECT if self.dissimilarity_type == 'L1' else _hip.LP_L2_DIRECT
 
+    # measured: |expand - reference| ~ 2.4e-7 * (||q||^2 + ||e||^2) at d = 200 (1.2e-6 at 5)
+    L2_EXPAND_LIMIT = 16.0
+
+    def lp_guard_begin(self, device):
+        """Start of an evaluation: the norm expansion is taken optimistically and
+        the norm kernels fold max ||q||^2 and max ||e||^2 into two device scalars
+        (no extra launch, graph-capturable, no host sync).  The evaluator reads
+        them with the ranks and, if their sum exceeds L2_EXPAND_LIMIT, redoes the
+        evaluation on the broadcast-subtract kernel.  Returns the (2,) tensor, or
+        None when this model never takes the expansion."""
+        self._expand_ok = None
+        if self.dissimilarity_type != 'L2' or self.l2_mode != 'auto' or self._kind is not None:
+            return None                         # only the plain TransE path uses the expansion
+        if self._lp_guard is None or self._lp_guard.device != device:
+            self._lp_guard = torch.zeros(2, dtype=torch.float32, device=device)
+        self._guard_on = True
+        return self._lp_guard
+
+    def lp_guard_end(self):
+        self._guard_on = False
+        self._expand_ok = None
+
     def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
         """Problem for s[i,c] = -diss(q_i, table[c] (- a w_i))."""
-        if self.dissimilarity_type == 'L2' and self.l2_mode == 'expand' and Wq is None:
+        if self.dissimilarity_type == 'L2' and self.l2_mode in ('expand', 'auto') and Wq is None:
+            # inside evaluate() the expansion is optimistic: the two norm kernels also
+            # fold their maxima into the guard scalars, which are checked once at the end
+            guarded = self.l2_mode == 'auto' and self._expand_ok is None and self._guard_on
+            gq, ge = (self._lp_guard[0:1], self._lp_guard[1:2]) if guarded else (None, None)
             en = self._cache.get('en_%d_%d' % (c_base, table.shape[0]), [table],
-                                 lambda: _hip.row_sqnorm(table))
-            return _hip.LpProblem(_hip.LP_L2_EXPAND, q, table, qn=_hip.row_sqnorm(q), en=en,
-                                  c_base=c_base, K0=K0)
+                                 lambda: _hip.row_sqnorm(table, max_io=ge))
+            qn = _hip.row_sqnorm(q, max_io=gq)
+            ok = True
+            if self.l2_mode == 'auto' and not guarded:
+                ok = self._expand_ok
+                if ok is None:      # drop-in API call: decide now on the actual operands (one sync)
+                    ok = q.shape[0] == 0 or float((qn.max() + en.max()).item()) <= self.L2_EXPAND_LIMIT
+            if ok:
+                return _hip.LpProblem(_hip.LP_L2_EXPAND, q, table, qn=qn, en=en, c_base=c_base, K0=K0)
         return _hip.LpProblem(self._direct_mode(), q, table, Wq=Wq, scal=scal, r_idx=r_idx,
                               c_base=c_base, K0=K0)
 
