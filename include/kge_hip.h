@@ -249,6 +249,34 @@ int kge_corrupt_scatter(const int64_t *heads, const int64_t *tails, const uint8_
                         int64_t *neg_heads, int64_t *neg_tails, int32_t *ws, kge_stream_t stream);
 
 /* library / build info */
+/* ---- certified f16-split prefilter of the fused rank count ------------------------
+ * (TransE-L2 norm expansion only; torchkge_amd/csrc/lp_split_mfma.hip has the error
+ * analysis.)  kge_lp_split_count + kge_lp_split_recheck leave in raw_count exactly
+ * what kge_lp_count_ge leaves there: >= 99.9% of the (query, candidate) pairs are
+ * decided by an f16 hi/lo-split MFMA product with a rigorous error band, the pairs
+ * inside the band are re-scored by the exact fp32 chain.
+ *
+ * A split operand is [rows_p][units_p] cells of 64 bytes (see the .hip file);
+ * kge_lp_split_units / kge_lp_split_rows_padded give its dimensions.
+ *   aug_mode 0: no augmentation column; 1: column K = aug[row] * aug_mul (candidates:
+ *   aug = ||e||^2, aug_mul = -0.5); 2: column K = aug_mul (queries: 1.0).
+ * enmax: device scalar >= max_c ||e_c||^2 (as accumulated by kge_row_sqnorm's max_io).
+ * eps_scale multiplies the error band (1.0 = the proven bound; tests shrink it).
+ * thr: scratch, 2 * kge_lp_split_rows_padded(B, 1) floats.  list: cap x 2 int32 scratch;
+ * list_count: device int32; *overflow is set to 1.0f if more than cap pairs (or more
+ * than 2048 in one 256 x 192 tile) fell inside the band -- raw_count is then invalid
+ * and the caller must redo the count with kge_lp_count_ge. */
+int kge_lp_split_units(int K, int with_aug);
+int64_t kge_lp_split_rows_padded(int64_t rows, int is_query);
+int kge_lp_split_rows(const float *X, int64_t ld, int64_t rows, int K, int is_query, int aug_mode,
+                      const float *aug, float aug_mul, void *out, kge_stream_t stream);
+int kge_lp_split_count(const kge_lp_desc *d, const void *Qs, const void *Es, const float *s_true,
+                       const float *enmax, float eps_scale, float *thr, int32_t *raw_count,
+                       int32_t *list, int32_t cap, int32_t *list_count, float *overflow,
+                       kge_stream_t stream);
+int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
+                         const int32_t *list_count, int32_t *raw_count, kge_stream_t stream);
+
 int kge_abi_version(void);
 const char *kge_build_arch(void);
 

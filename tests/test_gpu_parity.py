@@ -748,3 +748,58 @@ def test_l2_auto_mode_guards_norm_expansion(hip):
             got = [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]
             for k in range(4):
                 assert bool(((got[k] >= ties[k, :, 0]) & (got[k] <= ties[k, :, 1])).all())
+
+
+@pytest.mark.parametrize('B,N,K', [(64, 300, 32), (1000, 3000, 200), (193, 257, 17), (5, 2, 1), (700, 1500, 203)])
+def test_split_prefilter_counts_equal_exact_counts(hip, B, N, K):
+    """kge_lp_split_count + kge_lp_split_recheck (f16 hi/lo-split MFMA prefilter with a
+    proven error band, exact re-scoring inside the band) leave exactly the counts of
+    kge_lp_count_ge -- also with the band shrunk 16x (the bound is not tight by luck)."""
+    g = torch.Generator().manual_seed(B + N)
+    E = torch.nn.functional.normalize(torch.randn(N, K, generator=g), dim=1)
+    R = torch.nn.functional.normalize(torch.randn(9, K, generator=g), dim=1)
+    h = torch.randint(0, N, (B,), generator=g); r = torch.randint(0, 9, (B,), generator=g)
+    t = torch.randint(0, N, (B,), generator=g)
+    E[N // 2] = E[0]                                   # exact duplicates: ties with the true entity
+    dE, dq, dt = E.cuda(), (E[h] + R[r]).cuda().contiguous(), t.cuda()
+    guard = torch.zeros(4, device='cuda')
+    en = hip.row_sqnorm(dE, max_io=guard[1:2]); qn = hip.row_sqnorm(dq, max_io=guard[0:1])
+    prob = hip.LpProblem(hip.LP_L2_EXPAND, dq, dE, qn=qn, en=en)
+    st = prob.pair_scores(dt)
+    exact = prob.count_ge(st)
+    prob.split = {'Es': hip.split_rows(dE, aug=en), 'enmax': guard[1:2], 'overflow': guard[2:3]}
+    try:
+        for eps in (1.0, 1.0 / 16):
+            hip.SPLIT_EPS_SCALE = eps
+            got = prob.count_ge(st)
+            assert torch.equal(got, exact)
+            n_unc = int(prob.last_split[0].item())
+            assert B <= n_unc <= 64 * B              # at least the true entity of every query is re-scored
+    finally:
+        hip.SPLIT_EPS_SCALE = 1.0
+    assert float(guard[2]) == 0.0
+
+
+def test_split_prefilter_overflow_falls_back_to_exact(hip):
+    """More near-ties than the uncertain-pair list holds (here: every entity has the
+    same embedding) raise the overflow flag; the evaluator then redoes the evaluation
+    with the exact fp32 counts."""
+    import torchkge_amd as tk
+    n_ent, n_rel, d, n = 3000, 3, 32, 40
+    g = torch.Generator().manual_seed(5)
+    E = torch.nn.functional.normalize(torch.randn(1, d, generator=g), dim=1).repeat(n_ent, 1)
+    R = torch.nn.functional.normalize(torch.randn(n_rel, d, generator=g), dim=1)
+    h = torch.randint(0, n_ent, (n,), generator=g); t = torch.randint(0, n_ent, (n,), generator=g)
+    r = torch.randint(0, n_rel, (n,), generator=g)
+    m = build_model('transe', 2, [E, R], n_ent, n_rel)
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    ev = tk.LinkPredictionEvaluator(m, kg)
+    ev.evaluate(b_size=64, verbose=False)
+    assert m._split_ok is True                         # reset after the evaluation
+    m.split_filter = False
+    ev2 = tk.LinkPredictionEvaluator(m, kg)
+    ev2.evaluate(b_size=64, verbose=False)
+    for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
+        assert torch.equal(getattr(ev, nm), getattr(ev2, nm))
+    assert int(ev.rank_true_tails.min()) == n_ent      # everything ties: rank = number of entities

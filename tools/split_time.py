@@ -1,0 +1,53 @@
+"""Timing of the split count kernel alone (HIP events), for KGE_SPLIT_DBG probes."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchkge_amd import _hip  # noqa: E402
+from tools.split_dev import problem  # noqa: E402
+
+B, N, K = 32768, 14541, 200
+E, q, t = problem(B, N, K)
+guard = torch.zeros(4, device='cuda')
+en = _hip.row_sqnorm(E, max_io=guard[1:2])
+qn = _hip.row_sqnorm(q, max_io=guard[0:1])
+prob = _hip.LpProblem(_hip.LP_L2_EXPAND, q, E, qn=qn, en=en)
+st = prob.pair_scores(t)
+Es = _hip.split_rows(E, aug=en)
+Qs = _hip.split_rows(q, is_query=True)
+lib = _hip.load_library()
+Bp = int(lib.kge_lp_split_rows_padded(B, 1))
+thr = torch.empty(2 * Bp, device='cuda')
+cap = 64 * B
+lst = torch.empty(2 * cap, dtype=torch.int32, device='cuda')
+nl = torch.zeros(1, dtype=torch.int32, device='cuda')
+raw = torch.zeros(B, dtype=torch.int32, device='cuda')
+
+
+def count():
+    _hip._check(lib.kge_lp_split_count(ctypes.byref(prob.desc), _hip._p(Qs), _hip._p(Es), _hip._p(st),
+                                       _hip._p(guard[1:2]), 1.0, _hip._p(thr), _hip._p(raw), _hip._p(lst), cap,
+                                       _hip._p(nl), _hip._p(guard[2:3]), _hip._stream()), 'count')
+
+
+def recheck():
+    _hip._check(lib.kge_lp_split_recheck(ctypes.byref(prob.desc), _hip._p(st), _hip._p(lst), cap, _hip._p(nl),
+                                         _hip._p(raw), _hip._stream()), 'recheck')
+
+
+for name, fn in (('count', count), ('recheck', recheck)):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    print('%s dbg=%s waves=%s: %.3f ms (pairs listed %d)' % (
+        name, os.environ.get('KGE_SPLIT_DBG', '0'), os.environ.get('KGE_SPLIT_WAVES', '8'),
+        a.elapsed_time(b) / 10, int(nl.item())))

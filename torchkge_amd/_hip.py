@@ -53,6 +53,11 @@ _SIGNATURES = {
     'kge_lp_scores': [ctypes.POINTER(LpDesc), _vp, _i64, _vp],
     'kge_lp_pair_scores': [ctypes.POINTER(LpDesc), _vp, _vp, _i64, _vp, _vp],
     'kge_lp_count_ge': [ctypes.POINTER(LpDesc), _vp, _vp, _vp],
+    'kge_lp_split_units': [_int, _int],
+    'kge_lp_split_rows': [_vp, _i64, _i64, _int, _int, _int, _vp, ctypes.c_float, _vp, _vp],
+    'kge_lp_split_count': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp,
+                           ctypes.c_int32, _vp, _vp, _vp],
+    'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
@@ -64,7 +69,7 @@ _SIGNATURES = {
     'kge_topk': [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp],
 }
 # every symbol include/kge_hip.h declares
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version',
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version', 'kge_lp_split_rows_padded',
                                                'kge_build_arch'])
 
 _lib = None
@@ -87,6 +92,8 @@ def load_library():
         fn.restype = _int
     lib.kge_corrupt_ws_elems.argtypes = [_i64]
     lib.kge_corrupt_ws_elems.restype = _i64
+    lib.kge_lp_split_rows_padded.argtypes = [_i64, _int]
+    lib.kge_lp_split_rows_padded.restype = _i64
     lib.kge_abi_version.argtypes = []
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
@@ -198,6 +205,32 @@ def ewise(op, a, b, c=None, d=None):
     return out
 
 
+SPLIT_EPS_SCALE = 1.0          # multiplies the proven error band of the f16-split prefilter (tests shrink it)
+SPLIT_LIST_PER_QUERY = 64      # capacity of the uncertain-pair list, per query of the batch
+
+
+def split_rows(X, K=None, is_query=False, aug=None, aug_mul=None):
+    """f16 hi/lo split operand of kge_lp_split_count (uint8 tensor holding
+    [rows_p][units_p][64 bytes]); candidates carry -||e||^2/2 in column K
+    (aug = ||e||^2), queries carry 1."""
+    lib = load_library()
+    require_cuda(X, aug)
+    X = f32c(X)
+    rows, ld = X.shape[0], X.stride(0)
+    K = X.shape[1] if K is None else K
+    if is_query:
+        aug_mode, aug_mul = 2, 1.0
+    else:
+        aug_mode, aug_mul = 1, (-0.5 if aug_mul is None else aug_mul)
+    units_p = int(lib.kge_lp_split_units(K, 1))
+    rows_p = int(lib.kge_lp_split_rows_padded(rows, 1 if is_query else 0))
+    out = torch.empty(max(rows_p, 1) * units_p * 64, dtype=torch.uint8, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(lib.kge_lp_split_rows(_p(X), ld, rows, K, 1 if is_query else 0, aug_mode, _p(aug), aug_mul,
+                                     _p(out), _stream()), 'kge_lp_split_rows')
+    return out
+
+
 def row_sqnorm(X, K=None, max_io=None):
     lib = load_library()
     require_cuda(X)
@@ -276,6 +309,7 @@ class LpProblem(object):
                 d.r_idx = r_idx.data_ptr()
         self.desc = d
         self.B, self.N = int(d.B), int(d.N)
+        self.split = None
 
     def scores(self, out=None):
         lib = load_library()
@@ -300,9 +334,34 @@ class LpProblem(object):
         lib = load_library()
         if raw is None:
             raw = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        if self.split is not None and self.B > 0 and self.N > 0:
+            return self._count_ge_split(s_true, raw)
         with torch.cuda.device(self.device):
             _check(lib.kge_lp_count_ge(ctypes.byref(self.desc), _p(s_true), _p(raw), _stream()),
                    'kge_lp_count_ge')
+        return raw
+
+    def _count_ge_split(self, s_true, raw):
+        """Same counts as kge_lp_count_ge through the certified f16-split
+        prefilter (kge_lp_split_count) + exact recheck of the pairs inside the
+        error band; self.split = {'Es', 'enmax', 'overflow'} is set by the model."""
+        lib = load_library()
+        sp = self.split
+        q = self.keep[0]
+        K = int(self.desc.K0)
+        Qs = split_rows(q, K=K, is_query=True)
+        Bp = int(lib.kge_lp_split_rows_padded(self.B, 1))
+        thr = torch.empty(2 * Bp, dtype=torch.float32, device=self.device)
+        cap = int(min(SPLIT_LIST_PER_QUERY * self.B, 2 ** 31 - 1))
+        lst = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
+        n_list = torch.empty(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib.kge_lp_split_count(ctypes.byref(self.desc), _p(Qs), _p(sp['Es']), _p(s_true),
+                                          _p(sp['enmax']), SPLIT_EPS_SCALE, _p(thr), _p(raw), _p(lst), cap,
+                                          _p(n_list), _p(sp['overflow']), _stream()), 'kge_lp_split_count')
+            _check(lib.kge_lp_split_recheck(ctypes.byref(self.desc), _p(s_true), _p(lst), cap, _p(n_list),
+                                            _p(raw), _stream()), 'kge_lp_split_recheck')
+        self.last_split = (n_list, Qs, thr, lst)      # kept alive until the launches have run; tests read n_list
         return raw
 
     def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None):

@@ -1,0 +1,557 @@
+// Certified fp16-split prefilter for the fused rank count (gfx950).
+//
+// The rank of a test fact only needs  #{c : s[i,c] >= s_true[i]}  (get_rank,
+// utils/operations.py:37-61), not the scores.  For TransE-L2 through the norm
+// expansion  s = -max(||q||^2 + ||e||^2 - 2 q.e, 0)  the comparison
+// s[i,c] >= s_true[i] is  q.e - ||e_c||^2/2 >= (||q_i||^2 + s_true_i)/2 .
+// This file evaluates the left side APPROXIMATELY on the f16 matrix cores
+// (16x the fp32 MFMA rate) with a rigorous error bound eps_i:
+//
+//   x  = hi + lo + rho,  hi = f16(x), lo = f16(x - hi), |rho| <= 2^-22 |x|
+//   q.e ~ sum_k  qh*eh + qh*el + ql*eh          (3 v_mfma_f32_32x32x16_f16, fp32 accumulate)
+//
+// and classifies every (query, candidate) pair against two per-query thresholds:
+//   acc >= a_hi : certainly counted          acc < a_lo : certainly not counted
+//   a_lo <= acc < a_hi : UNCERTAIN -> appended to a list and re-scored by the
+//   exact scalar chain (kge_common.h: lp_pair_score, bit-identical to the fp32
+//   MFMA tile kernel and to oracle/kge_oracle.c).
+// raw_count[i] first receives #{acc >= a_lo}; kge_lp_split_recheck then takes 1
+// off for every listed pair whose exact score is below s_true.  The resulting
+// counts are therefore EXACTLY those of kge_lp_count_ge -- integer work stays
+// bit-exact -- while ~99.9% of the pairs never touch the fp32 pipe.
+//
+// Error bound used for the thresholds (split_thr_kernel), per unit of
+// P = ||q|| * max||e|| + max||e||^2 / 2  >=  sum_k |q_k e_k| + |aug term|:
+//   split residual   3 * 2^-22        (ql*el dropped, rho_q*e, q*rho_e)
+//   accumulation     n_terms * 2^-24  (n_terms = 3 * 16 * units fp32 adds, any order)
+//   exact chain      K * 2^-24        (the scalar fmaf chain it is compared with)
+// all doubled (covers truncating instead of rounding adders), plus absolute
+// terms for f16 subnormal lo parts (flushed or not) and for the roundings of
+// the threshold arithmetic itself.  tests/test_gpu_parity.py checks the counts
+// against the exact kernel and that they stay exact with the band shrunk 16x.
+//
+// Data layout: a split operand is [rows_p][units_p] cells of 64 bytes,
+//   cell = [hi k0..7][hi k8..15][lo k0..7][lo k8..15]   (f16, k within the 16-unit)
+// rows_p = rows rounded up to the tile (256 candidates / 192 queries; zero rows), units_p = k16 units rounded up
+// to 2; column K of the un-split matrix holds the augmentation (1 for queries,
+// -||e||^2/2 for candidates), everything scaled by 2^12 to sit inside f16 range
+// (|x| <= 4 is implied by the evaluator's norm guard, L2_EXPAND_LIMIT).
+//
+// Kernel: block tile 256 candidates (MFMA rows) x 192 queries (MFMA columns =
+// lanes), 8 waves of 64 x 96 (2x3 tiles of 32x32: 96 accumulator VGPRs, two waves
+// per SIMD -- accumulators stay in architectural VGPRs, which the VALU epilogue
+// can compare directly; AGPR accumulators would cost a v_accvgpr_read each), K staged 32 at a time through double-buffered LDS with an
+// XOR swizzle (16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)): both the
+// b128 stores and the MFMA fragment b128 loads are bank-conflict free without
+// padding.  Queries on the lane axis make thresholds and counters per-lane
+// constants, so the epilogue is two compares and an add per element.
+#include "kge_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TQ = 192, TC = 256;               // 256 accumulator registers leave hipcc no slack: 4 x 3 tiles
+constexpr int NT = 3;                           // 32x32 query tiles per wave (2 wave columns)
+constexpr int E_STAGE_BYTES = TC * 128;         // candidate operand, one stage (2 k16 units)
+constexpr int Q_STAGE_BYTES = TQ * 128;
+constexpr int STAGE_BYTES = E_STAGE_BYTES + Q_STAGE_BYTES;
+constexpr int UNC_CAP = 2048;                   // uncertain pairs buffered per tile
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES + 16 + UNC_CAP * 4;
+constexpr int SPLIT_SCALE_LOG2 = 12;
+
+struct SplitParams {
+    const char *Es, *Qs;  // split operands
+    int row_bytes;        // units_p * 64
+    int units;            // k16 units holding data (MFMA work)
+    int stages;           // units_p / 2
+    int64_t B, N;
+    const float2 *thr;    // (a_lo, a_hi) per padded query, scaled like the accumulators
+    int32_t *raw_count;
+    int32_t *list;        // cap x (query, candidate)
+    int32_t cap;
+    int32_t *list_count;  // device scalar
+    float *overflow;      // set to 1 when a buffer or the list overflowed
+    int q_panels, c_tiles;
+    int64_t n_items;
+    int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 2 no LDS stores,
+                          // 4 no epilogue, 8 LDS stores at the end of the stage
+};
+
+// ---- operand preparation ---------------------------------------------------
+__global__ void split_rows_kernel(const float *__restrict__ X, int64_t ld, int64_t rows, int64_t rows_p, int K,
+                                  int aug_mode, const float *__restrict__ aug, float aug_mul, float scale,
+                                  int units_p, uint4 *__restrict__ out)
+{
+    const int64_t total = rows_p * units_p;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / units_p;
+        const int u = (int)(idx % units_p);
+        union { _Float16 h[16]; uint4 v[2]; } hi, lo;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = u * 16 + e;
+            float x = 0.f;
+            if (row < rows) {
+                if (k < K) x = X[row * ld + k];
+                else if (k == K && aug_mode == 1) x = aug[row] * aug_mul;
+                else if (k == K && aug_mode == 2) x = aug_mul;
+            }
+            x *= scale;
+            _Float16 h = (_Float16)x;                   // round to nearest even
+            _Float16 l = (_Float16)(x - (float)h);      // x - hi is exact in fp32
+            if (row >= rows && k == K && aug_mode == 1) {
+                // padding candidate: hi = lo = -65504 makes its accumulator -2 * 65504 * 2^12,
+                // below every threshold a norm-guarded query can have (>= -16 * 2^24)
+                h = (_Float16)(-65504.f);
+                l = (_Float16)(-65504.f);
+            }
+            hi.h[e] = h;
+            lo.h[e] = l;
+        }
+        uint4 *o = out + idx * 4;
+        o[0] = hi.v[0]; o[1] = hi.v[1]; o[2] = lo.v[0]; o[3] = lo.v[1];
+    }
+}
+
+__global__ void split_thr_kernel(const float *__restrict__ qn, const float *__restrict__ s_true,
+                                 const float *__restrict__ enmax_p, int64_t B, int64_t Bp, int K, int units,
+                                 float eps_scale, float out_scale, float2 *__restrict__ thr, int32_t *list_count)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Bp; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= B) { thr[i] = make_float2(INFINITY, INFINITY); continue; }
+        const float q = qn[i], em = *enmax_p;
+        const float u = -s_true[i];                      // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
+        const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
+        const float eps_rel = 2.0f * ((float)(48 * units + K) * two24 + 3.0f * two22);
+        const float qnrm = sqrtf(q) * 1.000001f, enrm = sqrtf(em) * 1.000001f;
+        const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
+        const float eps_dot = eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
+        const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
+        const float mid = 0.5f * (q - u);
+        const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
+        thr[i] = make_float2((mid - hw) * out_scale, (mid + hw) * out_scale);
+    }
+}
+
+// ---- the count kernel --------------------------------------------------------
+template <int NWAVES, bool DBG>
+__global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
+{
+    const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
+    constexpr int NTHREADS = 64 * NWAVES;
+    constexpr int MT = TC / 32 / (NWAVES / 2);                      // 32x32 candidate tiles per wave
+    constexpr int EJ = TC * 8 / NTHREADS, QJ = TQ * 8 / NTHREADS;   // staged 16-byte chunks per thread
+    constexpr int SROWS = NTHREADS / 8;                             // rows covered by one staging pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *unc_cnt = reinterpret_cast<int *>(smem + 2 * STAGE_BYTES);
+    unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;   // waves: (NWAVES/2) x 2
+
+    // contiguous, balanced range of (query panel, candidate tile) items; blocks
+    // of one XCD (bid % 8) get adjacent ranges
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7, loc = bid >> 3;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    const int64_t item_begin = p.n_items * lid / nb, item_end = p.n_items * (lid + 1) / nb;
+    const int nitems = (int)(item_end - item_begin);
+    if (nitems <= 0) return;
+    const int S = p.stages, G = nitems * S;
+    if (tid == 0) *unc_cnt = 0;
+
+    // staging: 8 lanes cover one 128-byte row segment of a stage
+    const int srow = tid >> 3, scs = tid & 7;
+    const int sch = scs ^ ((srow >> 1) & 7);        // global chunk that lands in LDS chunk slot scs
+    const int st_lds = srow * 128 + scs * 16;
+    const int64_t rstep = (int64_t)SROWS * p.row_bytes;
+    static_assert((EJ == 4 && QJ == 3) || (EJ == 8 && QJ == 6), "staging below is written out for 8 or 4 waves");
+    // scalars, not arrays: hipcc leaves a uint4[] that is live across the loop in scratch memory
+    uint4 stE0, stE1, stE2, stE3, stE4, stE5, stE6, stE7, stQ0, stQ1, stQ2, stQ3, stQ4, stQ5;
+    int pf_it = 0, pf_s = 0;
+    const char *pfE = nullptr, *pfQ = nullptr;
+    auto pf_new_item = [&]() __attribute__((always_inline)) {
+        const int item = (int)item_begin + pf_it;
+        const int64_t q0 = (int64_t)(item / p.c_tiles) * TQ, c0 = (int64_t)(item % p.c_tiles) * TC;
+        pfE = p.Es + (c0 + srow) * p.row_bytes + sch * 16;
+        pfQ = p.Qs + (q0 + srow) * p.row_bytes + sch * 16;
+    };
+#define KGE_LD(PTR, J) (*reinterpret_cast<const uint4 *>((PTR) + (J) * rstep + pf_s * 128))
+    auto prefetch = [&]() __attribute__((always_inline)) {
+        stE0 = KGE_LD(pfE, 0); stE1 = KGE_LD(pfE, 1); stE2 = KGE_LD(pfE, 2); stE3 = KGE_LD(pfE, 3);
+        if constexpr (EJ == 8) {
+            stE4 = KGE_LD(pfE, 4); stE5 = KGE_LD(pfE, 5); stE6 = KGE_LD(pfE, 6); stE7 = KGE_LD(pfE, 7);
+        }
+        stQ0 = KGE_LD(pfQ, 0); stQ1 = KGE_LD(pfQ, 1); stQ2 = KGE_LD(pfQ, 2);
+        if constexpr (QJ == 6) { stQ3 = KGE_LD(pfQ, 3); stQ4 = KGE_LD(pfQ, 4); stQ5 = KGE_LD(pfQ, 5); }
+        if (++pf_s == S) {
+            pf_s = 0;
+            if (++pf_it < nitems) pf_new_item();
+        }
+    };
+#undef KGE_LD
+#define KGE_ST(BASE, J, V) (*reinterpret_cast<uint4 *>((BASE) + st_lds + (J) * SROWS * 128) = (V))
+    auto stage_store = [&](int buf) __attribute__((always_inline)) {
+        char *Eb = smem + buf * STAGE_BYTES, *Qb = Eb + E_STAGE_BYTES;
+        KGE_ST(Eb, 0, stE0); KGE_ST(Eb, 1, stE1); KGE_ST(Eb, 2, stE2); KGE_ST(Eb, 3, stE3);
+        if constexpr (EJ == 8) { KGE_ST(Eb, 4, stE4); KGE_ST(Eb, 5, stE5); KGE_ST(Eb, 6, stE6); KGE_ST(Eb, 7, stE7); }
+        KGE_ST(Qb, 0, stQ0); KGE_ST(Qb, 1, stQ1); KGE_ST(Qb, 2, stQ2);
+        if constexpr (QJ == 6) { KGE_ST(Qb, 3, stQ3); KGE_ST(Qb, 4, stQ4); KGE_ST(Qb, 5, stQ5); }
+    };
+#undef KGE_ST
+
+    // fragment addressing: row r of a tile, chunk (u*4 + piece*2 + half) ^ ((r>>1)&7)
+    const int sw = (l31 >> 1) & 7;
+    const int a_row = (wr * (MT * 32) + l31) * 128;
+    const int b_row = E_STAGE_BYTES + (wc * 96 + l31) * 128;
+    int coff[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) coff[u][pc] = ((u * 4 + pc * 2 + half) ^ sw) * 16;
+
+    f32x16 acc[MT][NT];
+    int cnt[NT] = {0, 0, 0};
+    float alo[NT], ahi[NT];
+    auto load_panel = [&](int64_t q0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float2 t = p.thr[q0 + wc * 96 + nt * 32 + l31];
+            alo[nt] = t.x;
+            ahi[nt] = t.y;
+        }
+    };
+    auto flush_counts = [&](int64_t q0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int v = cnt[nt] + __shfl_xor(cnt[nt], 32, 64);
+            const int64_t q = q0 + wc * 96 + nt * 32 + l31;
+            if (half == 0 && v != 0 && q < p.B) atomicAdd(&p.raw_count[q], v);
+            cnt[nt] = 0;
+        }
+    };
+
+    int64_t cur_q0 = (item_begin / p.c_tiles) * TQ;
+    load_panel(cur_q0);
+    pf_new_item();
+    prefetch();
+    stage_store(0);
+    __syncthreads();
+
+#define KGE_SLOAD(AH, AL, BH, BL, U)                                                                \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                              \
+        AH[mt] = *reinterpret_cast<const f16x8 *>(sb + a_row + mt * 4096 + coff[U][0]);             \
+        AL[mt] = *reinterpret_cast<const f16x8 *>(sb + a_row + mt * 4096 + coff[U][1]);             \
+    }                                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                              \
+        BH[nt] = *reinterpret_cast<const f16x8 *>(sb + b_row + nt * 4096 + coff[U][0]);             \
+        BL[nt] = *reinterpret_cast<const f16x8 *>(sb + b_row + nt * 4096 + coff[U][1]);             \
+    }
+#define KGE_SMMA(AH, AL, BH, BL)                                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BH[nt], acc[mt][nt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BL[nt], acc[mt][nt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[mt], BH[nt], acc[mt][nt], 0, 0, 0);
+
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    f16x8 zero8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) zero8[r] = (_Float16)0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16;
+
+    f16x8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
+    int it = 0, s = 0;
+    for (int g = 0; g < G; ++g) {
+        const int buf = g & 1;
+        const bool more = g + 1 < G;
+        if (more && !(dbg & 1)) prefetch();
+        const char *sb = smem + buf * STAGE_BYTES;
+        const int nunits = min(2, p.units - 2 * s);
+
+        if (!(dbg & 16) || g == 0) {
+            KGE_SLOAD(ah0, al0, bh0, bl0, 0)
+            KGE_SLOAD(ah1, al1, bh1, bl1, 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        KGE_SMMA(ah0, al0, bh0, bl0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !(dbg & 10)) stage_store(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nunits == 2) { // the last stage of a tile may hold a single k16 unit
+            KGE_SMMA(ah1, al1, bh1, bl1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && (dbg & 8) && !(dbg & 2)) stage_store(buf ^ 1);
+
+        const bool tile_done = s == S - 1;
+        if (tile_done && !(dbg & 4)) {
+            const int item = (int)item_begin + it;
+            const int ct = item % p.c_tiles;
+            const int64_t c0 = (int64_t)ct * TC;
+            // opaque to the optimiser: otherwise the ~100 list-entry constants below are
+            // hoisted out of the tile loop and held in registers across the MFMA stream
+            int cl_base = wr * (MT * 32) + 4 * half, ql_base = wc * 96 + l31;
+            asm volatile("" : "+v"(cl_base), "+v"(ql_base));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {   // 4 accumulator registers = rows 8*g4 + 4*half + {0..3}
+                        unsigned long long any = 0ull;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[mt][nt][g4 * 4 + e];
+                            const bool ge = v >= alo[nt];
+                            cnt[nt] += ge ? 1 : 0;
+                            any |= __ballot(ge && !(v >= ahi[nt]));
+                        }
+                        if (any) { // some lane holds an uncertain pair among these 4 rows: list them
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[mt][nt][g4 * 4 + e];
+                                if (v >= alo[nt] && !(v >= ahi[nt])) {
+                                    const int cl = cl_base + mt * 32 + e + 8 * g4;
+                                    const int idx = atomicAdd(unc_cnt, 1);
+                                    if (idx < UNC_CAP)
+                                        unc_list[idx] = ((unsigned)cl << 8) | (unsigned)(ql_base + nt * 32);
+                                }
+                            }
+                        }
+                    }
+                    acc[mt][nt] = zero16;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            if (wid == 0) { // hand this tile's uncertain pairs to the global list
+                const int n = *unc_cnt;
+                const int nc = min(n, UNC_CAP);
+                if (n > 0) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(p.list_count, nc);
+                    base = __shfl(base, 0, 64);
+                    if (n > UNC_CAP && lane == 0) *p.overflow = 1.0f;
+                    for (int i = lane; i < nc; i += 64) {
+                        const unsigned e = unc_list[i];
+                        const int pos = base + i;
+                        if (pos < p.cap) {
+                            p.list[2 * pos] = (int32_t)(cur_q0 + (e & 255u));
+                            p.list[2 * pos + 1] = (int32_t)(c0 + (e >> 8));
+                        } else {
+                            *p.overflow = 1.0f;
+                        }
+                    }
+                    if (lane == 0) *unc_cnt = 0;
+                }
+            }
+            if (more) { // query panel change (block-uniform): flush counters, load the next thresholds
+                const int64_t next_q0 = (int64_t)((item + 1) / p.c_tiles) * TQ;
+                if (next_q0 != cur_q0) {
+                    flush_counts(cur_q0);
+                    cur_q0 = next_q0;
+                    load_panel(cur_q0);
+                }
+            }
+        }
+        if (++s == S) { s = 0; ++it; }
+        if (!(dbg & 32)) __syncthreads();
+    }
+#undef KGE_SMMA
+#undef KGE_SLOAD
+    flush_counts(cur_q0);
+}
+
+// Exact re-scoring of the listed pairs: one lane per pair runs the scalar chain of
+// the fp32 path (lp_chain_dot: same order, one accumulator -- it cannot be split
+// across lanes), but the two rows of each of a wavefront's 64 pairs are fetched
+// COOPERATIVELY, 40 k at a time, as 160-byte row segments (10 lanes x float4 per
+// row instead of 64 lanes touching 64 different lines per load) and handed to
+// their lane through LDS (row stride 44 floats: conflict-free b128 stores and loads).
+constexpr int RC_KC = 40, RC_LD = 44;
+
+template <bool VEC4>
+__global__ __launch_bounds__(64) void split_recheck_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                           const int32_t *__restrict__ list, int32_t cap,
+                                                           const int32_t *__restrict__ list_count, int32_t *raw_count)
+{
+    __shared__ __attribute__((aligned(16))) float qs[64 * RC_LD];
+    __shared__ __attribute__((aligned(16))) float es[64 * RC_LD];
+    const int lane = threadIdx.x;
+    const int n = min(*list_count, cap);
+    const int ngroups = (n + 63) >> 6;
+    const int K = d.K0;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int pi = grp * 64 + lane;
+        const bool valid = pi < n;
+        const int pj = valid ? pi : grp * 64;       // idle lanes shadow the group's first pair
+        const int qi = list[2 * pj], ci = list[2 * pj + 1];
+        float acc = 0.f;
+        for (int k0 = 0; k0 < K; k0 += RC_KC) {
+            const int kc = min(RC_KC, K - k0);
+            const int pieces = (kc + 3) >> 2;
+            for (int idx = lane; idx < 64 * pieces; idx += 64) {   // uniform trip count
+                const int rr = idx / pieces, pc = idx - rr * pieces;
+                const int rq = __shfl(qi, rr, 64), rc = __shfl(ci, rr, 64);
+                const float *qp = d.A0 + (int64_t)rq * d.lda0 + k0 + pc * 4;
+                const float *ep = d.T0 + (int64_t)rc * d.ldt0 + k0 + pc * 4;
+                float4 qv, ev;
+                if (VEC4) {
+                    qv = *reinterpret_cast<const float4 *>(qp);
+                    ev = *reinterpret_cast<const float4 *>(ep);
+                } else {
+                    const int left = kc - pc * 4;
+                    qv.x = qp[0]; ev.x = ep[0];
+                    qv.y = left > 1 ? qp[1] : 0.f; ev.y = left > 1 ? ep[1] : 0.f;
+                    qv.z = left > 2 ? qp[2] : 0.f; ev.z = left > 2 ? ep[2] : 0.f;
+                    qv.w = left > 3 ? qp[3] : 0.f; ev.w = left > 3 ? ep[3] : 0.f;
+                }
+                *reinterpret_cast<float4 *>(qs + rr * RC_LD + pc * 4) = qv;
+                *reinterpret_cast<float4 *>(es + rr * RC_LD + pc * 4) = ev;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // one wave per block: LDS is in order
+            acc = lp_chain_dot(qs + lane * RC_LD, es + lane * RC_LD, kc, acc);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        if (valid) {
+            const float sc = lp_epilogue(d.mode, acc, d.qn[qi], d.en[ci]);
+            if (!(sc >= s_true[qi])) atomicSub(&raw_count[qi], 1);
+        }
+    }
+}
+
+template <int NWAVES, bool DBG>
+int launch_split(const SplitParams &p, int grid, hipStream_t s)
+{
+    auto k = lp_split_count_kernel<NWAVES, DBG>;
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NWAVES), SMEM_BYTES, s, p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+int split_num_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+} // namespace
+
+extern "C" int kge_lp_split_units(int K, int with_aug)
+{
+    return (int)round_up((K + (with_aug ? 1 : 0) + 15) / 16, 2);
+}
+
+extern "C" int64_t kge_lp_split_rows_padded(int64_t rows, int is_query) { return round_up(rows, is_query ? TQ : TC); }
+
+extern "C" int kge_lp_split_rows(const float *X, int64_t ld, int64_t rows, int K, int is_query, int aug_mode,
+                                 const float *aug, float aug_mul, void *out, kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ld < K || aug_mode < 0 || aug_mode > 2) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!X || !out || (aug_mode == 1 && !aug)) return KGE_EINVAL;
+    const int units_p = kge_lp_split_units(K, aug_mode != 0);
+    const int64_t rows_p = kge_lp_split_rows_padded(rows, is_query);
+    const int64_t total = rows_p * units_p;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, kge_s(stream), X, ld, rows, rows_p, K, aug_mode,
+                       aug, aug_mul, (float)(1 << SPLIT_SCALE_LOG2), units_p, reinterpret_cast<uint4 *>(out));
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_lp_split_count(const kge_lp_desc *d, const void *Qs, const void *Es, const float *s_true,
+                                  const float *enmax, float eps_scale, float *thr, int32_t *raw_count,
+                                  int32_t *list, int32_t cap, int32_t *list_count, float *overflow,
+                                  kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->mode != KGE_LP_L2_EXPAND || d->K1 != 0) return KGE_EINVAL;
+    if (d->B == 0 || d->N == 0) return 0;
+    if (!Qs || !Es || !s_true || !enmax || !thr || !raw_count || !list || cap <= 0 || !list_count || !overflow)
+        return KGE_EINVAL;
+    if (d->B > INT32_MAX || d->N > INT32_MAX) return KGE_EINVAL;
+    hipStream_t s = kge_s(stream);
+    const int K = d->K0;
+    const int units_p = kge_lp_split_units(K, 1);
+    const int units = (K + 1 + 15) / 16;
+    const int64_t Bp = kge_lp_split_rows_padded(d->B, 1);
+    const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
+    hipLaunchKernelGGL(split_thr_kernel, dim3((int)((Bp + 255) / 256)), dim3(256), 0, s, d->qn, s_true, enmax, d->B,
+                       Bp, K, units, eps_scale, out_scale, reinterpret_cast<float2 *>(thr), list_count);
+    KGE_CHECK_LAUNCH();
+
+    SplitParams p;
+    p.Es = reinterpret_cast<const char *>(Es);
+    p.Qs = reinterpret_cast<const char *>(Qs);
+    p.row_bytes = units_p * 64;
+    p.units = units;
+    p.stages = units_p / 2;
+    p.B = d->B;
+    p.N = d->N;
+    p.thr = reinterpret_cast<const float2 *>(thr);
+    p.raw_count = raw_count;
+    p.list = list;
+    p.cap = cap;
+    p.list_count = list_count;
+    p.overflow = overflow;
+    p.q_panels = (int)((d->B + TQ - 1) / TQ);
+    p.c_tiles = (int)((d->N + TC - 1) / TC);
+    p.n_items = (int64_t)p.q_panels * p.c_tiles;
+    p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
+    const int slots = split_num_cus();
+    const int grid = (int)(p.n_items < slots ? p.n_items : slots);
+    if (p.dbg) return launch_split<8, true>(p, grid, s);
+    return kge_env_int("KGE_SPLIT_WAVES", 8) == 4 ? launch_split<4, false>(p, grid, s) : launch_split<8, false>(p, grid, s);
+}
+
+extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
+                                    const int32_t *list_count, int32_t *raw_count, kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0 || d->N == 0) return 0;
+    if (!s_true || !list || cap <= 0 || !list_count || !raw_count) return KGE_EINVAL;
+    if (d->mode != KGE_LP_L2_EXPAND || d->K1 != 0) return KGE_EINVAL;
+    const bool vec4 = (d->K0 % 4 == 0) && (d->lda0 % 4 == 0) && (d->ldt0 % 4 == 0) && kge_aligned16(d->A0) &&
+                      kge_aligned16(d->T0);
+    const int grid = split_num_cus() * kge_env_int("KGE_SPLIT_RECHECK_WAVES", 7);
+    if (vec4)
+        hipLaunchKernelGGL(split_recheck_kernel<true>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list, cap,
+                           list_count, raw_count);
+    else
+        hipLaunchKernelGGL(split_recheck_kernel<false>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list,
+                           cap, list_count, raw_count);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}

@@ -280,11 +280,18 @@ class LinkPredictionEvaluator(object):
         if guard is not None:
             # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
             # cancellation error could exceed the score tolerance -> redo on the VALU kernel
-            worst = guard.sum()
+            flags = torch.stack([guard[0] + guard[1], guard[2]])
             if world > 1:
-                kdist.all_reduce_max(worst, self.group)     # every rank must take the same branch
-            if not float(worst.item()) <= self.model.L2_EXPAND_LIMIT:
+                kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
+            worst, overflow = flags.tolist()
+            redo = False
+            if not worst <= self.model.L2_EXPAND_LIMIT:
                 self.model._expand_ok = False
+                redo = True
+            elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
+                self.model._split_ok = False
+                redo = True
+            if redo:
                 out = torch.empty(4, n_local, dtype=torch.int64, device=device)
                 run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                     kg.relations[f_lo:f_hi].to(device), out)

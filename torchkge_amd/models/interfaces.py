@@ -212,8 +212,10 @@ class TranslationModel(Model):
         # tolerance (||q||^2 + ||e||^2 <= L2_EXPAND_LIMIT), direct otherwise.
         self.l2_mode = 'auto'
         self._expand_ok = None      # True/False: forced by the evaluator; None: guarded (see below)
-        self._lp_guard = None       # device scalar: max ||q||^2 + ||e||^2 seen during an evaluation
+        self._lp_guard = None       # device (4,): max ||q||^2, max ||e||^2, split-list overflow, spare
         self._guard_on = False
+        self.split_filter = True    # fused rank counts via the f16-split prefilter + exact recheck
+        self._split_ok = True       # cleared by the evaluator when the uncertain-pair list overflowed
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # reference TransH/TransD state_dicts carry the (n_rel, n_ent, d)
@@ -238,13 +240,14 @@ class TranslationModel(Model):
         if self.dissimilarity_type != 'L2' or self.l2_mode != 'auto' or self._kind is not None:
             return None                         # only the plain TransE path uses the expansion
         if self._lp_guard is None or self._lp_guard.device != device:
-            self._lp_guard = torch.zeros(2, dtype=torch.float32, device=device)
+            self._lp_guard = torch.zeros(4, dtype=torch.float32, device=device)
         self._guard_on = True
         return self._lp_guard
 
     def lp_guard_end(self):
         self._guard_on = False
         self._expand_ok = None
+        self._split_ok = True
 
     def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
         """Problem for s[i,c] = -diss(q_i, table[c] (- a w_i))."""
@@ -262,7 +265,14 @@ class TranslationModel(Model):
                 if ok is None:      # drop-in API call: decide now on the actual operands (one sync)
                     ok = q.shape[0] == 0 or float((qn.max() + en.max()).item()) <= self.L2_EXPAND_LIMIT
             if ok:
-                return _hip.LpProblem(_hip.LP_L2_EXPAND, q, table, qn=qn, en=en, c_base=c_base, K0=K0)
+                prob = _hip.LpProblem(_hip.LP_L2_EXPAND, q, table, qn=qn, en=en, c_base=c_base, K0=K0)
+                if guarded and self.split_filter and self._split_ok:
+                    # rank counts through the certified f16-split prefilter (16x MFMA rate)
+                    Kq = q.shape[1] if K0 is None else K0
+                    Es = self._cache.get('es_%d_%d' % (c_base, table.shape[0]), [table],
+                                         lambda: _hip.split_rows(table, K=Kq, aug=en))
+                    prob.split = {'Es': Es, 'enmax': ge, 'overflow': self._lp_guard[2:3]}
+                return prob
         return _hip.LpProblem(self._direct_mode(), q, table, Wq=Wq, scal=scal, r_idx=r_idx,
                               c_base=c_base, K0=K0)
 
