@@ -46,6 +46,7 @@ WORKLOADS = {
     'transe_nations': ('transe', 'nations', 50, 2),
 }
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+PEAK_F16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA (~2.5 PF, no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -62,6 +63,8 @@ def parse():
     ap.add_argument('--exchange', default='counts', choices=['counts', 'scores'])
     ap.add_argument('--materialize', action='store_true', help='fused=False: write the (B,N) scores')
     ap.add_argument('--l2-mode', default='auto', choices=['auto', 'expand', 'direct'])
+    ap.add_argument('--no-split', action='store_true',
+                    help='rank counts on the fp32 MFMA kernel only (no f16-split prefilter)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -119,6 +122,7 @@ def main():
     model = make_model(kind, p, tables, n_ent, n_rel).to(device)
     if kind == 'transe':
         model.l2_mode = args.l2_mode
+        model.split_filter = not args.no_split
 
     # synthetic KG of the dataset's shape; filters span the full graph (train+valid+test)
     cfg_seed = 1000 + sorted(WORKLOADS).index(args.workload)
@@ -165,6 +169,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the same evaluation with the rank counts on the fp32 MFMA kernel only (reported beside the headline)
+    f32_only_ms = None
+    if getattr(model, 'split_filter', False) and rank == 0 and world == 1:
+        model.split_filter = False
+        for _ in range(2):
+            ev.evaluate(args.batch, verbose=False)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ev.evaluate(args.batch, verbose=False)
+        sync()
+        f32_only_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        f32_ranks = [ev.rank_true_heads.clone(), ev.rank_true_tails.clone(), ev.filt_rank_true_heads.clone(),
+                     ev.filt_rank_true_tails.clone()]
+        model.split_filter = True
+        ev.evaluate(args.batch, verbose=False)
+        same = all(torch.equal(a, b) for a, b in zip(f32_ranks, [ev.rank_true_heads, ev.rank_true_tails,
+                                                                 ev.filt_rank_true_heads, ev.filt_rank_true_tails]))
+        if not same:
+            raise SystemExit('bench: f16-split ranks differ from the fp32 ranks')
+
     # scored triples of the whole job per step
     total_units = n_test * 2 * n_ent * (world if replicas else 1)
     value = total_units * args.steps / elapsed
@@ -182,12 +207,20 @@ def main():
     if rank == 0:
         B = min(args.batch, n_test)
         h, t, r = kg_test.head_idx[:B], kg_test.tail_idx[:B], kg_test.relations[:B]
+        guard_on = hasattr(model, 'lp_guard_begin') and model.lp_guard_begin(device) is not None
         with model.lp_session():
-            prob = model.lp_problem(h, t, r, 'tail', ent_lo=lo_r, ent_hi=hi_r)
+            prob = model.lp_problem(h, t, r, 'tail', ent_lo=lo_r, ent_hi=hi_r)   # as evaluate() builds it
             s_true = prob.pair_scores(t)
             raw = torch.zeros(B, dtype=torch.int32, device=device)
             scores_buf = torch.empty(B, n_ent, device=device) if args.materialize else None
-            run = (lambda: prob.scores(scores_buf)) if args.materialize else (lambda: prob.count_ge(s_true, raw))
+            split = prob.split is not None and not args.materialize
+            if split:       # dominant kernel of the fused path: the f16-split MFMA count kernel
+                prep = prob.split_prepare()
+                run = lambda: prob.split_count(prep, s_true, raw)
+            elif args.materialize:
+                run = lambda: prob.scores(scores_buf)
+            else:
+                run = lambda: prob.count_ge(s_true, raw)
             for _ in range(3):
                 run()
             reps = 20
@@ -199,9 +232,25 @@ def main():
             e1.record()
             torch.cuda.synchronize(device)
             kern_s = e0.elapsed_time(e1) / 1e3 / reps
+        if guard_on:
+            model.lp_guard_end()
         K = d * (2 if kind == 'complex' else 1)
         mode = prob.desc.mode
-        if mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND):
+        peak = PEAK_FP32_TFLOPS
+        extra = {}
+        if split:
+            # executed matrix-core work: 3 f16 products (hi*hi, hi*lo, lo*hi) over K+1 columns
+            # padded to 16: 2 flop each; the algorithmic fp32 work of the same pairs is 2K
+            k16 = (K + 1 + 15) // 16 * 16
+            flops_per_pair = 3 * 2 * k16
+            kname = 'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)'
+            peak = PEAK_F16_TFLOPS
+            extra = {'algorithmic_flops_per_pair': 2 * K,
+                     'fp32_equivalent_TFLOPs': round(2 * K * B * n_ent / kern_s / 1e12, 2),
+                     'note': 'ranks are bit-identical to the fp32 path (pairs inside the proven error band are '
+                             're-scored exactly by kge_lp_split_recheck); achieved counts the f16 MFMA flops '
+                             'actually executed, peak is the dense f16 MFMA peak'}
+        elif mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND):
             flops_per_pair = 2 * K           # one fp32 MFMA FMA per (pair, k)
             kname = 'lp_gemm_kernel (fp32 MFMA 32x32x2)'
         else:
@@ -213,13 +262,14 @@ def main():
         if os.path.exists(tfile):
             try:
                 # measured off-line with rocprofv3 --pmc (see profiles/), bytes per launch
-                traffic = (json.load(open(tfile)).get(args.workload) or {}).get('bytes_per_launch')
+                traffic = (json.load(open(tfile)).get(args.workload + ('' if split else ':no-split')) or {}).get('bytes_per_launch')
             except Exception:
                 traffic = None
-        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_TFLOPS, 4), 'traffic': traffic,
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4),
                 'pairs_per_launch': B * n_ent, 'flops_per_pair': flops_per_pair}
+        roof.update(extra)
 
     # ---- secondary numbers of the same hot path: scoring_function (K1) and corrupt_batch (K5) ----
     sec = None
@@ -311,12 +361,15 @@ def main():
                                                        'rank counts' if args.exchange == 'counts' else 'score tiles')
         else:
             par = 'query-shards-%d' % world
+        used_split = bool(roof and 'fp32_equivalent_TFLOPs' in roof)
+        dtype = 'f32 (f16 hi/lo-split MFMA prefilter + exact f32 recheck; ranks bit-identical to f32)' \
+            if used_split else 'f32'
         line = {
             'metric': 'link-prediction triples scored/sec (filtered LP eval, both sides)',
             'value': round(value, 1), 'unit': 'triples_scored/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
                                    'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
                                        kind, d, p, shape + (' x%d entity shards' % world if ent_weak else ''), n_ent_full, n_rel, n_test, args.batch),
@@ -324,6 +377,9 @@ def main():
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
             'roofline': roof, 'cpu_baseline': cpu, 'secondary': sec,
+            'f32_mfma_only': None if f32_only_ms is None else {
+                'ms_per_step': round(f32_only_ms, 4), 'value': round(total_units / f32_only_ms * 1e3, 1),
+                'ranks_identical_to_headline_run': True},
         }
         print(json.dumps(line), flush=True)
     if world > 1:

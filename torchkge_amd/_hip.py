@@ -341,27 +341,46 @@ class LpProblem(object):
                    'kge_lp_count_ge')
         return raw
 
-    def _count_ge_split(self, s_true, raw):
-        """Same counts as kge_lp_count_ge through the certified f16-split
-        prefilter (kge_lp_split_count) + exact recheck of the pairs inside the
-        error band; self.split = {'Es', 'enmax', 'overflow'} is set by the model."""
+    def split_prepare(self):
+        """Per-batch operands of the f16-split prefilter: the split query matrix and
+        the scratch buffers (thresholds, uncertain-pair list, its counter)."""
         lib = load_library()
-        sp = self.split
-        q = self.keep[0]
         K = int(self.desc.K0)
-        Qs = split_rows(q, K=K, is_query=True)
+        Qs = split_rows(self.keep[0], K=K, is_query=True)
         Bp = int(lib.kge_lp_split_rows_padded(self.B, 1))
         thr = torch.empty(2 * Bp, dtype=torch.float32, device=self.device)
         cap = int(min(SPLIT_LIST_PER_QUERY * self.B, 2 ** 31 - 1))
         lst = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
         n_list = torch.empty(1, dtype=torch.int32, device=self.device)
+        return {'Qs': Qs, 'thr': thr, 'cap': cap, 'list': lst, 'n_list': n_list}
+
+    def split_count(self, prep, s_true, raw):
+        """kge_lp_split_count: thresholds + the f16 MFMA count kernel (raw += #{acc >= a_lo})."""
+        lib = load_library()
+        sp = self.split
         with torch.cuda.device(self.device):
-            _check(lib.kge_lp_split_count(ctypes.byref(self.desc), _p(Qs), _p(sp['Es']), _p(s_true),
-                                          _p(sp['enmax']), SPLIT_EPS_SCALE, _p(thr), _p(raw), _p(lst), cap,
-                                          _p(n_list), _p(sp['overflow']), _stream()), 'kge_lp_split_count')
-            _check(lib.kge_lp_split_recheck(ctypes.byref(self.desc), _p(s_true), _p(lst), cap, _p(n_list),
-                                            _p(raw), _stream()), 'kge_lp_split_recheck')
-        self.last_split = (n_list, Qs, thr, lst)      # kept alive until the launches have run; tests read n_list
+            _check(lib.kge_lp_split_count(ctypes.byref(self.desc), _p(prep['Qs']), _p(sp['Es']), _p(s_true),
+                                          _p(sp['enmax']), SPLIT_EPS_SCALE, _p(prep['thr']), _p(raw),
+                                          _p(prep['list']), prep['cap'], _p(prep['n_list']), _p(sp['overflow']),
+                                          _stream()), 'kge_lp_split_count')
+        return raw
+
+    def split_recheck(self, prep, s_true, raw):
+        """kge_lp_split_recheck: exact re-scoring of the pairs inside the error band."""
+        lib = load_library()
+        with torch.cuda.device(self.device):
+            _check(lib.kge_lp_split_recheck(ctypes.byref(self.desc), _p(s_true), _p(prep['list']), prep['cap'],
+                                            _p(prep['n_list']), _p(raw), _stream()), 'kge_lp_split_recheck')
+        return raw
+
+    def _count_ge_split(self, s_true, raw):
+        """Same counts as kge_lp_count_ge through the certified f16-split
+        prefilter + exact recheck of the pairs inside the error band;
+        self.split = {'Es', 'enmax', 'overflow'} is set by the model."""
+        prep = self.split_prepare()
+        self.split_count(prep, s_true, raw)
+        self.split_recheck(prep, s_true, raw)
+        self.last_split = (prep['n_list'], prep)     # kept alive until the launches have run; tests read n_list
         return raw
 
     def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None):

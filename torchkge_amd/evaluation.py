@@ -255,7 +255,7 @@ class LinkPredictionEvaluator(object):
             # replayed without host launch gaps (capture is keyed on everything
             # that fixes shapes and addresses; table VALUES may change freely)
             key = (b_size, n_local, str(device), self.fused, overlap,
-                   getattr(self.model, '_expand_ok', None),     # kernel choice is baked into the capture
+                   getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
                    tuple(p_.data_ptr() for p_ in self.model.parameters()))
             if self._graph_key != key:
                 st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
