@@ -101,6 +101,84 @@ __device__ __forceinline__ float lp_pair_score(const kge_lp_desc &d, int64_t i, 
     return -acc;
 }
 
+// ---- wave-cooperative exact pair scores (MFMA modes) ------------------------------
+// One lane per (query, candidate) pair runs the scalar chain above -- one
+// accumulator in a fixed order, it cannot be split across lanes -- but the two
+// rows of each of the wavefront's 64 pairs are fetched COOPERATIVELY, 40 k at a
+// time, as 160-byte row segments (10 lanes x float4 per row, all of a chunk's
+// loads in flight together) and handed to their lane through LDS (row stride 44
+// floats: conflict-free b128 stores and loads).  A lane-per-row gather touches 64
+// different cache lines per load instruction and is ~5x slower.
+// Every lane of the wavefront must call; `qs`/`es` are this wavefront's own
+// 64 x KGE_PS_LD floats of LDS.  Bit-identical to lp_pair_score.
+constexpr int KGE_PS_KC = 40, KGE_PS_LD = 44;
+
+static inline bool kge_lp_vec4(const kge_lp_desc &d)
+{
+    bool v = (d.K0 % 4 == 0) && (d.lda0 % 4 == 0) && (d.ldt0 % 4 == 0) && kge_aligned16(d.A0) && kge_aligned16(d.T0);
+    if (d.K1 > 0)
+        v = v && (d.K1 % 4 == 0) && (d.lda1 % 4 == 0) && (d.ldt1 % 4 == 0) && kge_aligned16(d.A1) && kge_aligned16(d.T1);
+    return v;
+}
+
+template <bool VEC4>
+__device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, int64_t lda,
+                                                   const float *__restrict__ T, int64_t ldt, int K, int qi, int ci,
+                                                   float *qs, float *es, float acc)
+{
+    const int lane = threadIdx.x & 63;
+    for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {
+        const int kc = min(KGE_PS_KC, K - k0);
+        if (VEC4 && kc == KGE_PS_KC) {
+            float4 qv[KGE_PS_KC / 4], ev[KGE_PS_KC / 4];
+#pragma unroll
+            for (int it = 0; it < KGE_PS_KC / 4; ++it) {
+                const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
+                const int rq = __shfl(qi, rr, 64), rc = __shfl(ci, rr, 64);
+                qv[it] = *reinterpret_cast<const float4 *>(A + (int64_t)rq * lda + k0 + pc * 4);
+                ev[it] = *reinterpret_cast<const float4 *>(T + (int64_t)rc * ldt + k0 + pc * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < KGE_PS_KC / 4; ++it) {
+                const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
+                *reinterpret_cast<float4 *>(qs + rr * KGE_PS_LD + pc * 4) = qv[it];
+                *reinterpret_cast<float4 *>(es + rr * KGE_PS_LD + pc * 4) = ev[it];
+            }
+        } else {
+            const int pieces = (kc + 3) >> 2;
+            for (int idx = lane; idx < 64 * pieces; idx += 64) { // uniform trip count
+                const int rr = idx / pieces, pc = idx - rr * pieces;
+                const int rq = __shfl(qi, rr, 64), rc = __shfl(ci, rr, 64);
+                const float *qp = A + (int64_t)rq * lda + k0 + pc * 4;
+                const float *ep = T + (int64_t)rc * ldt + k0 + pc * 4;
+                const int left = kc - pc * 4;
+                float4 qv, ev;
+                qv.x = qp[0]; ev.x = ep[0];
+                qv.y = left > 1 ? qp[1] : 0.f; ev.y = left > 1 ? ep[1] : 0.f;
+                qv.z = left > 2 ? qp[2] : 0.f; ev.z = left > 2 ? ep[2] : 0.f;
+                qv.w = left > 3 ? qp[3] : 0.f; ev.w = left > 3 ? ep[3] : 0.f;
+                *reinterpret_cast<float4 *>(qs + rr * KGE_PS_LD + pc * 4) = qv;
+                *reinterpret_cast<float4 *>(es + rr * KGE_PS_LD + pc * 4) = ev;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same wave: LDS executes in order
+        acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, kc, acc);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    return acc;
+}
+
+// MFMA modes only (KGE_LP_DOT / KGE_LP_L2_EXPAND); (qi, ci) must be valid rows on every lane
+template <bool VEC4>
+__device__ __forceinline__ float lp_pair_score_staged(const kge_lp_desc &d, int qi, int ci, float *qs, float *es)
+{
+    float acc = lp_staged_segment<VEC4>(d.A0, d.lda0, d.T0, d.ldt0, d.K0, qi, ci, qs, es, 0.0f);
+    if (d.K1 > 0) acc = lp_staged_segment<VEC4>(d.A1, d.lda1, d.T1, d.ldt1, d.K1, qi, ci, qs, es, acc);
+    float qn = 0.f, en = 0.f;
+    if (d.mode == KGE_LP_L2_EXPAND) { qn = d.qn[qi]; en = d.en[ci]; }
+    return lp_epilogue(d.mode, acc, qn, en);
+}
+
 // tuning knob for experiments (env KGE_LP_TARGET_BLOCKS), default `dflt`
 static inline int kge_env_int(const char *name, int dflt)
 {

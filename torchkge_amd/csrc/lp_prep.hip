@@ -130,6 +130,66 @@ __global__ void row_sqnorm_kernel(const float *__restrict__ X, int64_t ld, int64
         if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned *>(max_io), m);
     }
 }
+// The same chains with the rows fetched cooperatively: a wavefront owns 64 rows,
+// loads them 40 k at a time as 160-byte segments (10 lanes x float4 per row, all
+// loads of a chunk in flight) and hands each lane its row through LDS (stride 44
+// floats, conflict-free b128).  ~5x faster than 64 lanes striding 64 rows.
+__global__ __launch_bounds__(64) void row_sqnorm_staged_kernel(const float *__restrict__ X, int64_t ld, int64_t rows,
+                                                               int K, float *out, float *max_io)
+{
+    __shared__ __attribute__((aligned(16))) float xs[64 * KGE_PS_LD];
+    const int lane = threadIdx.x;
+    float big = 0.f;
+    const int64_t ngroups = (rows + 63) >> 6;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t row0 = grp * 64;
+        float acc = 0.f;
+        for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {   // K % 4 == 0, ld % 4 == 0, X 16-byte aligned (checked by the host)
+            const int kc = min(KGE_PS_KC, K - k0);
+            const int pieces = kc >> 2;
+            if (kc == KGE_PS_KC) {
+                float4 v[KGE_PS_KC / 4];
+#pragma unroll
+                for (int it = 0; it < KGE_PS_KC / 4; ++it) {
+                    const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
+                    const int64_t r = min(row0 + rr, rows - 1);
+                    v[it] = *reinterpret_cast<const float4 *>(X + r * ld + k0 + pc * 4);
+                }
+#pragma unroll
+                for (int it = 0; it < KGE_PS_KC / 4; ++it) {
+                    const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
+                    *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) = v[it];
+                }
+            } else {
+                for (int idx = lane; idx < 64 * pieces; idx += 64) {
+                    const int rr = idx / pieces, pc = idx - rr * pieces;
+                    const int64_t r = min(row0 + rr, rows - 1);
+                    *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) =
+                        *reinterpret_cast<const float4 *>(X + r * ld + k0 + pc * 4);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const float *x = xs + lane * KGE_PS_LD;
+            for (int k = 0; k < kc; k += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(x + k);
+                acc = fmaf(t.x, t.x, acc);
+                acc = fmaf(t.y, t.y, acc);
+                acc = fmaf(t.z, t.z, acc);
+                acc = fmaf(t.w, t.w, acc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        if (row0 + lane < rows) {
+            out[row0 + lane] = acc;
+            big = __uint_as_float(max(__float_as_uint(big), __float_as_uint(acc)));
+        }
+    }
+    if (max_io) {
+        unsigned m = __float_as_uint(big);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned *>(max_io), m);
+    }
+}
 __global__ void row_dot_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t ld,
                                int64_t rows, int K, float scale, float *out)
 {
@@ -192,8 +252,14 @@ extern "C" int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, f
     if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
     if (rows == 0) return 0;
     if (!X || !out) return KGE_EINVAL;
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, ld, rows, K, out,
-                       max_io);
+    if (K % 4 == 0 && ld % 4 == 0 && kge_aligned16(X)) {
+        const int64_t groups = (rows + 63) / 64;
+        hipLaunchKernelGGL(row_sqnorm_staged_kernel, dim3((int)(groups < 256 * 14 ? groups : 256 * 14)), dim3(64), 0,
+                           kge_s(stream), X, ld, rows, K, out, max_io);
+    } else {
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, ld, rows, K,
+                           out, max_io);
+    }
     KGE_CHECK_LAUNCH();
     return 0;
 }

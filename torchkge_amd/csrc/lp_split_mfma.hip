@@ -375,61 +375,25 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     flush_counts(cur_q0);
 }
 
-// Exact re-scoring of the listed pairs: one lane per pair runs the scalar chain of
-// the fp32 path (lp_chain_dot: same order, one accumulator -- it cannot be split
-// across lanes), but the two rows of each of a wavefront's 64 pairs are fetched
-// COOPERATIVELY, 40 k at a time, as 160-byte row segments (10 lanes x float4 per
-// row instead of 64 lanes touching 64 different lines per load) and handed to
-// their lane through LDS (row stride 44 floats: conflict-free b128 stores and loads).
-constexpr int RC_KC = 40, RC_LD = 44;
-
+// Exact re-scoring of the listed pairs: one lane per pair, rows staged cooperatively
+// (kge_common.h: lp_pair_score_staged).
 template <bool VEC4>
 __global__ __launch_bounds__(64) void split_recheck_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
                                                            const int32_t *__restrict__ list, int32_t cap,
                                                            const int32_t *__restrict__ list_count, int32_t *raw_count)
 {
-    __shared__ __attribute__((aligned(16))) float qs[64 * RC_LD];
-    __shared__ __attribute__((aligned(16))) float es[64 * RC_LD];
+    __shared__ __attribute__((aligned(16))) float qs[64 * KGE_PS_LD];
+    __shared__ __attribute__((aligned(16))) float es[64 * KGE_PS_LD];
     const int lane = threadIdx.x;
     const int n = min(*list_count, cap);
     const int ngroups = (n + 63) >> 6;
-    const int K = d.K0;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int pi = grp * 64 + lane;
         const bool valid = pi < n;
         const int pj = valid ? pi : grp * 64;       // idle lanes shadow the group's first pair
         const int qi = list[2 * pj], ci = list[2 * pj + 1];
-        float acc = 0.f;
-        for (int k0 = 0; k0 < K; k0 += RC_KC) {
-            const int kc = min(RC_KC, K - k0);
-            const int pieces = (kc + 3) >> 2;
-            for (int idx = lane; idx < 64 * pieces; idx += 64) {   // uniform trip count
-                const int rr = idx / pieces, pc = idx - rr * pieces;
-                const int rq = __shfl(qi, rr, 64), rc = __shfl(ci, rr, 64);
-                const float *qp = d.A0 + (int64_t)rq * d.lda0 + k0 + pc * 4;
-                const float *ep = d.T0 + (int64_t)rc * d.ldt0 + k0 + pc * 4;
-                float4 qv, ev;
-                if (VEC4) {
-                    qv = *reinterpret_cast<const float4 *>(qp);
-                    ev = *reinterpret_cast<const float4 *>(ep);
-                } else {
-                    const int left = kc - pc * 4;
-                    qv.x = qp[0]; ev.x = ep[0];
-                    qv.y = left > 1 ? qp[1] : 0.f; ev.y = left > 1 ? ep[1] : 0.f;
-                    qv.z = left > 2 ? qp[2] : 0.f; ev.z = left > 2 ? ep[2] : 0.f;
-                    qv.w = left > 3 ? qp[3] : 0.f; ev.w = left > 3 ? ep[3] : 0.f;
-                }
-                *reinterpret_cast<float4 *>(qs + rr * RC_LD + pc * 4) = qv;
-                *reinterpret_cast<float4 *>(es + rr * RC_LD + pc * 4) = ev;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // one wave per block: LDS is in order
-            acc = lp_chain_dot(qs + lane * RC_LD, es + lane * RC_LD, kc, acc);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-        if (valid) {
-            const float sc = lp_epilogue(d.mode, acc, d.qn[qi], d.en[ci]);
-            if (!(sc >= s_true[qi])) atomicSub(&raw_count[qi], 1);
-        }
+        const float sc = lp_pair_score_staged<VEC4>(d, qi, ci, qs, es);
+        if (valid && !(sc >= s_true[qi])) atomicSub(&raw_count[qi], 1);
     }
 }
 
@@ -543,8 +507,7 @@ extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, c
     if (d->B == 0 || d->N == 0) return 0;
     if (!s_true || !list || cap <= 0 || !list_count || !raw_count) return KGE_EINVAL;
     if (d->mode != KGE_LP_L2_EXPAND || d->K1 != 0) return KGE_EINVAL;
-    const bool vec4 = (d->K0 % 4 == 0) && (d->lda0 % 4 == 0) && (d->ldt0 % 4 == 0) && kge_aligned16(d->A0) &&
-                      kge_aligned16(d->T0);
+    const bool vec4 = kge_lp_vec4(*d);
     const int grid = split_num_cus() * kge_env_int("KGE_SPLIT_RECHECK_WAVES", 7);
     if (vec4)
         hipLaunchKernelGGL(split_recheck_kernel<true>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list, cap,

@@ -141,6 +141,25 @@ __global__ void pair_scores_kernel(const kge_lp_desc d, const int64_t *__restric
     }
 }
 
+// MFMA modes: one wavefront per block, rows staged cooperatively (lp_pair_score_staged)
+template <bool VEC4>
+__global__ __launch_bounds__(64) void pair_scores_staged_kernel(const kge_lp_desc d, const int64_t *__restrict__ qi,
+                                                                const int64_t *__restrict__ ci, int64_t P, float *out)
+{
+    __shared__ __attribute__((aligned(16))) float qs[64 * KGE_PS_LD];
+    __shared__ __attribute__((aligned(16))) float es[64 * KGE_PS_LD];
+    const int lane = threadIdx.x;
+    const int64_t ngroups = (P + 63) >> 6;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t p = grp * 64 + lane;
+        int64_t i = 0, c = -1;
+        if (p < P) { i = qi ? qi[p] : p; c = ci[p] - d.c_base; }
+        const bool ok = p < P && c >= 0 && c < d.N;
+        const float sc = lp_pair_score_staged<VEC4>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
+        if (p < P) out[p] = ok ? sc : 0.f;
+    }
+}
+
 // 8 lanes per query (8 queries per wavefront); the lanes of a group stride over
 // the query's filter segment and score each listed candidate with the same
 // arithmetic as the tile kernels.  Most segments hold a handful of entities.
@@ -177,6 +196,56 @@ __global__ __launch_bounds__(256) void filter_sub_kernel(const kge_lp_desc d, co
             found += __shfl_xor(found, o, 64);
         }
         if (i < d.B && sub_lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
+    }
+}
+
+// MFMA modes: the same 8-lanes-per-query walk, but every round's 64 (query, candidate)
+// pairs are scored through the cooperative row staging (one wavefront per block)
+template <bool VEC4>
+__global__ __launch_bounds__(64) void filter_sub_staged_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                               const int64_t *__restrict__ true_idx,
+                                                               const int64_t *__restrict__ seg_lo,
+                                                               const int64_t *__restrict__ seg_hi,
+                                                               const int32_t *__restrict__ targets,
+                                                               int32_t *sub_out, int32_t *found_out)
+{
+    constexpr int LPQ = 8;
+    __shared__ __attribute__((aligned(16))) float qs[64 * KGE_PS_LD];
+    __shared__ __attribute__((aligned(16))) float es[64 * KGE_PS_LD];
+    const int lane = threadIdx.x, sub_lane = lane & (LPQ - 1);
+    const int64_t nq = (d.B + 7) >> 3;                 // groups of 8 queries
+    for (int64_t qg = blockIdx.x; qg < nq; qg += gridDim.x) {
+        const int64_t i = qg * 8 + (lane >> 3);
+        const bool live = i < d.B;
+        int sub = 0, found = 0;
+        const float tv = live ? s_true[i] : 0.f;
+        const int64_t ti = live ? true_idx[i] : -1;
+        const int64_t lo = live ? seg_lo[i] : 0, hi = live ? seg_hi[i] : 0;
+        const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+        int len = (int)(hi - lo);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
+        for (int j0 = 0; j0 < len; j0 += LPQ) {        // wave-uniform trip count
+            const int64_t j = lo + j0 + sub_lane;
+            bool score = false;
+            int64_t c = 0;
+            if (j < hi) {
+                const int64_t cg = targets[j];
+                c = cg - d.c_base;
+                if (c >= 0 && c < d.N) {
+                    if (cg == ti) found = 1;
+                    else score = true;
+                }
+            }
+            const float sc = lp_pair_score_staged<VEC4>(d, score ? (int)i : 0, score ? (int)c : 0, qs, es);
+            if (score) sub += ((sc >= tv) ? 1 : 0) - neg_inf_counts;
+        }
+#pragma unroll
+        for (int o = LPQ / 2; o > 0; o >>= 1) {
+            sub += __shfl_xor(sub, o, 64);
+            found += __shfl_xor(found, o, 64);
+        }
+        if (live && sub_lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
     }
 }
 
@@ -345,7 +414,16 @@ extern "C" int kge_lp_pair_scores(const kge_lp_desc *d, const int64_t *qi, const
     if (P < 0) return KGE_EINVAL;
     if (P == 0) return 0;
     if (!ci || !out) return KGE_EINVAL;
-    hipLaunchKernelGGL(pair_scores_kernel, dim3(grid1d(P, 64)), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
+    if (d->mode <= KGE_LP_L2_EXPAND && d->B > 0 && d->N > 0 && d->B <= INT32_MAX && d->N <= INT32_MAX) {
+        const int64_t groups = (P + 63) / 64;
+        const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
+        if (kge_lp_vec4(*d))
+            hipLaunchKernelGGL(pair_scores_staged_kernel<true>, dim3(grid), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
+        else
+            hipLaunchKernelGGL(pair_scores_staged_kernel<false>, dim3(grid), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
+    } else {
+        hipLaunchKernelGGL(pair_scores_kernel, dim3(grid1d(P, 64)), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
+    }
     KGE_CHECK_LAUNCH();
     return 0;
 }
@@ -358,8 +436,19 @@ extern "C" int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, cons
     if (rc) return rc;
     if (d->B == 0) return 0;
     if (!s_true || !true_idx || !seg_lo || !seg_hi || !sub || !found) return KGE_EINVAL;
-    hipLaunchKernelGGL(filter_sub_kernel, dim3(grid1d(d->B, 32)), dim3(256), 0, kge_s(stream), *d, s_true, true_idx,
-                       seg_lo, seg_hi, targets, sub, found);
+    if (d->mode <= KGE_LP_L2_EXPAND && d->N > 0 && d->B <= INT32_MAX && d->N <= INT32_MAX) {
+        const int64_t groups = (d->B + 7) / 8;
+        const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
+        if (kge_lp_vec4(*d))
+            hipLaunchKernelGGL(filter_sub_staged_kernel<true>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true,
+                               true_idx, seg_lo, seg_hi, targets, sub, found);
+        else
+            hipLaunchKernelGGL(filter_sub_staged_kernel<false>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true,
+                               true_idx, seg_lo, seg_hi, targets, sub, found);
+    } else {
+        hipLaunchKernelGGL(filter_sub_kernel, dim3(grid1d(d->B, 32)), dim3(256), 0, kge_s(stream), *d, s_true, true_idx,
+                           seg_lo, seg_hi, targets, sub, found);
+    }
     KGE_CHECK_LAUNCH();
     return 0;
 }
