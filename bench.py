@@ -67,6 +67,7 @@ def parse():
                     help='rank counts on the fp32 MFMA kernel only (no f16-split prefilter)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
+    ap.add_argument('--overlap', action='store_true', help='two-stream overlap of the short kernels (default: single stream)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend; 'gloo' only to dry-run the N>1 logic on one GPU")
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
@@ -148,7 +149,7 @@ def main():
     if multi and not replicas:
         shard = 'entities' if args.shard == 'entities' else 'queries'
     ev = tk.LinkPredictionEvaluator(model, kg_test, fused=not args.materialize, shard=shard,
-                                    exchange=args.exchange, graph=not args.no_graph)
+                                    exchange=args.exchange, graph=not args.no_graph, overlap=args.overlap)
 
     def sync():
         torch.cuda.synchronize(device)

@@ -284,8 +284,8 @@ def test_evaluator_vs_reference(hip, kind, p):
     ev3.evaluate(b_size=B, verbose=False)
     for nm in names:
         assert torch.equal(getattr(ev, nm), getattr(ev3, nm))
-    # single-stream (no two-stream overlap of the short kernels) gives the same ranks
-    ev6 = tk.LinkPredictionEvaluator(m, kg_test, overlap=False)
+    # two-stream overlap of the short kernels (off by default: the count kernel fills every CU) gives the same ranks
+    ev6 = tk.LinkPredictionEvaluator(m, kg_test, overlap=True)
     ev6.evaluate(b_size=B, verbose=False)
     for nm in names:
         assert torch.equal(getattr(ev, nm), getattr(ev6, nm))

@@ -138,7 +138,7 @@ __global__ void split_thr_kernel(const float *__restrict__ qn, const float *__re
 }
 
 // ---- the count kernel --------------------------------------------------------
-template <int NWAVES, bool DBG>
+template <int NWAVES, bool DBG, bool GLDS>
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
@@ -180,6 +180,23 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         pfQ = p.Qs + (q0 + srow) * p.row_bytes + sch * 16;
     };
 #define KGE_LD(PTR, J) (*reinterpret_cast<const uint4 *>((PTR) + (J) * rstep + pf_s * 128))
+    // GLDS: global -> LDS directly (LDS-DMA, 1 KiB per wave-instruction: the 64 lanes' 16-byte
+    // pieces land at consecutive LDS addresses, which is exactly this wave's 8 rows x 128 bytes)
+    auto dma = [&](const char *g, char *l) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+    };
+    auto prefetch_dma = [&](int buf) __attribute__((always_inline)) {
+        char *Eb = smem + buf * STAGE_BYTES + wid * 1024, *Qb = Eb + E_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < EJ; ++j) dma(pfE + j * rstep + pf_s * 128, Eb + j * SROWS * 128);
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) dma(pfQ + j * rstep + pf_s * 128, Qb + j * SROWS * 128);
+        if (++pf_s == S) {
+            pf_s = 0;
+            if (++pf_it < nitems) pf_new_item();
+        }
+    };
     auto prefetch = [&]() __attribute__((always_inline)) {
         stE0 = KGE_LD(pfE, 0); stE1 = KGE_LD(pfE, 1); stE2 = KGE_LD(pfE, 2); stE3 = KGE_LD(pfE, 3);
         if constexpr (EJ == 8) {
@@ -237,8 +254,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     int64_t cur_q0 = (item_begin / p.c_tiles) * TQ;
     load_panel(cur_q0);
     pf_new_item();
-    prefetch();
-    stage_store(0);
+    if (GLDS) {
+        prefetch_dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        prefetch();
+        stage_store(0);
+    }
     __syncthreads();
 
 #define KGE_SLOAD(AH, AL, BH, BL, U)                                                                \
@@ -254,6 +276,17 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BH[nt], acc[mt][nt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BL[nt], acc[mt][nt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[mt], BH[nt], acc[mt][nt], 0, 0, 0);
+
+#define KGE_SMMA_FIRST(AH, AL, BH, BL) /* first unit of a tile: C = 0, accumulators need no clearing */ \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BH[nt], zero16, 0, 0, 0);  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BL[nt], acc[mt][nt], 0, 0, 0); \
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
         const bool more = g + 1 < G;
-        if (more && !(dbg & 1)) prefetch();
+        if (!GLDS && more && !(dbg & 1)) prefetch();
         const char *sb = smem + buf * STAGE_BYTES;
         const int nunits = min(2, p.units - 2 * s);
 
@@ -286,15 +319,21 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             KGE_SLOAD(ah1, al1, bh1, bl1, 1)
         }
         __builtin_amdgcn_sched_barrier(0);
-        KGE_SMMA(ah0, al0, bh0, bl0)
+        if (GLDS && more && !(dbg & 1)) prefetch_dma(buf ^ 1);   // after this stage's LDS reads were issued
         __builtin_amdgcn_sched_barrier(0);
-        if (more && !(dbg & 10)) stage_store(buf ^ 1);
+        if (s == 0) {
+            KGE_SMMA_FIRST(ah0, al0, bh0, bl0)
+        } else {
+            KGE_SMMA(ah0, al0, bh0, bl0)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!GLDS && more && !(dbg & 10)) stage_store(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         if (nunits == 2) { // the last stage of a tile may hold a single k16 unit
             KGE_SMMA(ah1, al1, bh1, bl1)
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more && (dbg & 8) && !(dbg & 2)) stage_store(buf ^ 1);
+        if (!GLDS && more && (dbg & 8) && !(dbg & 2)) stage_store(buf ^ 1);
 
         const bool tile_done = s == S - 1;
         if (tile_done && !(dbg & 4)) {
@@ -315,9 +354,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float v = acc[mt][nt][g4 * 4 + e];
-                            const bool ge = v >= alo[nt];
-                            cnt[nt] += ge ? 1 : 0;
-                            any |= __ballot(ge && !(v >= ahi[nt]));
+                            // cnt += (v >= a_lo) as compare + add-with-carry (hipcc emits cndmask + add)
+                            unsigned long long ge;
+                            asm volatile("v_cmp_ge_f32 %1, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, %1"
+                                         : "+v"(cnt[nt]), "=&s"(ge) : "v"(v), "v"(alo[nt]) : "vcc");
+                            any |= ge & ~__ballot(v >= ahi[nt]);
                         }
                         if (any) { // some lane holds an uncertain pair among these 4 rows: list them
 #pragma unroll
@@ -332,7 +373,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                             }
                         }
                     }
-                    acc[mt][nt] = zero16;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -368,8 +408,10 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             }
         }
         if (++s == S) { s = 0; ++it; }
+        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed in LDS
         if (!(dbg & 32)) __syncthreads();
     }
+#undef KGE_SMMA_FIRST
 #undef KGE_SMMA
 #undef KGE_SLOAD
     flush_counts(cur_q0);
@@ -397,10 +439,10 @@ __global__ __launch_bounds__(64) void split_recheck_kernel(const kge_lp_desc d, 
     }
 }
 
-template <int NWAVES, bool DBG>
+template <int NWAVES, bool DBG, bool GLDS>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
-    auto k = lp_split_count_kernel<NWAVES, DBG>;
+    auto k = lp_split_count_kernel<NWAVES, DBG, GLDS>;
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -495,8 +537,10 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const void *Qs, const vo
     p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
     const int slots = split_num_cus();
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
-    if (p.dbg) return launch_split<8, true>(p, grid, s);
-    return kge_env_int("KGE_SPLIT_WAVES", 8) == 4 ? launch_split<4, false>(p, grid, s) : launch_split<8, false>(p, grid, s);
+    if (p.dbg) return launch_split<8, true, false>(p, grid, s);
+    if (kge_env_int("KGE_SPLIT_WAVES", 8) == 4) return launch_split<4, false, false>(p, grid, s);
+    return kge_env_int("KGE_SPLIT_GLDS", 1) ? launch_split<8, false, true>(p, grid, s)
+                                            : launch_split<8, false, false>(p, grid, s);
 }
 
 extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,

@@ -98,7 +98,7 @@ class LinkPredictionEvaluator(object):
     """
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
-                 group=None, engine=None, graph=False, overlap=True):
+                 group=None, engine=None, graph=False, overlap=False):
         self.model = model
         self.kg = knowledge_graph
         n = knowledge_graph.n_facts
