@@ -29,7 +29,7 @@ raw = torch.zeros(B, dtype=torch.int32, device='cuda')
 
 def count():
     _hip._check(lib.kge_lp_split_count(ctypes.byref(prob.desc), _hip._p(Qs), _hip._p(Es), _hip._p(st),
-                                       _hip._p(guard[1:2]), 1.0, _hip._p(thr), _hip._p(raw), _hip._p(lst), cap,
+                                       _hip._p(guard[1:2]), float(os.environ.get('EPS', '1')), _hip._p(thr), _hip._p(raw), _hip._p(lst), cap,
                                        _hip._p(nl), _hip._p(guard[2:3]), _hip._stream()), 'count')
 
 

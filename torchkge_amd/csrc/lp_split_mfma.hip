@@ -75,8 +75,8 @@ struct SplitParams {
     float *overflow;      // set to 1 when a buffer or the list overflowed
     int q_panels, c_tiles;
     int64_t n_items;
-    int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 2 no LDS stores,
-                          // 4 no epilogue, 8 LDS stores at the end of the stage
+    int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 4 no epilogue,
+                          // 16 no LDS fragment reads, 32 no barriers, 128 every block streams tile (0,0)
 };
 
 // ---- operand preparation ---------------------------------------------------
@@ -138,7 +138,7 @@ __global__ void split_thr_kernel(const float *__restrict__ qn, const float *__re
 }
 
 // ---- the count kernel --------------------------------------------------------
-template <int NWAVES, bool DBG, bool GLDS>
+template <int NWAVES, bool DBG>
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
@@ -152,73 +152,54 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;   // waves: (NWAVES/2) x 2
 
-    // contiguous, balanced range of (query panel, candidate tile) items; blocks
-    // of one XCD (bid % 8) get adjacent ranges
+    // Work order.  The (query panel, candidate tile) items are listed with QG = 4 query panels
+    // interleaved under a sweep of the candidate tiles:  (g*4+0, ct) (g*4+1, ct) .. (g*4+3, ct)
+    // (g*4+0, ct+1) ...;  XCD x (the blocks with bid % 8 == x, one per CU) owns an eighth of the
+    // list and its blocks take the positions  start + loc, start + loc + nbx, ...  So at any moment
+    // the ~32 CUs that share an L2 work on 4 query panels x 8 candidate tiles: every split row
+    // that enters the L2 is used by 8 (queries) or 4 (candidates) CUs before it is evicted, and a
+    // block stays on one query panel for a whole sweep (its rank counters live in registers).
+    constexpr int QG = 4;
     const int nb = gridDim.x, bid = blockIdx.x;
-    const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7, loc = bid >> 3;
-    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
-    const int64_t item_begin = p.n_items * lid / nb, item_end = p.n_items * (lid + 1) / nb;
-    const int nitems = (int)(item_end - item_begin);
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int nbx = (nb - xcd + 7) >> 3;                                   // blocks on this XCD
+    const int nx = nb < 8 ? nb : 8;                                        // XCD slots in use
+    const int64_t x_begin = p.n_items * xcd / nx, x_end = p.n_items * (xcd + 1) / nx;
+    const int64_t item_begin = x_begin + loc;
+    const int nitems = item_begin < x_end ? (int)((x_end - item_begin + nbx - 1) / nbx) : 0;
     if (nitems <= 0) return;
+    const int per_group = QG * p.c_tiles, n_groups = (p.q_panels + QG - 1) / QG;
+    auto item_qp_ct = [&](int i, int &qp, int &ct) __attribute__((always_inline)) {   // i-th item of this block
+        const int idx = (int)item_begin + i * nbx;
+        const int grp = min(idx / per_group, n_groups - 1);
+        const int r = idx - grp * per_group, gsz = min(QG, p.q_panels - grp * QG);
+        ct = r / gsz;
+        qp = grp * QG + (r - ct * gsz);
+    };
     const int S = p.stages, G = nitems * S;
     if (tid == 0) *unc_cnt = 0;
 
     // staging: 8 lanes cover one 128-byte row segment of a stage
     const int srow = tid >> 3, scs = tid & 7;
     const int sch = scs ^ ((srow >> 1) & 7);        // global chunk that lands in LDS chunk slot scs
-    const int st_lds = srow * 128 + scs * 16;
     const int64_t rstep = (int64_t)SROWS * p.row_bytes;
-    static_assert((EJ == 4 && QJ == 3) || (EJ == 8 && QJ == 6), "staging below is written out for 8 or 4 waves");
-    // scalars, not arrays: hipcc leaves a uint4[] that is live across the loop in scratch memory
-    uint4 stE0, stE1, stE2, stE3, stE4, stE5, stE6, stE7, stQ0, stQ1, stQ2, stQ3, stQ4, stQ5;
+    static_assert(EJ == 4 && QJ == 3, "the stage body below places 4 + 3 LDS-DMA pieces per wave");
     int pf_it = 0, pf_s = 0;
     const char *pfE = nullptr, *pfQ = nullptr;
     auto pf_new_item = [&]() __attribute__((always_inline)) {
-        const int item = (int)item_begin + pf_it;
-        const int64_t q0 = (int64_t)(item / p.c_tiles) * TQ, c0 = (int64_t)(item % p.c_tiles) * TC;
+        int qp, ct;
+        item_qp_ct(pf_it, qp, ct);
+        if (dbg & 128) qp = ct = 0;     // every block streams tile (0,0): cache-ceiling probe
+        const int64_t q0 = (int64_t)qp * TQ, c0 = (int64_t)ct * TC;
         pfE = p.Es + (c0 + srow) * p.row_bytes + sch * 16;
         pfQ = p.Qs + (q0 + srow) * p.row_bytes + sch * 16;
     };
-#define KGE_LD(PTR, J) (*reinterpret_cast<const uint4 *>((PTR) + (J) * rstep + pf_s * 128))
-    // GLDS: global -> LDS directly (LDS-DMA, 1 KiB per wave-instruction: the 64 lanes' 16-byte
-    // pieces land at consecutive LDS addresses, which is exactly this wave's 8 rows x 128 bytes)
+    // global -> LDS directly (LDS-DMA, 1 KiB per wave-instruction: the 64 lanes' 16-byte pieces land
+    // at consecutive LDS addresses, which is exactly this wave's 8 rows x 128 bytes of the stage)
     auto dma = [&](const char *g, char *l) __attribute__((always_inline)) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                          (__attribute__((address_space(3))) void *)l, 16, 0, 0);
     };
-    auto prefetch_dma = [&](int buf) __attribute__((always_inline)) {
-        char *Eb = smem + buf * STAGE_BYTES + wid * 1024, *Qb = Eb + E_STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < EJ; ++j) dma(pfE + j * rstep + pf_s * 128, Eb + j * SROWS * 128);
-#pragma unroll
-        for (int j = 0; j < QJ; ++j) dma(pfQ + j * rstep + pf_s * 128, Qb + j * SROWS * 128);
-        if (++pf_s == S) {
-            pf_s = 0;
-            if (++pf_it < nitems) pf_new_item();
-        }
-    };
-    auto prefetch = [&]() __attribute__((always_inline)) {
-        stE0 = KGE_LD(pfE, 0); stE1 = KGE_LD(pfE, 1); stE2 = KGE_LD(pfE, 2); stE3 = KGE_LD(pfE, 3);
-        if constexpr (EJ == 8) {
-            stE4 = KGE_LD(pfE, 4); stE5 = KGE_LD(pfE, 5); stE6 = KGE_LD(pfE, 6); stE7 = KGE_LD(pfE, 7);
-        }
-        stQ0 = KGE_LD(pfQ, 0); stQ1 = KGE_LD(pfQ, 1); stQ2 = KGE_LD(pfQ, 2);
-        if constexpr (QJ == 6) { stQ3 = KGE_LD(pfQ, 3); stQ4 = KGE_LD(pfQ, 4); stQ5 = KGE_LD(pfQ, 5); }
-        if (++pf_s == S) {
-            pf_s = 0;
-            if (++pf_it < nitems) pf_new_item();
-        }
-    };
-#undef KGE_LD
-#define KGE_ST(BASE, J, V) (*reinterpret_cast<uint4 *>((BASE) + st_lds + (J) * SROWS * 128) = (V))
-    auto stage_store = [&](int buf) __attribute__((always_inline)) {
-        char *Eb = smem + buf * STAGE_BYTES, *Qb = Eb + E_STAGE_BYTES;
-        KGE_ST(Eb, 0, stE0); KGE_ST(Eb, 1, stE1); KGE_ST(Eb, 2, stE2); KGE_ST(Eb, 3, stE3);
-        if constexpr (EJ == 8) { KGE_ST(Eb, 4, stE4); KGE_ST(Eb, 5, stE5); KGE_ST(Eb, 6, stE6); KGE_ST(Eb, 7, stE7); }
-        KGE_ST(Qb, 0, stQ0); KGE_ST(Qb, 1, stQ1); KGE_ST(Qb, 2, stQ2);
-        if constexpr (QJ == 6) { KGE_ST(Qb, 3, stQ3); KGE_ST(Qb, 4, stQ4); KGE_ST(Qb, 5, stQ5); }
-    };
-#undef KGE_ST
 
     // fragment addressing: row r of a tile, chunk (u*4 + piece*2 + half) ^ ((r>>1)&7)
     const int sw = (l31 >> 1) & 7;
@@ -251,15 +232,25 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         }
     };
 
-    int64_t cur_q0 = (item_begin / p.c_tiles) * TQ;
+    int64_t cur_q0;
+    {
+        int qp, ct;
+        item_qp_ct(0, qp, ct);
+        cur_q0 = (int64_t)qp * TQ;
+    }
     load_panel(cur_q0);
     pf_new_item();
-    if (GLDS) {
-        prefetch_dma(0);
+    {   // stage 0 of the first tile
+        char *nE = smem + wid * 1024, *nQ = nE + E_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < EJ; ++j) dma(pfE + j * rstep, nE + j * SROWS * 128);
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) dma(pfQ + j * rstep, nQ + j * SROWS * 128);
+        if (++pf_s == S) {
+            pf_s = 0;
+            if (++pf_it < nitems) pf_new_item();
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        prefetch();
-        stage_store(0);
     }
     __syncthreads();
 
@@ -272,27 +263,14 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         BH[nt] = *reinterpret_cast<const f16x8 *>(sb + b_row + nt * 4096 + coff[U][0]);             \
         BL[nt] = *reinterpret_cast<const f16x8 *>(sb + b_row + nt * 4096 + coff[U][1]);             \
     }
-#define KGE_SMMA(AH, AL, BH, BL)                                                                    \
+#define KGE_SMMA_P(A, B, C) /* one of the three split products over the wave's MT x NT tiles, given C */ \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BH[nt], acc[mt][nt], 0, 0, 0); \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mt], B[nt], C, 0, 0, 0);
+#define KGE_SMMA_PA(A, B)                                                                           \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BL[nt], acc[mt][nt], 0, 0, 0); \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[mt], BH[nt], acc[mt][nt], 0, 0, 0);
-
-#define KGE_SMMA_FIRST(AH, AL, BH, BL) /* first unit of a tile: C = 0, accumulators need no clearing */ \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BH[nt], zero16, 0, 0, 0);  \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], BL[nt], acc[mt][nt], 0, 0, 0); \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[mt], BH[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
 
     f32x16 zero16;
 #pragma unroll
@@ -310,35 +288,54 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
         const bool more = g + 1 < G;
-        if (!GLDS && more && !(dbg & 1)) prefetch();
         const char *sb = smem + buf * STAGE_BYTES;
         const int nunits = min(2, p.units - 2 * s);
+        const bool two = nunits == 2;              // the last stage of a tile may hold a single k16 unit
+        const bool pf = more && !(dbg & 1);
+        // LDS-DMA of the next stage into the other buffer, one piece at a time between the MFMA
+        // groups: an LDS-DMA instruction holds the issuing wave for 60+ cycles, which hides behind
+        // matrix work only if the pieces are spread over the stage (and the other wave of the SIMD
+        // is in its MFMAs)
+        char *nE = smem + (buf ^ 1) * STAGE_BYTES + wid * 1024, *nQ = nE + E_STAGE_BYTES;
+        const char *gE = pfE + pf_s * 128, *gQ = pfQ + pf_s * 128;
 
-        if (!(dbg & 16) || g == 0) {
-            KGE_SLOAD(ah0, al0, bh0, bl0, 0)
-            KGE_SLOAD(ah1, al1, bh1, bl1, 1)
+        if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah0, al0, bh0, bl0, 0) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah1, al1, bh1, bl1, 1) }
+        if (pf) dma(gE, nE);
+        __builtin_amdgcn_sched_barrier(0);
+        KGE_SMMA_PA(ah0, bl0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf) { dma(gE + rstep, nE + SROWS * 128); dma(gE + 2 * rstep, nE + 2 * SROWS * 128); }
+        __builtin_amdgcn_sched_barrier(0);
+        KGE_SMMA_PA(al0, bh0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf) dma(gE + 3 * rstep, nE + 3 * SROWS * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) { KGE_SMMA_PA(ah1, bh1) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf) dma(gQ, nQ);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) { KGE_SMMA_PA(ah1, bl1) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf) dma(gQ + rstep, nQ + SROWS * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) { KGE_SMMA_PA(al1, bh1) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf) {
+            dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128);
+            if (++pf_s == S) {
+                pf_s = 0;
+                if (++pf_it < nitems) pf_new_item();
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (GLDS && more && !(dbg & 1)) prefetch_dma(buf ^ 1);   // after this stage's LDS reads were issued
-        __builtin_amdgcn_sched_barrier(0);
-        if (s == 0) {
-            KGE_SMMA_FIRST(ah0, al0, bh0, bl0)
-        } else {
-            KGE_SMMA(ah0, al0, bh0, bl0)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!GLDS && more && !(dbg & 10)) stage_store(buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (nunits == 2) { // the last stage of a tile may hold a single k16 unit
-            KGE_SMMA(ah1, al1, bh1, bl1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!GLDS && more && (dbg & 8) && !(dbg & 2)) stage_store(buf ^ 1);
 
         const bool tile_done = s == S - 1;
         if (tile_done && !(dbg & 4)) {
-            const int item = (int)item_begin + it;
-            const int ct = item % p.c_tiles;
+            int qp_cur, ct;
+            item_qp_ct(it, qp_cur, ct);
             const int64_t c0 = (int64_t)ct * TC;
             // opaque to the optimiser: otherwise the ~100 list-entry constants below are
             // hoisted out of the tile loop and held in registers across the MFMA stream
@@ -399,7 +396,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                 }
             }
             if (more) { // query panel change (block-uniform): flush counters, load the next thresholds
-                const int64_t next_q0 = (int64_t)((item + 1) / p.c_tiles) * TQ;
+                int qp_next, ct_next;
+                item_qp_ct(it + 1, qp_next, ct_next);
+                const int64_t next_q0 = (int64_t)qp_next * TQ;
                 if (next_q0 != cur_q0) {
                     flush_counts(cur_q0);
                     cur_q0 = next_q0;
@@ -408,11 +407,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             }
         }
         if (++s == S) { s = 0; ++it; }
-        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
         if (!(dbg & 32)) __syncthreads();
     }
-#undef KGE_SMMA_FIRST
-#undef KGE_SMMA
+#undef KGE_SMMA_PA
+#undef KGE_SMMA_P
 #undef KGE_SLOAD
     flush_counts(cur_q0);
 }
@@ -439,10 +438,10 @@ __global__ __launch_bounds__(64) void split_recheck_kernel(const kge_lp_desc d, 
     }
 }
 
-template <int NWAVES, bool DBG, bool GLDS>
+template <int NWAVES, bool DBG>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
-    auto k = lp_split_count_kernel<NWAVES, DBG, GLDS>;
+    auto k = lp_split_count_kernel<NWAVES, DBG>;
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -537,10 +536,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const void *Qs, const vo
     p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
     const int slots = split_num_cus();
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
-    if (p.dbg) return launch_split<8, true, false>(p, grid, s);
-    if (kge_env_int("KGE_SPLIT_WAVES", 8) == 4) return launch_split<4, false, false>(p, grid, s);
-    return kge_env_int("KGE_SPLIT_GLDS", 1) ? launch_split<8, false, true>(p, grid, s)
-                                            : launch_split<8, false, false>(p, grid, s);
+    return p.dbg ? launch_split<8, true>(p, grid, s) : launch_split<8, false>(p, grid, s);
 }
 
 extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
