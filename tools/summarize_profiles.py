@@ -49,7 +49,7 @@ def main(out):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 k = short(r['Kernel_Name'])
-                if 'lp_gemm' in k or 'lp_direct' in k or 'score_fwd' in k:
+                if 'lp_gemm' in k or 'lp_direct' in k or 'score_fwd' in k or 'lp_split' in k or 'recheck' in k:
                     agg[(r['Counter_Name'], k)].append(float(r['Counter_Value']))
             for (c, k), v in sorted(agg.items()):
                 print('| %s | %s | %d | %.6g |' % (c, k, len(v), sum(v) / len(v)))

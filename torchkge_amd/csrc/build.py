@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
         o = os.path.join(bdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs + [os.path.abspath(__file__)]):
-            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+            jobs.append([hipcc] + FLAGS + os.environ.get('KGE_HIPCC_EXTRA', '').split() + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

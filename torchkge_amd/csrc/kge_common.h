@@ -111,7 +111,11 @@ __device__ __forceinline__ float lp_pair_score(const kge_lp_desc &d, int64_t i, 
 // different cache lines per load instruction and is ~5x slower.
 // Every lane of the wavefront must call; `qs`/`es` are this wavefront's own
 // 64 x KGE_PS_LD floats of LDS.  Bit-identical to lp_pair_score.
-constexpr int KGE_PS_KC = 40, KGE_PS_LD = 44;
+#ifndef KGE_PS_KC_V
+#define KGE_PS_KC_V 40
+#define KGE_PS_LD_V 44
+#endif
+constexpr int KGE_PS_KC = KGE_PS_KC_V, KGE_PS_LD = KGE_PS_LD_V;
 
 static inline bool kge_lp_vec4(const kge_lp_desc &d)
 {

@@ -304,25 +304,17 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah1, al1, bh1, bl1, 1) }
-        if (pf) dma(gE, nE);
+        if (pf) { dma(gE, nE); dma(gE + rstep, nE + SROWS * 128); }
         __builtin_amdgcn_sched_barrier(0);
         KGE_SMMA_PA(ah0, bl0)
         __builtin_amdgcn_sched_barrier(0);
-        if (pf) { dma(gE + rstep, nE + SROWS * 128); dma(gE + 2 * rstep, nE + 2 * SROWS * 128); }
+        if (pf) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
         __builtin_amdgcn_sched_barrier(0);
         KGE_SMMA_PA(al0, bh0)
         __builtin_amdgcn_sched_barrier(0);
-        if (pf) dma(gE + 3 * rstep, nE + 3 * SROWS * 128);
+        if (pf) { dma(gQ, nQ); dma(gQ + rstep, nQ + SROWS * 128); }
         __builtin_amdgcn_sched_barrier(0);
         if (two) { KGE_SMMA_PA(ah1, bh1) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (pf) dma(gQ, nQ);
-        __builtin_amdgcn_sched_barrier(0);
-        if (two) { KGE_SMMA_PA(ah1, bl1) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (pf) dma(gQ + rstep, nQ + SROWS * 128);
-        __builtin_amdgcn_sched_barrier(0);
-        if (two) { KGE_SMMA_PA(al1, bh1) }
         __builtin_amdgcn_sched_barrier(0);
         if (pf) {
             dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128);
@@ -331,6 +323,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                 if (++pf_it < nitems) pf_new_item();
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) { KGE_SMMA_PA(ah1, bl1) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) { KGE_SMMA_PA(al1, bh1) }
+        __builtin_amdgcn_sched_barrier(0);
 
         const bool tile_done = s == S - 1;
         if (tile_done && !(dbg & 4)) {
@@ -548,7 +545,7 @@ extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, c
     if (!s_true || !list || cap <= 0 || !list_count || !raw_count) return KGE_EINVAL;
     if (d->mode != KGE_LP_L2_EXPAND || d->K1 != 0) return KGE_EINVAL;
     const bool vec4 = kge_lp_vec4(*d);
-    const int grid = split_num_cus() * kge_env_int("KGE_SPLIT_RECHECK_WAVES", 7);
+    const int grid = split_num_cus() * kge_env_int("KGE_SPLIT_RECHECK_WAVES", 160 * 1024 / (2 * 64 * KGE_PS_LD * 4));
     if (vec4)
         hipLaunchKernelGGL(split_recheck_kernel<true>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list, cap,
                            list_count, raw_count);
