@@ -123,7 +123,7 @@ def main():
     model = make_model(kind, p, tables, n_ent, n_rel).to(device)
     if kind == 'transe':
         model.l2_mode = args.l2_mode
-        model.split_filter = not args.no_split
+    model.split_filter = not args.no_split
 
     # synthetic KG of the dataset's shape; filters span the full graph (train+valid+test)
     cfg_seed = 1000 + sorted(WORKLOADS).index(args.workload)

@@ -250,29 +250,44 @@ int kge_corrupt_scatter(const int64_t *heads, const int64_t *tails, const uint8_
 
 /* library / build info */
 /* ---- certified f16-split prefilter of the fused rank count ------------------------
- * (TransE-L2 norm expansion only; torchkge_amd/csrc/lp_split_mfma.hip has the error
- * analysis.)  kge_lp_split_count + kge_lp_split_recheck leave in raw_count exactly
+ * (torchkge_amd/csrc/lp_split_mfma.hip has the error analysis.)  kge_lp_split_count + kge_lp_split_recheck leave in raw_count exactly
  * what kge_lp_count_ge leaves there: >= 99.9% of the (query, candidate) pairs are
  * decided by an f16 hi/lo-split MFMA product with a rigorous error band, the pairs
  * inside the band are re-scored by the exact fp32 chain.
  *
  * A split operand is [rows_p][units_p] cells of 64 bytes (see the .hip file);
  * kge_lp_split_units / kge_lp_split_rows_padded give its dimensions.
- *   aug_mode 0: no augmentation column; 1: column K = aug[row] * aug_mul (candidates:
- *   aug = ||e||^2, aug_mul = -0.5); 2: column K = aug_mul (queries: 1.0).
- * enmax: device scalar >= max_c ||e_c||^2 (as accumulated by kge_row_sqnorm's max_io).
- * eps_scale multiplies the error band (1.0 = the proven bound; tests shrink it).
- * thr: scratch, 2 * kge_lp_split_rows_padded(B, 1) floats.  list: cap x 2 int32 scratch;
- * list_count: device int32; *overflow is set to 1.0f if more than cap pairs (or more
- * than 2048 in one 256 x 192 tile) fell inside the band -- raw_count is then invalid
- * and the caller must redo the count with kge_lp_count_ge. */
+ * Modes: KGE_LP_L2_EXPAND (TransE-L2) and KGE_LP_DOT (DistMult, ComplEx: K0 + K1 columns).
+ * *overflow is set to 1.0f if more than cap pairs (or more than 2048 in one 256 x 192
+ * tile) fell inside the band -- raw_count is then invalid and the caller must redo the
+ * count with kge_lp_count_ge.  The squared-norm maxima are the device scalars that
+ * kge_row_sqnorm accumulates through max_io. */
+typedef struct kge_split_args {
+    const void *Qs, *Es;          /* split operands (kge_lp_split_rows) */
+    const float *qn0, *qn1;       /* KGE_LP_DOT: ||q_i||^2 per K-segment (qn1 NULL when K1 == 0); L2_EXPAND: desc.qn is used */
+    const float *qmax0, *qmax1;   /* KGE_LP_DOT: device scalars >= max_i qn0 / qn1 (they fix the query operand's scale) */
+    const float *emax0, *emax1;   /* device scalars >= max_c ||e_c||^2 per K-segment (emax1 NULL when K1 == 0) */
+    float eps_scale;              /* multiplies the error band (1.0 = the proven bound; tests shrink it) */
+    float *thr;                   /* scratch: 2 * kge_lp_split_rows_padded(B, 1) floats */
+    int32_t *list;                /* scratch: cap x 2 int32 (query, local candidate) */
+    int32_t cap;
+    int32_t *list_count;          /* device int32 */
+    float *overflow;              /* device float, set to 1.0f on overflow (see above) */
+} kge_split_args;
+
 int kge_lp_split_units(int K, int with_aug);
 int64_t kge_lp_split_rows_padded(int64_t rows, int is_query);
-int kge_lp_split_rows(const float *X, int64_t ld, int64_t rows, int K, int is_query, int aug_mode,
-                      const float *aug, float aug_mul, void *out, kge_stream_t stream);
-int kge_lp_split_count(const kge_lp_desc *d, const void *Qs, const void *Es, const float *s_true,
-                       const float *enmax, float eps_scale, float *thr, int32_t *raw_count,
-                       int32_t *list, int32_t cap, int32_t *list_count, float *overflow,
+/* [X0 | X1] (K1 may be 0) -> split operand with one extra column K0+K1:
+ *   aug_mode 1: aug[row] * aug_mul            (L2 candidates: aug = ||e||^2, aug_mul = -0.5)
+ *   aug_mode 2: aug_mul                       (L2 queries: 1.0)
+ *   aug_mode 3: guard column of DOT queries   (aug = ||q||^2; meets the -65504 of padding candidates)
+ *   aug_mode 4: 0                             (DOT candidates)
+ * norm2max0/1: device scalars with the squared-norm maxima that fix the power-of-two scale
+ * (NULL: the fixed 2^12 of the norm-guarded L2 mode). */
+int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                      int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
+                      const float *norm2max1, void *out, kge_stream_t stream);
+int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
                          const int32_t *list_count, int32_t *raw_count, kge_stream_t stream);

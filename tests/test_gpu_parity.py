@@ -803,3 +803,40 @@ def test_split_prefilter_overflow_falls_back_to_exact(hip):
     for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
         assert torch.equal(getattr(ev, nm), getattr(ev2, nm))
     assert int(ev.rank_true_tails.min()) == n_ent      # everything ties: rank = number of entities
+
+
+@pytest.mark.parametrize('B,N,K,K1,scale', [(300, 1000, 64, 0, 1.0), (257, 700, 40, 40, 30.0), (100, 513, 17, 17, 1e-3),
+                                          (64, 300, 200, 200, 1.0)])
+def test_split_prefilter_dot_mode_counts_equal_exact_counts(hip, B, N, K, K1, scale):
+    """KGE_LP_DOT (DistMult / ComplEx, two K-segments, arbitrary magnitudes -- the
+    operands carry their own power-of-two scales): split counts == exact counts,
+    also with negative true scores (padding candidates must never count)."""
+    g = torch.Generator().manual_seed(B * 7 + K)
+    T0 = (torch.randn(N, K, generator=g) * scale).cuda()
+    T1 = (torch.randn(N, K1, generator=g) * scale).cuda() if K1 else None
+    A0 = (torch.randn(B, K, generator=g) * scale).cuda()
+    A1 = (torch.randn(B, K1, generator=g) * scale).cuda() if K1 else None
+    A0[0] = 0.0                                         # an all-zero query: every score ties at 0
+    if A1 is not None:
+        A1[0] = 0.0
+    t = torch.randint(0, N, (B,), generator=g).cuda()
+    prob = hip.LpProblem(hip.LP_DOT, A0, T0, A1=A1, T1=T1)
+    st = prob.pair_scores(t)
+    assert bool((st < 0).any())
+    exact = prob.count_ge(st)
+    guard = torch.zeros(8, device='cuda')
+    hip.row_sqnorm(T0, max_io=guard[1:2])
+    if T1 is not None:
+        hip.row_sqnorm(T1, max_io=guard[5:6])
+    Es = hip.split_rows(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=guard[5:6] if T1 is not None else None)
+    prob.split = {'Es': Es, 'enmax': guard[1:2], 'enmax1': guard[5:6] if T1 is not None else None,
+                  'overflow': guard[2:3]}
+    try:
+        for eps in (1.0, 1.0 / 16):
+            hip.SPLIT_EPS_SCALE = eps
+            got = prob.count_ge(st)
+            assert torch.equal(got, exact), (eps, int((got != exact).sum()))
+    finally:
+        hip.SPLIT_EPS_SCALE = 1.0
+    if N > 64 * 2:
+        assert float(guard[2]) == 0.0 or int(exact[0]) == N   # only the all-tie query may overflow a tile buffer

@@ -39,6 +39,15 @@ class LpDesc(ctypes.Structure):
     ]
 
 
+class SplitArgs(ctypes.Structure):
+    """struct kge_split_args (include/kge_hip.h)."""
+    _fields_ = [
+        ('Qs', _vp), ('Es', _vp), ('qn0', _vp), ('qn1', _vp), ('qmax0', _vp), ('qmax1', _vp),
+        ('emax0', _vp), ('emax1', _vp), ('eps_scale', ctypes.c_float),
+        ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
+    ]
+
+
 _SIGNATURES = {
     'kge_score_triples': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp],
     'kge_score_triples_bwd': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp,
@@ -54,9 +63,9 @@ _SIGNATURES = {
     'kge_lp_pair_scores': [ctypes.POINTER(LpDesc), _vp, _vp, _i64, _vp, _vp],
     'kge_lp_count_ge': [ctypes.POINTER(LpDesc), _vp, _vp, _vp],
     'kge_lp_split_units': [_int, _int],
-    'kge_lp_split_rows': [_vp, _i64, _i64, _int, _int, _int, _vp, ctypes.c_float, _vp, _vp],
-    'kge_lp_split_count': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp,
-                           ctypes.c_int32, _vp, _vp, _vp],
+    'kge_lp_split_rows': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _int, _vp, ctypes.c_float, _vp, _vp, _vp,
+                          _vp],
+    'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
@@ -98,7 +107,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 2:
+    if lib.kge_abi_version() != 3:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -206,28 +215,37 @@ def ewise(op, a, b, c=None, d=None):
 
 
 SPLIT_EPS_SCALE = 1.0          # multiplies the proven error band of the f16-split prefilter (tests shrink it)
-SPLIT_LIST_PER_QUERY = 64      # capacity of the uncertain-pair list, per query of the batch
+SPLIT_LIST_PER_QUERY = 64      # capacity of the uncertain-pair list per query of the batch (floor; grows with N)
 
 
-def split_rows(X, K=None, is_query=False, aug=None, aug_mul=None):
+def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None):
     """f16 hi/lo split operand of kge_lp_split_count (uint8 tensor holding
-    [rows_p][units_p][64 bytes]); candidates carry -||e||^2/2 in column K
-    (aug = ||e||^2), queries carry 1."""
+    [rows_p][units_p][64 bytes]) of [X | X1].  L2 mode (dot=False): candidates
+    carry -||e||^2/2 in the extra column (aug = ||e||^2), queries carry 1, fixed
+    scale.  DOT mode: queries carry their guard column (aug = ||q||^2), the
+    scale comes from the device scalars nmax0 (+ nmax1)."""
     lib = load_library()
-    require_cuda(X, aug)
+    require_cuda(X, X1, aug, nmax0, nmax1)
     X = f32c(X)
     rows, ld = X.shape[0], X.stride(0)
     K = X.shape[1] if K is None else K
-    if is_query:
-        aug_mode, aug_mul = 2, 1.0
+    ld1 = 0
+    if X1 is not None:
+        X1 = f32c(X1)
+        K1 = X1.shape[1] if K1 is None else K1
+        ld1 = X1.stride(0)
     else:
-        aug_mode, aug_mul = 1, (-0.5 if aug_mul is None else aug_mul)
-    units_p = int(lib.kge_lp_split_units(K, 1))
+        K1 = 0
+    if dot:
+        aug_mode, aug_mul = (3, 1.0) if is_query else (4, 0.0)
+    else:
+        aug_mode, aug_mul = (2, 1.0) if is_query else (1, -0.5)
+    units_p = int(lib.kge_lp_split_units(K + K1, 1))
     rows_p = int(lib.kge_lp_split_rows_padded(rows, 1 if is_query else 0))
     out = torch.empty(max(rows_p, 1) * units_p * 64, dtype=torch.uint8, device=X.device)
     with torch.cuda.device(X.device):
-        _check(lib.kge_lp_split_rows(_p(X), ld, rows, K, 1 if is_query else 0, aug_mode, _p(aug), aug_mul,
-                                     _p(out), _stream()), 'kge_lp_split_rows')
+        _check(lib.kge_lp_split_rows(_p(X), ld, K, _p(X1), ld1, K1, rows, 1 if is_query else 0, aug_mode, _p(aug),
+                                     aug_mul, _p(nmax0), _p(nmax1), _p(out), _stream()), 'kge_lp_split_rows')
     return out
 
 
@@ -346,23 +364,46 @@ class LpProblem(object):
         the scratch buffers (thresholds, uncertain-pair list, its counter)."""
         lib = load_library()
         K = int(self.desc.K0)
-        Qs = split_rows(self.keep[0], K=K, is_query=True)
+        A0, A1 = self.keep[0], self.keep[2]
+        extra = {}
+        if int(self.desc.mode) == LP_DOT:
+            qmax = torch.zeros(2, dtype=torch.float32, device=self.device)
+            qn0 = row_sqnorm(A0, K=K, max_io=qmax[0:1])
+            qn1 = row_sqnorm(A1, max_io=qmax[1:2]) if A1 is not None else None
+            qn = qn0 if qn1 is None else qn0 + qn1
+            Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
+                            nmax1=qmax[1:2] if A1 is not None else None)
+            extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
+        else:
+            Qs = split_rows(A0, K=K, is_query=True)
         Bp = int(lib.kge_lp_split_rows_padded(self.B, 1))
         thr = torch.empty(2 * Bp, dtype=torch.float32, device=self.device)
-        cap = int(min(SPLIT_LIST_PER_QUERY * self.B, 2 ** 31 - 1))
+        # the band holds ~1e-3 of a query's candidates for an untrained model (far fewer for a trained one)
+        cap = int(min(max(SPLIT_LIST_PER_QUERY, self.N // 100) * self.B, 2 ** 31 - 1))
         lst = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
         n_list = torch.empty(1, dtype=torch.int32, device=self.device)
-        return {'Qs': Qs, 'thr': thr, 'cap': cap, 'list': lst, 'n_list': n_list}
+        prep = {'Qs': Qs, 'thr': thr, 'cap': cap, 'list': lst, 'n_list': n_list}
+        prep.update(extra)
+        return prep
 
     def split_count(self, prep, s_true, raw):
         """kge_lp_split_count: thresholds + the f16 MFMA count kernel (raw += #{acc >= a_lo})."""
         lib = load_library()
         sp = self.split
+        a = SplitArgs()
+        a.Qs, a.Es = _p(prep['Qs']), _p(sp['Es'])
+        a.qn0, a.qn1 = _p(prep.get('qn0')), _p(prep.get('qn1'))
+        qmax = prep.get('qmax')
+        if qmax is not None:
+            a.qmax0 = qmax.data_ptr()
+            a.qmax1 = qmax.data_ptr() + 4 if prep.get('qn1') is not None else None
+        a.emax0, a.emax1 = _p(sp['enmax']), _p(sp.get('enmax1'))
+        a.eps_scale = SPLIT_EPS_SCALE
+        a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']
+        a.list_count, a.overflow = _p(prep['n_list']), _p(sp['overflow'])
         with torch.cuda.device(self.device):
-            _check(lib.kge_lp_split_count(ctypes.byref(self.desc), _p(prep['Qs']), _p(sp['Es']), _p(s_true),
-                                          _p(sp['enmax']), SPLIT_EPS_SCALE, _p(prep['thr']), _p(raw),
-                                          _p(prep['list']), prep['cap'], _p(prep['n_list']), _p(sp['overflow']),
-                                          _stream()), 'kge_lp_split_count')
+            _check(lib.kge_lp_split_count(ctypes.byref(self.desc), ctypes.byref(a), _p(s_true), _p(raw), _stream()),
+                   'kge_lp_split_count')
         return raw
 
     def split_recheck(self, prep, s_true, raw):

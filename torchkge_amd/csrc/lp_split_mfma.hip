@@ -80,60 +80,118 @@ struct SplitParams {
 };
 
 // ---- operand preparation ---------------------------------------------------
-__global__ void split_rows_kernel(const float *__restrict__ X, int64_t ld, int64_t rows, int64_t rows_p, int K,
-                                  int aug_mode, const float *__restrict__ aug, float aug_mul, float scale,
-                                  int units_p, uint4 *__restrict__ out)
+// power-of-two scale that puts rows of squared norm <= norm2max just inside f16 range
+__device__ __forceinline__ float split_scale(float norm2max)
 {
-    const int64_t total = rows_p * units_p;
+    const float m = sqrtf(norm2max);
+    if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
+    float e = floorf(log2f(16384.0f / m)) - 1.0f;      // one binade of slack for the roundings above
+    e = fminf(fmaxf(e, -100.0f), 100.0f);
+    return ldexpf(1.0f, (int)e);
+}
+
+struct SplitRowsParams {
+    const float *X0, *X1;     // segment 1 optional (ComplEx: [Re | Im])
+    int64_t ld0, ld1;
+    int K0, K1;
+    int64_t rows, rows_p;
+    int aug_mode;             // 0 none; 1: aug[row]*aug_mul (candidates, L2); 2: aug_mul (queries, L2);
+                              // 3: query guard column of the DOT mode; 4: 0 for real rows (candidates, DOT)
+    const float *aug;
+    float aug_mul;
+    const float *nmax0, *nmax1;   // device scalars: squared-norm maxima -> scale (NULL: 2^12)
+    int units_p;
+    uint4 *out;
+};
+
+__global__ void split_rows_kernel(const SplitRowsParams p)
+{
+    const int64_t total = p.rows_p * p.units_p;
+    float scale = (float)(1 << SPLIT_SCALE_LOG2), nmax = 0.f;
+    if (p.nmax0) {
+        nmax = *p.nmax0 + (p.nmax1 ? *p.nmax1 : 0.f);
+        scale = split_scale(nmax);
+    }
+    const int K = p.K0 + p.K1;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / units_p;
-        const int u = (int)(idx % units_p);
+        const int64_t row = idx / p.units_p;
+        const int u = (int)(idx % p.units_p);
         union { _Float16 h[16]; uint4 v[2]; } hi, lo;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int k = u * 16 + e;
             float x = 0.f;
-            if (row < rows) {
-                if (k < K) x = X[row * ld + k];
-                else if (k == K && aug_mode == 1) x = aug[row] * aug_mul;
-                else if (k == K && aug_mode == 2) x = aug_mul;
+            if (row < p.rows) {
+                if (k < p.K0) x = p.X0[row * p.ld0 + k];
+                else if (k < K) x = p.X1[row * p.ld1 + (k - p.K0)];
+                else if (k == K && p.aug_mode == 1) x = p.aug[row] * p.aug_mul;
+                else if (k == K && p.aug_mode == 2) x = p.aug_mul;
+                else if (k == K && p.aug_mode == 3) x = 0.25f * (sqrtf(p.aug[row]) + sqrtf(nmax) * 0.00390625f);
             }
             x *= scale;
+            if (row < p.rows && k == K && p.aug_mode == 3) x = fmaxf(x, 1.0f);
             _Float16 h = (_Float16)x;                   // round to nearest even
             _Float16 l = (_Float16)(x - (float)h);      // x - hi is exact in fp32
-            if (row >= rows && k == K && aug_mode == 1) {
-                // padding candidate: hi = lo = -65504 makes its accumulator -2 * 65504 * 2^12,
-                // below every threshold a norm-guarded query can have (>= -16 * 2^24)
+            if (row >= p.rows && k == K && (p.aug_mode == 1 || p.aug_mode == 4)) {
+                // padding candidate: hi = lo = -65504 in the column that meets the queries' guard
+                // column drives its accumulator below every threshold (L2: <= -2*65504*2^12 against
+                // >= -16*2^24 for norm-guarded queries; DOT: <= -32752*S_q*||q|| against >= -16384*S_q*||q||)
                 h = (_Float16)(-65504.f);
                 l = (_Float16)(-65504.f);
             }
             hi.h[e] = h;
             lo.h[e] = l;
         }
-        uint4 *o = out + idx * 4;
+        uint4 *o = p.out + idx * 4;
         o[0] = hi.v[0]; o[1] = hi.v[1]; o[2] = lo.v[0]; o[3] = lo.v[1];
     }
 }
 
-__global__ void split_thr_kernel(const float *__restrict__ qn, const float *__restrict__ s_true,
-                                 const float *__restrict__ enmax_p, int64_t B, int64_t Bp, int K, int units,
-                                 float eps_scale, float out_scale, float2 *__restrict__ thr, int32_t *list_count)
+struct SplitThrParams {
+    int mode;                       // KGE_LP_L2_EXPAND or KGE_LP_DOT
+    const float *qn0, *qn1;         // per-query squared norms (segment 1 optional)
+    const float *s_true;
+    const float *qmax0, *qmax1;     // device scalars (DOT: scale of the query operand)
+    const float *emax0, *emax1;     // device scalars: max ||e||^2 per segment
+    int64_t B, Bp;
+    int K, units;
+    float eps_scale;
+    float2 *thr;
+    int32_t *list_count;
+};
+
+__global__ void split_thr_kernel(const SplitThrParams p)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Bp; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i >= B) { thr[i] = make_float2(INFINITY, INFINITY); continue; }
-        const float q = qn[i], em = *enmax_p;
-        const float u = -s_true[i];                      // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
-        const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
-        const float eps_rel = 2.0f * ((float)(48 * units + K) * two24 + 3.0f * two22);
-        const float qnrm = sqrtf(q) * 1.000001f, enrm = sqrtf(em) * 1.000001f;
-        const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
-        const float eps_dot = eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
-        const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
-        const float mid = 0.5f * (q - u);
-        const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
-        thr[i] = make_float2((mid - hw) * out_scale, (mid + hw) * out_scale);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
+    const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
+    const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
+    const float eps_rel = 2.0f * ((float)(48 * p.units + p.K) * two24 + 3.0f * two22);
+    const float enrm = sqrtf(em) * 1.000001f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.Bp; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= p.B) { p.thr[i] = make_float2(INFINITY, INFINITY); continue; }
+        const float q = p.qn0[i] + (p.qn1 ? p.qn1[i] : 0.f);
+        const float qnrm = sqrtf(q) * 1.000001f;
+        if (p.mode == KGE_LP_L2_EXPAND) {
+            const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
+            const float u = -p.s_true[i];                    // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
+            const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
+            const float eps_dot = eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
+            const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * p.eps_scale;
+            const float mid = 0.5f * (q - u);
+            const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
+            p.thr[i] = make_float2((mid - hw) * out_scale, (mid + hw) * out_scale);
+        } else {
+            // count c iff dot_c >= s_true; both operands carry their own power-of-two scale
+            const float qm = *p.qmax0 + (p.qmax1 ? *p.qmax1 : 0.f);
+            const float out_scale = split_scale(qm) * split_scale(em);
+            const float st = p.s_true[i];
+            const float sqk = sqrtf((float)p.K);
+            const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
+            const float eps_dot = (eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
+            const float hw = eps_dot + two22 * fabsf(st);
+            p.thr[i] = make_float2((st - hw) * out_scale, (st + hw) * out_scale);
+        }
     }
 }
 
@@ -475,44 +533,67 @@ extern "C" int kge_lp_split_units(int K, int with_aug)
 
 extern "C" int64_t kge_lp_split_rows_padded(int64_t rows, int is_query) { return round_up(rows, is_query ? TQ : TC); }
 
-extern "C" int kge_lp_split_rows(const float *X, int64_t ld, int64_t rows, int K, int is_query, int aug_mode,
-                                 const float *aug, float aug_mul, void *out, kge_stream_t stream)
+extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1,
+                                 int64_t rows, int is_query, int aug_mode, const float *aug, float aug_mul,
+                                 const float *norm2max0, const float *norm2max1, void *out, kge_stream_t stream)
 {
-    if (rows < 0 || K <= 0 || ld < K || aug_mode < 0 || aug_mode > 2) return KGE_EINVAL;
-    if (rows == 0) return 0;
-    if (!X || !out || (aug_mode == 1 && !aug)) return KGE_EINVAL;
-    const int units_p = kge_lp_split_units(K, aug_mode != 0);
-    const int64_t rows_p = kge_lp_split_rows_padded(rows, is_query);
-    const int64_t total = rows_p * units_p;
+    if (rows < 0 || K0 <= 0 || K1 < 0 || ld0 < K0 || (K1 > 0 && ld1 < K1) || aug_mode < 0 || aug_mode > 4)
+        return KGE_EINVAL;
+    if (rows == 0 && is_query) return 0;
+    if ((rows > 0 && !X0) || (rows > 0 && K1 > 0 && !X1) || !out || ((aug_mode == 1 || aug_mode == 3) && rows > 0 && !aug))
+        return KGE_EINVAL;
+    SplitRowsParams p;
+    p.X0 = X0; p.X1 = X1; p.ld0 = ld0; p.ld1 = ld1; p.K0 = K0; p.K1 = K1;
+    p.rows = rows;
+    p.rows_p = kge_lp_split_rows_padded(rows, is_query);
+    p.aug_mode = aug_mode; p.aug = aug; p.aug_mul = aug_mul;
+    p.nmax0 = norm2max0; p.nmax1 = norm2max1;
+    p.units_p = kge_lp_split_units(K0 + K1, aug_mode != 0);
+    p.out = reinterpret_cast<uint4 *>(out);
+    const int64_t total = p.rows_p * p.units_p;
+    if (total == 0) return 0;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, kge_s(stream), X, ld, rows, rows_p, K, aug_mode,
-                       aug, aug_mul, (float)(1 << SPLIT_SCALE_LOG2), units_p, reinterpret_cast<uint4 *>(out));
+    hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int kge_lp_split_count(const kge_lp_desc *d, const void *Qs, const void *Es, const float *s_true,
-                                  const float *enmax, float eps_scale, float *thr, int32_t *raw_count,
-                                  int32_t *list, int32_t cap, int32_t *list_count, float *overflow,
-                                  kge_stream_t stream)
+extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true,
+                                  int32_t *raw_count, kge_stream_t stream)
 {
     int rc = kge_lp_desc_check(d);
     if (rc) return rc;
-    if (d->mode != KGE_LP_L2_EXPAND || d->K1 != 0) return KGE_EINVAL;
+    if (d->mode != KGE_LP_L2_EXPAND && d->mode != KGE_LP_DOT) return KGE_EINVAL;
     if (d->B == 0 || d->N == 0) return 0;
-    if (!Qs || !Es || !s_true || !enmax || !thr || !raw_count || !list || cap <= 0 || !list_count || !overflow)
+    if (!a || !a->Qs || !a->Es || !s_true || !a->emax0 || !a->thr || !raw_count || !a->list || a->cap <= 0 ||
+        !a->list_count || !a->overflow)
+        return KGE_EINVAL;
+    if (d->mode == KGE_LP_DOT && (!a->qn0 || !a->qmax0 || (d->K1 > 0 && (!a->qn1 || !a->qmax1 || !a->emax1))))
         return KGE_EINVAL;
     if (d->B > INT32_MAX || d->N > INT32_MAX) return KGE_EINVAL;
     hipStream_t s = kge_s(stream);
-    const int K = d->K0;
+    const int K = d->K0 + d->K1;
     const int units_p = kge_lp_split_units(K, 1);
     const int units = (K + 1 + 15) / 16;
     const int64_t Bp = kge_lp_split_rows_padded(d->B, 1);
-    const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
-    hipLaunchKernelGGL(split_thr_kernel, dim3((int)((Bp + 255) / 256)), dim3(256), 0, s, d->qn, s_true, enmax, d->B,
-                       Bp, K, units, eps_scale, out_scale, reinterpret_cast<float2 *>(thr), list_count);
+    SplitThrParams t;
+    t.mode = d->mode;
+    t.qn0 = d->mode == KGE_LP_L2_EXPAND ? d->qn : a->qn0;
+    t.qn1 = (d->mode == KGE_LP_DOT && d->K1 > 0) ? a->qn1 : nullptr;
+    t.s_true = s_true;
+    t.qmax0 = a->qmax0; t.qmax1 = d->K1 > 0 ? a->qmax1 : nullptr;
+    t.emax0 = a->emax0; t.emax1 = (d->mode == KGE_LP_DOT && d->K1 > 0) ? a->emax1 : nullptr;
+    t.B = d->B; t.Bp = Bp; t.K = K; t.units = units;
+    t.eps_scale = a->eps_scale;
+    t.thr = reinterpret_cast<float2 *>(a->thr);
+    t.list_count = a->list_count;
+    hipLaunchKernelGGL(split_thr_kernel, dim3((int)((Bp + 255) / 256)), dim3(256), 0, s, t);
     KGE_CHECK_LAUNCH();
 
+    const void *Es = a->Es, *Qs = a->Qs;
+    float *thr = a->thr, *overflow = a->overflow;
+    int32_t *list = a->list, *list_count = a->list_count;
+    const int32_t cap = a->cap;
     SplitParams p;
     p.Es = reinterpret_cast<const char *>(Es);
     p.Qs = reinterpret_cast<const char *>(Qs);
@@ -543,7 +624,7 @@ extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, c
     if (rc) return rc;
     if (d->B == 0 || d->N == 0) return 0;
     if (!s_true || !list || cap <= 0 || !list_count || !raw_count) return KGE_EINVAL;
-    if (d->mode != KGE_LP_L2_EXPAND || d->K1 != 0) return KGE_EINVAL;
+    if (d->mode != KGE_LP_L2_EXPAND && d->mode != KGE_LP_DOT) return KGE_EINVAL;
     const bool vec4 = kge_lp_vec4(*d);
     const int grid = split_num_cus() * kge_env_int("KGE_SPLIT_RECHECK_WAVES", 160 * 1024 / (2 * 64 * KGE_PS_LD * 4));
     if (vec4)

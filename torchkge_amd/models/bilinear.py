@@ -68,7 +68,8 @@ class DistMultModel(BilinearModel):
         tabs = [x.data for x in self._tables()]
         sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
         Q0 = _hip.lp_prep(_hip.DISTMULT, sd, tabs, self.emb_dim, self.emb_dim, h_idx, t_idx, r_idx)[0]
-        return _hip.LpProblem(_hip.LP_DOT, Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), c_base=ent_lo)
+        T0 = _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi)
+        return self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, c_base=ent_lo), T0, c_base=ent_lo)
 
 
 class ComplExModel(BilinearModel):
@@ -154,5 +155,6 @@ class ComplExModel(BilinearModel):
         sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
         Q0, Q1, _, _ = _hip.lp_prep(_hip.COMPLEX, sd, tabs, self.emb_dim, self.emb_dim, h_idx, t_idx,
                                     r_idx, want_q1=True)
-        return _hip.LpProblem(_hip.LP_DOT, Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), A1=Q1,
-                              T1=_shard(_hip.f32c(tabs[1]), ent_lo, ent_hi), c_base=ent_lo)
+        T0, T1 = _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), _shard(_hip.f32c(tabs[1]), ent_lo, ent_hi)
+        return self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, A1=Q1, T1=T1, c_base=ent_lo), T0, T1,
+                                      c_base=ent_lo)

@@ -114,10 +114,59 @@ class Model(Module):
         self.n_ent = n_entities
         self.n_rel = n_relations
         self._cache = _SessionCache()
+        # evaluation-time guard scalars (device, float32 x 8): [0] max ||q||^2 (L2 norm guard),
+        # [1] max ||e||^2 (segment 0), [2] split-list overflow flag, [5] max ||e||^2 (segment 1)
+        self._lp_guard = None
+        self._guard_on = False
+        self._expand_ok = None      # TransE-L2 only: True/False forced by the evaluator, None: guarded
+        self.split_filter = True    # fused rank counts via the f16-split prefilter + exact recheck
+        self._split_ok = True       # cleared by the evaluator when the uncertain-pair list overflowed
 
     # ---- engine hooks (overridden by concrete models) ---------------------
     def _tables(self):
         raise NotImplementedError
+
+    L2_EXPAND_LIMIT = float('inf')      # TranslationModel: bound on ||q||^2 + ||e||^2 for the norm expansion
+
+    def _uses_guard(self):
+        """Does an evaluation of this model need the guard scalars?"""
+        return bool(self.split_filter)
+
+    def lp_guard_begin(self, device):
+        """Start of an evaluation.  Returns the device guard vector (or None): the
+        norm kernels fold max ||q||^2 / max ||e||^2 into it and the split prefilter
+        raises its overflow flag there -- no extra launch, graph-capturable, no host
+        sync; the evaluator reads it once with the ranks."""
+        self._expand_ok = None
+        if not self._uses_guard():
+            return None
+        if self._lp_guard is None or self._lp_guard.device != device:
+            self._lp_guard = torch.zeros(8, dtype=torch.float32, device=device)
+        self._guard_on = True
+        return self._lp_guard
+
+    def lp_guard_end(self):
+        self._guard_on = False
+        self._expand_ok = None
+        self._split_ok = True
+
+    def _attach_dot_split(self, prob, T0, T1=None, c_base=0):
+        """Rank counts of a KGE_LP_DOT problem through the certified f16-split
+        prefilter (only inside an evaluation, where the guard vector exists)."""
+        if not (self._guard_on and self.split_filter and self._split_ok):
+            return prob
+        g = self._lp_guard
+        key = '%d_%d' % (c_base, T0.shape[0])
+
+        def build():
+            en0 = _hip.row_sqnorm(T0, max_io=g[1:2])
+            if T1 is not None:
+                _hip.row_sqnorm(T1, max_io=g[5:6])
+            del en0
+            return _hip.split_rows(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=g[5:6] if T1 is not None else None)
+        Es = self._cache.get('esd_' + key, [T0] + ([T1] if T1 is not None else []), build)
+        prob.split = {'Es': Es, 'enmax': g[1:2], 'enmax1': g[5:6] if T1 is not None else None, 'overflow': g[2:3]}
+        return prob
 
     def lp_session(self):
         """Context inside which per-entity precomputes are cached (tables must
@@ -211,11 +260,6 @@ class TranslationModel(Model):
         # are small enough for the cancellation error to stay inside the 1e-5 score
         # tolerance (||q||^2 + ||e||^2 <= L2_EXPAND_LIMIT), direct otherwise.
         self.l2_mode = 'auto'
-        self._expand_ok = None      # True/False: forced by the evaluator; None: guarded (see below)
-        self._lp_guard = None       # device (4,): max ||q||^2, max ||e||^2, split-list overflow, spare
-        self._guard_on = False
-        self.split_filter = True    # fused rank counts via the f16-split prefilter + exact recheck
-        self._split_ok = True       # cleared by the evaluator when the uncertain-pair list overflowed
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # reference TransH/TransD state_dicts carry the (n_rel, n_ent, d)
@@ -229,25 +273,9 @@ class TranslationModel(Model):
     # measured: |expand - reference| ~ 2.4e-7 * (||q||^2 + ||e||^2) at d = 200 (1.2e-6 at 5)
     L2_EXPAND_LIMIT = 16.0
 
-    def lp_guard_begin(self, device):
-        """Start of an evaluation: the norm expansion is taken optimistically and
-        the norm kernels fold max ||q||^2 and max ||e||^2 into two device scalars
-        (no extra launch, graph-capturable, no host sync).  The evaluator reads
-        them with the ranks and, if their sum exceeds L2_EXPAND_LIMIT, redoes the
-        evaluation on the broadcast-subtract kernel.  Returns the (2,) tensor, or
-        None when this model never takes the expansion."""
-        self._expand_ok = None
-        if self.dissimilarity_type != 'L2' or self.l2_mode != 'auto' or self._kind is not None:
-            return None                         # only the plain TransE path uses the expansion
-        if self._lp_guard is None or self._lp_guard.device != device:
-            self._lp_guard = torch.zeros(4, dtype=torch.float32, device=device)
-        self._guard_on = True
-        return self._lp_guard
-
-    def lp_guard_end(self):
-        self._guard_on = False
-        self._expand_ok = None
-        self._split_ok = True
+    def _uses_guard(self):
+        # only the plain TransE-L2 path takes the (optimistic) norm expansion and the split prefilter
+        return self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._kind is None
 
     def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
         """Problem for s[i,c] = -diss(q_i, table[c] (- a w_i))."""
