@@ -1,5 +1,4 @@
 """Timing of the split count kernel alone (HIP events), for KGE_SPLIT_DBG probes."""
-import ctypes
 import os
 import sys
 
@@ -16,26 +15,19 @@ en = _hip.row_sqnorm(E, max_io=guard[1:2])
 qn = _hip.row_sqnorm(q, max_io=guard[0:1])
 prob = _hip.LpProblem(_hip.LP_L2_EXPAND, q, E, qn=qn, en=en)
 st = prob.pair_scores(t)
-Es = _hip.split_rows(E, aug=en)
-Qs = _hip.split_rows(q, is_query=True)
-lib = _hip.load_library()
-Bp = int(lib.kge_lp_split_rows_padded(B, 1))
-thr = torch.empty(2 * Bp, device='cuda')
-cap = 64 * B
-lst = torch.empty(2 * cap, dtype=torch.int32, device='cuda')
-nl = torch.zeros(1, dtype=torch.int32, device='cuda')
+prob.split = {'Es': _hip.split_rows(E, aug=en), 'enmax': guard[1:2], 'overflow': guard[2:3]}
+_hip.SPLIT_EPS_SCALE = float(os.environ.get('EPS', '1'))
+prep = prob.split_prepare()
 raw = torch.zeros(B, dtype=torch.int32, device='cuda')
+nl = prep['n_list']
 
 
 def count():
-    _hip._check(lib.kge_lp_split_count(ctypes.byref(prob.desc), _hip._p(Qs), _hip._p(Es), _hip._p(st),
-                                       _hip._p(guard[1:2]), float(os.environ.get('EPS', '1')), _hip._p(thr), _hip._p(raw), _hip._p(lst), cap,
-                                       _hip._p(nl), _hip._p(guard[2:3]), _hip._stream()), 'count')
+    prob.split_count(prep, st, raw)
 
 
 def recheck():
-    _hip._check(lib.kge_lp_split_recheck(ctypes.byref(prob.desc), _hip._p(st), _hip._p(lst), cap, _hip._p(nl),
-                                         _hip._p(raw), _hip._stream()), 'recheck')
+    prob.split_recheck(prep, st, raw)
 
 
 for name, fn in (('count', count), ('recheck', recheck)):
