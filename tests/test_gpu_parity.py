@@ -840,3 +840,42 @@ def test_split_prefilter_dot_mode_counts_equal_exact_counts(hip, B, N, K, K1, sc
         hip.SPLIT_EPS_SCALE = 1.0
     if N > 64 * 2:
         assert float(guard[2]) == 0.0 or int(exact[0]) == N   # only the all-tie query may overflow a tile buffer
+
+
+def test_split_prefilter_random_shape_sweep(hip):
+    """Random shapes / magnitudes / alignments for both MFMA modes: split counts == exact counts
+    (K not a multiple of 4 takes the scalar staging paths; c_base != 0 is a candidate shard)."""
+    g = torch.Generator().manual_seed(2024)
+    for trial in range(14):
+        B = int(torch.randint(1, 700, (1,), generator=g)); N = int(torch.randint(1, 2500, (1,), generator=g))
+        K = int(torch.randint(1, 260, (1,), generator=g))
+        dot = trial % 2 == 1
+        K1 = int(torch.randint(1, 130, (1,), generator=g)) if (dot and trial % 4 == 3) else 0
+        mag = float(10.0 ** torch.empty(1).uniform_(-2, 1.5, generator=g)) if dot else 1.0
+        T0 = torch.randn(N, K, generator=g) * mag
+        A0 = torch.randn(B, K, generator=g) * mag
+        if not dot:                                   # TransE-like: unit entities, q = e + r
+            T0 = torch.nn.functional.normalize(T0, dim=1)
+            A0 = T0[torch.randint(0, N, (B,), generator=g)] + torch.nn.functional.normalize(A0, dim=1)
+        T1 = (torch.randn(N, K1, generator=g) * mag).cuda() if K1 else None
+        A1 = (torch.randn(B, K1, generator=g) * mag).cuda() if K1 else None
+        T0, A0 = T0.cuda(), A0.cuda().contiguous()
+        t = torch.randint(0, N, (B,), generator=g).cuda()
+        guard = torch.zeros(8, device='cuda')
+        if dot:
+            prob = hip.LpProblem(hip.LP_DOT, A0, T0, A1=A1, T1=T1)
+            hip.row_sqnorm(T0, max_io=guard[1:2])
+            if T1 is not None:
+                hip.row_sqnorm(T1, max_io=guard[5:6])
+            Es = hip.split_rows(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=guard[5:6] if T1 is not None else None)
+        else:
+            en = hip.row_sqnorm(T0, max_io=guard[1:2]); qn = hip.row_sqnorm(A0, max_io=guard[0:1])
+            prob = hip.LpProblem(hip.LP_L2_EXPAND, A0, T0, qn=qn, en=en)
+            Es = hip.split_rows(T0, aug=en)
+        st = prob.pair_scores(t)
+        exact = prob.count_ge(st)
+        prob.split = {'Es': Es, 'enmax': guard[1:2], 'enmax1': guard[5:6] if T1 is not None else None,
+                      'overflow': guard[2:3]}
+        got = prob.count_ge(st)
+        assert float(guard[2]) == 0.0, (trial, B, N, K, K1)
+        assert torch.equal(got, exact), (trial, B, N, K, K1, dot, int((got != exact).sum()))
