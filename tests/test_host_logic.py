@@ -250,3 +250,38 @@ def test_single_process_engine_hook_equals_reference():
         for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
             assert np.array_equal(getattr(ev, nm).numpy(), z[nm])
     assert abs(ev.mrr()[1] - z['mrr'][1]) < 1e-7
+
+
+def test_filter_index_torch_build_and_disk_cache(tmp_path):
+    """Device-style (torch sort / unique) CSR build == numpy build == dict build;
+    the on-disk cache round-trips."""
+    import numpy as np
+    from torchkge_amd.filter_index import FilterIndex
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    h = torch.randint(0, 60, (n,), generator=g); t = torch.randint(0, 60, (n,), generator=g)
+    r = torch.randint(0, 5, (n,), generator=g)
+    a = FilterIndex.from_triples(h.numpy(), r.numpy(), t.numpy(), 'cpu')
+    b = FilterIndex.from_triples_torch(h, r, t, 'cpu')
+    d = {}
+    for hh, rr, tt in zip(h.tolist(), r.tolist(), t.tolist()):
+        d.setdefault((hh, rr), set()).add(tt)
+    c = FilterIndex.from_dict({k: sorted(v) for k, v in d.items()}, 'cpu')
+    for x in (b, c):
+        assert torch.equal(a.keys, x.keys) and torch.equal(a.offsets, x.offsets)
+        assert torch.equal(a.targets[:int(a.offsets[-1])], x.targets[:int(x.offsets[-1])])
+    p = a.save(str(tmp_path / 'idx.npz'))
+    z = FilterIndex.load(p, 'cpu')
+    assert torch.equal(a.keys, z.keys) and torch.equal(a.offsets, z.offsets) and torch.equal(a.targets, z.targets)
+    # KnowledgeGraph-level cache: second graph object with the same triples loads the file
+    import torchkge_amd as tk
+    kw = dict(ent2ix={i: i for i in range(60)}, rel2ix={i: i for i in range(5)})
+    kg1 = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, **kw)
+    kg1.set_filter_cache(str(tmp_path / 'cache'))
+    i1 = kg1.filter_index('tails', 'cpu')
+    files = sorted((tmp_path / 'cache').iterdir())
+    assert len(files) == 1
+    kg2 = tk.KnowledgeGraph(kg={'heads': h.clone(), 'tails': t.clone(), 'relations': r.clone()}, **kw)
+    kg2.set_filter_cache(str(tmp_path / 'cache'))
+    i2 = kg2.filter_index('tails', 'cpu')
+    assert torch.equal(i1.keys, i2.keys) and torch.equal(i1.targets, i2.targets) and torch.equal(i1.keys, a.keys)

@@ -7,7 +7,7 @@ from .exceptions import NotYetEvaluatedError
 from .utils import MarginLoss, LogisticLoss
 from .utils import l1_dissimilarity, l2_dissimilarity
 from .data_structures import KnowledgeGraph, SmallKG
-from .evaluation import LinkPredictionEvaluator, RelationPredictionEvaluator
+from .evaluation import LinkPredictionEvaluator, RelationPredictionEvaluator, TripletClassificationEvaluator
 from .inference import EntityInference, RelationInference
 from .models import TransEModel, TransHModel, TransDModel, DistMultModel, ComplExModel
-from .sampling import BernoulliNegativeSampler, UniformNegativeSampler
+from .sampling import BernoulliNegativeSampler, UniformNegativeSampler, PositionalNegativeSampler

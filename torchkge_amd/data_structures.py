@@ -31,6 +31,16 @@ class _LazyDicts(object):
         self.src = (heads, tails, rels)   # CPU int64 tensors of the full graph
         self._dicts = None
         self._index = {}                  # (side, device) -> FilterIndex
+        self.cache_dir = None             # optional directory for the on-disk CSR cache
+
+    def _cache_file(self, side):
+        """<cache_dir>/filter_<side>_<n_facts>_<checksum>.npz -- keyed on the triples themselves."""
+        import hashlib
+        import os
+        h = hashlib.sha1()
+        for x in self.src:
+            h.update(np.ascontiguousarray(x.numpy()).tobytes())
+        return os.path.join(self.cache_dir, 'filter_%s_%d_%s.npz' % (side, int(self.src[0].shape[0]), h.hexdigest()[:16]))
 
     @staticmethod
     def _group(k1, k2, v):
@@ -57,11 +67,20 @@ class _LazyDicts(object):
         """side 'heads': (t, r) -> {h};  side 'tails': (h, r) -> {t}."""
         key = (side, str(device))
         if key not in self._index:
-            h, t, r = (x.numpy() for x in self.src)
+            import os
+            path = self._cache_file(side) if self.cache_dir else None
+            if path and os.path.exists(path):
+                self._index[key] = FilterIndex.load(path, device)
+                return self._index[key]
+            h, t, r = self.src
+            build = FilterIndex.from_triples_torch if torch.device(device).type == 'cuda' else FilterIndex.from_triples
             if side == 'heads':
-                self._index[key] = FilterIndex.from_triples(t, r, h, device)
+                self._index[key] = build(t, r, h, device)
             else:
-                self._index[key] = FilterIndex.from_triples(h, r, t, device)
+                self._index[key] = build(h, r, t, device)
+            if path:
+                os.makedirs(self.cache_dir, exist_ok=True)
+                self._index[key].save(path)
         return self._index[key]
 
 
@@ -126,10 +145,17 @@ class KnowledgeGraph(Dataset):
     def dict_of_rels(self):
         return self._explicit_dicts[2] if self._explicit_dicts is not None else self._lazy.dicts()[2]
 
+    def set_filter_cache(self, cache_dir):
+        """Keep the device filter CSRs of this graph on disk under ``cache_dir``
+        (file name keyed on a checksum of the triples): later runs load them
+        instead of re-sorting the graph."""
+        if self._lazy is not None:
+            self._lazy.cache_dir = cache_dir
+
     def filter_index(self, side, device):
         """Device FilterIndex of dict_of_heads (side='heads') or dict_of_tails
-        (side='tails'); built from the full-graph triples when they are known,
-        otherwise converted from the dict."""
+        (side='tails'); built from the full-graph triples when they are known
+        (on the device, by sort / unique), otherwise converted from the dict."""
         if self._lazy is not None:
             return self._lazy.index(side, device)
         from .filter_index import filter_index_for

@@ -69,6 +69,44 @@ class FilterIndex(object):
         offsets = np.concatenate([first, [k.shape[0]]])
         return cls(ukeys, offsets, v.astype(np.int32), device)
 
+    @classmethod
+    def from_triples_torch(cls, key1, key2, values, device):
+        """The same index built ON the target device with torch sort / unique_consecutive
+        (two stable sorts = lexicographic (key, value) order): at Wikidata5M scale (2e7 facts)
+        this replaces minutes of per-fact Python (data_structures.py:386-397) by a few
+        device-side sorts.  Bit-identical to from_triples."""
+        dev = torch.device(device)
+        key1 = torch.as_tensor(key1, dtype=torch.int64).to(dev)
+        key2 = torch.as_tensor(key2, dtype=torch.int64).to(dev)
+        v = torch.as_tensor(values, dtype=torch.int64).to(dev)
+        if key1.numel() == 0:
+            return cls(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int32), device)
+        k = key1 * KEY2_SPAN + key2
+        v, o = torch.sort(v, stable=True)
+        k = k[o]
+        k, o = torch.sort(k, stable=True)
+        v = v[o]
+        keep = torch.ones(k.shape[0], dtype=torch.bool, device=dev)
+        keep[1:] = (k[1:] != k[:-1]) | (v[1:] != v[:-1])
+        k, v = k[keep], v[keep]
+        ukeys, counts = torch.unique_consecutive(k, return_counts=True)
+        offsets = torch.zeros(ukeys.shape[0] + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(counts, 0)
+        return cls(ukeys, offsets, v.to(torch.int32), device)
+
+    # -- on-disk cache ---------------------------------------------------------
+    def save(self, path):
+        """Write the CSR (keys, offsets, targets) as one .npz file."""
+        n_t = int(self.offsets[-1].item()) if self.offsets.numel() else 0
+        np.savez(path, keys=self.keys.cpu().numpy(), offsets=self.offsets.cpu().numpy(),
+                 targets=self.targets.cpu().numpy()[:n_t])
+        return path
+
+    @classmethod
+    def load(cls, path, device):
+        z = np.load(path)
+        return cls(z['keys'], z['offsets'], z['targets'], device)
+
     # -- queries -------------------------------------------------------------
     def lookup(self, key1, key2):
         """(seg_lo, seg_hi) int64 device vectors; empty segment = key absent."""
