@@ -144,6 +144,25 @@ class LinkPredictionEvaluator(object):
             scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
         return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
 
+    def _rank_batch_sharded_counts(self, h, t, r, index_t, index_h, lo, hi):
+        """Entity-sharded batch, both sides together, with TWO collectives instead of
+        four: one all-reduce of the (2, B) true scores (the owner shard holds the value,
+        the others 0), one all-reduce of the (2, 3, B) partial rank counts."""
+        eng = self.engine
+        B = h.shape[0]
+        lo_t, hi_t = eng.lookup(index_t, h, r)
+        lo_h, hi_h = eng.lookup(index_h, t, r)
+        prob_t = eng.problem(self.model, h, t, r, 'tail', lo, hi)
+        prob_h = eng.problem(self.model, h, t, r, 'head', lo, hi)
+        s_true = torch.stack([eng.true_scores(prob_t, t), eng.true_scores(prob_h, h)])
+        kdist.all_reduce_sum(s_true, self.group)
+        counts = torch.stack([eng.partial_counts(prob_t, s_true[0], t, lo_t, hi_t, index_t.targets),
+                              eng.partial_counts(prob_h, s_true[1], h, lo_h, hi_h, index_h.targets)])
+        kdist.all_reduce_sum(counts, self.group)
+        rk_t, frk_t = eng.finalize(counts[0])
+        rk_h, frk_h = eng.finalize(counts[1])
+        return rk_t, frk_t, rk_h, frk_h
+
     def _rank_batch_overlapped(self, h, t, r, index_t, index_h):
         """Both sides of one batch on two HIP streams: the short kernels (filter
         lookup, query prep, true scores, filter correction) of one side run on an
@@ -239,6 +258,10 @@ class LinkPredictionEvaluator(object):
                     if overlap:
                         out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
                             self._rank_batch_overlapped(h, t, r, index_t, index_h)
+                        continue
+                    if sharded and self.fused and self.exchange == 'counts' and not self._generic_model:
+                        out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
+                            self._rank_batch_sharded_counts(h, t, r, index_t, index_h, lo, hi)
                         continue
                     out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                     out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
