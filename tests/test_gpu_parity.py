@@ -879,3 +879,24 @@ def test_split_prefilter_random_shape_sweep(hip):
         got = prob.count_ge(st)
         assert float(guard[2]) == 0.0, (trial, B, N, K, K1)
         assert torch.equal(got, exact), (trial, B, N, K, K1, dot, int((got != exact).sum()))
+
+
+def test_split_prefilter_nonfinite_embeddings_fall_back(hip):
+    """A diverged model (inf in an embedding): the split prefilter raises its flag and the
+    evaluator returns the ranks of the exact fp32 path."""
+    import torchkge_amd as tk
+    g = torch.Generator().manual_seed(8)
+    n_ent, n_rel, d, n = 400, 4, 32, 50
+    m = tk.DistMultModel(d, n_ent, n_rel).cuda()
+    m.ent_emb.weight.data[7, 3] = float('inf')
+    h = torch.randint(0, n_ent, (n,), generator=g); t = torch.randint(0, n_ent, (n,), generator=g)
+    r = torch.randint(0, n_rel, (n,), generator=g)
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r},
+                           ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)})
+    ev = tk.LinkPredictionEvaluator(m, kg)
+    ev.evaluate(b_size=64, verbose=False)
+    m.split_filter = False
+    ev2 = tk.LinkPredictionEvaluator(m, kg)
+    ev2.evaluate(b_size=64, verbose=False)
+    for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
+        assert torch.equal(getattr(ev, nm), getattr(ev2, nm))

@@ -159,13 +159,20 @@ struct SplitThrParams {
     float eps_scale;
     float2 *thr;
     int32_t *list_count;
+    float *overflow;
 };
 
 __global__ void split_thr_kernel(const SplitThrParams p)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
     const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
     const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *p.list_count = 0;
+        // non-finite norms (diverged embeddings): f16 operands would hold inf / NaN and the
+        // comparisons would silently fail -- hand the count back to the exact fp32 path
+        const float qm = p.qmax0 ? *p.qmax0 + (p.qmax1 ? *p.qmax1 : 0.f) : 0.f;
+        if (!(em < INFINITY) || !(qm < INFINITY)) *p.overflow = 1.0f;
+    }
     const float eps_rel = 2.0f * ((float)(48 * p.units + p.K) * two24 + 3.0f * two22);
     const float enrm = sqrtf(em) * 1.000001f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.Bp; i += (int64_t)gridDim.x * blockDim.x) {
@@ -587,6 +594,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.eps_scale = a->eps_scale;
     t.thr = reinterpret_cast<float2 *>(a->thr);
     t.list_count = a->list_count;
+    t.overflow = a->overflow;
     hipLaunchKernelGGL(split_thr_kernel, dim3((int)((Bp + 255) / 256)), dim3(256), 0, s, t);
     KGE_CHECK_LAUNCH();
 
