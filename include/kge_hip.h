@@ -89,8 +89,12 @@ enum {
     KGE_LP_DOT = 0,        /* s = A0.T0 (+ A1.T1)              bilinear, fp32 MFMA            */
     KGE_LP_L2_EXPAND = 1,  /* s = -max(qn+en-2*A0.T0, 0)       TransE L2 as fp32 MFMA GEMM     */
     KGE_LP_L1_DIRECT = 2,  /* s = -sum_k |A0 - T0 (+a*Wq)|     broadcast-subtract, fp32 VALU   */
-    KGE_LP_L2_DIRECT = 3   /* s = -sum_k (A0 - T0 (+a*Wq))^2   broadcast-subtract, fp32 VALU   */
+    KGE_LP_L2_DIRECT = 3,  /* s = -sum_k (A0 - T0 (+a*Wq))^2   broadcast-subtract, fp32 VALU   */
+    KGE_LP_L2_PROJH = 4,   /* TransH: ||u - e + x w||^2 expanded around u.e, x = X[r_i,c]   fp32 MFMA + gather */
+    KGE_LP_L2_PROJD = 5    /* TransD: ||u - e' - y_c w||^2 expanded around u.e', g = X[r_i,c] fp32 MFMA + gather */
 };
+/* the MFMA (GEMM-shaped) modes: everything but the two DIRECT ones */
+#define KGE_LP_IS_MFMA(mode) ((mode) <= KGE_LP_L2_EXPAND || (mode) >= KGE_LP_L2_PROJH)
 
 /*
  * Descriptor of one all-candidates scoring problem: B queries against the N
@@ -98,6 +102,13 @@ enum {
  *   score(i, c) for local candidate c in [0,N):
  *     DOT        : chain(A0[i], T0[c], K0) then chain(A1[i], T1[c], K1)
  *     L2_EXPAND  : -fmaxf(fmaf(-2, chain(A0[i],T0[c],K0), qn[i] + en[c]), 0)
+ *     L2_PROJH   : v = fmaf(-2, chain(A0[i],T0[c],K0), qn[i] + en[c]); x = X[r_idx[i], c];
+ *                  v = fmaf(x, fmaf(x, z_i, p_i), v); s = -fmaxf(v, 0)
+ *                  (TransH candidates e_c - x w_i with x = e_c.w_{r_i}: p_i = 2 u_i.w_i, z_i = ||w_i||^2 - 2)
+ *     L2_PROJD   : v as above; g = X[r_idx[i], c]; y = yc[c];
+ *                  v = fmaf(y, fmaf(y, z_i, fmaf(2, g, p_i)), v); s = -fmaxf(v, 0)
+ *                  (TransD candidates e'_c + y_c w_i, g = e'_c.w_{r_i}: p_i = -2 u_i.w_i, z_i = ||w_i||^2)
+ *                  with (p_i, z_i) = Wq[i*ldw + {0,1}] and X[r, c] = scal[r*scal_ld + c]
  *     L1/L2_DIRECT: diff_k = A0[i,k] - T0[c,k]; if Wq: diff_k = fmaf(a, Wq[i,k], diff_k)
  *                   with a = scal[c*scal_ld + (scal_ld > 1 ? r_idx[i] : 0)];
  *                   acc += |diff_k|  or  acc = fmaf(diff_k, diff_k, acc);  s = -acc
@@ -122,9 +133,10 @@ typedef struct kge_lp_desc {
     const float *T1; int64_t ldt1;   /* (N,K1) or NULL */
     const float *qn;           /* (B) ||A0[i]||^2   (L2_EXPAND) */
     const float *en;           /* (N) ||T0[c]||^2   (L2_EXPAND) */
-    const float *Wq; int64_t ldw;    /* (B,K0) per-query direction or NULL (DIRECT) */
-    const float *scal; int64_t scal_ld; /* (N,scal_ld) per-candidate scalars (DIRECT + Wq) */
-    const int64_t *r_idx;      /* (B) column of scal used by query i (when scal_ld > 1) */
+    const float *Wq; int64_t ldw;    /* DIRECT: (B,K0) per-query direction or NULL; PROJ: (B,2) = (p_i, z_i) */
+    const float *scal; int64_t scal_ld; /* DIRECT + Wq: (N,scal_ld) per-candidate scalars; PROJ: X (n_rel, scal_ld >= N) */
+    const int64_t *r_idx;      /* (B) DIRECT: column of scal used by query i (when scal_ld > 1); PROJ: row of X */
+    const float *yc;           /* (N) per-candidate scalar y_c (L2_PROJD) */
 } kge_lp_desc;
 
 /* ---- K1: fused gather + normalise + score (scoring_function) ------------- */

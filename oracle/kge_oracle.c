@@ -141,6 +141,26 @@ void orc_lp_gemm_chain(const float *A0, int64_t lda0, const float *T0, int64_t l
         }
 }
 
+/* The projection modes of kge_lp_desc (include/kge_hip.h: KGE_LP_L2_PROJH = 4, KGE_LP_L2_PROJD = 5):
+ *   v = fmaf(-2, chain(A[i], T[c]), qn[i] + en[c]);  x = X[r_idx[i]*ldx + c];  (p, z) = pz[2i], pz[2i+1]
+ *   PROJH (TransH, translation.py:183-284 with candidates e_c - x w):  v = fmaf(x, fmaf(x, z, p), v)
+ *   PROJD (TransD, translation.py:538-652 with candidates e'_c + y_c w): v = fmaf(y, fmaf(y, z, fmaf(2, x, p)), v)
+ *   s = -max(v, 0) */
+void orc_lp_proj_chain(int mode, const float *A, int64_t lda, const float *T, int64_t ldt, int64_t K,
+                       int64_t B, int64_t N, const float *qn, const float *en, const float *X, int64_t ldx,
+                       const int64_t *r_idx, const float *yc, const float *pz, float *out)
+{
+    for (int64_t i = 0; i < B; ++i)
+        for (int64_t c = 0; c < N; ++c) {
+            float dot = chain_dot(A + i * lda, T + c * ldt, K, 0, 0, 0);
+            float v = fmaf(-2.0f, dot, qn[i] + en[c]);
+            float x = X[r_idx[i] * ldx + c], p = pz[2 * i], z = pz[2 * i + 1];
+            if (mode == 4) v = fmaf(x, fmaf(x, z, p), v);
+            else v = fmaf(yc[c], fmaf(yc[c], z, fmaf(2.0f, x, p)), v);
+            out[i * N + c] = -fmaxf(v, 0.0f);
+        }
+}
+
 /* squared row norms with the same chain: n[i] = sum_k x[i,k]^2 (fmaf chain). */
 void orc_row_sqnorm_chain(const float *X, int64_t ld, int64_t rows, int64_t K, float *out)
 {

@@ -900,3 +900,37 @@ def test_split_prefilter_nonfinite_embeddings_fall_back(hip):
     ev2.evaluate(b_size=64, verbose=False)
     for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
         assert torch.equal(getattr(ev, nm), getattr(ev2, nm))
+
+
+@pytest.mark.parametrize('mode_name,B,N,K,R', [('H', 130, 300, 64, 7), ('D', 257, 129, 40, 5), ('H', 33, 1000, 203, 11),
+                                               ('D', 64, 515, 200, 3)])
+def test_projection_modes_bit_exact_vs_chain(hip, mode_name, B, N, K, R):
+    """KGE_LP_L2_PROJH / _PROJD (TransH / TransD as an fp32 MFMA GEMM + per-pair gather):
+    tile kernel == pair kernel == oracle/kge_oracle.c bit for bit; rank counts consistent."""
+    import ctypes as C
+    lib = oracle_clib()
+    mode = hip.LP_L2_PROJH if mode_name == 'H' else hip.LP_L2_PROJD
+    g = torch.Generator().manual_seed(B + N + K)
+    A = torch.randn(B, K, generator=g) * 0.3
+    T = torch.randn(N, K, generator=g) * 0.3
+    X = torch.randn(R, N, generator=g) * 0.2
+    yc = torch.randn(N, generator=g) * 0.2
+    pz = torch.randn(B, 2, generator=g) * 0.5
+    r_idx = torch.randint(0, R, (B,), generator=g)
+    dA, dT = A.cuda(), T.cuda()
+    qn, en = hip.row_sqnorm(dA), hip.row_sqnorm(dT)
+    prob = hip.LpProblem(mode, dA, dT, qn=qn, en=en, Wq=pz.cuda(), scal=X.cuda(), r_idx=r_idx.cuda(),
+                         yc=yc.cuda() if mode_name == 'D' else None)
+    S = prob.scores().cpu()
+    ref = np.empty((B, N), dtype=np.float32)
+    i64 = C.c_int64
+    lib.orc_lp_proj_chain(C.c_int(4 if mode_name == 'H' else 5), fptr(A.numpy()), i64(K), fptr(T.numpy()), i64(K),
+                          i64(K), i64(B), i64(N), fptr(qn.cpu().numpy()), fptr(en.cpu().numpy()), fptr(X.numpy()),
+                          i64(N), r_idx.numpy().ctypes.data_as(C.c_void_p), fptr(yc.numpy()), fptr(pz.numpy()),
+                          fptr(ref))
+    assert np.array_equal(S.numpy(), ref)
+    t = torch.randint(0, N, (B,), generator=g).cuda()
+    st = prob.pair_scores(t)
+    assert torch.equal(st.cpu(), S[torch.arange(B), t.cpu()])
+    cnt = prob.count_ge(st).cpu()
+    assert torch.equal(cnt, (S >= st.cpu().view(-1, 1)).sum(1).to(torch.int32))

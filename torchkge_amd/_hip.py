@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkge_hip.so')
 TRANSE_L1, TRANSE_L2, TRANSH, TRANSD, DISTMULT, COMPLEX = range(6)
 SIDE_TAIL, SIDE_HEAD, SIDE_PROJ_H, SIDE_PROJ_T = range(4)
 EW_ADD, EW_SUB, EW_MUL, EW_MULSUB, EW_MULADD = range(5)
-LP_DOT, LP_L2_EXPAND, LP_L1_DIRECT, LP_L2_DIRECT = range(4)
+LP_DOT, LP_L2_EXPAND, LP_L1_DIRECT, LP_L2_DIRECT, LP_L2_PROJH, LP_L2_PROJD = range(6)
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -35,7 +35,7 @@ class LpDesc(ctypes.Structure):
         ('A1', _vp), ('lda1', _i64), ('T1', _vp), ('ldt1', _i64),
         ('qn', _vp), ('en', _vp),
         ('Wq', _vp), ('ldw', _i64), ('scal', _vp), ('scal_ld', _i64),
-        ('r_idx', _vp),
+        ('r_idx', _vp), ('yc', _vp),
     ]
 
 
@@ -107,7 +107,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 3:
+    if lib.kge_abi_version() != 4:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -303,9 +303,9 @@ class LpProblem(object):
     descriptor entry points."""
 
     def __init__(self, mode, A0, T0, A1=None, T1=None, qn=None, en=None, Wq=None, scal=None,
-                 r_idx=None, c_base=0, K0=None):
-        require_cuda(A0, T0, A1, T1, qn, en, Wq, scal, r_idx)
-        self.keep = [A0, T0, A1, T1, qn, en, Wq, scal, r_idx]
+                 r_idx=None, c_base=0, K0=None, yc=None):
+        require_cuda(A0, T0, A1, T1, qn, en, Wq, scal, r_idx, yc)
+        self.keep = [A0, T0, A1, T1, qn, en, Wq, scal, r_idx, yc]
         self.device = A0.device
         d = LpDesc()
         d.mode = mode
@@ -325,6 +325,8 @@ class LpProblem(object):
             d.scal_ld = 1 if scal.dim() == 1 else scal.stride(0)
             if r_idx is not None:
                 d.r_idx = r_idx.data_ptr()
+        if yc is not None:
+            d.yc = yc.data_ptr()
         self.desc = d
         self.B, self.N = int(d.B), int(d.N)
         self.split = None

@@ -71,16 +71,32 @@ __device__ __forceinline__ float lp_epilogue(int mode, float dot, float qn, floa
     return dot;
 }
 
+// epilogue of the projection modes (include/kge_hip.h): `v0` = fmaf(-2, dot, qn + en)
+__device__ __forceinline__ float lp_epilogue_proj(int mode, float v0, float x, float y, float p, float z)
+{
+    float v;
+    if (mode == KGE_LP_L2_PROJH) v = fmaf(x, fmaf(x, z, p), v0);
+    else v = fmaf(y, fmaf(y, z, fmaf(2.0f, x, p)), v0);
+    return -fmaxf(v, 0.0f);
+}
+__device__ __forceinline__ float lp_epilogue_any(const kge_lp_desc &d, float dot, int64_t i, int64_t c)
+{
+    if (d.mode == KGE_LP_DOT) return dot;
+    const float v0 = fmaf(-2.0f, dot, d.qn[i] + d.en[c]);
+    if (d.mode == KGE_LP_L2_EXPAND) return -fmaxf(v0, 0.0f);
+    const float x = d.scal[d.r_idx[i] * d.scal_ld + c];
+    const float y = d.mode == KGE_LP_L2_PROJD ? d.yc[c] : 0.f;
+    return lp_epilogue_proj(d.mode, v0, x, y, d.Wq[i * d.ldw], d.Wq[i * d.ldw + 1]);
+}
+
 // score of query i against LOCAL candidate c, any mode (scalar reference path
 // used by the pair / filter kernels; bit-identical to the tile kernels).
 __device__ __forceinline__ float lp_pair_score(const kge_lp_desc &d, int64_t i, int64_t c)
 {
-    if (d.mode == KGE_LP_DOT || d.mode == KGE_LP_L2_EXPAND) {
+    if (KGE_LP_IS_MFMA(d.mode)) {
         float acc = lp_chain_dot(d.A0 + i * d.lda0, d.T0 + c * d.ldt0, d.K0, 0.0f);
         if (d.K1 > 0) acc = lp_chain_dot(d.A1 + i * d.lda1, d.T1 + c * d.ldt1, d.K1, acc);
-        float qn = 0.f, en = 0.f;
-        if (d.mode == KGE_LP_L2_EXPAND) { qn = d.qn[i]; en = d.en[c]; }
-        return lp_epilogue(d.mode, acc, qn, en);
+        return lp_epilogue_any(d, acc, i, c);
     }
     const float *q = d.A0 + i * d.lda0;
     const float *t = d.T0 + c * d.ldt0;
@@ -172,15 +188,13 @@ __device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, 
     return acc;
 }
 
-// MFMA modes only (KGE_LP_DOT / KGE_LP_L2_EXPAND); (qi, ci) must be valid rows on every lane
+// MFMA modes only (KGE_LP_IS_MFMA); (qi, ci) must be valid rows on every lane
 template <bool VEC4>
 __device__ __forceinline__ float lp_pair_score_staged(const kge_lp_desc &d, int qi, int ci, float *qs, float *es)
 {
     float acc = lp_staged_segment<VEC4>(d.A0, d.lda0, d.T0, d.ldt0, d.K0, qi, ci, qs, es, 0.0f);
     if (d.K1 > 0) acc = lp_staged_segment<VEC4>(d.A1, d.lda1, d.T1, d.ldt1, d.K1, qi, ci, qs, es, acc);
-    float qn = 0.f, en = 0.f;
-    if (d.mode == KGE_LP_L2_EXPAND) { qn = d.qn[qi]; en = d.en[ci]; }
-    return lp_epilogue(d.mode, acc, qn, en);
+    return lp_epilogue_any(d, acc, qi, ci);
 }
 
 // tuning knob for experiments (env KGE_LP_TARGET_BLOCKS), default `dflt`
@@ -193,13 +207,18 @@ static inline int kge_env_int(const char *name, int dflt)
 static inline int kge_lp_desc_check(const kge_lp_desc *d)
 {
     if (!d) return KGE_EINVAL;
-    if (d->mode < KGE_LP_DOT || d->mode > KGE_LP_L2_DIRECT) return KGE_EINVAL;
+    if (d->mode < KGE_LP_DOT || d->mode > KGE_LP_L2_PROJD) return KGE_EINVAL;
     if (d->B < 0 || d->N < 0 || d->K0 <= 0 || d->K1 < 0) return KGE_EINVAL;
     if (d->B == 0 || d->N == 0) return 0; // empty problem: nothing is dereferenced
     if (!d->A0 || !d->T0) return KGE_EINVAL;
     if (d->K1 > 0 && (!d->A1 || !d->T1)) return KGE_EINVAL;
     if (d->K1 > 0 && d->mode != KGE_LP_DOT) return KGE_EINVAL;
     if (d->mode == KGE_LP_L2_EXPAND && (!d->qn || !d->en)) return KGE_EINVAL;
+    if (d->mode >= KGE_LP_L2_PROJH) {
+        if (!d->qn || !d->en || !d->Wq || d->ldw < 2 || !d->scal || d->scal_ld < d->N || !d->r_idx) return KGE_EINVAL;
+        if (d->mode == KGE_LP_L2_PROJD && !d->yc) return KGE_EINVAL;
+        return 0;
+    }
     if (d->Wq && (!d->scal || d->scal_ld < 1 || (d->scal_ld > 1 && !d->r_idx))) return KGE_EINVAL;
     if (d->Wq && d->mode < KGE_LP_L1_DIRECT) return KGE_EINVAL;
     return 0;

@@ -35,7 +35,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
 constexpr int TILE_FLOATS = BM * LDS_LD;                     // one operand tile
-constexpr int SMEM_BYTES = 4 * TILE_FLOATS * 4 + 3 * BM * 4; // 2 bufs x (A,B) + row counters, s_true, qn
+constexpr int SMEM_BYTES = 4 * TILE_FLOATS * 4 + 6 * BM * 4; // 2 bufs x (A,B) + row counters, s_true, qn, (p, z, X row) of the PROJ modes
 
 struct GemmParams {
     kge_lp_desc d;
@@ -171,12 +171,22 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
     int *rc = reinterpret_cast<int *>(smem + 4 * TILE_FLOATS);
     float *st_s = smem + 4 * TILE_FLOATS + BM;
     float *qn_s = st_s + BM;
+    float *p_s = qn_s + BM, *z_s = p_s + BM;                 // PROJ modes: per-query (p_i, z_i)
+    int *xo_s = reinterpret_cast<int *>(z_s + BM);           //             and their row r_i of X
+    constexpr bool EXPANDED = MODE != KGE_LP_DOT;            // qn / en enter the epilogue
+    constexpr bool PROJ = MODE >= KGE_LP_L2_PROJH;
     auto load_panel = [&](int64_t row0) {
         if (tid < BM) {
             const int64_t row = row0 + tid;
             rc[tid] = 0;
             st_s[tid] = (COUNT && row < d.B) ? p.s_true[row] : 0.f;
-            qn_s[tid] = (MODE == KGE_LP_L2_EXPAND && row < d.B) ? d.qn[row] : 0.f;
+            qn_s[tid] = (EXPANDED && row < d.B) ? d.qn[row] : 0.f;
+            if (PROJ) {
+                const int64_t rc = row < d.B ? row : d.B - 1;
+                p_s[tid] = d.Wq[rc * d.ldw];
+                z_s[tid] = d.Wq[rc * d.ldw + 1];
+                xo_s[tid] = (int)d.r_idx[rc];
+            }
         }
     };
     auto flush_counts = [&](int64_t row0) { // block-uniform call sites only
@@ -237,9 +247,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
         KGE_MMA(af, bf)                                                                             \
     }
 
-    float en_pref[NT];
+    float en_pref[NT], y_pref[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) en_pref[nt] = 0.f;
+    for (int nt = 0; nt < NT; ++nt) { en_pref[nt] = 0.f; y_pref[nt] = 0.f; }
     int it = 0, s = 0;
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
@@ -249,12 +259,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
         const bool seg1 = s >= steps0;
         const int kb0 = (seg1 ? s - steps0 : s) << 2;
         const int nblk = min(4, (seg1 ? nb1 : nb0) - kb0);
-        if (MODE == KGE_LP_L2_EXPAND && s == S - 1) { // ||e_c||^2 of this tile's columns: issued a whole
+        if (EXPANDED && s == S - 1) { // ||e_c||^2 of this tile's columns: issued a whole
             const int item = (int)item_begin + it;    // step ahead of the epilogue that consumes them
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int64_t col = (int64_t)(item % p.col_tiles) * BN + wc * NT * 32 + nt * 32 + l31;
                 en_pref[nt] = d.en[min(col, d.N - 1)]; // clamped, unconditional
+                if (MODE == KGE_LP_L2_PROJD) y_pref[nt] = d.yc[min(col, d.N - 1)];
             }
         }
 
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
             for (int nt = 0; nt < NT; ++nt) {
                 const int64_t col = colb + nt * 32 + l31;
                 cmask[nt] = col < d.N ? 1 : 0;
-                enr[nt] = (MODE == KGE_LP_L2_EXPAND) ? en_pref[nt] : 0.f;
+                enr[nt] = EXPANDED ? en_pref[nt] : 0.f;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -303,8 +314,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
                 for (int gq = 0; gq < 4; ++gq) {
                     const int lrow0 = (wr * MT + mt) * 32 + 8 * gq + 4 * half;
                     stv[gq] = COUNT ? *reinterpret_cast<const float4 *>(st_s + lrow0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    qnv[gq] = (MODE == KGE_LP_L2_EXPAND) ? *reinterpret_cast<const float4 *>(qn_s + lrow0)
-                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                    qnv[gq] = EXPANDED ? *reinterpret_cast<const float4 *>(qn_s + lrow0)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -313,7 +324,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
                         const int gq = r >> 2, e = r & 3;
                         const float qn = e == 0 ? qnv[gq].x : (e == 1 ? qnv[gq].y : (e == 2 ? qnv[gq].z : qnv[gq].w));
                         const float st = e == 0 ? stv[gq].x : (e == 1 ? stv[gq].y : (e == 2 ? stv[gq].z : stv[gq].w));
-                        const float sc = lp_epilogue(MODE, acc[mt][nt][r], qn, enr[nt]);
+                        float sc;
+                        if (PROJ) { // per-pair gather X[r_i, c]: 128 B per lane half (one row of X, 32 consecutive columns)
+                            const int lrow = (wr * MT + mt) * 32 + e + 8 * gq + 4 * half;
+                            const int64_t colc = min(colb + nt * 32 + l31, d.N - 1);
+                            const float x = d.scal[(int64_t)xo_s[lrow] * d.scal_ld + colc];
+                            const float v0 = fmaf(-2.0f, acc[mt][nt][r], qn + enr[nt]);
+                            sc = lp_epilogue_proj(MODE, v0, x, y_pref[nt], p_s[lrow], z_s[lrow]);
+                        } else {
+                            sc = lp_epilogue(MODE, acc[mt][nt][r], qn, enr[nt]);
+                        }
                         if (WRITE) {
                             const int64_t row = cur_row0 + (wr * MT + mt) * 32 + e + 8 * gq + 4 * half;
                             if (cmask[nt] && row < d.B) p.out[row * p.ldo + colb + nt * 32 + l31] = sc;
@@ -368,6 +388,12 @@ int dispatch(const GemmParams &p, bool vec4, int grid, hipStream_t s)
     if (p.d.mode == KGE_LP_DOT)
         return vec4 ? launch<true, COUNT, KGE_LP_DOT, NWM, NWN>(p, grid, s)
                     : launch<false, COUNT, KGE_LP_DOT, NWM, NWN>(p, grid, s);
+    if (p.d.mode == KGE_LP_L2_PROJH)
+        return vec4 ? launch<true, COUNT, KGE_LP_L2_PROJH, NWM, NWN>(p, grid, s)
+                    : launch<false, COUNT, KGE_LP_L2_PROJH, NWM, NWN>(p, grid, s);
+    if (p.d.mode == KGE_LP_L2_PROJD)
+        return vec4 ? launch<true, COUNT, KGE_LP_L2_PROJD, NWM, NWN>(p, grid, s)
+                    : launch<false, COUNT, KGE_LP_L2_PROJD, NWM, NWN>(p, grid, s);
     return vec4 ? launch<true, COUNT, KGE_LP_L2_EXPAND, NWM, NWN>(p, grid, s)
                 : launch<false, COUNT, KGE_LP_L2_EXPAND, NWM, NWN>(p, grid, s);
 }

@@ -392,7 +392,7 @@ extern "C" int kge_lp_scores(const kge_lp_desc *d, float *out, int64_t ldo, kge_
     if (rc) return rc;
     if (d->B == 0 || d->N == 0) return 0;
     if (!out || ldo < d->N) return KGE_EINVAL;
-    if (d->mode <= KGE_LP_L2_EXPAND) return kge_lp_gemm_run(d, out, ldo, nullptr, nullptr, kge_s(stream));
+    if (KGE_LP_IS_MFMA(d->mode)) return kge_lp_gemm_run(d, out, ldo, nullptr, nullptr, kge_s(stream));
     return kge_lp_direct_run(d, out, ldo, nullptr, nullptr, kge_s(stream));
 }
 
@@ -402,7 +402,7 @@ extern "C" int kge_lp_count_ge(const kge_lp_desc *d, const float *s_true, int32_
     if (rc) return rc;
     if (d->B == 0 || d->N == 0) return 0;
     if (!s_true || !raw_count) return KGE_EINVAL;
-    if (d->mode <= KGE_LP_L2_EXPAND) return kge_lp_gemm_run(d, nullptr, 0, s_true, raw_count, kge_s(stream));
+    if (KGE_LP_IS_MFMA(d->mode)) return kge_lp_gemm_run(d, nullptr, 0, s_true, raw_count, kge_s(stream));
     return kge_lp_direct_run(d, nullptr, 0, s_true, raw_count, kge_s(stream));
 }
 
@@ -414,7 +414,7 @@ extern "C" int kge_lp_pair_scores(const kge_lp_desc *d, const int64_t *qi, const
     if (P < 0) return KGE_EINVAL;
     if (P == 0) return 0;
     if (!ci || !out) return KGE_EINVAL;
-    if (d->mode <= KGE_LP_L2_EXPAND && d->B > 0 && d->N > 0 && d->B <= INT32_MAX && d->N <= INT32_MAX) {
+    if (KGE_LP_IS_MFMA(d->mode) && d->B > 0 && d->N > 0 && d->B <= INT32_MAX && d->N <= INT32_MAX) {
         const int64_t groups = (P + 63) / 64;
         const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
         if (kge_lp_vec4(*d))
@@ -436,7 +436,7 @@ extern "C" int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, cons
     if (rc) return rc;
     if (d->B == 0) return 0;
     if (!s_true || !true_idx || !seg_lo || !seg_hi || !sub || !found) return KGE_EINVAL;
-    if (d->mode <= KGE_LP_L2_EXPAND && d->N > 0 && d->B <= INT32_MAX && d->N <= INT32_MAX) {
+    if (KGE_LP_IS_MFMA(d->mode) && d->N > 0 && d->B <= INT32_MAX && d->N <= INT32_MAX) {
         const int64_t groups = (d->B + 7) / 8;
         const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
         if (kge_lp_vec4(*d))
@@ -490,5 +490,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 3; }
+extern "C" int kge_abi_version(void) { return 4; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -274,24 +274,32 @@ class TranslationModel(Model):
     L2_EXPAND_LIMIT = 16.0
 
     def _uses_guard(self):
-        # only the plain TransE-L2 path takes the (optimistic) norm expansion and the split prefilter
-        return self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._kind is None
+        # the L2 models take the norm expansion (TransE: + the split prefilter) optimistically
+        return self.dissimilarity_type == 'L2' and self.l2_mode == 'auto'
+
+    def _proj_problem(self, q, table, Wq, r_idx, c_base, K0, qn, en):
+        """TransH / TransD: the expansion around u.e with the per-pair projection term
+        (KGE_LP_L2_PROJH / _PROJD); None = this model has no such form."""
+        return None
 
     def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
         """Problem for s[i,c] = -diss(q_i, table[c] (- a w_i))."""
-        if self.dissimilarity_type == 'L2' and self.l2_mode in ('expand', 'auto') and Wq is None:
+        if self.dissimilarity_type == 'L2' and self.l2_mode in ('expand', 'auto') and \
+                (Wq is None or (self._kind is not None and r_idx is not None)):
             # inside evaluate() the expansion is optimistic: the two norm kernels also
             # fold their maxima into the guard scalars, which are checked once at the end
             guarded = self.l2_mode == 'auto' and self._expand_ok is None and self._guard_on
             gq, ge = (self._lp_guard[0:1], self._lp_guard[1:2]) if guarded else (None, None)
             en = self._cache.get('en_%d_%d' % (c_base, table.shape[0]), [table],
-                                 lambda: _hip.row_sqnorm(table, max_io=ge))
+                                 lambda: _hip.row_sqnorm(table, K=K0, max_io=ge))
             qn = _hip.row_sqnorm(q, max_io=gq)
             ok = True
             if self.l2_mode == 'auto' and not guarded:
                 ok = self._expand_ok
                 if ok is None:      # drop-in API call: decide now on the actual operands (one sync)
                     ok = q.shape[0] == 0 or float((qn.max() + en.max()).item()) <= self.L2_EXPAND_LIMIT
+            if ok and Wq is not None:
+                return self._proj_problem(q, table, Wq, r_idx, c_base, K0, qn, en)
             if ok:
                 prob = _hip.LpProblem(_hip.LP_L2_EXPAND, q, table, qn=qn, en=en, c_base=c_base, K0=K0)
                 if guarded and self.split_filter and self._split_ok:
@@ -301,6 +309,8 @@ class TranslationModel(Model):
                                          lambda: _hip.split_rows(table, K=Kq, aug=en))
                     prob.split = {'Es': Es, 'enmax': ge, 'overflow': self._lp_guard[2:3]}
                 return prob
+        if callable(scal):          # built only when the broadcast-subtract kernel is really taken
+            scal = scal()
         return _hip.LpProblem(self._direct_mode(), q, table, Wq=Wq, scal=scal, r_idx=r_idx,
                               c_base=c_base, K0=K0)
 

@@ -132,6 +132,17 @@ class TransHModel(TranslationModel):
         return self._cache.get('transh_a_%d_%d' % (lo, hi), [E, W],
                                lambda: _hip.LpProblem(_hip.LP_DOT, Es, W).scores())
 
+    def _proj_problem(self, q, table, Wq, r_idx, c_base, K0, qn, en):
+        """-||u - (e_c - x w)||^2 with x = e_c.w_{r_i}, expanded around the GEMM term u.e_c
+        (KGE_LP_L2_PROJH): X[r, c] = W[r].E[c] is one small GEMM per evaluation, the
+        per-query scalars are p = 2 u.w and z = ||w||^2 - 2."""
+        W = _hip.f32c(self.norm_vect.weight.data)
+        XT = self._cache.get('transh_aT_%d_%d' % (c_base, table.shape[0]), [table, W],
+                             lambda: _hip.LpProblem(_hip.LP_DOT, W, table).scores())
+        pz = torch.stack([_hip.row_dot(q, Wq, scale=2.0), _hip.row_sqnorm(Wq) - 2.0], dim=1).contiguous()
+        return _hip.LpProblem(_hip.LP_L2_PROJH, q, table, qn=qn, en=en, Wq=pz, scal=XT, r_idx=r_idx,
+                              c_base=c_base)
+
     def evaluate_projections(self):
         """Kept for API compatibility (translation.py:260-284); the engine needs
         no (n_rel, n_ent, d) cache, so this only marks the projections valid."""
@@ -153,7 +164,7 @@ class TransHModel(TranslationModel):
         E, W = _hip.f32c(self.ent_emb.weight.data), self.norm_vect.weight.data
         Wq = _hip.gather_rows(W, cand.r_idx)
         return self._translational_problem(q, _shard(E, ent_lo, ent_hi), Wq=Wq,
-                                           scal=self._a_matrix(ent_lo, ent_hi), r_idx=cand.r_idx,
+                                           scal=lambda: self._a_matrix(ent_lo, ent_hi), r_idx=cand.r_idx,
                                            c_base=ent_lo)
 
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
@@ -163,7 +174,7 @@ class TransHModel(TranslationModel):
         d = self.emb_dim
         Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSH, sd, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)
         return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
-                                           scal=self._a_matrix(ent_lo, ent_hi),
+                                           scal=lambda: self._a_matrix(ent_lo, ent_hi),
                                            r_idx=_hip.i64c(r_idx), c_base=ent_lo)
 
 
@@ -225,17 +236,32 @@ class TransDModel(TranslationModel):
         r = _hip.gather_rows(tabs[1], r_idx)
         return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), max(h_idx.shape[0], t_idx.shape[0]))
 
-    def _problem(self, q, Wq, ent_lo, ent_hi):
+    def _problem(self, q, Wq, ent_lo, ent_hi, r_idx=None):
         E = _hip.f32c(self.ent_emb.weight.data)
         # candidates use E[c, :d_r]: same rows, inner dim K0 = d_r, leading dim d_e
         return self._translational_problem(q, _shard(E, ent_lo, ent_hi), Wq=Wq,
-                                           scal=self._neg_sigma(ent_lo, ent_hi), c_base=ent_lo,
-                                           K0=self.rel_emb_dim)
+                                           scal=lambda: self._neg_sigma(ent_lo, ent_hi), c_base=ent_lo,
+                                           K0=self.rel_emb_dim, r_idx=r_idx)
+
+    def _proj_problem(self, q, table, Wq, r_idx, c_base, K0, qn, en):
+        """-||u - (e'_c + y_c w)||^2, e' = e[:d_r], y_c = ep_c.e_c, expanded around the GEMM
+        term u.e'_c (KGE_LP_L2_PROJD): G[r, c] = Rp[r].e'_c is one small GEMM per evaluation,
+        the per-query scalars are p = -2 u.w and z = ||w||^2."""
+        lo, hi = c_base, c_base + table.shape[0]
+        Rp = _hip.f32c(self.rel_proj_vect.weight.data)
+        Ep = _hip.f32c(self.ent_proj_vect.weight.data)
+        GT = self._cache.get('transd_gT_%d_%d' % (lo, hi), [table, Rp],
+                             lambda: _hip.LpProblem(_hip.LP_DOT, Rp, table, K0=K0).scores())
+        sigma = self._cache.get('transd_sp_%d_%d' % (lo, hi), [table, Ep],
+                                lambda: _hip.row_dot(_shard(Ep, lo, hi), table, scale=1.0))
+        pz = torch.stack([_hip.row_dot(q, Wq, scale=-2.0), _hip.row_sqnorm(Wq)], dim=1).contiguous()
+        return _hip.LpProblem(_hip.LP_L2_PROJD, q, table, qn=qn, en=en, Wq=pz, scal=GT, r_idx=r_idx, yc=sigma,
+                              c_base=c_base, K0=K0)
 
     def _handle_problem(self, q, cand, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
         Wq = _hip.gather_rows(self.rel_proj_vect.weight.data, cand.r_idx)
-        return self._problem(q, Wq, ent_lo, ent_hi)
+        return self._problem(q, Wq, ent_lo, ent_hi, r_idx=cand.r_idx)
 
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
@@ -243,4 +269,4 @@ class TransDModel(TranslationModel):
         sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
         Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSD, sd, tabs, self.ent_emb_dim, self.rel_emb_dim,
                                     h_idx, t_idx, r_idx, want_w=True)
-        return self._problem(Q0, Wq, ent_lo, ent_hi)
+        return self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_hip.i64c(r_idx))
