@@ -307,39 +307,74 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN) / 2) void lp_gemm_kerne
                 cmask[nt] = col < d.N ? 1 : 0;
                 enr[nt] = EXPANDED ? en_pref[nt] : 0.f;
             }
+            if constexpr (PROJ) {
+                // projection modes: per (tile row group of 4 rows) fetch the rows' scalars once, issue the
+                // 4 x NT gathers X[r_i, c] together (each a 128-byte segment per lane half), then combine
+                int64_t colc[NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float4 stv[4], qnv[4]; // rows 8*gq + 4*half + {0..3} of this 32-row tile
+                for (int nt = 0; nt < NT; ++nt) colc[nt] = min(colb + nt * 32 + l31, d.N - 1);
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int lrow0 = (wr * MT + mt) * 32 + 8 * gq + 4 * half;
-                    stv[gq] = COUNT ? *reinterpret_cast<const float4 *>(st_s + lrow0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    qnv[gq] = EXPANDED ? *reinterpret_cast<const float4 *>(qn_s + lrow0)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int lrow0 = (wr * MT + mt) * 32 + 8 * gq + 4 * half;
+                        const float4 stv = COUNT ? *reinterpret_cast<const float4 *>(st_s + lrow0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 qnv = *reinterpret_cast<const float4 *>(qn_s + lrow0);
+                        const float4 pv = *reinterpret_cast<const float4 *>(p_s + lrow0);
+                        const float4 zv = *reinterpret_cast<const float4 *>(z_s + lrow0);
+                        const int4 xov = *reinterpret_cast<const int4 *>(xo_s + lrow0);
+                        const float *xr[4] = {d.scal + (int64_t)xov.x * d.scal_ld, d.scal + (int64_t)xov.y * d.scal_ld,
+                                              d.scal + (int64_t)xov.z * d.scal_ld, d.scal + (int64_t)xov.w * d.scal_ld};
+                        const float qn4[4] = {qnv.x, qnv.y, qnv.z, qnv.w}, st4[4] = {stv.x, stv.y, stv.z, stv.w};
+                        const float p4[4] = {pv.x, pv.y, pv.z, pv.w}, z4[4] = {zv.x, zv.y, zv.z, zv.w};
+                        float xv[NT][4];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xv[nt][e] = xr[e][colc[nt]];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = gq * 4 + e;
+                                const float v0 = fmaf(-2.0f, acc[mt][nt][r], qn4[e] + enr[nt]);
+                                const float sc = lp_epilogue_proj(MODE, v0, xv[nt][e], y_pref[nt], p4[e], z4[e]);
+                                if (WRITE) {
+                                    const int64_t row = cur_row0 + lrow0 + e;
+                                    if (cmask[nt] && row < d.B) p.out[row * p.ldo + colb + nt * 32 + l31] = sc;
+                                }
+                                if (COUNT) cnt[mt][gq] += (sc >= st4[e]) ? (unsigned)cmask[nt] << (8 * e) : 0u;
+                                acc[mt][nt][r] = 0.f;
+                            }
+                        }
+                    }
                 }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int gq = r >> 2, e = r & 3;
-                        const float qn = e == 0 ? qnv[gq].x : (e == 1 ? qnv[gq].y : (e == 2 ? qnv[gq].z : qnv[gq].w));
-                        const float st = e == 0 ? stv[gq].x : (e == 1 ? stv[gq].y : (e == 2 ? stv[gq].z : stv[gq].w));
-                        float sc;
-                        if (PROJ) { // per-pair gather X[r_i, c]: 128 B per lane half (one row of X, 32 consecutive columns)
-                            const int lrow = (wr * MT + mt) * 32 + e + 8 * gq + 4 * half;
-                            const int64_t colc = min(colb + nt * 32 + l31, d.N - 1);
-                            const float x = d.scal[(int64_t)xo_s[lrow] * d.scal_ld + colc];
-                            const float v0 = fmaf(-2.0f, acc[mt][nt][r], qn + enr[nt]);
-                            sc = lp_epilogue_proj(MODE, v0, x, y_pref[nt], p_s[lrow], z_s[lrow]);
-                        } else {
-                            sc = lp_epilogue(MODE, acc[mt][nt][r], qn, enr[nt]);
+            } else {
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float4 stv[4], qnv[4]; // rows 8*gq + 4*half + {0..3} of this 32-row tile
+    #pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int lrow0 = (wr * MT + mt) * 32 + 8 * gq + 4 * half;
+                        stv[gq] = COUNT ? *reinterpret_cast<const float4 *>(st_s + lrow0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        qnv[gq] = EXPANDED ? *reinterpret_cast<const float4 *>(qn_s + lrow0)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int gq = r >> 2, e = r & 3;
+                            const float qn = e == 0 ? qnv[gq].x : (e == 1 ? qnv[gq].y : (e == 2 ? qnv[gq].z : qnv[gq].w));
+                            const float st = e == 0 ? stv[gq].x : (e == 1 ? stv[gq].y : (e == 2 ? stv[gq].z : stv[gq].w));
+                            const float sc = lp_epilogue(MODE, acc[mt][nt][r], qn, enr[nt]);
+                            if (WRITE) {
+                                const int64_t row = cur_row0 + (wr * MT + mt) * 32 + e + 8 * gq + 4 * half;
+                                if (cmask[nt] && row < d.B) p.out[row * p.ldo + colb + nt * 32 + l31] = sc;
+                            }
+                            if (COUNT) cnt[mt][gq] += (sc >= st) ? (unsigned)cmask[nt] << (8 * e) : 0u;
+                            acc[mt][nt][r] = 0.f;
                         }
-                        if (WRITE) {
-                            const int64_t row = cur_row0 + (wr * MT + mt) * 32 + e + 8 * gq + 4 * half;
-                            if (cmask[nt] && row < d.B) p.out[row * p.ldo + colb + nt * 32 + l31] = sc;
-                        }
-                        if (COUNT) cnt[mt][gq] += (sc >= st) ? (unsigned)cmask[nt] << (8 * e) : 0u;
-                        acc[mt][nt][r] = 0.f;
                     }
                 }
             }
