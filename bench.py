@@ -44,6 +44,9 @@ WORKLOADS = {
     'complex_wn18rr': ('complex', 'wn18rr', 200, 2),
     'distmult_fb15k': ('distmult', 'fb15k', 400, 2),
     'transe_nations': ('transe', 'nations', 50, 2),
+    'transh_fb15k237': ('transh', 'fb15k237', 200, 2),
+    'transd_fb15k237': ('transd', 'fb15k237', 200, 2),
+    'transe_l1_fb15k237': ('transe', 'fb15k237', 200, 1),
 }
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
 PEAK_F16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA (~2.5 PF, no sparsity)
@@ -83,6 +86,11 @@ def make_model(kind, p, tables, n_ent, n_rel):
         m, names = tk.DistMultModel(d, n_ent, n_rel), ['ent_emb', 'rel_emb']
     elif kind == 'complex':
         m, names = tk.ComplExModel(d, n_ent, n_rel), ['re_ent_emb', 'im_ent_emb', 're_rel_emb', 'im_rel_emb']
+    elif kind == 'transh':
+        m, names = tk.TransHModel(d, n_ent, n_rel), ['ent_emb', 'rel_emb', 'norm_vect']
+    elif kind == 'transd':
+        m, names = tk.TransDModel(d, tables[1].shape[1], n_ent, n_rel), ['ent_emb', 'rel_emb', 'ent_proj_vect',
+                                                                          'rel_proj_vect']
     else:
         raise ValueError(kind)
     m.load_state_dict({n + '.weight': t for n, t in zip(names, tables)})
@@ -121,7 +129,7 @@ def main():
     n_ent = n_ent1 * (world if ent_weak else 1)
     tables = orc.init_tables(kind, n_ent, n_rel, d, seed=0)
     model = make_model(kind, p, tables, n_ent, n_rel).to(device)
-    if kind == 'transe':
+    if kind in ('transe', 'transh', 'transd'):
         model.l2_mode = args.l2_mode
     model.split_filter = not args.no_split
 
@@ -251,9 +259,10 @@ def main():
                      'note': 'ranks are bit-identical to the fp32 path (pairs inside the proven error band are '
                              're-scored exactly by kge_lp_split_recheck); achieved counts the f16 MFMA flops '
                              'actually executed, peak is the dense f16 MFMA peak'}
-        elif mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND):
+        elif mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND, _hip.LP_L2_PROJH, _hip.LP_L2_PROJD):
             flops_per_pair = 2 * K           # one fp32 MFMA FMA per (pair, k)
-            kname = 'lp_gemm_kernel (fp32 MFMA 32x32x2)'
+            kname = 'lp_gemm_kernel (fp32 MFMA 32x32x2%s)' % (
+                ', per-pair projection gather' if mode >= _hip.LP_L2_PROJH else '')
         else:
             flops_per_pair = 3 * K           # sub, mul, add on the VALU
             kname = 'lp_direct_kernel (fp32 VALU)'
@@ -291,7 +300,7 @@ def main():
             return e0.elapsed_time(e1) / 1e3 / reps
         with torch.no_grad():
             t_sf = ev_time(lambda: model.scoring_function(h2, t2, r2))
-        bytes_per_triple = (24 * d + 28) if kind == 'complex' else (12 * d + 28)
+        bytes_per_triple = {'complex': 24 * d + 28, 'transh': 16 * d + 28, 'transd': 20 * d + 28}.get(kind, 12 * d + 28)
         samp = tk.BernoulliNegativeSampler(kg)
         t_cb = ev_time(lambda: samp.corrupt_batch(h2, t2, r2), reps=10)
         sec = {'scoring_function': {'triples_per_s': round(Bt / t_sf, 1), 'batch': Bt, 'ms': round(t_sf * 1e3, 4),

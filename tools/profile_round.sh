@@ -11,6 +11,8 @@ python $R/bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_tran
 python $R/bench.py --steps 10 --warmup 3 --workload complex_wn18rr --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_complex_wn18rr.json
 python $R/bench.py --steps 5 --warmup 2 --workload distmult_fb15k --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_distmult_fb15k.json
 python $R/bench.py --steps 10 --warmup 3 --no-split --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transe_fb15k237_nosplit.json
+python $R/bench.py --steps 5 --warmup 2 --workload transh_fb15k237 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transh_fb15k237.json
+python $R/bench.py --steps 5 --warmup 2 --workload transd_fb15k237 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transd_fb15k237.json
 python $R/bench.py --steps 10 --warmup 3 --l2-mode direct --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transe_fb15k237_l2direct.json
 python $R/bench.py --steps 10 --warmup 3 --materialize --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transe_fb15k237_materialized.json
 # per-kernel time of the bench command
