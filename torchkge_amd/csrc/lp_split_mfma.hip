@@ -1,9 +1,10 @@
-// Certified fp16-split prefilter for the fused rank count (gfx950).
+// Certified f16-split prefilter for the fused rank count (gfx950).
 //
 // The rank of a test fact only needs  #{c : s[i,c] >= s_true[i]}  (get_rank,
 // utils/operations.py:37-61), not the scores.  For TransE-L2 through the norm
 // expansion  s = -max(||q||^2 + ||e||^2 - 2 q.e, 0)  the comparison
-// s[i,c] >= s_true[i] is  q.e - ||e_c||^2/2 >= (||q_i||^2 + s_true_i)/2 .
+// s[i,c] >= s_true[i] is  q.e - ||e_c||^2/2 >= (||q_i||^2 + s_true_i)/2 ;
+// for DistMult / ComplEx (KGE_LP_DOT, K = K0 + K1 columns) it is  q.e >= s_true_i.
 // This file evaluates the left side APPROXIMATELY on the f16 matrix cores
 // (16x the fp32 MFMA rate) with a rigorous error bound eps_i:
 //
@@ -13,38 +14,46 @@
 // and classifies every (query, candidate) pair against two per-query thresholds:
 //   acc >= a_hi : certainly counted          acc < a_lo : certainly not counted
 //   a_lo <= acc < a_hi : UNCERTAIN -> appended to a list and re-scored by the
-//   exact scalar chain (kge_common.h: lp_pair_score, bit-identical to the fp32
-//   MFMA tile kernel and to oracle/kge_oracle.c).
+//   exact scalar chain (kge_common.h: lp_pair_score_staged, bit-identical to the
+//   fp32 MFMA tile kernel and to oracle/kge_oracle.c).
 // raw_count[i] first receives #{acc >= a_lo}; kge_lp_split_recheck then takes 1
 // off for every listed pair whose exact score is below s_true.  The resulting
 // counts are therefore EXACTLY those of kge_lp_count_ge -- integer work stays
 // bit-exact -- while ~99.9% of the pairs never touch the fp32 pipe.
 //
 // Error bound used for the thresholds (split_thr_kernel), per unit of
-// P = ||q|| * max||e|| + max||e||^2 / 2  >=  sum_k |q_k e_k| + |aug term|:
+// P >= sum_k |q_k e_k| (+ |augmentation term|), P = ||q|| * max||e|| (+ max||e||^2 / 2):
 //   split residual   3 * 2^-22        (ql*el dropped, rho_q*e, q*rho_e)
 //   accumulation     n_terms * 2^-24  (n_terms = 3 * 16 * units fp32 adds, any order)
 //   exact chain      K * 2^-24        (the scalar fmaf chain it is compared with)
 // all doubled (covers truncating instead of rounding adders), plus absolute
 // terms for f16 subnormal lo parts (flushed or not) and for the roundings of
-// the threshold arithmetic itself.  tests/test_gpu_parity.py checks the counts
-// against the exact kernel and that they stay exact with the band shrunk 16x.
+// the threshold arithmetic itself.  tools/probe/mfma_probe.hip measures what the
+// MFMA really does (two passes of acc + 8 products, addends truncated 24 bits
+// below the largest, one RNE rounding; subnormals kept): <= 9 * 2^-24 per pass,
+// inside the assumption.  tests/test_gpu_parity.py checks the counts against the
+// exact kernel, also with the band shrunk 16x.
 //
 // Data layout: a split operand is [rows_p][units_p] cells of 64 bytes,
 //   cell = [hi k0..7][hi k8..15][lo k0..7][lo k8..15]   (f16, k within the 16-unit)
-// rows_p = rows rounded up to the tile (256 candidates / 192 queries; zero rows), units_p = k16 units rounded up
-// to 2; column K of the un-split matrix holds the augmentation (1 for queries,
-// -||e||^2/2 for candidates), everything scaled by 2^12 to sit inside f16 range
-// (|x| <= 4 is implied by the evaluator's norm guard, L2_EXPAND_LIMIT).
+// rows_p = rows rounded up to the tile (256 candidates / 192 queries; zero rows),
+// units_p = k16 units rounded up to 2; one extra column carries the augmentation
+// (L2: 1 for queries, -||e||^2/2 for candidates; DOT: a per-query guard value
+// against 0); padding candidates hold -65504 there and can never count.  L2
+// operands are scaled by 2^12 (|x| <= 4 is implied by the evaluator's norm guard,
+// L2_EXPAND_LIMIT), DOT operands by a power of two derived on the device from
+// the squared-norm maxima (split_scale).
 //
 // Kernel: block tile 256 candidates (MFMA rows) x 192 queries (MFMA columns =
 // lanes), 8 waves of 64 x 96 (2x3 tiles of 32x32: 96 accumulator VGPRs, two waves
 // per SIMD -- accumulators stay in architectural VGPRs, which the VALU epilogue
-// can compare directly; AGPR accumulators would cost a v_accvgpr_read each), K staged 32 at a time through double-buffered LDS with an
-// XOR swizzle (16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)): both the
-// b128 stores and the MFMA fragment b128 loads are bank-conflict free without
-// padding.  Queries on the lane axis make thresholds and counters per-lane
-// constants, so the epilogue is two compares and an add per element.
+// can compare directly; AGPR accumulators would cost a v_accvgpr_read each).
+// K is staged 32 at a time into double-buffered LDS by LDS-DMA
+// (global_load_lds_dwordx4, pieces issued between the MFMA groups) with an XOR
+// swizzle (16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)): the fragment
+// ds_read_b128 are bank-conflict free without padding.  Queries on the lane axis
+// make thresholds and counters per-lane constants, so the epilogue is two
+// compares and an add-with-carry per element.
 #include "kge_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
