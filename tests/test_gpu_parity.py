@@ -667,6 +667,14 @@ def test_wikidata5m_scale_properties(hip):
     i = torch.arange(0, nq, 7, device='cuda')
     ref = (A[i].double() * Tre[true[i]].double()).sum(1) + (Bq[i].double() * Tim[true[i]].double()).sum(1)
     assert (s_true[i].double() - ref).abs().max().item() < 1e-6
+    # (iii) the f16-split prefilter at this scale (19.4 GB split table, K = 1024 + guard column)
+    del S, sub
+    guard = torch.zeros(8, device='cuda')
+    hip.row_sqnorm(Tre, max_io=guard[1:2]); hip.row_sqnorm(Tim, max_io=guard[5:6])
+    prob.split = {'Es': hip.split_rows(Tre, X1=Tim, dot=True, nmax0=guard[1:2], nmax1=guard[5:6]),
+                  'enmax': guard[1:2], 'enmax1': guard[5:6], 'overflow': guard[2:3]}
+    got = prob.count_ge(s_true)
+    assert float(guard[2]) == 0.0 and torch.equal(got, raw)
 
 
 def test_random_shape_sweep_bit_exact(hip):
