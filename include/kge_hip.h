@@ -269,7 +269,10 @@ int kge_corrupt_scatter(const int64_t *heads, const int64_t *tails, const uint8_
  *
  * A split operand is [rows_p][units_p] cells of 64 bytes (see the .hip file);
  * kge_lp_split_units / kge_lp_split_rows_padded give its dimensions.
- * Modes: KGE_LP_L2_EXPAND (TransE-L2) and KGE_LP_DOT (DistMult, ComplEx: K0 + K1 columns).
+ * Modes: KGE_LP_L2_EXPAND (TransE-L2), KGE_LP_DOT (DistMult, ComplEx: K0 + K1 columns) and the
+ * projection modes KGE_LP_L2_PROJH/_PROJD (TransH, TransD: split operands as for L2_EXPAND; desc.scal
+ * must then be 16-byte aligned with scal_ld % 4 == 0 and readable up to the 256-padded candidate
+ * edge, desc.yc likewise).
  * *overflow is set to 1.0f if more than cap pairs (or more than 2048 in one 256 x 192
  * tile) fell inside the band -- raw_count is then invalid and the caller must redo the
  * count with kge_lp_count_ge.  The squared-norm maxima are the device scalars that
@@ -279,8 +282,9 @@ typedef struct kge_split_args {
     const float *qn0, *qn1;       /* KGE_LP_DOT: ||q_i||^2 per K-segment (qn1 NULL when K1 == 0); L2_EXPAND: desc.qn is used */
     const float *qmax0, *qmax1;   /* KGE_LP_DOT: device scalars >= max_i qn0 / qn1 (they fix the query operand's scale) */
     const float *emax0, *emax1;   /* device scalars >= max_c ||e_c||^2 per K-segment (emax1 NULL when K1 == 0) */
+    const float *xabsmax, *yabsmax; /* L2_PROJH/_PROJD: device scalars >= max |X[r,c]| (and >= max |yc[c]|, PROJD), see kge_absmax */
     float eps_scale;              /* multiplies the error band (1.0 = the proven bound; tests shrink it) */
-    float *thr;                   /* scratch: 2 * kge_lp_split_rows_padded(B, 1) floats */
+    float *thr;                   /* scratch: 4 * kge_lp_split_rows_padded(B, 1) floats */
     int32_t *list;                /* scratch: cap x 2 int32 (query, local candidate) */
     int32_t cap;
     int32_t *list_count;          /* device int32 */
@@ -301,6 +305,8 @@ int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int
                       const float *norm2max1, void *out, kge_stream_t stream);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
+/* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
+int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
                          const int32_t *list_count, int32_t *raw_count, kge_stream_t stream);
 

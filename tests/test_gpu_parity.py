@@ -973,3 +973,47 @@ def test_projection_modes_shards_concatenate_bit_identically(hip, kind):
         Sd = m.lp_problem(h, t, r, 'tail').scores()
     assert (S - Sd).abs().max().item() < TOL
     assert np.abs(S.cpu().numpy() - z['s_tail']).max() < TOL
+
+
+@pytest.mark.parametrize('mode_name,B,N,K,R', [('H', 300, 1000, 64, 7), ('D', 257, 700, 40, 5), ('H', 1000, 3000, 200, 37),
+                                               ('D', 500, 2049, 200, 11)])
+def test_split_prefilter_projection_modes_counts_equal_exact_counts(hip, mode_name, B, N, K, R):
+    """TransH / TransD projection modes through the f16-split prefilter (the per-pair term
+    x(xz+p) resp. y(yz+2g+p) is added to the approximate accumulator in the epilogue):
+    counts == exact fp32 counts, also with the band shrunk 16x."""
+    mode = hip.LP_L2_PROJH if mode_name == 'H' else hip.LP_L2_PROJD
+    g = torch.Generator().manual_seed(B + N + K)
+    T = torch.nn.functional.normalize(torch.randn(N, K, generator=g), dim=1)
+    W = torch.nn.functional.normalize(torch.randn(R, K, generator=g), dim=1)
+    r_idx = torch.randint(0, R, (B,), generator=g)
+    A = T[torch.randint(0, N, (B,), generator=g)] + 0.7 * torch.nn.functional.normalize(torch.randn(B, K, generator=g), dim=1)
+    dT, dA, dW = T.cuda(), A.cuda().contiguous(), W.cuda()
+    Np = hip.padded_cols(N)
+    Xb = torch.zeros(R, Np, device='cuda')
+    X = hip.LpProblem(hip.LP_DOT, dW, dT).scores(Xb[:, :N])
+    ycb = torch.zeros(Np, device='cuda')
+    ycb[:N] = torch.randn(N, generator=g).cuda() * 0.3
+    Wq = dW[r_idx.cuda()]
+    if mode_name == 'H':
+        pz = torch.stack([hip.row_dot(dA, Wq, scale=2.0), hip.row_sqnorm(Wq) - 2.0], 1).contiguous()
+    else:
+        pz = torch.stack([hip.row_dot(dA, Wq, scale=-2.0), hip.row_sqnorm(Wq)], 1).contiguous()
+    guard = torch.zeros(8, device='cuda')
+    en = hip.row_sqnorm(dT, max_io=guard[1:2]); qn = hip.row_sqnorm(dA, max_io=guard[0:1])
+    prob = hip.LpProblem(mode, dA, dT, qn=qn, en=en, Wq=pz, scal=X, r_idx=r_idx.cuda(),
+                         yc=ycb[:N] if mode_name == 'D' else None)
+    t = torch.randint(0, N, (B,), generator=g).cuda()
+    st = prob.pair_scores(t)
+    exact = prob.count_ge(st)
+    hip.absmax(X, guard[3:4]); hip.absmax(ycb, guard[4:5])
+    prob.split = {'Es': hip.split_rows(dT, aug=en), 'enmax': guard[1:2], 'overflow': guard[2:3],
+                  'xabsmax': guard[3:4], 'yabsmax': guard[4:5] if mode_name == 'D' else None}
+    try:
+        for eps in (1.0, 1.0 / 16):
+            hip.SPLIT_EPS_SCALE = eps
+            got = prob.count_ge(st)
+            assert torch.equal(got, exact), (eps, int((got != exact).sum()))
+    finally:
+        hip.SPLIT_EPS_SCALE = 1.0
+    assert float(guard[2]) == 0.0
+    assert B <= int(prob.last_split[0].item()) <= 64 * B

@@ -43,7 +43,7 @@ class SplitArgs(ctypes.Structure):
     """struct kge_split_args (include/kge_hip.h)."""
     _fields_ = [
         ('Qs', _vp), ('Es', _vp), ('qn0', _vp), ('qn1', _vp), ('qmax0', _vp), ('qmax1', _vp),
-        ('emax0', _vp), ('emax1', _vp), ('eps_scale', ctypes.c_float),
+        ('emax0', _vp), ('emax1', _vp), ('xabsmax', _vp), ('yabsmax', _vp), ('eps_scale', ctypes.c_float),
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
     ]
 
@@ -67,6 +67,7 @@ _SIGNATURES = {
                           _vp],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
+    'kge_absmax': [_vp, _i64, _vp, _vp],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
@@ -107,7 +108,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 4:
+    if lib.kge_abi_version() != 5:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -249,6 +250,22 @@ def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False,
     return out
 
 
+def absmax(x, max_io):
+    """max_io[0] = max(max_io[0], max |x|) on the device (no sync)."""
+    lib = load_library()
+    require_cuda(x, max_io)
+    x = f32c(x)
+    with torch.cuda.device(x.device):
+        _check(lib.kge_absmax(_p(x), x.numel(), _p(max_io), _stream()), 'kge_absmax')
+    return max_io
+
+
+def padded_cols(n):
+    """Row length (in floats) of a per-candidate matrix that the split count kernel may read
+    up to the edge of its last 256-candidate tile."""
+    return int(load_library().kge_lp_split_rows_padded(n, 0))
+
+
 def row_sqnorm(X, K=None, max_io=None):
     lib = load_library()
     require_cuda(X)
@@ -379,7 +396,7 @@ class LpProblem(object):
         else:
             Qs = split_rows(A0, K=K, is_query=True)
         Bp = int(lib.kge_lp_split_rows_padded(self.B, 1))
-        thr = torch.empty(2 * Bp, dtype=torch.float32, device=self.device)
+        thr = torch.empty(4 * Bp, dtype=torch.float32, device=self.device)
         # the band holds ~1e-3 of a query's candidates for an untrained model (far fewer for a trained one)
         cap = int(min(max(SPLIT_LIST_PER_QUERY, self.N // 100) * self.B, 2 ** 31 - 1))
         lst = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
@@ -400,6 +417,7 @@ class LpProblem(object):
             a.qmax0 = qmax.data_ptr()
             a.qmax1 = qmax.data_ptr() + 4 if prep.get('qn1') is not None else None
         a.emax0, a.emax1 = _p(sp['enmax']), _p(sp.get('enmax1'))
+        a.xabsmax, a.yabsmax = _p(sp.get('xabsmax')), _p(sp.get('yabsmax'))
         a.eps_scale = SPLIT_EPS_SCALE
         a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']
         a.list_count, a.overflow = _p(prep['n_list']), _p(sp['overflow'])

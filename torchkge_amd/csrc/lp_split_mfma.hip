@@ -67,7 +67,7 @@ constexpr int E_STAGE_BYTES = TC * 128;         // candidate operand, one stage 
 constexpr int Q_STAGE_BYTES = TQ * 128;
 constexpr int STAGE_BYTES = E_STAGE_BYTES + Q_STAGE_BYTES;
 constexpr int UNC_CAP = 2048;                   // uncertain pairs buffered per tile
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES + 16 + UNC_CAP * 4;
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES + 16 + UNC_CAP * 4 + TQ * 20;   // + per-panel (thr4, X row) of the projection modes
 constexpr int SPLIT_SCALE_LOG2 = 12;
 
 struct SplitParams {
@@ -77,6 +77,11 @@ struct SplitParams {
     int stages;           // units_p / 2
     int64_t B, N;
     const float2 *thr;    // (a_lo, a_hi) per padded query, scaled like the accumulators
+    const float4 *thr4;   // projection modes: (a_lo, a_hi, p_i, z_i) per padded query
+    const float *X;       // projection modes: X (n_rel, ldx), ldx % 4 == 0, readable up to the padded tile edge
+    int64_t ldx;
+    const int64_t *r_idx; // row of X per query
+    const float *yc;      // PROJD: y_c per (padded) candidate
     int32_t *raw_count;
     int32_t *list;        // cap x (query, candidate)
     int32_t cap;
@@ -157,6 +162,16 @@ __global__ void split_rows_kernel(const SplitRowsParams p)
     }
 }
 
+__global__ void absmax_kernel(const float *__restrict__ x, int64_t n, float *max_io)
+{
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));      // NaN-free inputs assumed: a NaN element is simply skipped by fmaxf
+    unsigned u = __float_as_uint(m);
+    for (int off = 32; off > 0; off >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, off, 64));
+    if ((threadIdx.x & 63) == 0 && u) atomicMax(reinterpret_cast<unsigned *>(max_io), u);
+}
+
 struct SplitThrParams {
     int mode;                       // KGE_LP_L2_EXPAND or KGE_LP_DOT
     const float *qn0, *qn1;         // per-query squared norms (segment 1 optional)
@@ -169,6 +184,10 @@ struct SplitThrParams {
     float2 *thr;
     int32_t *list_count;
     float *overflow;
+    const float *pz;                // projection modes: (p_i, z_i) pairs, stride ldw
+    int64_t ldw;
+    const float *xabsmax, *yabsmax; // device scalars >= max |X|, max |y_c|
+    float4 *thr4;
 };
 
 __global__ void split_thr_kernel(const SplitThrParams p)
@@ -185,17 +204,32 @@ __global__ void split_thr_kernel(const SplitThrParams p)
     const float eps_rel = 2.0f * ((float)(48 * p.units + p.K) * two24 + 3.0f * two22);
     const float enrm = sqrtf(em) * 1.000001f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.Bp; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i >= p.B) { p.thr[i] = make_float2(INFINITY, INFINITY); continue; }
+        if (i >= p.B) {
+            if (p.mode >= KGE_LP_L2_PROJH) p.thr4[i] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+            else p.thr[i] = make_float2(INFINITY, INFINITY);
+            continue;
+        }
         const float q = p.qn0[i] + (p.qn1 ? p.qn1[i] : 0.f);
         const float qnrm = sqrtf(q) * 1.000001f;
-        if (p.mode == KGE_LP_L2_EXPAND) {
+        if (p.mode == KGE_LP_L2_EXPAND || p.mode >= KGE_LP_L2_PROJH) {
             const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
             const float u = -p.s_true[i];                    // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
             const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
             const float eps_dot = eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
             const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * p.eps_scale;
             const float mid = 0.5f * (q - u);
-            const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
+            float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
+            if (p.mode >= KGE_LP_L2_PROJH) {
+                // + the projection term corr = x (x z + p)  resp.  y (y z + 2 g + p): it is computed exactly in fp32
+                // by both paths but enters in a different association -> a few ulps of its largest possible size
+                const float pi = p.pz[i * p.ldw], zi = p.pz[i * p.ldw + 1];
+                const float xm = *p.xabsmax, ym = p.mode == KGE_LP_L2_PROJD ? *p.yabsmax : 0.f;
+                const float cmax = p.mode == KGE_LP_L2_PROJH ? xm * (xm * fabsf(zi) + fabsf(pi))
+                                                             : ym * (ym * fabsf(zi) + 2.0f * xm + fabsf(pi));
+                hw += 8.0f * two22 * cmax * p.eps_scale + two22 * cmax;
+                p.thr4[i] = make_float4((mid - hw) * out_scale, (mid + hw) * out_scale, pi, zi);
+                continue;
+            }
             p.thr[i] = make_float2((mid - hw) * out_scale, (mid + hw) * out_scale);
         } else {
             // count c iff dot_c >= s_true; both operands carry their own power-of-two scale
@@ -212,7 +246,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
 }
 
 // ---- the count kernel --------------------------------------------------------
-template <int NWAVES, bool DBG>
+template <int NWAVES, bool DBG, int PM>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
@@ -223,6 +257,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *unc_cnt = reinterpret_cast<int *>(smem + 2 * STAGE_BYTES);
     unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + 16);
+    float4 *pthr = reinterpret_cast<float4 *>(smem + 2 * STAGE_BYTES + 16 + UNC_CAP * 4);   // PM: per query of the panel
+    int *prow = reinterpret_cast<int *>(pthr + TQ);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;   // waves: (NWAVES/2) x 2
 
@@ -287,8 +323,15 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 
     f32x16 acc[MT][NT];
     int cnt[NT] = {0, 0, 0};
-    float alo[NT], ahi[NT];
+    float alo[NT] = {0.f, 0.f, 0.f}, ahi[NT] = {0.f, 0.f, 0.f};
     auto load_panel = [&](int64_t q0) __attribute__((always_inline)) {
+        if (PM) {   // thresholds + projection scalars + X row of the panel's queries live in LDS
+            if (tid < TQ) {
+                pthr[tid] = p.thr4[q0 + tid];
+                prow[tid] = (int)p.r_idx[min(q0 + tid, p.B - 1)];
+            }
+            return;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const float2 t = p.thr[q0 + wc * 96 + nt * 32 + l31];
@@ -414,25 +457,58 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             asm volatile("" : "+v"(cl_base), "+v"(ql_base));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                float lo_n = alo[nt], hi_n = ahi[nt], p_n = 0.f, z_n = 0.f;
+                const float *xrow = nullptr;
+                if (PM) {
+                    const int ql = wc * 96 + nt * 32 + l31;
+                    const float4 t4 = pthr[ql];
+                    lo_n = t4.x; hi_n = t4.y; p_n = t4.z; z_n = t4.w;
+                    xrow = p.X + (int64_t)prow[ql] * p.ldx + c0 + wr * (MT * 32) + 4 * half;
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+                    float4 x4[4], y4[4];
+                    if (PM) {   // the 4 quads' gathers X[r_i, c..c+3] (and y_c) issued together
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            x4[g4] = *reinterpret_cast<const float4 *>(xrow + mt * 32 + 8 * g4);
+                            if (PM == 2)
+                                y4[g4] = *reinterpret_cast<const float4 *>(p.yc + c0 + wr * (MT * 32) + 4 * half + mt * 32 + 8 * g4);
+                        }
+                    }
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {   // 4 accumulator registers = rows 8*g4 + 4*half + {0..3}
                         unsigned long long any = 0ull;
+                        float vq[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = acc[mt][nt][g4 * 4 + e];
+                            vq[e] = acc[mt][nt][g4 * 4 + e];
+                            if (PM) {   // acc - 2^23 * corr: the comparison of v = qn + en - 2 dot + corr against u
+                                const float xe = e == 0 ? x4[g4].x : (e == 1 ? x4[g4].y : (e == 2 ? x4[g4].z : x4[g4].w));
+                                float corr;
+                                if (PM == 1) {
+                                    corr = xe * fmaf(xe, z_n, p_n);
+                                } else {
+                                    const float ye = e == 0 ? y4[g4].x : (e == 1 ? y4[g4].y : (e == 2 ? y4[g4].z : y4[g4].w));
+                                    corr = ye * fmaf(ye, z_n, fmaf(2.0f, xe, p_n));
+                                }
+                                vq[e] = fmaf(corr, -8388608.0f, vq[e]);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = vq[e];
                             // cnt += (v >= a_lo) as compare + add-with-carry (hipcc emits cndmask + add)
                             unsigned long long ge;
                             asm volatile("v_cmp_ge_f32 %1, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, %1"
-                                         : "+v"(cnt[nt]), "=&s"(ge) : "v"(v), "v"(alo[nt]) : "vcc");
-                            any |= ge & ~__ballot(v >= ahi[nt]);
+                                         : "+v"(cnt[nt]), "=&s"(ge) : "v"(v), "v"(lo_n) : "vcc");
+                            any |= ge & ~__ballot(v >= hi_n);
                         }
                         if (any) { // some lane holds an uncertain pair among these 4 rows: list them
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float v = acc[mt][nt][g4 * 4 + e];
-                                if (v >= alo[nt] && !(v >= ahi[nt])) {
+                                const float v = vq[e];
+                                if (v >= lo_n && !(v >= hi_n)) {
                                     const int cl = cl_base + mt * 32 + e + 8 * g4;
                                     const int idx = atomicAdd(unc_cnt, 1);
                                     if (idx < UNC_CAP)
@@ -509,10 +585,10 @@ __global__ __launch_bounds__(64) void split_recheck_kernel(const kge_lp_desc d, 
     }
 }
 
-template <int NWAVES, bool DBG>
+template <int NWAVES, bool DBG, int PM>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
-    auto k = lp_split_count_kernel<NWAVES, DBG>;
+    auto k = lp_split_count_kernel<NWAVES, DBG, PM>;
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -579,8 +655,12 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
 {
     int rc = kge_lp_desc_check(d);
     if (rc) return rc;
-    if (d->mode != KGE_LP_L2_EXPAND && d->mode != KGE_LP_DOT) return KGE_EINVAL;
+    if (!KGE_LP_IS_MFMA(d->mode)) return KGE_EINVAL;
+    const bool proj = d->mode >= KGE_LP_L2_PROJH;
     if (d->B == 0 || d->N == 0) return 0;
+    if (proj && (!a || !a->xabsmax || (d->mode == KGE_LP_L2_PROJD && !a->yabsmax) || d->scal_ld % 4 != 0 ||
+                 !kge_aligned16(d->scal)))
+        return KGE_EINVAL;
     if (!a || !a->Qs || !a->Es || !s_true || !a->emax0 || !a->thr || !raw_count || !a->list || a->cap <= 0 ||
         !a->list_count || !a->overflow)
         return KGE_EINVAL;
@@ -594,7 +674,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     const int64_t Bp = kge_lp_split_rows_padded(d->B, 1);
     SplitThrParams t;
     t.mode = d->mode;
-    t.qn0 = d->mode == KGE_LP_L2_EXPAND ? d->qn : a->qn0;
+    t.qn0 = d->mode != KGE_LP_DOT ? d->qn : a->qn0;
     t.qn1 = (d->mode == KGE_LP_DOT && d->K1 > 0) ? a->qn1 : nullptr;
     t.s_true = s_true;
     t.qmax0 = a->qmax0; t.qmax1 = d->K1 > 0 ? a->qmax1 : nullptr;
@@ -602,6 +682,9 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.B = d->B; t.Bp = Bp; t.K = K; t.units = units;
     t.eps_scale = a->eps_scale;
     t.thr = reinterpret_cast<float2 *>(a->thr);
+    t.thr4 = reinterpret_cast<float4 *>(a->thr);
+    t.pz = d->Wq; t.ldw = d->ldw;
+    t.xabsmax = a->xabsmax; t.yabsmax = a->yabsmax;
     t.list_count = a->list_count;
     t.overflow = a->overflow;
     hipLaunchKernelGGL(split_thr_kernel, dim3((int)((Bp + 255) / 256)), dim3(256), 0, s, t);
@@ -620,6 +703,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     p.B = d->B;
     p.N = d->N;
     p.thr = reinterpret_cast<const float2 *>(thr);
+    p.thr4 = reinterpret_cast<const float4 *>(thr);
+    p.X = d->scal; p.ldx = d->scal_ld; p.r_idx = d->r_idx; p.yc = d->yc;
     p.raw_count = raw_count;
     p.list = list;
     p.cap = cap;
@@ -631,7 +716,9 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
     const int slots = split_num_cus();
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
-    return p.dbg ? launch_split<8, true>(p, grid, s) : launch_split<8, false>(p, grid, s);
+    if (d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1>(p, grid, s);
+    if (d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2>(p, grid, s);
+    return p.dbg ? launch_split<8, true, 0>(p, grid, s) : launch_split<8, false, 0>(p, grid, s);
 }
 
 extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
@@ -641,7 +728,7 @@ extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, c
     if (rc) return rc;
     if (d->B == 0 || d->N == 0) return 0;
     if (!s_true || !list || cap <= 0 || !list_count || !raw_count) return KGE_EINVAL;
-    if (d->mode != KGE_LP_L2_EXPAND && d->mode != KGE_LP_DOT) return KGE_EINVAL;
+    if (!KGE_LP_IS_MFMA(d->mode)) return KGE_EINVAL;
     const bool vec4 = kge_lp_vec4(*d);
     const int grid = split_num_cus() * kge_env_int("KGE_SPLIT_RECHECK_WAVES", 160 * 1024 / (2 * 64 * KGE_PS_LD * 4));
     if (vec4)
@@ -650,6 +737,18 @@ extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, c
     else
         hipLaunchKernelGGL(split_recheck_kernel<false>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list,
                            cap, list_count, raw_count);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+/* *max_io = max(*max_io, max_i |x[i]|)  (device scalar, non-negative; the bound on the projection gather term) */
+extern "C" int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream)
+{
+    if (n < 0 || !max_io) return KGE_EINVAL;
+    if (n == 0) return 0;
+    if (!x) return KGE_EINVAL;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, kge_s(stream), x, n, max_io);
     KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -115,7 +115,8 @@ class Model(Module):
         self.n_rel = n_relations
         self._cache = _SessionCache()
         # evaluation-time guard scalars (device, float32 x 8): [0] max ||q||^2 (L2 norm guard),
-        # [1] max ||e||^2 (segment 0), [2] split-list overflow flag, [5] max ||e||^2 (segment 1)
+        # [1] max ||e||^2 (segment 0), [2] split-list overflow flag, [3] max |X|, [4] max |y_c| (projection
+        # modes), [5] max ||e||^2 (segment 1)
         self._lp_guard = None
         self._guard_on = False
         self._expand_ok = None      # TransE-L2 only: True/False forced by the evaluator, None: guarded
@@ -281,6 +282,24 @@ class TranslationModel(Model):
         """TransH / TransD: the expansion around u.e with the per-pair projection term
         (KGE_LP_L2_PROJH / _PROJD); None = this model has no such form."""
         return None
+
+    def _attach_proj_split(self, prob, table, en, X, yc, K0):
+        """Rank counts of a projection-mode problem through the f16-split prefilter
+        (inside an evaluation only): split table as for TransE-L2, plus device-side
+        bounds on |X| (and |y_c|) for the error band."""
+        if not (self._guard_on and self._expand_ok is None and self.l2_mode == 'auto' and self.split_filter
+                and self._split_ok):
+            return prob
+        g = self._lp_guard
+        key = '%d_%d' % (prob.desc.c_base, table.shape[0])
+        Kq = table.shape[1] if K0 is None else K0
+        Es = self._cache.get('es_' + key, [table], lambda: _hip.split_rows(table, K=Kq, aug=en))
+        self._cache.get('xmax_' + key, [X], lambda: _hip.absmax(X, g[3:4]))
+        if yc is not None:
+            self._cache.get('ymax_' + key, [yc], lambda: _hip.absmax(yc, g[4:5]))
+        prob.split = {'Es': Es, 'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': g[3:4],
+                      'yabsmax': g[4:5] if yc is not None else None}
+        return prob
 
     def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
         """Problem for s[i,c] = -diss(q_i, table[c] (- a w_i))."""

@@ -137,11 +137,16 @@ class TransHModel(TranslationModel):
         (KGE_LP_L2_PROJH): X[r, c] = W[r].E[c] is one small GEMM per evaluation, the
         per-query scalars are p = 2 u.w and z = ||w||^2 - 2."""
         W = _hip.f32c(self.norm_vect.weight.data)
-        XT = self._cache.get('transh_aT_%d_%d' % (c_base, table.shape[0]), [table, W],
-                             lambda: _hip.LpProblem(_hip.LP_DOT, W, table).scores())
+        n = table.shape[0]
+
+        def build():    # (n_rel, n) view of a row-padded buffer: the split kernel reads whole 256-candidate tiles
+            buf = torch.zeros(W.shape[0], _hip.padded_cols(n), dtype=torch.float32, device=table.device)
+            return _hip.LpProblem(_hip.LP_DOT, W, table).scores(buf[:, :n])
+        XT = self._cache.get('transh_aT_%d_%d' % (c_base, n), [table, W], build)
         pz = torch.stack([_hip.row_dot(q, Wq, scale=2.0), _hip.row_sqnorm(Wq) - 2.0], dim=1).contiguous()
-        return _hip.LpProblem(_hip.LP_L2_PROJH, q, table, qn=qn, en=en, Wq=pz, scal=XT, r_idx=r_idx,
+        prob = _hip.LpProblem(_hip.LP_L2_PROJH, q, table, qn=qn, en=en, Wq=pz, scal=XT, r_idx=r_idx,
                               c_base=c_base)
+        return self._attach_proj_split(prob, table, en, XT, None, K0)
 
     def evaluate_projections(self):
         """Kept for API compatibility (translation.py:260-284); the engine needs
@@ -250,13 +255,22 @@ class TransDModel(TranslationModel):
         lo, hi = c_base, c_base + table.shape[0]
         Rp = _hip.f32c(self.rel_proj_vect.weight.data)
         Ep = _hip.f32c(self.ent_proj_vect.weight.data)
-        GT = self._cache.get('transd_gT_%d_%d' % (lo, hi), [table, Rp],
-                             lambda: _hip.LpProblem(_hip.LP_DOT, Rp, table, K0=K0).scores())
-        sigma = self._cache.get('transd_sp_%d_%d' % (lo, hi), [table, Ep],
-                                lambda: _hip.row_dot(_shard(Ep, lo, hi), table, scale=1.0))
+        n = table.shape[0]
+
+        def build_g():
+            buf = torch.zeros(Rp.shape[0], _hip.padded_cols(n), dtype=torch.float32, device=table.device)
+            return _hip.LpProblem(_hip.LP_DOT, Rp, table, K0=K0).scores(buf[:, :n])
+
+        def build_s():
+            buf = torch.zeros(_hip.padded_cols(n), dtype=torch.float32, device=table.device)
+            buf[:n] = _hip.row_dot(_shard(Ep, lo, hi), table, scale=1.0)
+            return buf[:n]
+        GT = self._cache.get('transd_gT_%d_%d' % (lo, hi), [table, Rp], build_g)
+        sigma = self._cache.get('transd_sp_%d_%d' % (lo, hi), [table, Ep], build_s)
         pz = torch.stack([_hip.row_dot(q, Wq, scale=-2.0), _hip.row_sqnorm(Wq)], dim=1).contiguous()
-        return _hip.LpProblem(_hip.LP_L2_PROJD, q, table, qn=qn, en=en, Wq=pz, scal=GT, r_idx=r_idx, yc=sigma,
+        prob = _hip.LpProblem(_hip.LP_L2_PROJD, q, table, qn=qn, en=en, Wq=pz, scal=GT, r_idx=r_idx, yc=sigma,
                               c_base=c_base, K0=K0)
+        return self._attach_proj_split(prob, table, en, GT, sigma, K0)
 
     def _handle_problem(self, q, cand, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
