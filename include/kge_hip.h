@@ -147,12 +147,31 @@ int kge_score_triples(int kind, const float *t0, const float *t1, const float *t
                       int d_ent, int d_rel, const int64_t *h, const int64_t *t, const int64_t *r,
                       int64_t B, float *out, kge_stream_t stream);
 
-/* backward: adds d(sum_i go[i]*score_i)/d(table) into g0..g3 (same shapes as
- * t0..t3, caller-zeroed or accumulating) with fp32 atomics. */
+/* backward of d(sum_i go[i]*score_i)/d(table).
+ * rows == NULL: added into g0..g3 (same shapes as t0..t3, caller-zeroed or accumulating) with one
+ *   fp32 atomic per (triple, dimension).
+ * rows != NULL: no atomics; triple i stores its gradient rows at rows[(stream*B + i)*rows_ld ...]
+ *   (rows_ld >= d_ent), streams = (target table, index):
+ *     TransE / DistMult: 0 (g0,h) 1 (g0,t) 2 (g1,r)        TransH: 0 (g0,h) 1 (g0,t) 2 (g1,r) 3 (g2,r)
+ *     ComplEx: 0 (g0,h) 1 (g0,t) 2 (g1,h) 3 (g1,t) 4 (g2,r) 5 (g3,r)
+ *     TransD:  0 (g0,h) 1 (g0,t) 2 (g2,h) 3 (g2,t) 4 (g1,r) 5 (g3,r)
+ *   and the caller reduces them per target table with kge_segment_sum_rows. */
 int kge_score_triples_bwd(int kind, const float *t0, const float *t1, const float *t2,
                           const float *t3, int d_ent, int d_rel, const int64_t *h,
                           const int64_t *t, const int64_t *r, int64_t B, const float *go,
-                          float *g0, float *g1, float *g2, float *g3, kge_stream_t stream);
+                          float *g0, float *g1, float *g2, float *g3, float *rows, int64_t rows_ld,
+                          kge_stream_t stream);
+/* Row j of `rows` (j in [0, n0+n1)) belongs to target row key(j) = j < n0 ? k0[j] : k1[j-n0]; perm lists
+ * the rows grouped by key.  out[key] += sum of its rows: runs are summed in registers per 32-entry chunk
+ * of perm and flushed with one atomic row-add each. */
+int kge_segment_sum_rows(const float *rows, int64_t ld, int d, const int64_t *k0, int64_t n0, const int64_t *k1,
+                         int64_t n1, const int64_t *perm, float *out, int64_t out_ld, kge_stream_t stream);
+/* counting sort of the small-integer keys [k0 | k1] (ids < n_keys): kge_key_hist fills hist (caller-zeroed,
+ * n_keys int32), the caller turns it into exclusive offsets (int64), kge_key_scatter writes perm (cursor:
+ * n_keys int32, caller-zeroed).  Order inside a key group is unspecified. */
+int kge_key_hist(const int64_t *k0, int64_t n0, const int64_t *k1, int64_t n1, int32_t *hist, kge_stream_t stream);
+int kge_key_scatter(const int64_t *k0, int64_t n0, const int64_t *k1, int64_t n1, const int64_t *offsets,
+                    int32_t *cursor, int64_t *perm, kge_stream_t stream);
 
 /* ---- link-prediction query preparation ----------------------------------- */
 /* Fills the query-side operands of a kge_lp_desc for one side:

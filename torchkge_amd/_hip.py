@@ -51,7 +51,10 @@ class SplitArgs(ctypes.Structure):
 _SIGNATURES = {
     'kge_score_triples': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp],
     'kge_score_triples_bwd': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp,
-                              _vp, _vp, _vp, _vp, _vp],
+                              _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    'kge_segment_sum_rows': [_vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp],
+    'kge_key_hist': [_vp, _i64, _vp, _i64, _vp, _vp],
+    'kge_key_scatter': [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     'kge_lp_prep': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp,
                     _vp, _vp, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
@@ -108,7 +111,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 5:
+    if lib.kge_abi_version() != 6:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -167,18 +170,59 @@ def score_triples(kind, tables, d_ent, d_rel, h, t, r):
     return out
 
 
+# gradient-row streams of kge_score_triples_bwd's row mode: per model kind, for every table
+# (index into `tables`) the first stream, the number of adjacent streams and the index they use
+_BWD_STREAMS = {
+    TRANSE_L1: [(0, 0, 2, 'ht'), (1, 2, 1, 'r')], TRANSE_L2: [(0, 0, 2, 'ht'), (1, 2, 1, 'r')],
+    DISTMULT: [(0, 0, 2, 'ht'), (1, 2, 1, 'r')],
+    TRANSH: [(0, 0, 2, 'ht'), (1, 2, 1, 'r'), (2, 3, 1, 'r')],
+    COMPLEX: [(0, 0, 2, 'ht'), (1, 2, 2, 'ht'), (2, 4, 1, 'r'), (3, 5, 1, 'r')],
+    TRANSD: [(0, 0, 2, 'ht'), (2, 2, 2, 'ht'), (1, 4, 1, 'r'), (3, 5, 1, 'r')],
+}
+BWD_SORTED_MIN_BATCH = 2048     # below this the plain atomic scatter is as fast
+
+
 def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
-    """Returns a list of gradient tensors (or None) matching ``tables``."""
+    """Returns a list of gradient tensors (or None) matching ``tables``.  Large
+    batches take the sorted reduction (per-triple gradient rows, then one atomic
+    row-add per run of equal target rows) instead of one atomic per element."""
     lib = load_library()
     tabs = [f32c(x) for x in tables] + [None] * (4 - len(tables))
     grads = [torch.zeros_like(x) for x in tabs[:len(tables)]] + [None] * (4 - len(tables))
     go = f32c(grad_out)
     B = h.shape[0]
-    with torch.cuda.device(h.device):
+    dev = h.device
+    if B < BWD_SORTED_MIN_BATCH:
+        with torch.cuda.device(dev):
+            _check(lib.kge_score_triples_bwd(kind, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
+                                             d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(go),
+                                             _p(grads[0]), _p(grads[1]), _p(grads[2]), _p(grads[3]),
+                                             None, 0, _stream()), 'kge_score_triples_bwd')
+        return [g if n else None for g, n in zip(grads[:len(tables)], needs)]
+    streams = _BWD_STREAMS[kind]
+    n_streams = max(s0 + ns for _, s0, ns, _ in streams)
+    rows = torch.empty(n_streams * B * d_ent, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
         _check(lib.kge_score_triples_bwd(kind, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
-                                         d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(go),
-                                         _p(grads[0]), _p(grads[1]), _p(grads[2]), _p(grads[3]),
-                                         _stream()), 'kge_score_triples_bwd')
+                                         d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(go), None, None, None, None,
+                                         _p(rows), d_ent, _stream()), 'kge_score_triples_bwd')
+        perms = {}
+        for ti, s0, ns, key in streams:
+            if not needs[ti]:
+                continue
+            g = grads[ti]
+            k0, n0, k1, n1 = (h, B, t, B) if key == 'ht' else (r, B, None, 0)
+            if key not in perms:    # counting sort of the ids (they index g's rows): hist, cumsum, scatter
+                cnt = torch.zeros(2, g.shape[0], dtype=torch.int32, device=dev)
+                _check(lib.kge_key_hist(_p(k0), n0, _p(k1), n1, _p(cnt[0]), _stream()), 'kge_key_hist')
+                off = torch.cumsum(cnt[0], 0, dtype=torch.int64) - cnt[0]
+                perm = torch.empty(n0 + n1, dtype=torch.int64, device=dev)
+                _check(lib.kge_key_scatter(_p(k0), n0, _p(k1), n1, _p(off), _p(cnt[1]), _p(perm), _stream()),
+                       'kge_key_scatter')
+                perms[key] = perm
+            _check(lib.kge_segment_sum_rows(rows.data_ptr() + s0 * B * d_ent * 4, d_ent, g.shape[1], _p(k0), n0,
+                                            _p(k1), n1, _p(perms[key]), _p(g), g.stride(0), _stream()),
+                   'kge_segment_sum_rows')
     return [g if n else None for g, n in zip(grads[:len(tables)], needs)]
 
 

@@ -190,7 +190,25 @@ struct BwdParams {
     ScoreParams f;
     const float *go;
     float *g0, *g1, *g2, *g3;
+    // row mode (rows != NULL): no atomics -- every triple stores its gradient rows at
+    // rows[(stream * B + i) * rows_ld ...]; kge_segment_sum_rows then reduces them by target
+    // row in sorted order.  Streams (target table, index):
+    //   TransE / DistMult: 0 (g0,h) 1 (g0,t) 2 (g1,r)          TransH: 0 (g0,h) 1 (g0,t) 2 (g1,r) 3 (g2,r)
+    //   ComplEx: 0 (g0,h) 1 (g0,t) 2 (g1,h) 3 (g1,t) 4 (g2,r) 5 (g3,r)
+    //   TransD:  0 (g0,h) 1 (g0,t) 2 (g2,h) 3 (g2,t) 4 (g1,r) 5 (g3,r)
+    float *rows;
+    int64_t rows_ld;
 };
+
+template <bool VEC4, int NE>
+__device__ __forceinline__ void store_row(float *__restrict__ g, int d, int lane, const float (&x)[NE])
+{
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int k = elem_index<VEC4, NE>(e, lane);
+        if (k < d) g[k] = x[e];
+    }
+}
 
 template <bool VEC4, int NE>
 __device__ __forceinline__ void scatter_row(float *__restrict__ g, int d, int lane, const float (&x)[NE])
@@ -224,7 +242,19 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const B
     for (int64_t i = wave; i < p.B; i += nwaves) {
         const int64_t hi = p.h[i], ti = p.t[i], ri = p.r[i];
         const float go = q.go[i];
-        if (go == 0.f) continue;
+#define KGE_EMIT(STREAM, G, IDX, D, X)                                                              \
+    do {                                                                                            \
+        if (q.rows) store_row<VEC4, NE>(q.rows + ((int64_t)(STREAM) * p.B + i) * q.rows_ld, D, lane, X); \
+        else scatter_row<VEC4, NE>((G) + (IDX) * (D), D, lane, X);                                  \
+    } while (0)
+        if (go == 0.f) {
+            if (q.rows) {   // this triple's rows still have to exist (as zeros) for the reduction
+                const int ns = (p.kind == KGE_TRANSD || p.kind == KGE_COMPLEX) ? 6 : (p.kind == KGE_TRANSH ? 4 : 3);
+                for (int st = 0; st < ns; ++st)
+                    for (int k = lane; k < de; k += 64) q.rows[((int64_t)st * p.B + i) * q.rows_ld + k] = 0.f;
+            }
+            continue;
+        }
         if (p.kind == KGE_TRANSE_L1 || p.kind == KGE_TRANSE_L2) {
             float h[NE], t[NE], r[NE], gd[NE];
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
@@ -238,14 +268,14 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const B
                 const float sg = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
                 gd[e] = go * ((p.kind == KGE_TRANSE_L1) ? -sg : -2.f * diff);
             }
-            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gd);       // d/dr = gd
+            KGE_EMIT(2, q.g1, ri, dr, gd);       // d/dr = gd
             float gh[NE], gt[NE];
 #pragma unroll
             for (int e = 0; e < NE; ++e) { gh[e] = gd[e]; gt[e] = -gd[e]; }
             normalize_bwd<NE>(h, nh, gh);
             normalize_bwd<NE>(t, nt, gt);
-            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
-            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
+            KGE_EMIT(0, q.g0, hi, de, gh);
+            KGE_EMIT(1, q.g0, ti, de, gt);
         } else if (p.kind == KGE_DISTMULT) {
             float h[NE], t[NE], r[NE], gh[NE], gt[NE], gr[NE];
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
@@ -260,9 +290,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const B
             }
             normalize_bwd<NE>(h, nh, gh);
             normalize_bwd<NE>(t, nt, gt);
-            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
-            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
-            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gr);
+            KGE_EMIT(0, q.g0, hi, de, gh);
+            KGE_EMIT(1, q.g0, ti, de, gt);
+            KGE_EMIT(2, q.g1, ri, dr, gr);
         } else if (p.kind == KGE_COMPLEX) {
             float reh[NE], imh[NE], ret[NE], imt[NE], rer[NE], imr[NE], g[NE];
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, reh);
@@ -274,22 +304,22 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const B
             // s = reh(rer ret + imr imt) + imh(rer imt - imr ret)
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[e] = go * (rer[e] * ret[e] + imr[e] * imt[e]);
-            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, g); // d/d reh
+            KGE_EMIT(0, q.g0, hi, de, g); // d/d reh
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[e] = go * (rer[e] * imt[e] - imr[e] * ret[e]);
-            scatter_row<VEC4, NE>(q.g1 + hi * de, de, lane, g); // d/d imh
+            KGE_EMIT(2, q.g1, hi, de, g); // d/d imh
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * rer[e] - imh[e] * imr[e]);
-            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, g); // d/d ret
+            KGE_EMIT(1, q.g0, ti, de, g); // d/d ret
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * imr[e] + imh[e] * rer[e]);
-            scatter_row<VEC4, NE>(q.g1 + ti * de, de, lane, g); // d/d imt
+            KGE_EMIT(3, q.g1, ti, de, g); // d/d imt
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * ret[e] + imh[e] * imt[e]);
-            scatter_row<VEC4, NE>(q.g2 + ri * dr, dr, lane, g); // d/d rer
+            KGE_EMIT(4, q.g2, ri, dr, g); // d/d rer
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[e] = go * (reh[e] * imt[e] - imh[e] * ret[e]);
-            scatter_row<VEC4, NE>(q.g3 + ri * dr, dr, lane, g); // d/d imr
+            KGE_EMIT(5, q.g3, ri, dr, g); // d/d imr
         } else if (p.kind == KGE_TRANSH) {
             float h[NE], t[NE], r[NE], w[NE], gd[NE];
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
@@ -305,7 +335,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const B
                 const float diff = ((h[e] - hw * w[e]) + r[e]) - (t[e] - tw * w[e]);
                 gd[e] = go * (-2.f * diff);
             }
-            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gd); // d/dr
+            KGE_EMIT(2, q.g1, ri, dr, gd); // d/dr
             const float gdw = dotp<NE>(gd, w);
             float gh[NE], gt[NE], gw[NE];
 #pragma unroll
@@ -318,9 +348,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const B
             normalize_bwd<NE>(h, nh, gh);
             normalize_bwd<NE>(t, nt, gt);
             normalize_bwd<NE>(w, nw, gw);
-            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
-            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
-            scatter_row<VEC4, NE>(q.g2 + ri * dr, dr, lane, gw);
+            KGE_EMIT(0, q.g0, hi, de, gh);
+            KGE_EMIT(1, q.g0, ti, de, gt);
+            KGE_EMIT(3, q.g2, ri, dr, gw);
         } else { // KGE_TRANSD
             float h[NE], t[NE], hp[NE], tp[NE], r[NE], rp[NE], gd[NE];
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
@@ -357,13 +387,93 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_bwd_kernel(const B
             normalize_bwd<NE>(t, nt, gt);
             normalize_bwd<NE>(hp, nhp, ghp);
             normalize_bwd<NE>(tp, ntp, gtp);
-            scatter_row<VEC4, NE>(q.g1 + ri * dr, dr, lane, gr);
-            scatter_row<VEC4, NE>(q.g3 + ri * dr, dr, lane, grp);
-            scatter_row<VEC4, NE>(q.g0 + hi * de, de, lane, gh);
-            scatter_row<VEC4, NE>(q.g0 + ti * de, de, lane, gt);
-            scatter_row<VEC4, NE>(q.g2 + hi * de, de, lane, ghp);
-            scatter_row<VEC4, NE>(q.g2 + ti * de, de, lane, gtp);
+            KGE_EMIT(4, q.g1, ri, dr, gr);
+            KGE_EMIT(5, q.g3, ri, dr, grp);
+            KGE_EMIT(0, q.g0, hi, de, gh);
+            KGE_EMIT(1, q.g0, ti, de, gt);
+            KGE_EMIT(2, q.g2, hi, de, ghp);
+            KGE_EMIT(3, q.g2, ti, de, gtp);
         }
+    }
+}
+
+#undef KGE_EMIT
+
+// Reduction of per-triple gradient rows by target row, in SORTED key order: a wavefront walks 32
+// consecutive sorted entries, sums runs of equal keys in registers and flushes each run with one
+// atomic row-add -- a handful of atomics per chunk instead of one per (triple, dimension), and the
+// heavily shared relation rows (n_rel << B) stop serialising on the same addresses.
+template <int NE>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restrict__ rows, int64_t ld, int d,
+                                                          const int64_t *__restrict__ k0, int64_t n0,
+                                                          const int64_t *__restrict__ k1, int64_t n1,
+                                                          const int64_t *__restrict__ perm,
+                                                          float *__restrict__ out, int64_t out_ld)
+{
+    constexpr int CH = 32, UN = 4;
+    const int64_t M = n0 + n1;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t j0 = wave * CH; j0 < M; j0 += nwaves * CH) {
+        const int n = (int)min((int64_t)CH, M - j0);
+        // the chunk's (row, key) pairs: one coalesced load, then broadcast by shuffle
+        const int64_t jl = j0 + min(lane, n - 1);
+        const int64_t my_row = perm[jl], my_key = my_row < n0 ? k0[my_row] : k1[my_row - n0];
+        float acc[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc[e] = 0.f;
+        int64_t cur = __shfl(my_key, 0, 64);
+        for (int j = 0; j < n; j += UN) {
+            float v[UN][NE];
+            int64_t kk[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {      // UN independent row loads in flight
+                const int ju = min(j + u, n - 1);
+                kk[u] = __shfl(my_key, ju, 64);
+                const float *row = rows + __shfl(my_row, ju, 64) * ld;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int k = lane + 64 * e;
+                    v[u][e] = (k < d && j + u < n) ? row[k] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (j + u < n && kk[u] != cur) {    // wave-uniform
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const int k = lane + 64 * e;
+                        if (k < d && acc[e] != 0.f) atomicAdd(out + cur * out_ld + k, acc[e]);
+                        acc[e] = 0.f;
+                    }
+                    cur = kk[u];
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) acc[e] += v[u][e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int k = lane + 64 * e;
+            if (k < d && acc[e] != 0.f) atomicAdd(out + cur * out_ld + k, acc[e]);
+        }
+    }
+}
+
+// counting sort of small-integer keys (entity / relation ids): histogram, (host: cumsum), scatter
+__global__ void key_hist_kernel(const int64_t *__restrict__ k0, int64_t n0, const int64_t *__restrict__ k1, int64_t n1,
+                                int32_t *hist)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0 + n1; j += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&hist[j < n0 ? k0[j] : k1[j - n0]], 1);
+}
+__global__ void key_scatter_kernel(const int64_t *__restrict__ k0, int64_t n0, const int64_t *__restrict__ k1,
+                                   int64_t n1, const int64_t *__restrict__ offsets, int32_t *cursor, int64_t *perm)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0 + n1; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t key = j < n0 ? k0[j] : k1[j - n0];
+        perm[offsets[key] + atomicAdd(&cursor[key], 1)] = j;
     }
 }
 
@@ -431,15 +541,17 @@ extern "C" int kge_score_triples(int kind, const float *t0, const float *t1, con
 extern "C" int kge_score_triples_bwd(int kind, const float *t0, const float *t1, const float *t2,
                                      const float *t3, int d_ent, int d_rel, const int64_t *h,
                                      const int64_t *t, const int64_t *r, int64_t B, const float *go,
-                                     float *g0, float *g1, float *g2, float *g3, kge_stream_t stream)
+                                     float *g0, float *g1, float *g2, float *g3, float *rows, int64_t rows_ld,
+                                     kge_stream_t stream)
 {
     int rc = check_common(kind, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B);
     if (rc) return rc;
     if (B == 0) return 0;
-    if (!go || !g0 || !g1) return KGE_EINVAL;
-    if ((kind == KGE_TRANSH || kind == KGE_TRANSD || kind == KGE_COMPLEX) && !g2) return KGE_EINVAL;
-    if ((kind == KGE_TRANSD || kind == KGE_COMPLEX) && !g3) return KGE_EINVAL;
-    BwdParams q{{kind, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, nullptr}, go, g0, g1, g2, g3};
+    if (!go || (!rows && (!g0 || !g1))) return KGE_EINVAL;
+    if (rows && rows_ld < d_ent) return KGE_EINVAL;
+    if (!rows && (kind == KGE_TRANSH || kind == KGE_TRANSD || kind == KGE_COMPLEX) && !g2) return KGE_EINVAL;
+    if (!rows && (kind == KGE_TRANSD || kind == KGE_COMPLEX) && !g3) return KGE_EINVAL;
+    BwdParams q{{kind, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, nullptr}, go, g0, g1, g2, g3, rows, rows_ld};
     const bool vec4 = tables_vec4(t0, t1, t2, t3, d_ent, d_rel);
     auto sel = [](const BwdParams &qq, auto ne, bool v4, int64_t b, hipStream_t s) -> int {
         constexpr int NE = decltype(ne)::value;
@@ -449,4 +561,46 @@ extern "C" int kge_score_triples_bwd(int kind, const float *t0, const float *t1,
         return 0;
     };
     return dispatch_ne(q, d_ent, vec4, B, kge_s(stream), sel);
+}
+
+extern "C" int kge_segment_sum_rows(const float *rows, int64_t ld, int d, const int64_t *k0, int64_t n0,
+                                    const int64_t *k1, int64_t n1, const int64_t *perm, float *out, int64_t out_ld,
+                                    kge_stream_t stream)
+{
+    const int64_t M = n0 + n1;
+    if (n0 < 0 || n1 < 0 || d <= 0 || d > 1024 || ld < d || out_ld < d) return KGE_EINVAL;
+    if (M == 0) return 0;
+    if (!rows || (n0 > 0 && !k0) || (n1 > 0 && !k1) || !perm || !out) return KGE_EINVAL;
+    const int64_t chunks = (M + 31) / 32;
+    const int grid = (int)((chunks + 3) / 4 < 256 * 8 ? (chunks + 3) / 4 : 256 * 8);
+    hipStream_t s = kge_s(stream);
+    if (d <= 256) hipLaunchKernelGGL(segment_sum_kernel<4>, dim3(grid), dim3(256), 0, s, rows, ld, d, k0, n0, k1, n1, perm, out, out_ld);
+    else if (d <= 512) hipLaunchKernelGGL(segment_sum_kernel<8>, dim3(grid), dim3(256), 0, s, rows, ld, d, k0, n0, k1, n1, perm, out, out_ld);
+    else hipLaunchKernelGGL(segment_sum_kernel<16>, dim3(grid), dim3(256), 0, s, rows, ld, d, k0, n0, k1, n1, perm, out, out_ld);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_key_hist(const int64_t *k0, int64_t n0, const int64_t *k1, int64_t n1, int32_t *hist,
+                            kge_stream_t stream)
+{
+    if (n0 < 0 || n1 < 0 || !hist || (n0 > 0 && !k0) || (n1 > 0 && !k1)) return KGE_EINVAL;
+    if (n0 + n1 == 0) return 0;
+    const int64_t n = n0 + n1;
+    hipLaunchKernelGGL(key_hist_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0,
+                       kge_s(stream), k0, n0, k1, n1, hist);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_key_scatter(const int64_t *k0, int64_t n0, const int64_t *k1, int64_t n1, const int64_t *offsets,
+                               int32_t *cursor, int64_t *perm, kge_stream_t stream)
+{
+    if (n0 < 0 || n1 < 0 || !offsets || !cursor || !perm || (n0 > 0 && !k0) || (n1 > 0 && !k1)) return KGE_EINVAL;
+    if (n0 + n1 == 0) return 0;
+    const int64_t n = n0 + n1;
+    hipLaunchKernelGGL(key_scatter_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0,
+                       kge_s(stream), k0, n0, k1, n1, offsets, cursor, perm);
+    KGE_CHECK_LAUNCH();
+    return 0;
 }

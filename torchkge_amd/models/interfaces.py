@@ -190,16 +190,20 @@ class Model(Module):
                 negative_relations=None):
         """(pos, neg) scores; several negatives per fact tile the positives
         (interfaces.py:39-82)."""
-        pos = self.scoring_function(heads, tails, relations)
         if negative_relations is None:
             negative_relations = relations
+        n_neg = 1
         if negative_heads.shape[0] > negative_relations.shape[0]:
             n_neg = int(negative_heads.shape[0] / negative_relations.shape[0])
+            negative_relations = negative_relations.repeat(n_neg)
+        # positives and negatives in ONE fused kernel launch (and one backward): per-triple
+        # scores are independent, so this is the reference's two calls value for value
+        b = heads.shape[0]
+        scores = self.scoring_function(torch.cat([heads, negative_heads]), torch.cat([tails, negative_tails]),
+                                       torch.cat([relations, negative_relations]))
+        pos, neg = scores[:b], scores[b:]
+        if n_neg > 1:
             pos = pos.repeat(n_neg)
-            neg = self.scoring_function(negative_heads, negative_tails,
-                                        negative_relations.repeat(n_neg))
-        else:
-            neg = self.scoring_function(negative_heads, negative_tails, negative_relations)
         return pos, neg
 
     def scoring_function(self, h_idx, t_idx, r_idx):
