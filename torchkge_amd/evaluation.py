@@ -112,7 +112,7 @@ class LinkPredictionEvaluator(object):
         self.fused, self.shard, self.exchange, self.group = fused, shard, exchange, group
         self.engine = engine if engine is not None else HipRankEngine()
         self.graph = graph and engine is None       # replay evaluate() as one hipGraph (single GPU)
-        self._graph = self._graph_static = self._graph_key = None
+        self._graph = self._graph_static = self._graph_key = self._graph_src = None
         self.overlap = overlap                      # two-stream overlap of the short kernels (single GPU, fused)
         self._aux_stream = None
 
@@ -293,20 +293,29 @@ class LinkPredictionEvaluator(object):
                 with torch.cuda.graph(g):
                     run(st['h'], st['t'], st['r'], st['out'])
                 self._graph, self._graph_static, self._graph_key = g, st, key
+                self._graph_src = None
             st = self._graph_static
-            st['h'].copy_(kg.head_idx[f_lo:f_hi], non_blocking=True)
-            st['t'].copy_(kg.tail_idx[f_lo:f_hi], non_blocking=True)
-            st['r'].copy_(kg.relations[f_lo:f_hi], non_blocking=True)
+            src = tuple((x.data_ptr(), x._version, f_lo, f_hi) for x in (kg.head_idx, kg.tail_idx, kg.relations))
+            if src != self._graph_src:      # refresh the graph's static inputs only when the facts changed
+                st['h'].copy_(kg.head_idx[f_lo:f_hi], non_blocking=True)
+                st['t'].copy_(kg.tail_idx[f_lo:f_hi], non_blocking=True)
+                st['r'].copy_(kg.relations[f_lo:f_hi], non_blocking=True)
+                self._graph_src = src
             self._graph.replay()
             out = st['out']
 
+        res = None
         if guard is not None:
             # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
             # cancellation error could exceed the score tolerance -> redo on the VALU kernel
             flags = torch.stack([guard[0] + guard[1], guard[2]])
             if world > 1:
                 kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
-            worst, overflow = flags.tolist()
+                worst, overflow = flags.tolist()
+            else:   # one device-to-host transfer for the ranks and the two flags (8 bytes = one int64)
+                packed = torch.cat([out.reshape(-1), flags.view(torch.int64)]).cpu()
+                worst, overflow = packed[-1:].view(torch.float32).tolist()
+                res = packed[:-1].view(4, n_local)
             redo = False
             if not worst <= self.model.L2_EXPAND_LIMIT:
                 self.model._expand_ok = False
@@ -315,13 +324,15 @@ class LinkPredictionEvaluator(object):
                 self.model._split_ok = False
                 redo = True
             if redo:
+                res = None
                 out = torch.empty(4, n_local, dtype=torch.int64, device=device)
                 run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                     kg.relations[f_lo:f_hi].to(device), out)
             self.model.lp_guard_end()
         if self.shard == 'queries' and world > 1:
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
-        res = out.cpu()
+        if res is None:
+            res = out.cpu()
         self.rank_true_heads, self.rank_true_tails = res[0], res[1]
         self.filt_rank_true_heads, self.filt_rank_true_tails = res[2], res[3]
         self.evaluated = True
