@@ -47,6 +47,7 @@ WORKLOADS = {
     'transh_fb15k237': ('transh', 'fb15k237', 200, 2),
     'transd_fb15k237': ('transd', 'fb15k237', 200, 2),
     'transe_l1_fb15k237': ('transe', 'fb15k237', 200, 1),
+    'complex_wikidata5m': ('complex', 'wikidata5m', 512, 2),    # cfg5: 18.8 GB of tables; use --no-secondary
 }
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
 PEAK_F16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA (~2.5 PF, no sparsity)
@@ -69,6 +70,7 @@ def parse():
     ap.add_argument('--no-split', action='store_true',
                     help='rank counts on the fp32 MFMA kernel only (no f16-split prefilter)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the scoring_function / sampler / train-step timings')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
     ap.add_argument('--overlap', action='store_true', help='two-stream overlap of the short kernels (default: single stream)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -127,8 +129,14 @@ def main():
     # exchange partial results over RCCL -- per-GPU work is fixed as N grows.
     ent_weak = multi and args.scaling == 'weak' and args.shard == 'entities'
     n_ent = n_ent1 * (world if ent_weak else 1)
-    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=0)
-    model = make_model(kind, p, tables, n_ent, n_rel).to(device)
+    if n_ent > 2000000 and kind == 'complex':
+        # Wikidata5M scale: let the constructor draw the 2 x 9.4 GB tables once (same distribution)
+        torch.manual_seed(0)
+        model = tk.ComplExModel(d, n_ent, n_rel).to(device)
+        tables = None
+    else:
+        tables = orc.init_tables(kind, n_ent, n_rel, d, seed=0)
+        model = make_model(kind, p, tables, n_ent, n_rel).to(device)
     if kind in ('transe', 'transh', 'transd'):
         model.l2_mode = args.l2_mode
     model.split_filter = not args.no_split
@@ -283,7 +291,7 @@ def main():
 
     # ---- secondary numbers of the same hot path: scoring_function (K1) and corrupt_batch (K5) ----
     sec = None
-    if rank == 0:
+    if rank == 0 and not args.no_secondary:
         Bt = 32768                                     # training batch of docs/tutorials/transe.rst:25
         h2, t2, r2 = orc.synthetic_triples(n_ent_full, n_rel, Bt, seed=3, device=device)
 
