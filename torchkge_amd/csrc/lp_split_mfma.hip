@@ -23,10 +23,11 @@
 //
 // Error bound used for the thresholds (split_thr_kernel), per unit of
 // P >= sum_k |q_k e_k| (+ |augmentation term|), P = ||q|| * max||e|| (+ max||e||^2 / 2):
-//   split residual   3 * 2^-22        (ql*el dropped, rho_q*e, q*rho_e)
-//   accumulation     n_terms * 2^-24  (n_terms = 3 * 16 * units fp32 adds, any order)
-//   exact chain      K * 2^-24        (the scalar fmaf chain it is compared with)
-// all doubled (covers truncating instead of rounding adders), plus absolute
+//   split residual   3 * 2^-22            (ql*el dropped, rho_q*e, q*rho_e)
+//   accumulation     2 * n_terms * 2^-24  (n_terms = 3 * 16 * units fp32 adds in any order; the
+//                                          factor 2 covers adders that truncate instead of rounding)
+//   exact chain      K * 2^-24            (the scalar fmaf chain it is compared with)
+// plus absolute
 // terms for f16 subnormal lo parts (flushed or not) and for the roundings of
 // the threshold arithmetic itself.  tools/probe/mfma_probe.hip measures what the
 // MFMA really does (two passes of acc + 8 products, addends truncated 24 bits
@@ -201,7 +202,9 @@ __global__ void split_thr_kernel(const SplitThrParams p)
         const float qm = p.qmax0 ? *p.qmax0 + (p.qmax1 ? *p.qmax1 : 0.f) : 0.f;
         if (!(em < INFINITY) || !(qm < INFINITY)) *p.overflow = 1.0f;
     }
-    const float eps_rel = 2.0f * ((float)(48 * p.units + p.K) * two24 + 3.0f * two22);
+    // accumulation: 48*units fp32 additions, doubled (adders that truncate instead of rounding);
+    // exact chain: K fmaf roundings (gamma_K <= 1.01 K u); split residual 3 * 2^-22 * (1 + 2^-10)
+    const float eps_rel = (2.0f * (float)(48 * p.units) + 1.01f * (float)p.K) * two24 + 3.01f * two22;
     const float enrm = sqrtf(em) * 1.000001f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.Bp; i += (int64_t)gridDim.x * blockDim.x) {
         if (i >= p.B) {
