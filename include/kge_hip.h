@@ -302,6 +302,8 @@ typedef struct kge_split_args {
     const float *qmax0, *qmax1;   /* KGE_LP_DOT: device scalars >= max_i qn0 / qn1 (they fix the query operand's scale) */
     const float *emax0, *emax1;   /* device scalars >= max_c ||e_c||^2 per K-segment (emax1 NULL when K1 == 0) */
     const float *xabsmax, *yabsmax; /* L2_PROJH/_PROJD: device scalars >= max |X[r,c]| (and >= max |yc[c]|, PROJD), see kge_absmax */
+    int32_t accum_model;          /* 0: accumulation error bounded for ANY fp32 adder (2 * 2^-24 per product); 1: the
+                                   * measured behaviour of gfx950, valid only if kge_mfma_f16_selftest() returned 1 */
     float eps_scale;              /* multiplies the error band (1.0 = the proven bound; tests shrink it) */
     float *thr;                   /* scratch: 4 * kge_lp_split_rows_padded(B, 1) floats */
     int32_t *list;                /* scratch: cap x 2 int32 (query, local candidate) */
@@ -324,6 +326,10 @@ int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int
                       const float *norm2max1, void *out, kge_stream_t stream);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
+/* 1 if v_mfma_f32_32x32x16_f16 on the current device accumulates as the tighter error model assumes (two
+ * passes of acc + 8 products, addends truncated 24 bits below the largest, one RNE rounding), 0 if not.
+ * Launches a one-wave kernel on the null stream and synchronises: call once, outside any capture. */
+int kge_mfma_f16_selftest(void);
 /* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
 int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,

@@ -1047,3 +1047,10 @@ def test_backward_sorted_reduction_matches_atomic_scatter(hip, kind, p):
     for a, b in zip(*grads):
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+
+
+def test_mfma_f16_accumulation_selftest(hip):
+    """The tighter error band of the split prefilter (accum_model = 1) is only used when the
+    device's f16 MFMA accumulates as measured (tools/probe/mfma_probe.hip): on MI355X it does."""
+    assert hip.load_library().kge_mfma_f16_selftest() == 1
+    assert hip.split_accum_model() == 1

@@ -43,7 +43,8 @@ class SplitArgs(ctypes.Structure):
     """struct kge_split_args (include/kge_hip.h)."""
     _fields_ = [
         ('Qs', _vp), ('Es', _vp), ('qn0', _vp), ('qn1', _vp), ('qmax0', _vp), ('qmax1', _vp),
-        ('emax0', _vp), ('emax1', _vp), ('xabsmax', _vp), ('yabsmax', _vp), ('eps_scale', ctypes.c_float),
+        ('emax0', _vp), ('emax1', _vp), ('xabsmax', _vp), ('yabsmax', _vp), ('accum_model', ctypes.c_int32),
+        ('eps_scale', ctypes.c_float),
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
     ]
 
@@ -71,6 +72,7 @@ _SIGNATURES = {
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
+    'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
@@ -111,7 +113,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 6:
+    if lib.kge_abi_version() != 7:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -257,6 +259,20 @@ def ewise(op, a, b, c=None, d=None):
     with torch.cuda.device(a.device):
         _check(lib.kge_ewise(op, _p(a), _p(b), _p(c), _p(d), a.numel(), _p(out), _stream()), 'kge_ewise')
     return out
+
+
+_ACCUM_MODEL = None
+
+
+def split_accum_model():
+    """1 if this GPU's f16 MFMA passed the accumulation self-test (tighter error band of the
+    split prefilter), else 0 (band valid for any fp32 adder).  Tested once per process, the first
+    time a split count is prepared -- i.e. in evaluate()'s eager warm-up, never inside a capture."""
+    global _ACCUM_MODEL
+    if _ACCUM_MODEL is None:
+        rc = int(load_library().kge_mfma_f16_selftest())
+        _ACCUM_MODEL = 1 if rc == 1 else 0
+    return _ACCUM_MODEL
 
 
 SPLIT_EPS_SCALE = 1.0          # multiplies the proven error band of the f16-split prefilter (tests shrink it)
@@ -462,6 +478,7 @@ class LpProblem(object):
             a.qmax1 = qmax.data_ptr() + 4 if prep.get('qn1') is not None else None
         a.emax0, a.emax1 = _p(sp['enmax']), _p(sp.get('enmax1'))
         a.xabsmax, a.yabsmax = _p(sp.get('xabsmax')), _p(sp.get('yabsmax'))
+        a.accum_model = split_accum_model()
         a.eps_scale = SPLIT_EPS_SCALE
         a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']
         a.list_count, a.overflow = _p(prep['n_list']), _p(sp['overflow'])
