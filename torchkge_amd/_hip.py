@@ -138,6 +138,25 @@ def _stream():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
+class _NoSwitch(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Context that makes `device` current for a launch -- a no-op object when it already is
+    (torch.cuda.device costs ~10 us of host time per entry; there are ~30 launches per batch)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def _p(t):
     return None if t is None else _vp(t.data_ptr())
 
@@ -165,7 +184,7 @@ def score_triples(kind, tables, d_ent, d_rel, h, t, r):
     h, t, r = i64c(h), i64c(t), i64c(r)
     B = h.shape[0]
     out = torch.empty(B, dtype=torch.float32, device=h.device)
-    with torch.cuda.device(h.device):
+    with _on(h.device):
         _check(lib.kge_score_triples(kind, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
                                      d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(out), _stream()),
                'kge_score_triples')
@@ -195,7 +214,7 @@ def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
     B = h.shape[0]
     dev = h.device
     if B < BWD_SORTED_MIN_BATCH:
-        with torch.cuda.device(dev):
+        with _on(dev):
             _check(lib.kge_score_triples_bwd(kind, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
                                              d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(go),
                                              _p(grads[0]), _p(grads[1]), _p(grads[2]), _p(grads[3]),
@@ -204,7 +223,7 @@ def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
     streams = _BWD_STREAMS[kind]
     n_streams = max(s0 + ns for _, s0, ns, _ in streams)
     rows = torch.empty(n_streams * B * d_ent, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib.kge_score_triples_bwd(kind, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
                                          d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(go), None, None, None, None,
                                          _p(rows), d_ent, _stream()), 'kge_score_triples_bwd')
@@ -240,7 +259,7 @@ def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=Fal
     Q1 = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_q1 else None
     qn = torch.empty(B, dtype=torch.float32, device=dev) if want_qn else None
     Wq = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_w else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib.kge_lp_prep(kind, side, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
                                d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(Q0), _p(Q1), _p(qn),
                                _p(Wq), _stream()), 'kge_lp_prep')
@@ -256,7 +275,7 @@ def ewise(op, a, b, c=None, d=None):
     d = None if d is None else f32c(d)
     assert a.shape == b.shape
     out = torch.empty_like(a)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _check(lib.kge_ewise(op, _p(a), _p(b), _p(c), _p(d), a.numel(), _p(out), _stream()), 'kge_ewise')
     return out
 
@@ -304,7 +323,7 @@ def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False,
     units_p = int(lib.kge_lp_split_units(K + K1, 1))
     rows_p = int(lib.kge_lp_split_rows_padded(rows, 1 if is_query else 0))
     out = torch.empty(max(rows_p, 1) * units_p * 64, dtype=torch.uint8, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _check(lib.kge_lp_split_rows(_p(X), ld, K, _p(X1), ld1, K1, rows, 1 if is_query else 0, aug_mode, _p(aug),
                                      aug_mul, _p(nmax0), _p(nmax1), _p(out), _stream()), 'kge_lp_split_rows')
     return out
@@ -315,7 +334,7 @@ def absmax(x, max_io):
     lib = load_library()
     require_cuda(x, max_io)
     x = f32c(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib.kge_absmax(_p(x), x.numel(), _p(max_io), _stream()), 'kge_absmax')
     return max_io
 
@@ -333,7 +352,7 @@ def row_sqnorm(X, K=None, max_io=None):
     rows, ld = X.shape[0], X.stride(0)
     K = X.shape[1] if K is None else K
     out = torch.empty(rows, dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _check(lib.kge_row_sqnorm(_p(X), ld, rows, K, _p(out), _p(max_io), _stream()), 'kge_row_sqnorm')
     return out
 
@@ -345,7 +364,7 @@ def row_dot(X, Y, scale=1.0):
     assert X.shape == Y.shape
     rows, K = X.shape
     out = torch.empty(rows, dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _check(lib.kge_row_dot(_p(X), _p(Y), K, rows, K, ctypes.c_float(scale), _p(out), _stream()),
                'kge_row_dot')
     return out
@@ -357,7 +376,7 @@ def gather_rows(X, idx):
     X, idx = f32c(X), i64c(idx)
     rows, K = idx.shape[0], X.shape[1]
     out = torch.empty(rows, K, dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _check(lib.kge_gather_rows(_p(X), X.stride(0), _p(idx), rows, K, _p(out), _stream()),
                'kge_gather_rows')
     return out
@@ -369,7 +388,7 @@ def normalize_rows_(X):
     require_cuda(X)
     if not X.is_contiguous() or X.dtype != torch.float32:
         raise RuntimeError('normalize_rows_: need a contiguous float32 matrix')
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _check(lib.kge_normalize_rows(_p(X), X.stride(0), X.shape[0], X.shape[1], _stream()),
                'kge_normalize_rows')
     return X
@@ -412,7 +431,7 @@ class LpProblem(object):
         lib = load_library()
         if out is None:
             out = torch.empty(self.B, self.N, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(lib.kge_lp_scores(ctypes.byref(self.desc), _p(out), out.stride(0), _stream()),
                    'kge_lp_scores')
         return out
@@ -422,7 +441,7 @@ class LpProblem(object):
         ci = i64c(ci)
         P = ci.shape[0]
         out = torch.empty(P, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(lib.kge_lp_pair_scores(ctypes.byref(self.desc), _p(qi), _p(ci), P, _p(out),
                                           _stream()), 'kge_lp_pair_scores')
         return out
@@ -433,7 +452,7 @@ class LpProblem(object):
             raw = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         if self.split is not None and self.B > 0 and self.N > 0:
             return self._count_ge_split(s_true, raw)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(lib.kge_lp_count_ge(ctypes.byref(self.desc), _p(s_true), _p(raw), _stream()),
                    'kge_lp_count_ge')
         return raw
@@ -482,7 +501,7 @@ class LpProblem(object):
         a.eps_scale = SPLIT_EPS_SCALE
         a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']
         a.list_count, a.overflow = _p(prep['n_list']), _p(sp['overflow'])
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(lib.kge_lp_split_count(ctypes.byref(self.desc), ctypes.byref(a), _p(s_true), _p(raw), _stream()),
                    'kge_lp_split_count')
         return raw
@@ -490,7 +509,7 @@ class LpProblem(object):
     def split_recheck(self, prep, s_true, raw):
         """kge_lp_split_recheck: exact re-scoring of the pairs inside the error band."""
         lib = load_library()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(lib.kge_lp_split_recheck(ctypes.byref(self.desc), _p(s_true), _p(prep['list']), prep['cap'],
                                             _p(prep['n_list']), _p(raw), _stream()), 'kge_lp_split_recheck')
         return raw
@@ -511,7 +530,7 @@ class LpProblem(object):
             sub = torch.empty(self.B, dtype=torch.int32, device=self.device)
         if found is None:
             found = torch.empty(self.B, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(lib.kge_lp_filter_sub(ctypes.byref(self.desc), _p(s_true), _p(true_idx),
                                          _p(seg_lo), _p(seg_hi), _p(targets), _p(sub), _p(found),
                                          _stream()), 'kge_lp_filter_sub')
@@ -523,7 +542,7 @@ def rank_finalize(raw, sub, found):
     B = raw.shape[0]
     rank = torch.empty(B, dtype=torch.int64, device=raw.device)
     filt = torch.empty(B, dtype=torch.int64, device=raw.device)
-    with torch.cuda.device(raw.device):
+    with _on(raw.device):
         _check(lib.kge_rank_finalize(_p(raw), _p(sub), _p(found), B, _p(rank), _p(filt), _stream()),
                'kge_rank_finalize')
     return rank, filt
@@ -540,7 +559,7 @@ def lp_scores_batched(mode, q, cand):
         cand = cand.contiguous()
     B, N, K = cand.shape
     out = torch.empty(B, N, dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _check(lib.kge_lp_scores_batched(mode, _p(q), q.stride(0), _p(cand), cand.stride(0),
                                          cand.stride(1), B, N, K, _p(out), out.stride(0), _stream()),
                'kge_lp_scores_batched')
@@ -554,7 +573,7 @@ def get_rank(scores, true_idx, low_values=False):
     true_idx = i64c(true_idx)
     B, N = scores.shape
     rank = torch.empty(B, dtype=torch.int64, device=scores.device)
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         _check(lib.kge_get_rank(_p(scores), scores.stride(0), _p(true_idx), B, N,
                                 1 if low_values else 0, _p(rank), _stream()), 'kge_get_rank')
     return rank
@@ -566,7 +585,7 @@ def filter_lookup(keys, offsets, key1, key2, n_key2):
     B = key1.shape[0]
     lo = torch.empty(B, dtype=torch.int64, device=key1.device)
     hi = torch.empty(B, dtype=torch.int64, device=key1.device)
-    with torch.cuda.device(key1.device):
+    with _on(key1.device):
         _check(lib.kge_filter_lookup(_p(keys), keys.shape[0], _p(offsets), _p(key1), _p(key2),
                                      n_key2, B, _p(lo), _p(hi), _stream()), 'kge_filter_lookup')
     return lo, hi
@@ -575,7 +594,7 @@ def filter_lookup(keys, offsets, key1, key2, n_key2):
 def filter_scores_(scores, true_idx, seg_lo, seg_hi, targets):
     lib = load_library()
     B, N = scores.shape
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         _check(lib.kge_filter_scores(_p(scores), scores.stride(0), _p(true_idx), _p(seg_lo),
                                      _p(seg_hi), _p(targets), B, N, _stream()), 'kge_filter_scores')
     return scores
@@ -587,7 +606,7 @@ def filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
     B, N = scores.shape
     rank = torch.empty(B, dtype=torch.int64, device=scores.device)
     filt = torch.empty(B, dtype=torch.int64, device=scores.device)
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         _check(lib.kge_filtered_rank_from_scores(_p(scores), scores.stride(0), _p(true_idx),
                                                  _p(seg_lo), _p(seg_hi), _p(targets), B, N,
                                                  _p(rank), _p(filt), _stream()),
@@ -603,7 +622,7 @@ def topk(scores, k):
     B, N = scores.shape
     idx = torch.empty(B, k, dtype=torch.int64, device=scores.device)
     val = torch.empty(B, k, dtype=torch.float32, device=scores.device)
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         _check(lib.kge_topk(_p(scores), scores.stride(0), B, N, k, _p(idx), _p(val), _stream()), 'kge_topk')
     return val, idx
 
@@ -619,7 +638,7 @@ def corrupt_scatter(heads, tails, mask_u8, draws_h, draws_t, n_neg):
     nh = torch.empty(n, dtype=torch.int64, device=dev)
     nt = torch.empty(n, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.kge_corrupt_ws_elems(n)), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib.kge_corrupt_scatter(_p(heads), _p(tails), _p(mask_u8), _p(draws_h), _p(draws_t),
                                        B, n_neg, _p(nh), _p(nt), _p(ws), _stream()),
                'kge_corrupt_scatter')
