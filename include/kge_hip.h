@@ -305,6 +305,7 @@ typedef struct kge_split_args {
     int32_t accum_model;          /* 0: accumulation error bounded for ANY fp32 adder (2 * 2^-24 per product); 1: the
                                    * measured behaviour of gfx950, valid only if kge_mfma_f16_selftest() returned 1 */
     float eps_scale;              /* multiplies the error band (1.0 = the proven bound; tests shrink it) */
+    int32_t thr_ready;            /* 1: thr is already filled and *list_count zeroed (kge_lp_query_pipeline) */
     float *thr;                   /* scratch: 4 * kge_lp_split_rows_padded(B, 1) floats */
     int32_t *list;                /* scratch: cap x 2 int32 (query, local candidate) */
     int32_t cap;
@@ -330,6 +331,16 @@ int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const floa
  * passes of acc + 8 products, addends truncated 24 bits below the largest, one RNE rounding), 0 if not.
  * Launches a one-wave kernel on the null stream and synchronises: call once, outside any capture. */
 int kge_mfma_f16_selftest(void);
+/* TransE-L2 query side of one batch in ONE launch -- what kge_lp_prep, kge_row_sqnorm (queries),
+ * kge_lp_pair_scores (true scores), kge_lp_split_rows (queries) and the threshold kernel of
+ * kge_lp_split_count do separately, with bit-identical outputs: Q (B,d), qn (B), s_true (B), Qs, thr
+ * (2 * rows_padded(B,1) floats), *list_count = 0; *qmax_io = max(*qmax_io, max qn).  en = ||E[c]||^2 over
+ * the WHOLE entity table (no shard), emax its device-side maximum.  Follow with kge_lp_split_count
+ * (thr_ready = 1). */
+int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const int64_t *h, const int64_t *t,
+                          const int64_t *r, int64_t B, const float *en, const float *emax, float *qmax_io,
+                          int accum_model, float eps_scale, float *Q, float *qn, float *s_true, void *Qs,
+                          float *thr, int32_t *list_count, kge_stream_t stream);
 /* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
 int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,

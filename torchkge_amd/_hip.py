@@ -44,7 +44,7 @@ class SplitArgs(ctypes.Structure):
     _fields_ = [
         ('Qs', _vp), ('Es', _vp), ('qn0', _vp), ('qn1', _vp), ('qmax0', _vp), ('qmax1', _vp),
         ('emax0', _vp), ('emax1', _vp), ('xabsmax', _vp), ('yabsmax', _vp), ('accum_model', ctypes.c_int32),
-        ('eps_scale', ctypes.c_float),
+        ('eps_scale', ctypes.c_float), ('thr_ready', ctypes.c_int32),
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
     ]
 
@@ -72,6 +72,8 @@ _SIGNATURES = {
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
+    'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
@@ -113,7 +115,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 7:
+    if lib.kge_abi_version() != 8:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -329,6 +331,30 @@ def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False,
     return out
 
 
+def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io):
+    """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
+    s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
+    the threshold kernel."""
+    lib = load_library()
+    require_cuda(E, R, h, t, r, en, emax, qmax_io)
+    E, R = f32c(E), f32c(R)
+    h, t, r = i64c(h), i64c(t), i64c(r)
+    B, d, dev = h.shape[0], E.shape[1], E.device
+    Bp = int(lib.kge_lp_split_rows_padded(B, 1))
+    units_p = int(lib.kge_lp_split_units(d, 1))
+    out = {'Q': torch.empty(B, d, dtype=torch.float32, device=dev), 'qn': torch.empty(B, dtype=torch.float32, device=dev),
+           's_true': torch.empty(B, dtype=torch.float32, device=dev),
+           'Qs': torch.empty(max(Bp, 1) * units_p * 64, dtype=torch.uint8, device=dev),
+           'thr': torch.empty(4 * Bp, dtype=torch.float32, device=dev),
+           'n_list': torch.empty(1, dtype=torch.int32, device=dev)}
+    with _on(dev):
+        _check(lib.kge_lp_query_pipeline(side, _p(E), _p(R), d, _p(h), _p(t), _p(r), B, _p(en), _p(emax), _p(qmax_io),
+                                         split_accum_model(), SPLIT_EPS_SCALE, _p(out['Q']), _p(out['qn']),
+                                         _p(out['s_true']), _p(out['Qs']), _p(out['thr']), _p(out['n_list']),
+                                         _stream()), 'kge_lp_query_pipeline')
+    return out
+
+
 def absmax(x, max_io):
     """max_io[0] = max(max_io[0], max |x|) on the device (no sync)."""
     lib = load_library()
@@ -426,6 +452,7 @@ class LpProblem(object):
         self.desc = d
         self.B, self.N = int(d.B), int(d.N)
         self.split = None
+        self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
 
     def scores(self, out=None):
         lib = load_library()
@@ -437,6 +464,8 @@ class LpProblem(object):
         return out
 
     def pair_scores(self, ci, qi=None):
+        if self.pre is not None and qi is None and ci is self.pre['true_idx']:
+            return self.pre['s_true']       # already computed by the fused query pipeline (same chain)
         lib = load_library()
         ci = i64c(ci)
         P = ci.shape[0]
@@ -464,7 +493,10 @@ class LpProblem(object):
         K = int(self.desc.K0)
         A0, A1 = self.keep[0], self.keep[2]
         extra = {}
-        if int(self.desc.mode) == LP_DOT:
+        if self.pre is not None:
+            Qs, extra = self.pre['Qs'], {'thr_pre': self.pre['thr'], 'n_list_pre': self.pre['n_list'],
+                                         's_true_pre': self.pre['s_true']}
+        elif int(self.desc.mode) == LP_DOT:
             qmax = torch.zeros(2, dtype=torch.float32, device=self.device)
             qn0 = row_sqnorm(A0, K=K, max_io=qmax[0:1])
             qn1 = row_sqnorm(A1, max_io=qmax[1:2]) if A1 is not None else None
@@ -475,11 +507,11 @@ class LpProblem(object):
         else:
             Qs = split_rows(A0, K=K, is_query=True)
         Bp = int(lib.kge_lp_split_rows_padded(self.B, 1))
-        thr = torch.empty(4 * Bp, dtype=torch.float32, device=self.device)
+        thr = extra['thr_pre'] if 'thr_pre' in extra else torch.empty(4 * Bp, dtype=torch.float32, device=self.device)
         # the band holds ~1e-3 of a query's candidates for an untrained model (far fewer for a trained one)
         cap = int(min(max(SPLIT_LIST_PER_QUERY, self.N // 100) * self.B, 2 ** 31 - 1))
         lst = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
-        n_list = torch.empty(1, dtype=torch.int32, device=self.device)
+        n_list = extra['n_list_pre'] if 'n_list_pre' in extra else torch.empty(1, dtype=torch.int32, device=self.device)
         prep = {'Qs': Qs, 'thr': thr, 'cap': cap, 'list': lst, 'n_list': n_list}
         prep.update(extra)
         return prep
@@ -499,6 +531,9 @@ class LpProblem(object):
         a.xabsmax, a.yabsmax = _p(sp.get('xabsmax')), _p(sp.get('yabsmax'))
         a.accum_model = split_accum_model()
         a.eps_scale = SPLIT_EPS_SCALE
+        # thresholds written by the fused query pipeline are valid for its own true scores, once
+        a.thr_ready = 1 if (prep.get('s_true_pre') is s_true and not prep.get('thr_used')) else 0
+        prep['thr_used'] = True
         a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']
         a.list_count, a.overflow = _p(prep['n_list']), _p(sp['overflow'])
         with _on(self.device):

@@ -215,6 +215,23 @@ struct SplitThrParams {
     float c_acc;                    // accumulation-error coefficient per product (2: any adder; 1.25: measured model)
 };
 
+// (a_lo, a_hi) of the plain L2 expansion, unscaled half-width logic shared by split_thr_kernel and the fused
+// query pipeline (which must produce the same thresholds bit for bit)
+__device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int K, int units, float c_acc, float eps_scale)
+{
+    const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
+    const float eps_rel = (c_acc * (float)(48 * units) + 1.01f * (float)K) * two24 + 3.01f * two22;
+    const float enrm = sqrtf(em) * 1.000001f, qnrm = sqrtf(q) * 1.000001f;
+    const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
+    const float u = -st;                             // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
+    const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
+    const float eps_dot = eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
+    const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
+    const float mid = 0.5f * (q - u);
+    const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
+    return make_float2((mid - hw) * out_scale, (mid + hw) * out_scale);
+}
+
 __global__ void split_thr_kernel(const SplitThrParams p)
 {
     const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
@@ -239,7 +256,9 @@ __global__ void split_thr_kernel(const SplitThrParams p)
         }
         const float q = p.qn0[i] + (p.qn1 ? p.qn1[i] : 0.f);
         const float qnrm = sqrtf(q) * 1.000001f;
-        if (p.mode == KGE_LP_L2_EXPAND || p.mode >= KGE_LP_L2_PROJH) {
+        if (p.mode == KGE_LP_L2_EXPAND) {
+            p.thr[i] = split_thr_l2(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale);
+        } else if (p.mode >= KGE_LP_L2_PROJH) {
             const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
             const float u = -p.s_true[i];                    // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
             const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
@@ -258,7 +277,6 @@ __global__ void split_thr_kernel(const SplitThrParams p)
                 p.thr4[i] = make_float4((mid - hw) * out_scale, (mid + hw) * out_scale, pi, zi);
                 continue;
             }
-            p.thr[i] = make_float2((mid - hw) * out_scale, (mid + hw) * out_scale);
         } else {
             // count c iff dot_c >= s_true; both operands carry their own power-of-two scale
             const float qm = *p.qmax0 + (p.qmax1 ? *p.qmax1 : 0.f);
@@ -270,6 +288,119 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float hw = eps_dot + two22 * fabsf(st);
             p.thr[i] = make_float2((st - hw) * out_scale, (st + hw) * out_scale);
         }
+    }
+}
+
+// ---- fused query side of one TransE-L2 batch -----------------------------------
+// One wavefront per 64 queries does what lp_prep + row_sqnorm + pair_scores + split_rows(Q) + split_thr
+// do in five launches: q = e_src +- r (written for the later exact kernels), ||q||^2 and the exact true
+// score by the SAME sequential chains (one lane per query, rows staged cooperatively through LDS), the
+// two thresholds and the f16 split row.  Bit-identical outputs to the separate kernels.
+struct QueryPipeParams {
+    int tail;                       // 1: q = E[h] + R[r], true = t;  0: q = E[t] - R[r], true = h
+    const float *E, *R;
+    int d;
+    const int64_t *h, *t, *r;
+    int64_t B, Bp;
+    const float *en;                // ||E[c]||^2
+    const float *emax;              // device scalar max ||e||^2
+    float *qmax_io;                 // device scalar, max ||q||^2 folded in (may be NULL)
+    float c_acc, eps_scale;
+    int units, units_p;
+    float *Q, *qn, *s_true;
+    float2 *thr;
+    _Float16 *Qs;
+    int32_t *list_count;
+};
+
+template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
+__global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParams p)
+{
+    // rows staged cooperatively 48 k at a time (row stride 52 floats: conflict-free b128), the two
+    // sequential chains run one lane per query; few queries per wavefront = many wavefronts in flight
+    // (the chains are latency bound)
+    constexpr int KC = 48, LD = 52;
+    __shared__ __attribute__((aligned(16))) float qs[QPW * LD];
+    __shared__ __attribute__((aligned(16))) float ts[QPW * LD];
+    const int lane = threadIdx.x;
+    const int d = p.d, kpad = p.units_p * 16;
+    if (blockIdx.x == 0 && lane == 0) *p.list_count = 0;
+    const float em = *p.emax;
+    float qbig = 0.f;
+    const int64_t ngroups = (p.Bp + QPW - 1) / QPW;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t i = grp * QPW + lane;
+        const bool valid = lane < QPW && i < p.B;
+        const int64_t ic = valid ? i : 0;
+        const int64_t src = p.tail ? p.h[ic] : p.t[ic], tru = p.tail ? p.t[ic] : p.h[ic], ri = p.r[ic];
+        float qn = 0.f, acc = 0.f;
+        for (int k0 = 0; k0 < kpad; k0 += KC) {
+            const int kc = max(0, min(KC, d - k0));              // data columns of this chunk
+            const int pieces = kc >> 2;
+            for (int idx0 = 0; idx0 < QPW * pieces; idx0 += 64) { // uniform trip count (shuffles inside)
+                const int idx = idx0 + lane;
+                const bool act = idx < QPW * pieces;
+                const int rr = act ? idx / pieces : 0, pc = act ? idx - rr * pieces : 0;
+                const int64_t s_ = __shfl(src, rr, 64), r_ = __shfl(ri, rr, 64), t_ = __shfl(tru, rr, 64);
+                if (!act) continue;
+                const float4 e4 = *reinterpret_cast<const float4 *>(p.E + s_ * d + k0 + pc * 4);
+                const float4 r4 = *reinterpret_cast<const float4 *>(p.R + r_ * d + k0 + pc * 4);
+                const float4 t4 = *reinterpret_cast<const float4 *>(p.E + t_ * d + k0 + pc * 4);
+                float4 q4;                                       // lp_prep_kernel, translation.py:105-125
+                q4.x = p.tail ? e4.x + r4.x : e4.x - r4.x;
+                q4.y = p.tail ? e4.y + r4.y : e4.y - r4.y;
+                q4.z = p.tail ? e4.z + r4.z : e4.z - r4.z;
+                q4.w = p.tail ? e4.w + r4.w : e4.w - r4.w;
+                const int64_t row = grp * QPW + rr;
+                if (row < p.B) *reinterpret_cast<float4 *>(p.Q + row * d + k0 + pc * 4) = q4;
+                *reinterpret_cast<float4 *>(qs + rr * LD + pc * 4) = q4;
+                *reinterpret_cast<float4 *>(ts + rr * LD + pc * 4) = t4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (kc > 0 && lane < QPW) {
+                const float *x = qs + lane * LD;
+                for (int k = 0; k < kc; ++k) qn = fmaf(x[k], x[k], qn);         // row_sqnorm_kernel's chain
+                acc = lp_chain_dot(x, ts + lane * LD, kc, acc);                 // the pair kernel's chain
+            }
+            // split cells of this chunk: 8 consecutive k of one row per lane and pass
+            const int ngr = min(KC, kpad - k0) >> 3;
+            for (int idx = lane; idx < QPW * ngr; idx += 64) {
+                const int rr = idx / ngr, gq = idx - rr * ngr;
+                const int64_t row = grp * QPW + rr;
+                union { _Float16 h[8]; uint4 v; } hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + gq * 8 + e;
+                    float xv = 0.f;
+                    if (row < p.B) xv = k < d ? qs[rr * LD + gq * 8 + e] : (k == d ? 1.0f : 0.f);
+                    xv *= (float)(1 << SPLIT_SCALE_LOG2);
+                    const _Float16 hh = (_Float16)xv;
+                    hi.h[e] = hh;
+                    lo.h[e] = (_Float16)(xv - (float)hh);
+                }
+                const int kk = k0 + gq * 8, u = kk >> 4, hf = (kk >> 3) & 1;
+                uint4 *cell = reinterpret_cast<uint4 *>(p.Qs) + (row * p.units_p + u) * 4;
+                cell[hf] = hi.v;
+                cell[2 + hf] = lo.v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        if (lane < QPW && i < p.Bp) {
+            if (valid) {
+                const float st = lp_epilogue(KGE_LP_L2_EXPAND, acc, qn, p.en[tru]);
+                p.qn[i] = qn;
+                p.s_true[i] = st;
+                p.thr[i] = split_thr_l2(qn, st, em, d, p.units, p.c_acc, p.eps_scale);
+                qbig = __uint_as_float(max(__float_as_uint(qbig), __float_as_uint(qn)));
+            } else {
+                p.thr[i] = make_float2(INFINITY, INFINITY);
+            }
+        }
+    }
+    if (p.qmax_io) {
+        unsigned m = __float_as_uint(qbig);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned *>(p.qmax_io), m);
     }
 }
 
@@ -716,8 +847,10 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.c_acc = a->accum_model == 1 ? 1.25f : 2.0f;
     t.list_count = a->list_count;
     t.overflow = a->overflow;
-    hipLaunchKernelGGL(split_thr_kernel, dim3((int)((Bp + 255) / 256)), dim3(256), 0, s, t);
-    KGE_CHECK_LAUNCH();
+    if (!a->thr_ready) {    // (the fused query pipeline has already written thr and zeroed list_count)
+        hipLaunchKernelGGL(split_thr_kernel, dim3((int)((Bp + 255) / 256)), dim3(256), 0, s, t);
+        KGE_CHECK_LAUNCH();
+    }
 
     const void *Es = a->Es, *Qs = a->Qs;
     float *thr = a->thr, *overflow = a->overflow;
@@ -826,4 +959,41 @@ extern "C" int kge_mfma_f16_selftest(void)
     for (int t = 0; t < NT_; ++t)
         if (got[t] != expect[t]) return 0;
     return 1;
+}
+
+/* TransE-L2 query side of one batch in ONE launch (what kge_lp_prep + kge_row_sqnorm + kge_lp_pair_scores
+ * (true scores) + kge_lp_split_rows(queries) + the threshold kernel of kge_lp_split_count do separately),
+ * bit-identical outputs.  Q (B,d), qn (B), s_true (B), Qs (split operand), thr (2*Bp floats), *list_count = 0.
+ * The candidate table must be the whole entity table (no shard).  Then call kge_lp_split_count with
+ * thr_ready = 1. */
+extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const int64_t *h,
+                                     const int64_t *t, const int64_t *r, int64_t B, const float *en,
+                                     const float *emax, float *qmax_io, int accum_model, float eps_scale, float *Q,
+                                     float *qn, float *s_true, void *Qs, float *thr, int32_t *list_count,
+                                     kge_stream_t stream)
+{
+    if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!E || !R || !h || !t || !r || !en || !emax || !Q || !qn || !s_true || !Qs || !thr || !list_count) return KGE_EINVAL;
+    QueryPipeParams p;
+    p.tail = side == KGE_SIDE_TAIL;
+    p.E = E; p.R = R; p.d = d; p.h = h; p.t = t; p.r = r;
+    p.B = B; p.Bp = kge_lp_split_rows_padded(B, 1);
+    p.en = en; p.emax = emax; p.qmax_io = qmax_io;
+    p.c_acc = accum_model == 1 ? 1.25f : 2.0f; p.eps_scale = eps_scale;
+    p.units = (d + 1 + 15) / 16; p.units_p = kge_lp_split_units(d, 1);
+    p.Q = Q; p.qn = qn; p.s_true = s_true;
+    p.thr = reinterpret_cast<float2 *>(thr);
+    p.Qs = reinterpret_cast<_Float16 *>(Qs);
+    p.list_count = list_count;
+    if (d % 4 != 0 || !kge_aligned16(E) || !kge_aligned16(R)) return KGE_EINVAL;   // float4 staging
+    const int qpw = kge_env_int("KGE_QPIPE_QPW", 32);
+    const int64_t groups = (p.Bp + qpw - 1) / qpw;
+    const int grid = (int)(groups < 256 * 16 ? groups : 256 * 16);
+    if (qpw == 64) hipLaunchKernelGGL(query_pipeline_kernel<64>, dim3(grid), dim3(64), 0, kge_s(stream), p);
+    else if (qpw == 32) hipLaunchKernelGGL(query_pipeline_kernel<32>, dim3(grid), dim3(64), 0, kge_s(stream), p);
+    else if (qpw == 8) hipLaunchKernelGGL(query_pipeline_kernel<8>, dim3(grid), dim3(64), 0, kge_s(stream), p);
+    else hipLaunchKernelGGL(query_pipeline_kernel<16>, dim3(grid), dim3(64), 0, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    return 0;
 }
