@@ -110,7 +110,8 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)   # (>1 rank per GPU only in --backend gloo dry runs)
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if world > 1:
+    forced = os.environ.get('KGE_FORCE_COLLECTIVES') == '1' and 'RANK' in os.environ   # debug: collectives at N=1
+    if world > 1 or forced:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
@@ -123,7 +124,7 @@ def main():
 
     kind, shape, d, p = WORKLOADS[args.workload]
     n_ent1, n_rel, n_train, n_valid, n_test = orc.DATASET_SHAPES[shape]
-    multi = world > 1
+    multi = world > 1 or forced
     # weak scaling over entity shards (default for N > 1): the entity table grows to N
     # dataset-sized shards, each GPU scores ITS shard for every test triple and the ranks
     # exchange partial results over RCCL -- per-GPU work is fixed as N grows.
@@ -169,7 +170,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -181,14 +182,14 @@ def main():
         ev.evaluate(args.batch, verbose=False)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # the same evaluation with the rank counts on the fp32 MFMA kernel only (reported beside the headline)
     f32_only_ms = None
-    if getattr(model, 'split_filter', False) and rank == 0 and world == 1:
+    if getattr(model, 'split_filter', False) and rank == 0 and not multi:
         model.split_filter = False
         for _ in range(2):
             ev.evaluate(args.batch, verbose=False)
@@ -370,7 +371,7 @@ def main():
                              'what': 'corrupt_batch + Model.forward(pos,neg) + MarginLoss + backward + SGD step'}
 
     if rank == 0:
-        if world == 1:
+        if not multi:
             par = 'single'
         elif replicas:
             par = 'independent-replicas-%d' % world
@@ -386,12 +387,12 @@ def main():
             'metric': 'link-prediction triples scored/sec (filtered LP eval, both sides)',
             'value': round(value, 1), 'unit': 'triples_scored/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak',
+            'higher_is_better': True, 'scaling': args.scaling if multi else 'weak',
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
                                    'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
                                        kind, d, p, shape + (' x%d entity shards' % world if ent_weak else ''), n_ent_full, n_rel, n_test, args.batch),
-                       'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': not args.no_graph,
+                       'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': not args.no_graph and not multi,
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
             'roofline': roof, 'cpu_baseline': cpu, 'secondary': sec,
@@ -400,7 +401,7 @@ def main():
                 'ranks_identical_to_headline_run': True},
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

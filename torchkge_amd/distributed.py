@@ -15,8 +15,19 @@ partitioning below is the one BASELINE.json's north star names:
     entity and summed with zeros from the others (x + 0 is exact).
 Pure functions of (N, P, p) so P virtual shards can be checked on one device.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# KGE_FORCE_COLLECTIVES=1 (debug): take the sharded code paths and issue the collectives even
+# in a world of ONE rank, so the RCCL calls can be exercised on a single-GPU box.
+MIN_WORLD = 1 if os.environ.get('KGE_FORCE_COLLECTIVES') == '1' else 2
+
+
+def multi(world):
+    """True when the multi-rank code paths apply to a world of this size."""
+    return world >= MIN_WORLD and dist.is_available() and dist.is_initialized()
 
 
 def world_and_rank(group=None):
@@ -38,14 +49,14 @@ def shard_range(n, world, rank):
 
 def all_reduce_sum(t, group=None):
     """In-place SUM all-reduce (no-op when not distributed)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and multi(dist.get_world_size(group)):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
 def all_reduce_max(t, group=None):
     """In-place MAX all-reduce (no-op when not distributed)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and multi(dist.get_world_size(group)):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t
 
@@ -54,7 +65,7 @@ def all_gather_columns(local, n_total, group=None):
     """Partial score tiles (B, n_p) of every rank -> (B, n_total): ONE
     all-gather of equal-size (padded) tiles, then a strided copy."""
     world, rank = world_and_rank(group)
-    if world == 1:
+    if not multi(world):
         return local
     B = local.shape[0]
     per = shard_size(n_total, world)
@@ -72,7 +83,7 @@ def all_gather_columns(local, n_total, group=None):
 def all_gather_facts(local, n_total, group=None):
     """(4, n_p) rank rows of every query shard -> (4, n_total)."""
     world, rank = world_and_rank(group)
-    if world == 1:
+    if not multi(world):
         return local
     per = shard_size(n_total, world)
     send = local

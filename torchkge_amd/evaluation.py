@@ -229,9 +229,9 @@ class LinkPredictionEvaluator(object):
         self._generic_model = impl is None or impl is _BaseModel.lp_problem
 
         world, rank = kdist.world_and_rank(self.group) if self.shard else (1, 0)
-        sharded = self.shard == 'entities' and world > 1
+        sharded = self.shard == 'entities' and kdist.multi(world)
         lo, hi = kdist.shard_range(self.model.n_ent, world, rank) if sharded else (0, self.model.n_ent)
-        if self.shard == 'queries' and world > 1:
+        if self.shard == 'queries' and kdist.multi(world):
             f_lo, f_hi = kdist.shard_range(kg.n_facts, world, rank)
         else:
             f_lo, f_hi = 0, kg.n_facts
@@ -266,7 +266,7 @@ class LinkPredictionEvaluator(object):
                     out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                     out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
 
-        use_graph = self.graph and world == 1 and device.type == 'cuda' and n_local > 0
+        use_graph = self.graph and not kdist.multi(world) and device.type == 'cuda' and n_local > 0
         if not use_graph:
             heads = kg.head_idx[f_lo:f_hi].to(device)
             tails = kg.tail_idx[f_lo:f_hi].to(device)
@@ -309,7 +309,7 @@ class LinkPredictionEvaluator(object):
             # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
             # cancellation error could exceed the score tolerance -> redo on the VALU kernel
             flags = torch.stack([guard[0] + guard[1], guard[2]])
-            if world > 1:
+            if kdist.multi(world):
                 kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
                 worst, overflow = flags.tolist()
             else:   # one device-to-host transfer for the ranks and the two flags (8 bytes = one int64)
@@ -329,7 +329,7 @@ class LinkPredictionEvaluator(object):
                 run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                     kg.relations[f_lo:f_hi].to(device), out)
             self.model.lp_guard_end()
-        if self.shard == 'queries' and world > 1:
+        if self.shard == 'queries' and kdist.multi(world):
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
         if res is None:
             res = out.cpu()
