@@ -1054,3 +1054,52 @@ def test_mfma_f16_accumulation_selftest(hip):
     device's f16 MFMA accumulates as measured (tools/probe/mfma_probe.hip): on MI355X it does."""
     assert hip.load_library().kge_mfma_f16_selftest() == 1
     assert hip.split_accum_model() == 1
+
+
+@pytest.mark.parametrize('B,N,d', [(1, 7, 8), (31, 300, 52), (33, 300, 200), (257, 1000, 256), (1000, 2000, 100)])
+@pytest.mark.parametrize('side', ['tail', 'head'])
+def test_query_pipeline_equals_separate_kernels(hip, B, N, d, side):
+    """kge_lp_query_pipeline (TransE-L2 query side of a batch in one launch) writes bit for bit
+    what kge_lp_prep + kge_row_sqnorm + kge_lp_pair_scores + kge_lp_split_rows + the threshold
+    pass of kge_lp_split_count write, and the counts that follow are the exact counts."""
+    g = torch.Generator().manual_seed(B * 7 + d)
+    E = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=1).cuda()
+    R = (0.3 * torch.randn(5, d, generator=g)).cuda()
+    h = torch.randint(0, N, (B,), generator=g).cuda(); t = torch.randint(0, N, (B,), generator=g).cuda()
+    r = torch.randint(0, 5, (B,), generator=g).cuda()
+    sd = hip.SIDE_TAIL if side == 'tail' else hip.SIDE_HEAD
+    true = t if side == 'tail' else h
+    guard = torch.zeros(8, device='cuda')
+    en = hip.row_sqnorm(E, max_io=guard[1:2])
+    Es = hip.split_rows(E, aug=en)
+
+    # the separate kernels
+    Q0 = hip.lp_prep(hip.TRANSE_L2, sd, [E, R], d, d, h, t, r)[0]
+    g_ref = guard.clone()
+    qn = hip.row_sqnorm(Q0, max_io=g_ref[0:1])
+    ref = hip.LpProblem(hip.LP_L2_EXPAND, Q0, E, qn=qn, en=en)
+    st = ref.pair_scores(true)
+    exact = ref.count_ge(st)
+    ref.split = {'Es': Es, 'enmax': g_ref[1:2], 'overflow': g_ref[2:3]}
+    prep_ref = ref.split_prepare()
+    raw_ref = torch.zeros(B, dtype=torch.int32, device='cuda')
+    ref.split_count(prep_ref, st, raw_ref)
+
+    # the fused launch
+    pre = hip.lp_query_pipeline(sd, E, R, h, t, r, en, guard[1:2], guard[0:1])
+    assert torch.equal(pre['Q'], Q0)
+    assert torch.equal(pre['qn'].view(torch.int32), qn.view(torch.int32))
+    assert torch.equal(pre['s_true'].view(torch.int32), st.view(torch.int32))
+    assert torch.equal(pre['Qs'], prep_ref['Qs'])
+    Bp = pre['thr'].numel() // 4
+    assert torch.equal(pre['thr'][:2 * Bp].view(torch.int32), prep_ref['thr'][:2 * Bp].view(torch.int32))
+    assert float(guard[0]) == float(g_ref[0])                # max ||q||^2 folded into the guard
+
+    pre['true_idx'] = true
+    prob = hip.LpProblem(hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
+    prob.split = {'Es': Es, 'enmax': guard[1:2], 'overflow': guard[2:3]}
+    prob.pre = pre
+    st2 = prob.pair_scores(true)
+    assert st2 is pre['s_true']
+    assert torch.equal(prob.count_ge(st2), exact)
+    assert float(guard[2]) == 0.0

@@ -560,11 +560,15 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16;
 
     f16x8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
+    {
+        const char *sb = smem;
+        KGE_SLOAD(ah0, al0, bh0, bl0, 0)
+    }
     int it = 0, s = 0;
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
         const bool more = g + 1 < G;
-        const char *sb = smem + buf * STAGE_BYTES;
+        const char *sb = smem + buf * STAGE_BYTES;   // (reassigned: KGE_SLOAD reads through `sb`: KGE_SLOAD reads through `sb`)
         const int nunits = min(2, p.units - 2 * s);
         const bool two = nunits == 2;              // the last stage of a tile may hold a single k16 unit
         const bool pf = more && !(dbg & 1);
@@ -575,8 +579,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         char *nE = smem + (buf ^ 1) * STAGE_BYTES + wid * 1024, *nQ = nE + E_STAGE_BYTES;
         const char *gE = pfE + pf_s * 128, *gQ = pfQ + pf_s * 128;
 
-        if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah0, al0, bh0, bl0, 0) }
-        __builtin_amdgcn_sched_barrier(0);
+        // (this stage's first k16 fragments were fetched behind the previous stage's barrier, below)
         if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah1, al1, bh1, bl1, 1) }
@@ -601,6 +604,18 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         }
         __builtin_amdgcn_sched_barrier(0);
         if (two) { KGE_SMMA_PA(ah1, bl1) }
+        __builtin_amdgcn_sched_barrier(0);
+        // The stage's last MFMA group runs BEHIND the barrier, next to the fetch of the next stage's
+        // first fragments: right after a barrier all 8 waves read LDS at once (80 KB), and without
+        // matrix work in flight the MFMA pipe would idle for that long.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
+        if (!(dbg & 32)) __syncthreads();
+        if (more && !(dbg & 16)) {
+            const char *sb_cur = sb;
+            sb = smem + (buf ^ 1) * STAGE_BYTES;
+            KGE_SLOAD(ah0, al0, bh0, bl0, 0)
+            sb = sb_cur;
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (two) { KGE_SMMA_PA(al1, bh1) }
         __builtin_amdgcn_sched_barrier(0);
@@ -713,8 +728,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             }
         }
         if (++s == S) { s = 0; ++it; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
-        if (!(dbg & 32)) __syncthreads();
     }
 #undef KGE_SMMA_PA
 #undef KGE_SMMA_P
