@@ -474,11 +474,15 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     const int sw = (l31 >> 1) & 7;
     const int a_row = (wr * (MT * 32) + l31) * 128;
     const int b_row = E_STAGE_BYTES + (wc * 96 + l31) * 128;
-    int coff[2][2];
+    // byte addresses inside a stage of this lane's fragments: [k16 unit][hi / lo]
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    unsigned a_off[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) coff[u][pc] = ((u * 4 + pc * 2 + half) ^ sw) * 16;
+        for (int pc = 0; pc < 2; ++pc) a_off[u][pc] = lds0 + a_row + ((u * 4 + pc * 2 + half) ^ sw) * 16;
+    // the query fragments sit a wave-uniform distance behind the candidate fragments (scalar register)
+    const unsigned b_delta = __builtin_amdgcn_readfirstlane(b_row - a_row);
 
     f32x16 acc[MT][NT];
     int cnt[NT] = {0, 0, 0};
@@ -530,15 +534,26 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     }
     __syncthreads();
 
-#define KGE_SLOAD(AH, AL, BH, BL, U)                                                                \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                              \
-        AH[mt] = *reinterpret_cast<const f16x8 *>(sb + a_row + mt * 4096 + coff[U][0]);             \
-        AL[mt] = *reinterpret_cast<const f16x8 *>(sb + a_row + mt * 4096 + coff[U][1]);             \
-    }                                                                                               \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                              \
-        BH[nt] = *reinterpret_cast<const f16x8 *>(sb + b_row + nt * 4096 + coff[U][0]);             \
-        BL[nt] = *reinterpret_cast<const f16x8 *>(sb + b_row + nt * 4096 + coff[U][1]);             \
+    // Fragment loads are inline asm with hand-placed waits: hipcc tracks the LDS-DMA instructions as
+    // FLAT accesses, after which every lgkmcnt wait it inserts is a full drain -- it then waits for the
+    // fragment loads it has just issued (before MFMAs that do not use them) instead of letting them
+    // fly under the next MFMA group.  KGE_SWAIT ties the registers to the wait, so no use can move above it.
+    static_assert(MT == 2 && NT == 3, "KGE_SLOAD / KGE_SWAIT are written out for 2 x 3 tiles per wave");
+#define KGE_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR) : "memory")
+#define KGE_SLOAD(AH, AL, BH, BL, BASE, U)                                                          \
+    {                                                                                               \
+        const unsigned ah_ = (BASE) + a_off[U][0], al_ = (BASE) + a_off[U][1];                      \
+        const unsigned bh_ = ah_ + b_delta, bl_ = al_ + b_delta;                                    \
+        KGE_DSR(AH[0], ah_, 0); KGE_DSR(BH[0], bh_, 0); KGE_DSR(AH[1], ah_, 4096);                  \
+        KGE_DSR(BH[1], bh_, 4096); KGE_DSR(BH[2], bh_, 8192);                                       \
+        KGE_DSR(BL[0], bl_, 0); KGE_DSR(BL[1], bl_, 4096); KGE_DSR(BL[2], bl_, 8192);               \
+        KGE_DSR(AL[0], al_, 0); KGE_DSR(AL[1], al_, 4096);                                          \
+        /* the address registers stay live past the last load: no destination may be allocated on them */ \
+        asm volatile("" :: "v"(ah_), "v"(al_), "v"(bh_), "v"(bl_));                                 \
     }
+#define KGE_SWAIT(AH, AL, BH, BL)                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(AH[0]), "+v"(AH[1]), "+v"(AL[0]), "+v"(AL[1]),      \
+                 "+v"(BH[0]), "+v"(BH[1]), "+v"(BH[2]), "+v"(BL[0]), "+v"(BL[1]), "+v"(BL[2]) :: "memory");
 #define KGE_SMMA_P(A, B, C) /* one of the three split products over the wave's MT x NT tiles, given C */ \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
@@ -560,18 +575,18 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16;
 
     f16x8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
-    {
-        const char *sb = smem;
-        KGE_SLOAD(ah0, al0, bh0, bl0, 0)
-    }
+    KGE_SLOAD(ah0, al0, bh0, bl0, 0u, 0)
     int it = 0, s = 0;
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
         const bool more = g + 1 < G;
-        const char *sb = smem + buf * STAGE_BYTES;   // (reassigned: KGE_SLOAD reads through `sb`: KGE_SLOAD reads through `sb`)
+        const unsigned sb = buf * STAGE_BYTES, sb_next = (buf ^ 1) * STAGE_BYTES;
         const int nunits = min(2, p.units - 2 * s);
         const bool two = nunits == 2;              // the last stage of a tile may hold a single k16 unit
-        const bool pf = more && !(dbg & 1);
+        // In the product kernel the LDS-DMA pieces are issued unconditionally (after the block's last
+        // stage they re-fetch valid rows into the buffer nobody reads): a branch around them makes
+        // hipcc drain lgkmcnt to 0 at the join, i.e. wait for the fragment loads it just issued.
+        const bool pf = DBG ? (more && !(dbg & 1)) : true;
         // LDS-DMA of the next stage into the other buffer, one piece at a time between the MFMA
         // groups: an LDS-DMA instruction holds the issuing wave for 60+ cycles, which hides behind
         // matrix work only if the pieces are spread over the stage (and the other wave of the SIMD
@@ -580,10 +595,16 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         const char *gE = pfE + pf_s * 128, *gQ = pfQ + pf_s * 128;
 
         // (this stage's first k16 fragments were fetched behind the previous stage's barrier, below)
+        KGE_SWAIT(ah0, al0, bh0, bl0)
         if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah1, al1, bh1, bl1, 1) }
-        if (pf) { dma(gE, nE); dma(gE + rstep, nE + SROWS * 128); }
+        const char *gE1 = gE + rstep;
+        if (pf) { dma(gE, nE); dma(gE1, nE + SROWS * 128); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah1, al1, bh1, bl1, sb, 1) }
+        // (hipcc would drain lgkmcnt before a fragment load whose destination reuses the address
+        // registers of an LDS-DMA still in flight: keep those registers occupied until here)
+        asm volatile("" :: "v"(gE), "v"(gE1));
         __builtin_amdgcn_sched_barrier(0);
         KGE_SMMA_PA(ah0, bl0)
         __builtin_amdgcn_sched_barrier(0);
@@ -591,31 +612,25 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         __builtin_amdgcn_sched_barrier(0);
         KGE_SMMA_PA(al0, bh0)
         __builtin_amdgcn_sched_barrier(0);
-        if (pf) { dma(gQ, nQ); dma(gQ + rstep, nQ + SROWS * 128); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (two) { KGE_SMMA_PA(ah1, bh1) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (pf) {
-            dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128);
+        if (pf) { dma(gQ, nQ); dma(gQ + rstep, nQ + SROWS * 128); dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128); }
+        if (more && pf) {
             if (++pf_s == S) {
                 pf_s = 0;
                 if (++pf_it < nitems) pf_new_item();
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (two) { KGE_SMMA_PA(ah1, bl1) }
+        KGE_SWAIT(ah1, al1, bh1, bl1)
+        if (two) { KGE_SMMA_PA(ah1, bh1) }
         __builtin_amdgcn_sched_barrier(0);
-        // The stage's last MFMA group runs BEHIND the barrier, next to the fetch of the next stage's
-        // first fragments: right after a barrier all 8 waves read LDS at once (80 KB), and without
-        // matrix work in flight the MFMA pipe would idle for that long.
+        // The stage's last two MFMA groups run BEHIND the barrier, next to the fetch of the next
+        // stage's first fragments: right after a barrier all 8 waves read LDS at once (80 KB), and
+        // without matrix work in flight the MFMA pipe would idle for that long.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
         if (!(dbg & 32)) __syncthreads();
-        if (more && !(dbg & 16)) {
-            const char *sb_cur = sb;
-            sb = smem + (buf ^ 1) * STAGE_BYTES;
-            KGE_SLOAD(ah0, al0, bh0, bl0, 0)
-            sb = sb_cur;
-        }
+        if (more && !(dbg & 16)) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) { KGE_SMMA_PA(ah1, bl1) }
         __builtin_amdgcn_sched_barrier(0);
         if (two) { KGE_SMMA_PA(al1, bh1) }
         __builtin_amdgcn_sched_barrier(0);
@@ -732,6 +747,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 #undef KGE_SMMA_PA
 #undef KGE_SMMA_P
 #undef KGE_SLOAD
+#undef KGE_SWAIT
+#undef KGE_DSR
     flush_counts(cur_q0);
 }
 
