@@ -72,7 +72,8 @@ enum {
     KGE_SIDE_TAIL = 0,   /* candidates replace the tail: query = f(h, r)            */
     KGE_SIDE_HEAD = 1,   /* candidates replace the head: query = f(t, r)            */
     KGE_SIDE_PROJ_H = 2, /* kge_lp_prep only: Q0 = projected head, no relation term */
-    KGE_SIDE_PROJ_T = 3  /* kge_lp_prep only: Q0 = projected tail, no relation term */
+    KGE_SIDE_PROJ_T = 3, /* kge_lp_prep only: Q0 = projected tail, no relation term */
+    KGE_SIDE_BOTH = 4    /* kge_lp_query_pipeline only: 2B queries, [0,B) tail side then [B,2B) head side */
 };
 
 /* kge_ewise ops (query-side elementwise algebra of inference_scoring_function) */
@@ -249,6 +250,15 @@ int kge_get_rank(const float *scores, int64_t ld, const int64_t *true_idx, int64
 int kge_filter_lookup(const int64_t *keys, int64_t n_keys, const int64_t *offsets,
                       const int64_t *key1, const int64_t *key2, int64_t n_key2, int64_t B,
                       int64_t *seg_lo, int64_t *seg_hi, kge_stream_t stream);
+/* Both sides of B facts in one launch, for a 2B-query batch (tail-side queries first):
+ *   i <  B: key (h[i], r[i]) in the tail index,      true_idx[i]     = t[i]
+ *   i >= B: key (t[i-B], r[i-B]) in the head index,  true_idx[i]     = h[i-B], segment + targets_base_h
+ * (the caller keeps the two target arrays concatenated: head targets start at targets_base_h). */
+int kge_filter_lookup_both(const int64_t *keys_t, int64_t n_keys_t, const int64_t *offsets_t,
+                           const int64_t *keys_h, int64_t n_keys_h, const int64_t *offsets_h,
+                           int64_t targets_base_h, const int64_t *h, const int64_t *t, const int64_t *r,
+                           int64_t n_key2, int64_t B, int64_t *seg_lo, int64_t *seg_hi, int64_t *true_idx,
+                           kge_stream_t stream);
 
 /* in place: scores[i, c] = -inf for c in segment i, c != true_idx[i]; rows whose
  * segment is empty or does not contain true_idx[i] are left untouched.
@@ -336,7 +346,8 @@ int kge_mfma_f16_selftest(void);
  * kge_lp_split_count do separately, with bit-identical outputs: Q (B,d), qn (B), s_true (B), Qs, thr
  * (2 * rows_padded(B,1) floats), *list_count = 0; *qmax_io = max(*qmax_io, max qn).  en = ||E[c]||^2 over
  * the WHOLE entity table (no shard), emax its device-side maximum.  Follow with kge_lp_split_count
- * (thr_ready = 1). */
+ * (thr_ready = 1).  side = KGE_SIDE_BOTH: both sides of the B facts as ONE batch of 2B queries (tail-side
+ * queries first; every output has 2B rows) -- the ranks of evaluation.py:290-300 from one count launch. */
 int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const int64_t *h, const int64_t *t,
                           const int64_t *r, int64_t B, const float *en, const float *emax, float *qmax_io,
                           int accum_model, float eps_scale, float *Q, float *qn, float *s_true, void *Qs,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkge_hip.so')
 
 # enums of include/kge_hip.h
 TRANSE_L1, TRANSE_L2, TRANSH, TRANSD, DISTMULT, COMPLEX = range(6)
-SIDE_TAIL, SIDE_HEAD, SIDE_PROJ_H, SIDE_PROJ_T = range(4)
+SIDE_TAIL, SIDE_HEAD, SIDE_PROJ_H, SIDE_PROJ_T, SIDE_BOTH = range(5)
 EW_ADD, EW_SUB, EW_MUL, EW_MULSUB, EW_MULADD = range(5)
 LP_DOT, LP_L2_EXPAND, LP_L1_DIRECT, LP_L2_DIRECT, LP_L2_PROJH, LP_L2_PROJD = range(6)
 
@@ -80,6 +80,7 @@ _SIGNATURES = {
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
     'kge_get_rank': [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     'kge_filter_lookup': [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    'kge_filter_lookup_both': [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     'kge_filter_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
     'kge_filtered_rank_from_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     'kge_corrupt_scatter': [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
@@ -115,7 +116,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 8:
+    if lib.kge_abi_version() != 9:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -340,10 +341,11 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io):
     E, R = f32c(E), f32c(R)
     h, t, r = i64c(h), i64c(t), i64c(r)
     B, d, dev = h.shape[0], E.shape[1], E.device
-    Bp = int(lib.kge_lp_split_rows_padded(B, 1))
+    Bq = 2 * B if side == SIDE_BOTH else B          # SIDE_BOTH: tail-side queries, then head-side queries
+    Bp = int(lib.kge_lp_split_rows_padded(Bq, 1))
     units_p = int(lib.kge_lp_split_units(d, 1))
-    out = {'Q': torch.empty(B, d, dtype=torch.float32, device=dev), 'qn': torch.empty(B, dtype=torch.float32, device=dev),
-           's_true': torch.empty(B, dtype=torch.float32, device=dev),
+    out = {'Q': torch.empty(Bq, d, dtype=torch.float32, device=dev), 'qn': torch.empty(Bq, dtype=torch.float32, device=dev),
+           's_true': torch.empty(Bq, dtype=torch.float32, device=dev),
            'Qs': torch.empty(max(Bp, 1) * units_p * 64, dtype=torch.uint8, device=dev),
            'thr': torch.empty(4 * Bp, dtype=torch.float32, device=dev),
            'n_list': torch.empty(1, dtype=torch.int32, device=dev)}
@@ -453,6 +455,39 @@ class LpProblem(object):
         self.B, self.N = int(d.B), int(d.N)
         self.split = None
         self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
+
+    _CONCAT_MODES = (LP_DOT, LP_L2_EXPAND, LP_L2_PROJH, LP_L2_PROJD)
+
+    @classmethod
+    def concat(cls, a, b):
+        """The queries of `a` followed by the queries of `b` as ONE problem against
+        the same candidate table (both sides of a batch in one count launch), or
+        None if the two do not share mode / tables (MFMA modes only: there every
+        non-query operand is table-level)."""
+        da, db = a.desc, b.desc
+        mode = int(da.mode)
+        if mode != int(db.mode) or mode not in cls._CONCAT_MODES or a.pre is not None or b.pre is not None:
+            return None
+        if (int(da.K0), int(da.K1), int(da.c_base), int(da.N)) != (int(db.K0), int(db.K1), int(db.c_base), int(db.N)):
+            return None
+        for k in (1, 3, 5, 7, 9):                       # T0, T1, en, scal (table-level here), yc
+            x, y = a.keep[k], b.keep[k]
+            if (x is None) != (y is None):
+                return None
+            if x is not None and (x.data_ptr() != y.data_ptr() or x.shape != y.shape or x.stride() != y.stride()):
+                return None
+        if (a.split is None) != (b.split is None):
+            return None
+
+        def cat(k):
+            x, y = a.keep[k], b.keep[k]
+            if (x is None) != (y is None):
+                raise RuntimeError('LpProblem.concat: operand %d present on one side only' % k)
+            return None if x is None else torch.cat([x, y])
+        new = cls(mode, cat(0), a.keep[1], A1=cat(2), T1=a.keep[3], qn=cat(4), en=a.keep[5], Wq=cat(6),
+                  scal=a.keep[7], r_idx=cat(8), c_base=int(da.c_base), K0=int(da.K0), yc=a.keep[9])
+        new.split = a.split
+        return new
 
     def scores(self, out=None):
         lib = load_library()
@@ -624,6 +659,24 @@ def filter_lookup(keys, offsets, key1, key2, n_key2):
         _check(lib.kge_filter_lookup(_p(keys), keys.shape[0], _p(offsets), _p(key1), _p(key2),
                                      n_key2, B, _p(lo), _p(hi), _stream()), 'kge_filter_lookup')
     return lo, hi
+
+
+def filter_lookup_both(keys_t, offsets_t, keys_h, offsets_h, targets_base_h, h, t, r, n_key2):
+    """Both sides of B facts as one 2B-query batch (kge_filter_lookup_both):
+    (seg_lo, seg_hi, true_idx), tail-side queries first; head-side segments are
+    shifted by targets_base_h (the two target arrays are kept concatenated)."""
+    lib = load_library()
+    require_cuda(keys_t, keys_h, h, t, r)
+    h, t, r = i64c(h), i64c(t), i64c(r)
+    B = h.shape[0]
+    lo = torch.empty(2 * B, dtype=torch.int64, device=h.device)
+    hi = torch.empty(2 * B, dtype=torch.int64, device=h.device)
+    true = torch.empty(2 * B, dtype=torch.int64, device=h.device)
+    with _on(h.device):
+        _check(lib.kge_filter_lookup_both(_p(keys_t), keys_t.shape[0], _p(offsets_t), _p(keys_h), keys_h.shape[0],
+                                          _p(offsets_h), targets_base_h, _p(h), _p(t), _p(r), n_key2, B,
+                                          _p(lo), _p(hi), _p(true), _stream()), 'kge_filter_lookup_both')
+    return lo, hi, true
 
 
 def filter_scores_(scores, true_idx, seg_lo, seg_hi, targets):

@@ -297,7 +297,9 @@ __global__ void split_thr_kernel(const SplitThrParams p)
 // score by the SAME sequential chains (one lane per query, rows staged cooperatively through LDS), the
 // two thresholds and the f16 split row.  Bit-identical outputs to the separate kernels.
 struct QueryPipeParams {
-    int tail;                       // 1: q = E[h] + R[r], true = t;  0: q = E[t] - R[r], true = h
+    int tail;                       // 1: q = E[h] + R[r], true = t;  0: q = E[t] - R[r], true = h;
+                                    // 2: both sides in one batch -- queries [0, Bh) tail side, [Bh, 2 Bh) head side
+    int64_t Bh;                     // facts per side (tail == 2: B = 2 Bh)
     const float *E, *R;
     int d;
     const int64_t *h, *t, *r;
@@ -332,7 +334,10 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
         const int64_t i = grp * QPW + lane;
         const bool valid = lane < QPW && i < p.B;
         const int64_t ic = valid ? i : 0;
-        const int64_t src = p.tail ? p.h[ic] : p.t[ic], tru = p.tail ? p.t[ic] : p.h[ic], ri = p.r[ic];
+        const bool tl = p.tail == 2 ? ic < p.Bh : p.tail == 1;          // this query's side
+        const int64_t fi = (p.tail == 2 && ic >= p.Bh) ? ic - p.Bh : ic; // its fact
+        const int64_t src = tl ? p.h[fi] : p.t[fi], tru = tl ? p.t[fi] : p.h[fi], ri = p.r[fi];
+        const int tli = tl ? 1 : 0;
         float qn = 0.f, acc = 0.f;
         for (int k0 = 0; k0 < kpad; k0 += KC) {
             const int kc = max(0, min(KC, d - k0));              // data columns of this chunk
@@ -342,15 +347,16 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
                 const bool act = idx < QPW * pieces;
                 const int rr = act ? idx / pieces : 0, pc = act ? idx - rr * pieces : 0;
                 const int64_t s_ = __shfl(src, rr, 64), r_ = __shfl(ri, rr, 64), t_ = __shfl(tru, rr, 64);
+                const bool tl_ = __shfl(tli, rr, 64) != 0;
                 if (!act) continue;
                 const float4 e4 = *reinterpret_cast<const float4 *>(p.E + s_ * d + k0 + pc * 4);
                 const float4 r4 = *reinterpret_cast<const float4 *>(p.R + r_ * d + k0 + pc * 4);
                 const float4 t4 = *reinterpret_cast<const float4 *>(p.E + t_ * d + k0 + pc * 4);
                 float4 q4;                                       // lp_prep_kernel, translation.py:105-125
-                q4.x = p.tail ? e4.x + r4.x : e4.x - r4.x;
-                q4.y = p.tail ? e4.y + r4.y : e4.y - r4.y;
-                q4.z = p.tail ? e4.z + r4.z : e4.z - r4.z;
-                q4.w = p.tail ? e4.w + r4.w : e4.w - r4.w;
+                q4.x = tl_ ? e4.x + r4.x : e4.x - r4.x;
+                q4.y = tl_ ? e4.y + r4.y : e4.y - r4.y;
+                q4.z = tl_ ? e4.z + r4.z : e4.z - r4.z;
+                q4.w = tl_ ? e4.w + r4.w : e4.w - r4.w;
                 const int64_t row = grp * QPW + rr;
                 if (row < p.B) *reinterpret_cast<float4 *>(p.Q + row * d + k0 + pc * 4) = q4;
                 *reinterpret_cast<float4 *>(qs + rr * LD + pc * 4) = q4;
@@ -1002,13 +1008,15 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
                                      float *qn, float *s_true, void *Qs, float *thr, int32_t *list_count,
                                      kge_stream_t stream)
 {
-    if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
+    const bool both = side == KGE_SIDE_BOTH;
+    if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD && !both) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
     if (B == 0) return 0;
     if (!E || !R || !h || !t || !r || !en || !emax || !Q || !qn || !s_true || !Qs || !thr || !list_count) return KGE_EINVAL;
     QueryPipeParams p;
-    p.tail = side == KGE_SIDE_TAIL;
+    p.tail = both ? 2 : (side == KGE_SIDE_TAIL ? 1 : 0);
+    p.Bh = B;
     p.E = E; p.R = R; p.d = d; p.h = h; p.t = t; p.r = r;
-    p.B = B; p.Bp = kge_lp_split_rows_padded(B, 1);
+    p.B = both ? 2 * B : B; p.Bp = kge_lp_split_rows_padded(p.B, 1);
     p.en = en; p.emax = emax; p.qmax_io = qmax_io;
     p.c_acc = accum_model == 1 ? 1.25f : 2.0f; p.eps_scale = eps_scale;
     p.units = (d + 1 + 15) / 16; p.units_p = kge_lp_split_units(d, 1);

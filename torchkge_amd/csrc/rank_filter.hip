@@ -131,6 +131,30 @@ __global__ void filter_lookup_kernel(const int64_t *__restrict__ keys, int64_t n
     }
 }
 
+__global__ void filter_lookup_both_kernel(const int64_t *__restrict__ keys_t, int64_t n_t,
+                                          const int64_t *__restrict__ offs_t, const int64_t *__restrict__ keys_h,
+                                          int64_t n_h, const int64_t *__restrict__ offs_h, int64_t base_h,
+                                          const int64_t *__restrict__ h, const int64_t *__restrict__ t,
+                                          const int64_t *__restrict__ r, int64_t n_key2, int64_t B,
+                                          int64_t *seg_lo, int64_t *seg_hi, int64_t *true_idx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool tail = i < B;
+        const int64_t f = tail ? i : i - B;
+        const int64_t *keys = tail ? keys_t : keys_h, *offs = tail ? offs_t : offs_h;
+        const int64_t n_keys = tail ? n_t : n_h, base = tail ? 0 : base_h;
+        const int64_t key = (tail ? h[f] : t[f]) * n_key2 + r[f];
+        int64_t lo = 0, hi = n_keys;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n_keys && keys[lo] == key) { seg_lo[i] = offs[lo] + base; seg_hi[i] = offs[lo + 1] + base; }
+        else { seg_lo[i] = 0; seg_hi[i] = 0; }
+        true_idx[i] = tail ? t[f] : h[f];
+    }
+}
+
 __global__ void pair_scores_kernel(const kge_lp_desc d, const int64_t *__restrict__ qi,
                                    const int64_t *__restrict__ ci, int64_t P, float *out)
 {
@@ -359,6 +383,24 @@ extern "C" int kge_filter_lookup(const int64_t *keys, int64_t n_keys, const int6
     return 0;
 }
 
+extern "C" int kge_filter_lookup_both(const int64_t *keys_t, int64_t n_keys_t, const int64_t *offsets_t,
+                                      const int64_t *keys_h, int64_t n_keys_h, const int64_t *offsets_h,
+                                      int64_t targets_base_h, const int64_t *h, const int64_t *t, const int64_t *r,
+                                      int64_t n_key2, int64_t B, int64_t *seg_lo, int64_t *seg_hi,
+                                      int64_t *true_idx, kge_stream_t stream)
+{
+    if (B < 0 || n_keys_t < 0 || n_keys_h < 0 || n_key2 <= 0 || targets_base_h < 0) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!h || !t || !r || !seg_lo || !seg_hi || !true_idx || (n_keys_t > 0 && (!keys_t || !offsets_t)) ||
+        (n_keys_h > 0 && (!keys_h || !offsets_h)))
+        return KGE_EINVAL;
+    hipLaunchKernelGGL(filter_lookup_both_kernel, dim3(grid1d(2 * B, 256)), dim3(256), 0, kge_s(stream), keys_t,
+                       n_keys_t, offsets_t, keys_h, n_keys_h, offsets_h, targets_base_h, h, t, r, n_key2, B, seg_lo,
+                       seg_hi, true_idx);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_filter_scores(float *scores, int64_t ld, const int64_t *true_idx, const int64_t *seg_lo,
                                  const int64_t *seg_hi, const int32_t *targets, int64_t B, int64_t N,
                                  kge_stream_t stream)
@@ -490,5 +532,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 8; }
+extern "C" int kge_abi_version(void) { return 9; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -32,7 +32,7 @@ from tqdm.autonotebook import tqdm
 from . import _hip
 from . import distributed as kdist
 from .exceptions import NotYetEvaluatedError
-from .filter_index import filter_index_for
+from .filter_index import filter_index_for, KEY2_SPAN
 from .utils.data import get_n_batches
 from .utils.modeling import filter_scores
 from .utils.operations import get_rank
@@ -98,7 +98,7 @@ class LinkPredictionEvaluator(object):
     """
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
-                 group=None, engine=None, graph=False, overlap=False):
+                 group=None, engine=None, graph=False, overlap=False, both_sides=True):
         self.model = model
         self.kg = knowledge_graph
         n = knowledge_graph.n_facts
@@ -115,6 +115,10 @@ class LinkPredictionEvaluator(object):
         self._graph = self._graph_static = self._graph_key = self._graph_src = None
         self.overlap = overlap                      # two-stream overlap of the short kernels (single GPU, fused)
         self._aux_stream = None
+        # both sides of a batch as ONE 2B-query problem (single GPU, fused): every latency-bound short
+        # kernel of a batch runs once instead of twice, the all-candidates count kernel sees 2B queries
+        self.both_sides = both_sides
+        self._targets_cat = None
 
     # -- filter indices ------------------------------------------------------
     def _filter_indices(self, device):
@@ -143,6 +147,32 @@ class LinkPredictionEvaluator(object):
         if sharded:
             scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
         return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
+
+    def _rank_batch_both(self, h, t, r, index_t, index_h):
+        """Both sides of one batch through one problem of 2B queries (tail side first):
+        one filter lookup, one query-side launch, one count (+ recheck), one filter
+        correction, one finalize.  Ranks are per query: identical to two _rank_side
+        calls.  None = the model cannot merge the sides (the caller ranks them apart)."""
+        prob = self.model.lp_problem_both(h, t, r)
+        if prob is None:
+            return None
+        B = h.shape[0]
+        key = (index_t.targets.data_ptr(), index_h.targets.data_ptr(), index_t.targets.shape[0],
+               index_h.targets.shape[0])
+        if self._targets_cat is None or self._targets_cat[0] != key:
+            self._targets_cat = (key, torch.cat([index_t.targets, index_h.targets]))
+        targets = self._targets_cat[1]
+        seg_lo, seg_hi, true_idx = _hip.filter_lookup_both(index_t.keys, index_t.offsets, index_h.keys,
+                                                           index_h.offsets, index_t.targets.shape[0], h, t, r,
+                                                           KEY2_SPAN)
+        if prob.pre is not None:
+            prob.pre['true_idx'] = true_idx           # the fused query pipeline has scored exactly these pairs
+        s_true = prob.pair_scores(true_idx)
+        counts = torch.zeros(3, 2 * B, dtype=torch.int32, device=h.device)
+        prob.count_ge(s_true, counts[0])
+        prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, counts[1], counts[2])
+        rk, frk = _hip.rank_finalize(counts[0], counts[1], counts[2])
+        return rk[:B], frk[:B], rk[B:], frk[B:]
 
     def _rank_batch_sharded_counts(self, h, t, r, index_t, index_h, lo, hi):
         """Entity-sharded batch, both sides together, with TWO collectives instead of
@@ -246,6 +276,10 @@ class LinkPredictionEvaluator(object):
         overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
                    isinstance(self.engine, HipRankEngine) and device.type == 'cuda')
 
+        both = (self.both_sides and self.fused and not sharded and not self._generic_model and not overlap and
+                isinstance(self.engine, HipRankEngine) and device.type == 'cuda' and
+                hasattr(self.model, 'lp_problem_both') and hasattr(index_t, 'keys'))
+
         def run(heads, tails, rels, out):
             with session, torch.no_grad():
                 if guard is not None and self.model._expand_ok is None:
@@ -263,6 +297,11 @@ class LinkPredictionEvaluator(object):
                         out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
                             self._rank_batch_sharded_counts(h, t, r, index_t, index_h, lo, hi)
                         continue
+                    if both:
+                        res4 = self._rank_batch_both(h, t, r, index_t, index_h)
+                        if res4 is not None:
+                            out[1, sl], out[3, sl], out[0, sl], out[2, sl] = res4
+                            continue
                     out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                     out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
 
@@ -277,7 +316,7 @@ class LinkPredictionEvaluator(object):
             # the whole evaluate() as ONE hipGraph: ~20 short launches per batch
             # replayed without host launch gaps (capture is keyed on everything
             # that fixes shapes and addresses; table VALUES may change freely)
-            key = (b_size, n_local, str(device), self.fused, overlap,
+            key = (b_size, n_local, str(device), self.fused, overlap, both,
                    getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
                    tuple(p_.data_ptr() for p_ in self.model.parameters()))
             if self._graph_key != key:

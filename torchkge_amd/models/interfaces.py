@@ -169,6 +169,19 @@ class Model(Module):
         prob.split = {'Es': Es, 'enmax': g[1:2], 'enmax1': g[5:6] if T1 is not None else None, 'overflow': g[2:3]}
         return prob
 
+    def lp_problem_both(self, h_idx, t_idx, r_idx):
+        """Both sides of a batch as ONE problem of 2B queries (tail-side queries first)
+        against the entity table, or None when the two sides cannot share a launch.
+        Ranks are per query, so they do not depend on the batch composition; what
+        changes is that every latency-bound short kernel of a batch runs once."""
+        impl = getattr(self, 'lp_problem', None)
+        if impl is None:
+            return None
+        pt = self.lp_problem(h_idx, t_idx, r_idx, 'tail')
+        if int(pt.desc.mode) not in _hip.LpProblem._CONCAT_MODES:
+            return None
+        return _hip.LpProblem.concat(pt, self.lp_problem(h_idx, t_idx, r_idx, 'head'))
+
     def lp_session(self):
         """Context inside which per-entity precomputes are cached (tables must
         not change while it is open)."""

@@ -84,6 +84,12 @@ class TransEModel(TranslationModel):
         return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
 
+    def lp_problem_both(self, h_idx, t_idx, r_idx):
+        if (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
+                and self.split_filter and self._split_ok and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
+            return self._fused_query_problem(h_idx, t_idx, r_idx, _hip.SIDE_BOTH, [x.data for x in self._tables()])
+        return super().lp_problem_both(h_idx, t_idx, r_idx)
+
     def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs):
         """Inside evaluate(), unsharded: the whole query side of a batch (q, ||q||^2, true scores,
         split queries, thresholds) from ONE kernel; the evaluator's pair_scores(true_idx) /
@@ -94,7 +100,8 @@ class TransEModel(TranslationModel):
         en = self._cache.get('en_' + key, [E], lambda: _hip.row_sqnorm(E, max_io=g[1:2]))
         Es = self._cache.get('es_' + key, [E], lambda: _hip.split_rows(E, aug=en))
         pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1])
-        pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else h_idx
+        # (SIDE_BOTH: the evaluator fills in the concatenated true indices it gets from the filter lookup)
+        pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
         prob.split = {'Es': Es, 'enmax': g[1:2], 'overflow': g[2:3]}
         prob.pre = pre
