@@ -274,7 +274,7 @@ def test_evaluator_vs_reference(hip, kind, p):
         assert a.dtype == torch.int64 and a.shape[0] == nt and not a.is_cuda
         assert torch.equal(a, getattr(ev2, nm))
     # composed public API path (what a user-defined Model subclass gets)
-    ev3 = tk.LinkPredictionEvaluator(m, kg_test)
+    ev3 = tk.LinkPredictionEvaluator(m, kg_test, both_sides=False)
     import types
 
     def generic_side(self, h, t, r, side, index, lo, hi, sharded):
@@ -289,6 +289,11 @@ def test_evaluator_vs_reference(hip, kind, p):
     ev6.evaluate(b_size=B, verbose=False)
     for nm in names:
         assert torch.equal(getattr(ev, nm), getattr(ev6, nm))
+    # the default ranks both sides of a batch as ONE problem of 2B queries; side by side gives the same ranks
+    ev7 = tk.LinkPredictionEvaluator(m, kg_test, both_sides=False)
+    ev7.evaluate(b_size=5, verbose=False)
+    for nm in names:
+        assert torch.equal(getattr(ev, nm), getattr(ev7, nm))
     # hipGraph replay of the whole evaluate(): capture call and two replays, tables changed in between
     ev4 = tk.LinkPredictionEvaluator(m, kg_test, graph=True)
     ev4.evaluate(b_size=B, verbose=False)
@@ -1103,3 +1108,48 @@ def test_query_pipeline_equals_separate_kernels(hip, B, N, d, side):
     assert st2 is pre['s_true']
     assert torch.equal(prob.count_ge(st2), exact)
     assert float(guard[2]) == 0.0
+
+
+def test_filter_lookup_both_equals_two_lookups(hip):
+    """kge_filter_lookup_both = kge_filter_lookup on the tail index and on the head index
+    (head segments shifted by the tail index's target count), plus the concatenated true ids."""
+    from torchkge_amd.filter_index import FilterIndex, KEY2_SPAN
+    g = torch.Generator().manual_seed(5)
+    n_ent, n_rel, n = 50, 7, 400
+    h = torch.randint(0, n_ent, (n,), generator=g); t = torch.randint(0, n_ent, (n,), generator=g)
+    r = torch.randint(0, n_rel, (n,), generator=g)
+    d_t, d_h = {}, {}
+    for a, b, c in zip(h.tolist(), t.tolist(), r.tolist()):
+        d_t.setdefault((a, c), set()).add(b)
+        d_h.setdefault((b, c), set()).add(a)
+    it, ih = FilterIndex.from_dict(d_t, 'cuda'), FilterIndex.from_dict(d_h, 'cuda')
+    qh = torch.randint(0, n_ent + 5, (333,), generator=g).cuda()      # some keys absent
+    qt = torch.randint(0, n_ent + 5, (333,), generator=g).cuda()
+    qr = torch.randint(0, n_rel, (333,), generator=g).cuda()
+    lo, hi, true = hip.filter_lookup_both(it.keys, it.offsets, ih.keys, ih.offsets, it.targets.shape[0], qh, qt, qr,
+                                          KEY2_SPAN)
+    lo_t, hi_t = it.lookup(qh, qr)
+    lo_h, hi_h = ih.lookup(qt, qr)
+    base = it.targets.shape[0]
+    found_h = hi_h > lo_h
+    assert torch.equal(lo[:333], lo_t) and torch.equal(hi[:333], hi_t)
+    assert torch.equal(lo[333:], torch.where(found_h, lo_h + base, lo_h))
+    assert torch.equal(hi[333:], torch.where(found_h, hi_h + base, hi_h))
+    assert torch.equal(true, torch.cat([qt, qh]))
+    cat = torch.cat([it.targets, ih.targets])
+    for i in (0, 17, 332):
+        assert torch.equal(cat[lo[333 + i]:hi[333 + i]], ih.targets[lo_h[i]:hi_h[i]])
+
+
+def test_lp_problem_concat_rules(hip):
+    """LpProblem.concat merges two sides only when they share mode and candidate table."""
+    g = torch.Generator().manual_seed(2)
+    E = torch.randn(40, 16, generator=g).cuda(); E2 = torch.randn(40, 16, generator=g).cuda()
+    qa, qb = torch.randn(5, 16, generator=g).cuda(), torch.randn(3, 16, generator=g).cuda()
+    a, b = hip.LpProblem(hip.LP_DOT, qa, E), hip.LpProblem(hip.LP_DOT, qb, E)
+    c = hip.LpProblem.concat(a, b)
+    assert c is not None and c.B == 8
+    assert torch.equal(c.scores(), torch.cat([a.scores(), b.scores()]))
+    assert hip.LpProblem.concat(a, hip.LpProblem(hip.LP_DOT, qb, E2)) is None          # another table
+    assert hip.LpProblem.concat(hip.LpProblem(hip.LP_L2_DIRECT, qa, E),
+                                hip.LpProblem(hip.LP_L2_DIRECT, qb, E)) is None          # not an MFMA mode
