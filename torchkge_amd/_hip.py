@@ -77,6 +77,7 @@ _SIGNATURES = {
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
     'kge_get_rank': [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     'kge_filter_lookup': [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -116,7 +117,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 9:
+    if lib.kge_abi_version() != 10:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -616,6 +617,20 @@ def rank_finalize(raw, sub, found):
         _check(lib.kge_rank_finalize(_p(raw), _p(sub), _p(found), B, _p(rank), _p(filt), _stream()),
                'kge_rank_finalize')
     return rank, filt
+
+
+def rank_finalize_both(raw, sub, found, out, off):
+    """kge_rank_finalize_both: the ranks of a 2B-query batch into the (4, n) int64 result matrix
+    `out` (rows: head raw, tail raw, head filtered, tail filtered) at columns off .. off + B - 1."""
+    lib = load_library()
+    require_cuda(raw, out)
+    B = raw.shape[0] // 2
+    if out.dtype != torch.int64 or out.dim() != 2 or out.shape[0] != 4 or out.stride(1) != 1:
+        raise RuntimeError('rank_finalize_both: out must be a (4, n) int64 matrix with unit column stride')
+    with _on(raw.device):
+        _check(lib.kge_rank_finalize_both(_p(raw), _p(sub), _p(found), B, _p(out), out.stride(0), off, _stream()),
+               'kge_rank_finalize_both')
+    return out
 
 
 def lp_scores_batched(mode, q, cand):

@@ -283,6 +283,21 @@ __global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int3
     }
 }
 
+// 2B-query batches (tail-side queries first): ranks straight into the evaluator's (4, n) result rows
+// [head raw, tail raw, head filtered, tail filtered] at column off + fact
+__global__ void rank_finalize_both_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
+                                          const int32_t *__restrict__ found, int64_t B, int64_t *out, int64_t ld,
+                                          int64_t off)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool tail = i < B;
+        const int64_t f = off + (tail ? i : i - B);
+        const int64_t r = raw[i];
+        out[(tail ? 1 : 0) * ld + f] = r;
+        out[(tail ? 3 : 2) * ld + f] = found[i] ? r - sub[i] : r;
+    }
+}
+
 // generic per-query candidate matrices: one wavefront per (query, candidate)
 __global__ __launch_bounds__(256) void lp_batched_kernel(int mode, const float *__restrict__ q, int64_t ldq,
                                                          const float *__restrict__ cand, int64_t stride_b,
@@ -507,6 +522,18 @@ extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const i
     return 0;
 }
 
+extern "C" int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
+                                      int64_t *out, int64_t ld, int64_t off, kge_stream_t stream)
+{
+    if (B < 0 || off < 0 || ld < off + B) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!raw || !sub || !found || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(rank_finalize_both_kernel, dim3(grid1d(2 * B, 256)), dim3(256), 0, kge_s(stream), raw, sub,
+                       found, B, out, ld, off);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_lp_scores_batched(int mode, const float *q, int64_t ldq, const float *cand,
                                      int64_t stride_b, int64_t stride_n, int64_t B, int64_t N, int K,
                                      float *out, int64_t ldo, kge_stream_t stream)
@@ -532,5 +559,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 9; }
+extern "C" int kge_abi_version(void) { return 10; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

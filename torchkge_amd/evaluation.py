@@ -148,14 +148,15 @@ class LinkPredictionEvaluator(object):
             scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
         return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
 
-    def _rank_batch_both(self, h, t, r, index_t, index_h):
+    def _rank_batch_both(self, h, t, r, index_t, index_h, out, off):
         """Both sides of one batch through one problem of 2B queries (tail side first):
         one filter lookup, one query-side launch, one count (+ recheck), one filter
         correction, one finalize.  Ranks are per query: identical to two _rank_side
-        calls.  None = the model cannot merge the sides (the caller ranks them apart)."""
+        calls, written into columns off.. of the (4, n) result matrix.  False = the model
+        cannot merge the sides (the caller ranks them apart)."""
         prob = self.model.lp_problem_both(h, t, r)
         if prob is None:
-            return None
+            return False
         B = h.shape[0]
         key = (index_t.targets.data_ptr(), index_h.targets.data_ptr(), index_t.targets.shape[0],
                index_h.targets.shape[0])
@@ -171,8 +172,8 @@ class LinkPredictionEvaluator(object):
         counts = torch.zeros(3, 2 * B, dtype=torch.int32, device=h.device)
         prob.count_ge(s_true, counts[0])
         prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, counts[1], counts[2])
-        rk, frk = _hip.rank_finalize(counts[0], counts[1], counts[2])
-        return rk[:B], frk[:B], rk[B:], frk[B:]
+        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off)
+        return True
 
     def _rank_batch_sharded_counts(self, h, t, r, index_t, index_h, lo, hi):
         """Entity-sharded batch, both sides together, with TWO collectives instead of
@@ -280,7 +281,12 @@ class LinkPredictionEvaluator(object):
                 isinstance(self.engine, HipRankEngine) and device.type == 'cuda' and
                 hasattr(self.model, 'lp_problem_both') and hasattr(index_t, 'keys'))
 
-        def run(heads, tails, rels, out):
+        def alloc_out():
+            # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
+            flat = torch.empty(4 * n_local + 1, dtype=torch.int64, device=device)
+            return flat, flat[:4 * n_local].view(4, n_local), flat[4 * n_local:].view(torch.float32)
+
+        def run(heads, tails, rels, out, fl):
             with session, torch.no_grad():
                 if guard is not None and self.model._expand_ok is None:
                     guard.zero_()
@@ -297,21 +303,21 @@ class LinkPredictionEvaluator(object):
                         out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
                             self._rank_batch_sharded_counts(h, t, r, index_t, index_h, lo, hi)
                         continue
-                    if both:
-                        res4 = self._rank_batch_both(h, t, r, index_t, index_h)
-                        if res4 is not None:
-                            out[1, sl], out[3, sl], out[0, sl], out[2, sl] = res4
-                            continue
+                    if both and self._rank_batch_both(h, t, r, index_t, index_h, out, i * b_size):
+                        continue
                     out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                     out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
+                if guard is not None:   # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks
+                    torch.add(guard[0:1], guard[1:2], out=fl[0:1])
+                    fl[1:2].copy_(guard[2:3])
 
         use_graph = self.graph and not kdist.multi(world) and device.type == 'cuda' and n_local > 0
         if not use_graph:
             heads = kg.head_idx[f_lo:f_hi].to(device)
             tails = kg.tail_idx[f_lo:f_hi].to(device)
             rels = kg.relations[f_lo:f_hi].to(device)
-            out = torch.empty(4, n_local, dtype=torch.int64, device=device)
-            run(heads, tails, rels, out)
+            flat, out, fl = alloc_out()
+            run(heads, tails, rels, out, fl)
         else:
             # the whole evaluate() as ONE hipGraph: ~20 short launches per batch
             # replayed without host launch gaps (capture is keyed on everything
@@ -322,15 +328,15 @@ class LinkPredictionEvaluator(object):
             if self._graph_key != key:
                 st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
                       'r': kg.relations[f_lo:f_hi].to(device).clone(),
-                      'out': torch.empty(4, n_local, dtype=torch.int64, device=device)}
+                      'out': alloc_out()}
                 side = torch.cuda.Stream(device)
                 side.wait_stream(torch.cuda.current_stream(device))
                 with torch.cuda.stream(side):            # warm-up outside capture (lazy inits, attribute sets)
-                    run(st['h'], st['t'], st['r'], st['out'])
+                    run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
                 torch.cuda.current_stream(device).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    run(st['h'], st['t'], st['r'], st['out'])
+                    run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
                 self._graph, self._graph_static, self._graph_key = g, st, key
                 self._graph_src = None
             st = self._graph_static
@@ -341,18 +347,18 @@ class LinkPredictionEvaluator(object):
                 st['r'].copy_(kg.relations[f_lo:f_hi], non_blocking=True)
                 self._graph_src = src
             self._graph.replay()
-            out = st['out']
+            flat, out, fl = st['out']
 
         res = None
         if guard is not None:
             # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
             # cancellation error could exceed the score tolerance -> redo on the VALU kernel
-            flags = torch.stack([guard[0] + guard[1], guard[2]])
             if kdist.multi(world):
+                flags = fl.clone()
                 kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
                 worst, overflow = flags.tolist()
             else:   # one device-to-host transfer for the ranks and the two flags (8 bytes = one int64)
-                packed = torch.cat([out.reshape(-1), flags.view(torch.int64)]).cpu()
+                packed = flat.cpu()
                 worst, overflow = packed[-1:].view(torch.float32).tolist()
                 res = packed[:-1].view(4, n_local)
             redo = False
@@ -364,9 +370,9 @@ class LinkPredictionEvaluator(object):
                 redo = True
             if redo:
                 res = None
-                out = torch.empty(4, n_local, dtype=torch.int64, device=device)
+                flat, out, fl = alloc_out()
                 run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
-                    kg.relations[f_lo:f_hi].to(device), out)
+                    kg.relations[f_lo:f_hi].to(device), out, fl)
             self.model.lp_guard_end()
         if self.shard == 'queries' and kdist.multi(world):
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
