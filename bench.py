@@ -227,8 +227,20 @@ def main():
         h, t, r = kg_test.head_idx[:B], kg_test.tail_idx[:B], kg_test.relations[:B]
         guard_on = hasattr(model, 'lp_guard_begin') and model.lp_guard_begin(device) is not None
         with model.lp_session():
-            prob = model.lp_problem(h, t, r, 'tail', ent_lo=lo_r, ent_hi=hi_r)   # as evaluate() builds it
-            s_true = prob.pair_scores(t)
+            prob = None
+            both = (shard is None and not args.materialize and ev.both_sides and not args.overlap
+                    and hasattr(model, 'lp_problem_both'))
+            if both:    # as evaluate() builds it: both sides of the batch as one problem of 2B queries
+                prob = model.lp_problem_both(h, t, r)
+            if prob is not None:
+                true = torch.cat([t, h])
+                if prob.pre is not None:
+                    prob.pre['true_idx'] = true
+                s_true = prob.pair_scores(true)
+                B = 2 * B
+            else:
+                prob = model.lp_problem(h, t, r, 'tail', ent_lo=lo_r, ent_hi=hi_r)
+                s_true = prob.pair_scores(t)
             raw = torch.zeros(B, dtype=torch.int32, device=device)
             scores_buf = torch.empty(B, n_ent, device=device) if args.materialize else None
             split = prob.split is not None and not args.materialize
