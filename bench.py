@@ -73,6 +73,8 @@ def parse():
     ap.add_argument('--no-secondary', action='store_true', help='skip the scoring_function / sampler / train-step timings')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
     ap.add_argument('--overlap', action='store_true', help='two-stream overlap of the short kernels (default: single stream)')
+    ap.add_argument('--no-both', action='store_true', help='rank the two sides of a batch one after the other '
+                                                          '(default: one 2B-query problem per batch)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend; 'gloo' only to dry-run the N>1 logic on one GPU")
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
@@ -166,7 +168,8 @@ def main():
     if multi and not replicas:
         shard = 'entities' if args.shard == 'entities' else 'queries'
     ev = tk.LinkPredictionEvaluator(model, kg_test, fused=not args.materialize, shard=shard,
-                                    exchange=args.exchange, graph=not args.no_graph, overlap=args.overlap)
+                                    exchange=args.exchange, graph=not args.no_graph, overlap=args.overlap,
+                                    both_sides=not args.no_both)
 
     def sync():
         torch.cuda.synchronize(device)

@@ -73,7 +73,8 @@ enum {
     KGE_SIDE_HEAD = 1,   /* candidates replace the head: query = f(t, r)            */
     KGE_SIDE_PROJ_H = 2, /* kge_lp_prep only: Q0 = projected head, no relation term */
     KGE_SIDE_PROJ_T = 3, /* kge_lp_prep only: Q0 = projected tail, no relation term */
-    KGE_SIDE_BOTH = 4    /* kge_lp_query_pipeline only: 2B queries, [0,B) tail side then [B,2B) head side */
+    KGE_SIDE_BOTH = 4    /* kge_lp_prep / kge_lp_query_pipeline: both sides of the B facts as 2B queries, [0,B) the
+                          * tail-side queries f(h,r), [B,2B) the head-side queries f(t,r); outputs have 2B rows */
 };
 
 /* kge_ewise ops (query-side elementwise algebra of inference_scoring_function) */

@@ -1139,17 +1139,3 @@ def test_filter_lookup_both_equals_two_lookups(hip):
     cat = torch.cat([it.targets, ih.targets])
     for i in (0, 17, 332):
         assert torch.equal(cat[lo[333 + i]:hi[333 + i]], ih.targets[lo_h[i]:hi_h[i]])
-
-
-def test_lp_problem_concat_rules(hip):
-    """LpProblem.concat merges two sides only when they share mode and candidate table."""
-    g = torch.Generator().manual_seed(2)
-    E = torch.randn(40, 16, generator=g).cuda(); E2 = torch.randn(40, 16, generator=g).cuda()
-    qa, qb = torch.randn(5, 16, generator=g).cuda(), torch.randn(3, 16, generator=g).cuda()
-    a, b = hip.LpProblem(hip.LP_DOT, qa, E), hip.LpProblem(hip.LP_DOT, qb, E)
-    c = hip.LpProblem.concat(a, b)
-    assert c is not None and c.B == 8
-    assert torch.equal(c.scores(), torch.cat([a.scores(), b.scores()]))
-    assert hip.LpProblem.concat(a, hip.LpProblem(hip.LP_DOT, qb, E2)) is None          # another table
-    assert hip.LpProblem.concat(hip.LpProblem(hip.LP_L2_DIRECT, qa, E),
-                                hip.LpProblem(hip.LP_L2_DIRECT, qb, E)) is None          # not an MFMA mode

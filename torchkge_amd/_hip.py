@@ -251,6 +251,11 @@ def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
     return [g if n else None for g, n in zip(grads[:len(tables)], needs)]
 
 
+def side_code(side):
+    """'tail' / 'head' / 'both' (both sides of a batch as one 2B-query problem, tail side first)."""
+    return {'tail': SIDE_TAIL, 'head': SIDE_HEAD, 'both': SIDE_BOTH}[side]
+
+
 def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=False,
             want_q1=False):
     lib = load_library()
@@ -259,13 +264,16 @@ def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=Fal
     h, t, r = i64c(h), i64c(t), i64c(r)
     B = h.shape[0]
     dev = h.device
+    n_facts = B
+    if side == SIDE_BOTH:       # 2B queries: the tail-side queries of the B facts, then the head-side ones
+        B = 2 * B
     Q0 = torch.empty(B, d_rel, dtype=torch.float32, device=dev)
     Q1 = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_q1 else None
     qn = torch.empty(B, dtype=torch.float32, device=dev) if want_qn else None
     Wq = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_w else None
     with _on(dev):
         _check(lib.kge_lp_prep(kind, side, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
-                               d_ent, d_rel, _p(h), _p(t), _p(r), B, _p(Q0), _p(Q1), _p(qn),
+                               d_ent, d_rel, _p(h), _p(t), _p(r), n_facts, _p(Q0), _p(Q1), _p(qn),
                                _p(Wq), _stream()), 'kge_lp_prep')
     return Q0, Q1, qn, Wq
 
@@ -456,39 +464,6 @@ class LpProblem(object):
         self.B, self.N = int(d.B), int(d.N)
         self.split = None
         self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
-
-    _CONCAT_MODES = (LP_DOT, LP_L2_EXPAND, LP_L2_PROJH, LP_L2_PROJD)
-
-    @classmethod
-    def concat(cls, a, b):
-        """The queries of `a` followed by the queries of `b` as ONE problem against
-        the same candidate table (both sides of a batch in one count launch), or
-        None if the two do not share mode / tables (MFMA modes only: there every
-        non-query operand is table-level)."""
-        da, db = a.desc, b.desc
-        mode = int(da.mode)
-        if mode != int(db.mode) or mode not in cls._CONCAT_MODES or a.pre is not None or b.pre is not None:
-            return None
-        if (int(da.K0), int(da.K1), int(da.c_base), int(da.N)) != (int(db.K0), int(db.K1), int(db.c_base), int(db.N)):
-            return None
-        for k in (1, 3, 5, 7, 9):                       # T0, T1, en, scal (table-level here), yc
-            x, y = a.keep[k], b.keep[k]
-            if (x is None) != (y is None):
-                return None
-            if x is not None and (x.data_ptr() != y.data_ptr() or x.shape != y.shape or x.stride() != y.stride()):
-                return None
-        if (a.split is None) != (b.split is None):
-            return None
-
-        def cat(k):
-            x, y = a.keep[k], b.keep[k]
-            if (x is None) != (y is None):
-                raise RuntimeError('LpProblem.concat: operand %d present on one side only' % k)
-            return None if x is None else torch.cat([x, y])
-        new = cls(mode, cat(0), a.keep[1], A1=cat(2), T1=a.keep[3], qn=cat(4), en=a.keep[5], Wq=cat(6),
-                  scal=a.keep[7], r_idx=cat(8), c_base=int(da.c_base), K0=int(da.K0), yc=a.keep[9])
-        new.split = a.split
-        return new
 
     def scores(self, out=None):
         lib = load_library()

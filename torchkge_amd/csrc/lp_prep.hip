@@ -41,12 +41,15 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
     const int de = p.d_ent, dr = p.d_rel;
-    const bool tail = p.side == KGE_SIDE_TAIL;
-    const bool proj = p.side >= KGE_SIDE_PROJ_H; // projection only, no relation term
-    const bool use_h = tail || p.side == KGE_SIDE_PROJ_H;
-    for (int64_t i = wave; i < p.B; i += nwaves) {
-        const int64_t ei = use_h ? p.h[i] : p.t[i]; // the entity that stays in the query
-        const int64_t ri = p.r[i];
+    const bool both = p.side == KGE_SIDE_BOTH;   // 2B queries: [0,B) tail side, [B,2B) head side
+    const bool proj = p.side == KGE_SIDE_PROJ_H || p.side == KGE_SIDE_PROJ_T; // projection only, no relation term
+    const int64_t nq = both ? 2 * p.B : p.B;
+    for (int64_t i = wave; i < nq; i += nwaves) {
+        const bool tail = both ? i < p.B : p.side == KGE_SIDE_TAIL;
+        const bool use_h = tail || p.side == KGE_SIDE_PROJ_H;
+        const int64_t f = (both && i >= p.B) ? i - p.B : i;   // the fact this query belongs to
+        const int64_t ei = use_h ? p.h[f] : p.t[f]; // the entity that stays in the query
+        const int64_t ri = p.r[f];
         float *q0 = p.Q0 + i * dr;
         switch (p.kind) {
         case KGE_TRANSE_L1:
@@ -314,7 +317,7 @@ extern "C" int kge_lp_prep(int kind, int side, const float *t0, const float *t1,
                            kge_stream_t stream)
 {
     if (kind < KGE_TRANSE_L1 || kind > KGE_COMPLEX) return KGE_EINVAL;
-    if (side < KGE_SIDE_TAIL || side > KGE_SIDE_PROJ_T) return KGE_EINVAL;
+    if (side < KGE_SIDE_TAIL || side > KGE_SIDE_BOTH) return KGE_EINVAL;
     if (!t0 || !t1 || d_ent <= 0 || d_rel <= 0 || B < 0) return KGE_EINVAL;
     if (B == 0) return 0;
     if (!h || !t || !r || !Q0) return KGE_EINVAL;
@@ -323,8 +326,9 @@ extern "C" int kge_lp_prep(int kind, int side, const float *t0, const float *t1,
     if (kind == KGE_TRANSD && (!t2 || !t3 || !Wq || d_ent < d_rel)) return KGE_EINVAL;
     if (kind != KGE_TRANSD && d_ent != d_rel) return KGE_EINVAL;
     PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq};
-    hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(B)), dim3(WPB * 64), 0, kge_s(stream), p);
+    const int64_t nq = side == KGE_SIDE_BOTH ? 2 * B : B;
+    hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(nq)), dim3(WPB * 64), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
-    if (qn) return kge_row_sqnorm(Q0, d_rel, B, d_rel, qn, nullptr, stream);
+    if (qn) return kge_row_sqnorm(Q0, d_rel, nq, d_rel, qn, nullptr, stream);
     return 0;
 }

@@ -66,7 +66,7 @@ class DistMultModel(BilinearModel):
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
         tabs = [x.data for x in self._tables()]
-        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        sd = _hip.side_code(side)
         Q0 = _hip.lp_prep(_hip.DISTMULT, sd, tabs, self.emb_dim, self.emb_dim, h_idx, t_idx, r_idx)[0]
         T0 = _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi)
         return self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, c_base=ent_lo), T0, c_base=ent_lo)
@@ -152,7 +152,7 @@ class ComplExModel(BilinearModel):
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
         tabs = [x.data for x in self._tables()]
-        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        sd = _hip.side_code(side)
         Q0, Q1, _, _ = _hip.lp_prep(_hip.COMPLEX, sd, tabs, self.emb_dim, self.emb_dim, h_idx, t_idx,
                                     r_idx, want_q1=True)
         T0, T1 = _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), _shard(_hip.f32c(tabs[1]), ent_lo, ent_hi)

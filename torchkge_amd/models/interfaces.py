@@ -171,16 +171,10 @@ class Model(Module):
 
     def lp_problem_both(self, h_idx, t_idx, r_idx):
         """Both sides of a batch as ONE problem of 2B queries (tail-side queries first)
-        against the entity table, or None when the two sides cannot share a launch.
-        Ranks are per query, so they do not depend on the batch composition; what
-        changes is that every latency-bound short kernel of a batch runs once."""
-        impl = getattr(self, 'lp_problem', None)
-        if impl is None:
-            return None
-        pt = self.lp_problem(h_idx, t_idx, r_idx, 'tail')
-        if int(pt.desc.mode) not in _hip.LpProblem._CONCAT_MODES:
-            return None
-        return _hip.LpProblem.concat(pt, self.lp_problem(h_idx, t_idx, r_idx, 'head'))
+        against the entity table: ``lp_problem(..., side='both')``.  Ranks are per
+        query, so they do not depend on the batch composition; what changes is that
+        every latency-bound short kernel of a batch runs once."""
+        return self.lp_problem(h_idx, t_idx, r_idx, 'both')
 
     def lp_session(self):
         """Context inside which per-entity precomputes are cached (tables must

@@ -74,7 +74,7 @@ class TransEModel(TranslationModel):
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
         tabs = [x.data for x in self._tables()]
-        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        sd = _hip.side_code(side)
         if (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
                 and self.split_filter and self._split_ok and ent_lo == 0 and ent_hi == self.n_ent
                 and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
@@ -83,12 +83,6 @@ class TransEModel(TranslationModel):
                                    h_idx, t_idx, r_idx)
         return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
-
-    def lp_problem_both(self, h_idx, t_idx, r_idx):
-        if (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
-                and self.split_filter and self._split_ok and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
-            return self._fused_query_problem(h_idx, t_idx, r_idx, _hip.SIDE_BOTH, [x.data for x in self._tables()])
-        return super().lp_problem_both(h_idx, t_idx, r_idx)
 
     def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs):
         """Inside evaluate(), unsharded: the whole query side of a batch (q, ||q||^2, true scores,
@@ -106,6 +100,12 @@ class TransEModel(TranslationModel):
         prob.split = {'Es': Es, 'enmax': g[1:2], 'overflow': g[2:3]}
         prob.pre = pre
         return prob
+
+
+def _both_r(r_idx, sd):
+    """Relation id per query: the 2B queries of a both-sides batch are the B facts twice."""
+    r_idx = _hip.i64c(r_idx)
+    return torch.cat([r_idx, r_idx]) if sd == _hip.SIDE_BOTH else r_idx
 
 
 class TransHModel(TranslationModel):
@@ -202,12 +202,12 @@ class TransHModel(TranslationModel):
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
         tabs = [x.data for x in self._tables()]
-        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        sd = _hip.side_code(side)
         d = self.emb_dim
         Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSH, sd, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)
         return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi),
-                                           r_idx=_hip.i64c(r_idx), c_base=ent_lo)
+                                           r_idx=_both_r(r_idx, sd), c_base=ent_lo)
 
 
 class TransDModel(TranslationModel):
@@ -307,7 +307,7 @@ class TransDModel(TranslationModel):
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
         tabs = [x.data for x in self._tables()]
-        sd = _hip.SIDE_TAIL if side == 'tail' else _hip.SIDE_HEAD
+        sd = _hip.side_code(side)
         Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSD, sd, tabs, self.ent_emb_dim, self.rel_emb_dim,
                                     h_idx, t_idx, r_idx, want_w=True)
-        return self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_hip.i64c(r_idx))
+        return self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_both_r(r_idx, sd))
