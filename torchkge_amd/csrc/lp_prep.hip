@@ -204,6 +204,43 @@ __global__ void row_dot_kernel(const float *__restrict__ X, const float *__restr
     }
 }
 
+// the same chain with both rows staged cooperatively (see row_sqnorm_staged_kernel)
+__global__ __launch_bounds__(64) void row_dot_staged_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                            int64_t ld, int64_t rows, int K, float scale, float *out)
+{
+    __shared__ __attribute__((aligned(16))) float xs[64 * KGE_PS_LD];
+    __shared__ __attribute__((aligned(16))) float ys[64 * KGE_PS_LD];
+    const int lane = threadIdx.x;
+    const int64_t ngroups = (rows + 63) >> 6;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t row0 = grp * 64;
+        float acc = 0.f;
+        for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {   // K % 4 == 0, ld % 4 == 0, 16-byte aligned (checked by the host)
+            const int kc = min(KGE_PS_KC, K - k0);
+            const int pieces = kc >> 2;
+            for (int idx = lane; idx < 64 * pieces; idx += 64) {
+                const int rr = idx / pieces, pc = idx - rr * pieces;
+                const int64_t r = min(row0 + rr, rows - 1);
+                *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) =
+                    *reinterpret_cast<const float4 *>(X + r * ld + k0 + pc * 4);
+                *reinterpret_cast<float4 *>(ys + rr * KGE_PS_LD + pc * 4) =
+                    *reinterpret_cast<const float4 *>(Y + r * ld + k0 + pc * 4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const float *x = xs + lane * KGE_PS_LD, *y = ys + lane * KGE_PS_LD;
+            for (int k = 0; k < kc; k += 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(x + k), b = *reinterpret_cast<const float4 *>(y + k);
+                acc = fmaf(a.x, b.x, acc);
+                acc = fmaf(a.y, b.y, acc);
+                acc = fmaf(a.z, b.z, acc);
+                acc = fmaf(a.w, b.w, acc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        if (row0 + lane < rows) out[row0 + lane] = scale * acc;
+    }
+}
+
 __global__ void ewise_kernel(int op, const float *__restrict__ a, const float *__restrict__ b,
                              const float *__restrict__ c, const float *__restrict__ d, int64_t n, float *out)
 {
@@ -273,7 +310,13 @@ extern "C" int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t r
     if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
     if (rows == 0) return 0;
     if (!X || !Y || !out) return KGE_EINVAL;
-    hipLaunchKernelGGL(row_dot_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, Y, ld, rows, K, scale, out);
+    if (K % 4 == 0 && ld % 4 == 0 && kge_aligned16(X) && kge_aligned16(Y)) {
+        const int64_t groups = (rows + 63) / 64;
+        hipLaunchKernelGGL(row_dot_staged_kernel, dim3((int)(groups < 256 * 14 ? groups : 256 * 14)), dim3(64), 0,
+                           kge_s(stream), X, Y, ld, rows, K, scale, out);
+    } else {
+        hipLaunchKernelGGL(row_dot_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, Y, ld, rows, K, scale, out);
+    }
     KGE_CHECK_LAUNCH();
     return 0;
 }
