@@ -59,6 +59,7 @@
 #include "kge_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -235,6 +236,10 @@ struct SplitThrParams {
 
 // (a_lo, a_hi) of the plain L2 expansion, unscaled half-width logic shared by split_thr_kernel and the fused
 // query pipeline (which must produce the same thresholds bit for bit)
+// The count kernel reads "v >= a_lo" off the sign of v - a_lo, which is wrong only for v = -0, a_lo = +0:
+// a zero threshold is moved down to the next normal number (widening the band is always safe).
+__device__ __forceinline__ float split_nonzero_lo(float lo) { return lo == 0.f ? -1.17549435e-38f : lo; }
+
 __device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int K, int units, float c_acc, float eps_scale)
 {
     const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
@@ -247,7 +252,7 @@ __device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int 
     const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
     const float mid = 0.5f * (q - u);
     const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
-    return make_float2((mid - hw) * out_scale, (mid + hw) * out_scale);
+    return make_float2(split_nonzero_lo((mid - hw) * out_scale), (mid + hw) * out_scale);
 }
 
 __global__ void split_thr_kernel(const SplitThrParams p)
@@ -292,7 +297,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
                 const float cmax = p.mode == KGE_LP_L2_PROJH ? xm * (xm * fabsf(zi) + fabsf(pi))
                                                              : ym * (ym * fabsf(zi) + 2.0f * xm + fabsf(pi));
                 hw += 8.0f * two22 * cmax * p.eps_scale + two22 * cmax;
-                p.thr4[i] = make_float4((mid - hw) * out_scale, (mid + hw) * out_scale, pi, zi);
+                p.thr4[i] = make_float4(split_nonzero_lo((mid - hw) * out_scale), (mid + hw) * out_scale, pi, zi);
                 continue;
             }
         } else {
@@ -304,7 +309,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
             const float eps_dot = (eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
             const float hw = eps_dot + two22 * fabsf(st);
-            p.thr[i] = make_float2((st - hw) * out_scale, (st + hw) * out_scale);
+            p.thr[i] = make_float2(split_nonzero_lo((st - hw) * out_scale), (st + hw) * out_scale);
         }
     }
 }
@@ -678,6 +683,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                     lo_n = t4.x; hi_n = t4.y; p_n = t4.z; z_n = t4.w;
                     xrow = p.X + (int64_t)prow[ql] * p.ldx + c0 + wr * (MT * 32) + 4 * half;
                 }
+                asm volatile("" : "+v"(lo_n), "+v"(hi_n));   // (keeps the derived constants out of the MFMA loop's registers)
+                const f32x2 nlo2 = {-lo_n, -lo_n};
+                // band width as bits; padding queries carry a_lo = a_hi = +inf (inf - inf = NaN, of either sign):
+                // width 0 there, so that none of their pairs can be listed
+                const float hwf = hi_n - lo_n;
+                const unsigned hwb = hwf >= 0.f ? __float_as_uint(hwf) : 0u;
+                unsigned smask = 0u;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     float4 x4[4], y4[4];
@@ -691,7 +703,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                     }
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {   // 4 accumulator registers = rows 8*g4 + 4*half + {0..3}
-                        unsigned long long any = 0ull;
                         float vq[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -708,20 +719,31 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                                 vq[e] = fmaf(corr, -8388608.0f, vq[e]);
                             }
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = vq[e];
-                            // cnt += (v >= a_lo) as compare + add-with-carry (hipcc emits cndmask + add)
-                            unsigned long long ge;
-                            asm volatile("v_cmp_ge_f32 %1, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, %1"
-                                         : "+v"(cnt[nt]), "=&s"(ge) : "v"(v), "v"(lo_n) : "vcc");
-                            any |= ge & ~__ballot(v >= hi_n);
-                        }
+                        // 2.25 VALU per element instead of 3 VALU + 2 SALU (compare / add-with-carry /
+                        // compare / mask logic): w = v - a_lo as packed f32 adds; the SIGN bits of the 32
+                        // w's of this lane's query are shifted into one register (v >= a_lo  <=>  sign clear:
+                        // a float subtraction never gets the sign wrong, and a_lo is never +-0) and counted
+                        // with one popcount per 32 elements; a pair is uncertain (a_lo <= v < a_hi) only if
+                        // 0 <= w <= fl(a_hi - a_lo) -- rounding is monotonic -- i.e. iff the bits of w,
+                        // read as unsigned, are <= those of the band width: one unsigned min3 + min per quad.
+                        const f32x2 w01 = (f32x2){vq[0], vq[1]} + nlo2, w23 = (f32x2){vq[2], vq[3]} + nlo2;
+                        const unsigned b0 = __float_as_uint(w01.x), b1 = __float_as_uint(w01.y);
+                        const unsigned b2 = __float_as_uint(w23.x), b3 = __float_as_uint(w23.y);
+                        smask = __builtin_amdgcn_alignbit(smask, b0, 31);
+                        smask = __builtin_amdgcn_alignbit(smask, b1, 31);
+                        smask = __builtin_amdgcn_alignbit(smask, b2, 31);
+                        smask = __builtin_amdgcn_alignbit(smask, b3, 31);
+                        const unsigned mq = min(min(min(b0, b1), b2), b3);
+                        const unsigned long long any = __ballot(mq <= hwb);
+                        // (w replaces v in the accumulator registers -- they are dead after the epilogue, the next
+                        // tile starts from C = 0 -- so the epilogue needs no registers of its own)
+                        acc[mt][nt][g4 * 4 + 0] = w01.x; acc[mt][nt][g4 * 4 + 1] = w01.y;
+                        acc[mt][nt][g4 * 4 + 2] = w23.x; acc[mt][nt][g4 * 4 + 3] = w23.y;
                         if (any) { // some lane holds an uncertain pair among these 4 rows: list them
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float v = vq[e];
-                                if (v >= lo_n && !(v >= hi_n)) {
+                                // 0 <= w <= fl(a_hi - a_lo): every pair of the band, and only counted pairs
+                                if (__float_as_uint(acc[mt][nt][g4 * 4 + e]) <= hwb) {
                                     const int cl = cl_base + mt * 32 + e + 8 * g4;
                                     const int idx = atomicAdd(unc_cnt, 1);
                                     if (idx < UNC_CAP)
@@ -729,12 +751,14 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                                 }
                             }
                         }
+                        __builtin_amdgcn_sched_barrier(0);   // one quad at a time: its temporaries die here
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                cnt[nt] += 32 - __popc(smask);      // the 32 elements (2 tiles x 16) of this lane's query
             }
             __syncthreads();
-            if (wid == 0) { // hand this tile's uncertain pairs to the global list
+            if (wid == 0 && !(dbg & 64)) { // hand this tile's uncertain pairs to the global list
                 const int n = *unc_cnt;
                 const int nc = min(n, UNC_CAP);
                 if (n > 0) {
