@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + 16);
     float4 *pthr = reinterpret_cast<float4 *>(smem + 2 * STAGE_BYTES + 16 + UNC_CAP * 4);   // PM: per query of the panel
     int *prow = reinterpret_cast<int *>(pthr + TQ);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the LDS-DMA targets become SALU arithmetic)
     const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;   // waves: (NWAVES/2) x 2
 
     // Work order.  The (query panel, candidate tile) items are listed with QG = 4 query panels
@@ -655,8 +655,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         // The stage's last two MFMA groups run BEHIND the barrier, next to the fetch of the next
         // stage's first fragments: right after a barrier all 8 waves read LDS at once (80 KB), and
         // without matrix work in flight the MFMA pipe would idle for that long.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
-        if (!(dbg & 32)) __syncthreads();
+        if (!(dbg & 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
+        if (dbg & 512) __builtin_amdgcn_s_barrier();   // probe: barrier without waiting for the DMA pieces
+        else if (!(dbg & 32)) __syncthreads();
         if (more && !(dbg & 16)) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
         __builtin_amdgcn_sched_barrier(0);
         if (two) { KGE_SMMA_PA(ah1, bl1) }
