@@ -73,14 +73,27 @@ class OracleRankEngine(object):
         hi = torch.where(hit, index.offsets[(posc + 1).clamp(max=index.offsets.shape[0] - 1)], torch.zeros_like(key))
         return lo, hi
 
+    def lookup_both(self, index_t, index_h, h, t, r):
+        lo_t, hi_t = self.lookup(index_t, h, r)
+        lo_h, hi_h = self.lookup(index_h, t, r)
+        base = index_t.targets.shape[0]
+        found = hi_h > lo_h
+        return (torch.cat([lo_t, torch.where(found, lo_h + base, lo_h)]),
+                torch.cat([hi_t, torch.where(found, hi_h + base, hi_h)]),
+                torch.cat([t, h]), torch.cat([index_t.targets, index_h.targets]))
+
     def problem(self, model, h, t, r, side, lo, hi):
         from oracle import kge_oracle as orc
-        full = orc.lp_scores(self.kind, self.tables, h, t, r, side, self.p)
+        if side == 'both':      # 2B queries: tail side first
+            full = torch.cat([orc.lp_scores(self.kind, self.tables, h, t, r, 'tail', self.p),
+                              orc.lp_scores(self.kind, self.tables, h, t, r, 'head', self.p)])
+        else:
+            full = orc.lp_scores(self.kind, self.tables, h, t, r, side, self.p)
 
         class P(object):
             pass
         pr = P()
-        pr.B, pr.lo, pr.hi, pr.full = h.shape[0], lo, hi, full
+        pr.B, pr.lo, pr.hi, pr.full = full.shape[0], lo, hi, full
         return pr
 
     def true_scores(self, prob, true_idx):
@@ -108,6 +121,12 @@ class OracleRankEngine(object):
         raw = counts[0].long()
         filt = torch.where(counts[2] > 0, raw - counts[1].long(), raw)
         return raw, filt
+
+    def finalize_both(self, counts, out, off):
+        raw, filt = self.finalize(counts)
+        B = raw.shape[0] // 2
+        out[1, off:off + B], out[3, off:off + B] = raw[:B], filt[:B]
+        out[0, off:off + B], out[2, off:off + B] = raw[B:], filt[B:]
 
     def local_scores(self, prob):
         return prob.full[:, prob.lo:prob.hi].contiguous()

@@ -53,12 +53,28 @@ class HipRankEngine(object):
     def lookup(index, key1, key2):
         return index.lookup(key1, key2)
 
+    _targets_cat = None
+
+    def lookup_both(self, index_t, index_h, h, t, r):
+        """Both sides of a batch as 2B queries (tail side first): filter segments into the
+        concatenated target arrays of the two indices, the 2B true ids, and that array."""
+        key = (index_t.targets.data_ptr(), index_h.targets.data_ptr(), index_t.targets.shape[0],
+               index_h.targets.shape[0])
+        if self._targets_cat is None or self._targets_cat[0] != key:
+            self._targets_cat = (key, torch.cat([index_t.targets, index_h.targets]))
+        seg_lo, seg_hi, true_idx = _hip.filter_lookup_both(index_t.keys, index_t.offsets, index_h.keys,
+                                                           index_h.offsets, index_t.targets.shape[0], h, t, r,
+                                                           KEY2_SPAN)
+        return seg_lo, seg_hi, true_idx, self._targets_cat[1]
+
     @staticmethod
     def problem(model, h, t, r, side, lo, hi):
         return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi)
 
     @staticmethod
     def true_scores(prob, true_idx):
+        if prob.pre is not None and prob.pre.get('true_idx') is None:
+            prob.pre['true_idx'] = true_idx     # both-sides batch: the fused query pipeline scored exactly these pairs
         return prob.pair_scores(true_idx)
 
     @staticmethod
@@ -72,6 +88,11 @@ class HipRankEngine(object):
     @staticmethod
     def finalize(counts):
         return _hip.rank_finalize(counts[0], counts[1], counts[2])
+
+    @staticmethod
+    def finalize_both(counts, out, off):
+        """Ranks of a 2B-query batch into the (4, n) result matrix at columns off..off+B-1."""
+        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off)
 
     @staticmethod
     def local_scores(prob):
@@ -118,7 +139,6 @@ class LinkPredictionEvaluator(object):
         # both sides of a batch as ONE 2B-query problem (single GPU, fused): every latency-bound short
         # kernel of a batch runs once instead of twice, the all-candidates count kernel sees 2B queries
         self.both_sides = both_sides
-        self._targets_cat = None
 
     # -- filter indices ------------------------------------------------------
     def _filter_indices(self, device):
@@ -148,51 +168,23 @@ class LinkPredictionEvaluator(object):
             scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
         return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
 
-    def _rank_batch_both(self, h, t, r, index_t, index_h, out, off):
+    def _rank_batch_both(self, h, t, r, index_t, index_h, out, off, lo, hi, sharded):
         """Both sides of one batch through one problem of 2B queries (tail side first):
         one filter lookup, one query-side launch, one count (+ recheck), one filter
-        correction, one finalize.  Ranks are per query: identical to two _rank_side
-        calls, written into columns off.. of the (4, n) result matrix.  False = the model
-        cannot merge the sides (the caller ranks them apart)."""
-        prob = self.model.lp_problem_both(h, t, r)
-        if prob is None:
-            return False
-        B = h.shape[0]
-        key = (index_t.targets.data_ptr(), index_h.targets.data_ptr(), index_t.targets.shape[0],
-               index_h.targets.shape[0])
-        if self._targets_cat is None or self._targets_cat[0] != key:
-            self._targets_cat = (key, torch.cat([index_t.targets, index_h.targets]))
-        targets = self._targets_cat[1]
-        seg_lo, seg_hi, true_idx = _hip.filter_lookup_both(index_t.keys, index_t.offsets, index_h.keys,
-                                                           index_h.offsets, index_t.targets.shape[0], h, t, r,
-                                                           KEY2_SPAN)
-        if prob.pre is not None:
-            prob.pre['true_idx'] = true_idx           # the fused query pipeline has scored exactly these pairs
-        s_true = prob.pair_scores(true_idx)
-        counts = torch.zeros(3, 2 * B, dtype=torch.int32, device=h.device)
-        prob.count_ge(s_true, counts[0])
-        prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, counts[1], counts[2])
-        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off)
-        return True
-
-    def _rank_batch_sharded_counts(self, h, t, r, index_t, index_h, lo, hi):
-        """Entity-sharded batch, both sides together, with TWO collectives instead of
-        four: one all-reduce of the (2, B) true scores (the owner shard holds the value,
-        the others 0), one all-reduce of the (2, 3, B) partial rank counts."""
+        correction, one finalize into columns off.. of the (4, n) result matrix.  Ranks
+        are per query: identical to two _rank_side calls.  Entity-sharded: TWO collectives
+        per batch -- the (2B) true scores (the owner shard holds the value, the others 0;
+        x + 0 is exact) and the (3, 2B) partial rank counts."""
         eng = self.engine
-        B = h.shape[0]
-        lo_t, hi_t = eng.lookup(index_t, h, r)
-        lo_h, hi_h = eng.lookup(index_h, t, r)
-        prob_t = eng.problem(self.model, h, t, r, 'tail', lo, hi)
-        prob_h = eng.problem(self.model, h, t, r, 'head', lo, hi)
-        s_true = torch.stack([eng.true_scores(prob_t, t), eng.true_scores(prob_h, h)])
-        kdist.all_reduce_sum(s_true, self.group)
-        counts = torch.stack([eng.partial_counts(prob_t, s_true[0], t, lo_t, hi_t, index_t.targets),
-                              eng.partial_counts(prob_h, s_true[1], h, lo_h, hi_h, index_h.targets)])
-        kdist.all_reduce_sum(counts, self.group)
-        rk_t, frk_t = eng.finalize(counts[0])
-        rk_h, frk_h = eng.finalize(counts[1])
-        return rk_t, frk_t, rk_h, frk_h
+        seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
+        prob = eng.problem(self.model, h, t, r, 'both', lo, hi)
+        s_true = eng.true_scores(prob, true_idx)
+        if sharded:
+            kdist.all_reduce_sum(s_true, self.group)
+        counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets)
+        if sharded:
+            kdist.all_reduce_sum(counts, self.group)
+        eng.finalize_both(counts, out, off)
 
     def _rank_batch_overlapped(self, h, t, r, index_t, index_h):
         """Both sides of one batch on two HIP streams: the short kernels (filter
@@ -277,9 +269,8 @@ class LinkPredictionEvaluator(object):
         overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
                    isinstance(self.engine, HipRankEngine) and device.type == 'cuda')
 
-        both = (self.both_sides and self.fused and not sharded and not self._generic_model and not overlap and
-                isinstance(self.engine, HipRankEngine) and device.type == 'cuda' and
-                hasattr(self.model, 'lp_problem_both') and hasattr(index_t, 'keys'))
+        both = (self.both_sides and self.fused and not self._generic_model and not overlap and
+                not (sharded and self.exchange == 'scores') and hasattr(self.engine, 'lookup_both'))
 
         def alloc_out():
             # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
@@ -299,11 +290,8 @@ class LinkPredictionEvaluator(object):
                         out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
                             self._rank_batch_overlapped(h, t, r, index_t, index_h)
                         continue
-                    if sharded and self.fused and self.exchange == 'counts' and not self._generic_model:
-                        out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
-                            self._rank_batch_sharded_counts(h, t, r, index_t, index_h, lo, hi)
-                        continue
-                    if both and self._rank_batch_both(h, t, r, index_t, index_h, out, i * b_size):
+                    if both:
+                        self._rank_batch_both(h, t, r, index_t, index_h, out, i * b_size, lo, hi, sharded)
                         continue
                     out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                     out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
