@@ -407,7 +407,9 @@ def main():
             'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
                                    'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
                                        kind, d, p, shape + (' x%d entity shards' % world if ent_weak else ''), n_ent_full, n_rel, n_test, args.batch),
-                       'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': not args.no_graph and not multi,
+                       'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': (not args.no_graph) and (not multi or shard == 'queries' or
+                                                               (shard == 'entities' and args.exchange == 'counts'
+                                                                and not args.materialize and not args.no_both)),
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
             'roofline': roof, 'cpu_baseline': cpu, 'secondary': sec,

@@ -103,6 +103,41 @@ class HipRankEngine(object):
         return _hip.filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets)
 
 
+class _GraphSegments(object):
+    """evaluate() of one entity shard as hipGraph segments with the collectives between them:
+    the short launches of a batch replay without host gaps, the RCCL calls stay ordinary
+    eager calls on the same stream (nothing collective is ever captured)."""
+
+    def __init__(self):
+        self.items = []                 # ('g', CUDAGraph) | ('c', callable)
+        self.pool = torch.cuda.graph_pool_handle()   # one pool: later segments read earlier segments' tensors
+        self._g = self._ctx = None
+
+    def begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(self._g, pool=self.pool)
+        self._ctx.__enter__()
+
+    def end(self, exc=(None, None, None)):
+        if self._ctx is not None:
+            ctx, self._ctx = self._ctx, None
+            ctx.__exit__(*exc)
+            if exc[0] is None:
+                self.items.append(('g', self._g))
+
+    def cut(self, fn):
+        self.end()
+        self.items.append(('c', fn))
+        self.begin()
+
+    def replay(self):
+        for kind, x in self.items:
+            if kind == 'g':
+                x.replay()
+            else:
+                x()
+
+
 class LinkPredictionEvaluator(object):
     """Evaluate a model by link prediction (evaluation.py:207-425).
 
@@ -139,6 +174,7 @@ class LinkPredictionEvaluator(object):
         # both sides of a batch as ONE 2B-query problem (single GPU, fused): every latency-bound short
         # kernel of a batch runs once instead of twice, the all-candidates count kernel sees 2B queries
         self.both_sides = both_sides
+        self._cut = None        # set while evaluate() is being captured as graph segments (see _GraphSegments)
 
     # -- filter indices ------------------------------------------------------
     def _filter_indices(self, device):
@@ -180,11 +216,19 @@ class LinkPredictionEvaluator(object):
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi)
         s_true = eng.true_scores(prob, true_idx)
         if sharded:
-            kdist.all_reduce_sum(s_true, self.group)
+            self._collective(lambda: kdist.all_reduce_sum(s_true, self.group))
         counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets)
         if sharded:
-            kdist.all_reduce_sum(counts, self.group)
+            self._collective(lambda: kdist.all_reduce_sum(counts, self.group))
         eng.finalize_both(counts, out, off)
+
+    def _collective(self, fn):
+        """Run a collective now -- or, while evaluate() is being captured, close the current
+        graph segment, record the call, and open the next segment."""
+        if self._cut is None:
+            fn()
+        else:
+            self._cut(fn)
 
     def _rank_batch_overlapped(self, h, t, r, index_t, index_h):
         """Both sides of one batch on two HIP streams: the short kernels (filter
@@ -299,7 +343,12 @@ class LinkPredictionEvaluator(object):
                     torch.add(guard[0:1], guard[1:2], out=fl[0:1])
                     fl[1:2].copy_(guard[2:3])
 
-        use_graph = self.graph and not kdist.multi(world) and device.type == 'cuda' and n_local > 0
+        # one hipGraph when run() contains no collective (single GPU, query shards); graph segments with
+        # the collectives between them for entity shards exchanging counts; eager otherwise
+        multi = kdist.multi(world)
+        segmented = multi and sharded and both
+        use_graph = (self.graph and device.type == 'cuda' and n_local > 0 and
+                     (not multi or self.shard == 'queries' or segmented))
         if not use_graph:
             heads = kg.head_idx[f_lo:f_hi].to(device)
             tails = kg.tail_idx[f_lo:f_hi].to(device)
@@ -310,7 +359,7 @@ class LinkPredictionEvaluator(object):
             # the whole evaluate() as ONE hipGraph: ~20 short launches per batch
             # replayed without host launch gaps (capture is keyed on everything
             # that fixes shapes and addresses; table VALUES may change freely)
-            key = (b_size, n_local, str(device), self.fused, overlap, both,
+            key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, lo, hi, f_lo, f_hi,
                    getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
                    tuple(p_.data_ptr() for p_ in self.model.parameters()))
             if self._graph_key != key:
@@ -322,9 +371,23 @@ class LinkPredictionEvaluator(object):
                 with torch.cuda.stream(side):            # warm-up outside capture (lazy inits, attribute sets)
                     run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
                 torch.cuda.current_stream(device).wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
+                if segmented:
+                    g = _GraphSegments()
+                    self._cut = g.cut
+                    g.begin()
+                    try:
+                        run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
+                    except BaseException:
+                        import sys
+                        g.end(sys.exc_info())
+                        raise
+                    finally:
+                        self._cut = None
+                    g.end()
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
                 self._graph, self._graph_static, self._graph_key = g, st, key
                 self._graph_src = None
             st = self._graph_static
