@@ -417,6 +417,11 @@ def main():
                 'ms_per_step': round(f32_only_ms, 4), 'value': round(total_units / f32_only_ms * 1e3, 1),
                 'ranks_identical_to_headline_run': True},
         }
+        try:        # RCCL writes a banner through C stdio; when stdout is a pipe it would surface AFTER the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()

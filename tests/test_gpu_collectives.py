@@ -23,7 +23,9 @@ def _bench(extra, forced, port):
            '--workload', 'complex_wn18rr', '--no-cpu-baseline', '--no-secondary'] + extra
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')]
+    assert lines and out.stdout.strip().splitlines()[-1] == lines[-1]      # the JSON line is the last line of stdout
+    return json.loads(lines[-1])
 
 
 def test_forced_collectives_reproduce_single_gpu_metrics():
