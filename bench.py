@@ -101,6 +101,15 @@ def make_model(kind, p, tables, n_ent, n_rel):
     return m
 
 
+def _flush_c_stdio():
+    """RCCL writes a banner through C stdio; on a piped stdout it would otherwise surface after the JSON line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -417,12 +426,13 @@ def main():
                 'ms_per_step': round(f32_only_ms, 4), 'value': round(total_units / f32_only_ms * 1e3, 1),
                 'ranks_identical_to_headline_run': True},
         }
-        try:        # RCCL writes a banner through C stdio; when stdout is a pipe it would surface AFTER the JSON line
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
+        _flush_c_stdio()
+        if multi:
+            dist.barrier()      # the other ranks have flushed their stdout too: the JSON line comes last
         print(json.dumps(line), flush=True)
+    elif multi:
+        _flush_c_stdio()
+        dist.barrier()
     if multi:
         dist.destroy_process_group()
 
