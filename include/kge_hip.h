@@ -322,6 +322,9 @@ typedef struct kge_split_args {
                                    * measured behaviour of gfx950, valid only if kge_mfma_f16_selftest() returned 1 */
     float eps_scale;              /* multiplies the error band (1.0 = the proven bound; tests shrink it) */
     int32_t thr_ready;            /* 1: thr is already filled and *list_count zeroed (kge_lp_query_pipeline) */
+    const float *q_cell_ss;       /* optional: the queries' cell sums (kge_lp_split_rows) and ...                      */
+    const float *e2pref;          /* ... the candidates' prefix squared-norm maxima (kge_lp_split_prefix_max): the band  */
+                                  /* then charges each k16 unit with its own magnitude bound (NULL: full ||q|| ||e||)   */
     float *thr;                   /* scratch: 4 * kge_lp_split_rows_padded(B, 1) floats */
     int32_t *list;                /* scratch: cap x 2 int32 (query, local candidate) */
     int32_t cap;
@@ -340,7 +343,14 @@ int64_t kge_lp_split_rows_padded(int64_t rows, int is_query);
  * (NULL: the fixed 2^12 of the norm-guarded L2 mode). */
 int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
                       int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
-                      const float *norm2max1, void *out, kge_stream_t stream);
+                      const float *norm2max1, void *out, float *cell_ss, kge_stream_t stream);
+/* cell_ss (optional, [units_p][rows_padded] floats): per k16 cell the sum of squares of its data values.
+ * kge_lp_split_prefix_max folds the cell sums of a CANDIDATE operand into e2pref[u] = max over rows of the squared
+ * norm of the first (u+1)*16 columns (units_p floats, zeroed by the caller).  With the queries' cell sums in
+ * kge_split_args.q_cell_ss the error band uses || q[:k] || * sqrt(e2pref) as the accumulator's magnitude in unit u
+ * (Cauchy-Schwarz on the prefix) instead of || q || || e || throughout: about half the accumulation term. */
+int kge_lp_split_prefix_max(const float *cell_ss, int64_t rows, int is_query, int units_p, float *e2pref,
+                            kge_stream_t stream);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
 /* 1 if v_mfma_f32_32x32x16_f16 on the current device accumulates as the tighter error model assumes (two
@@ -357,7 +367,8 @@ int kge_mfma_f16_selftest(void);
 int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const int64_t *h, const int64_t *t,
                           const int64_t *r, int64_t B, const float *en, const float *emax, float *qmax_io,
                           int accum_model, float eps_scale, float *Q, float *qn, float *s_true, void *Qs,
-                          float *thr, int32_t *list_count, kge_stream_t stream);
+                          float *thr, int32_t *list_count, const float *e2pref /* optional, see above */,
+                          kge_stream_t stream);
 /* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
 int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,

@@ -780,7 +780,8 @@ def test_split_prefilter_counts_equal_exact_counts(hip, B, N, K):
     prob = hip.LpProblem(hip.LP_L2_EXPAND, dq, dE, qn=qn, en=en)
     st = prob.pair_scores(dt)
     exact = prob.count_ge(st)
-    prob.split = {'Es': hip.split_rows(dE, aug=en), 'enmax': guard[1:2], 'overflow': guard[2:3]}
+    Es, e2 = hip.split_table(dE, aug=en)
+    prob.split = {'Es': Es, 'e2pref': e2, 'enmax': guard[1:2], 'overflow': guard[2:3]}   # prefix-norm band
     try:
         for eps in (1.0, 1.0 / 16):
             hip.SPLIT_EPS_SCALE = eps
@@ -841,8 +842,8 @@ def test_split_prefilter_dot_mode_counts_equal_exact_counts(hip, B, N, K, K1, sc
     hip.row_sqnorm(T0, max_io=guard[1:2])
     if T1 is not None:
         hip.row_sqnorm(T1, max_io=guard[5:6])
-    Es = hip.split_rows(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=guard[5:6] if T1 is not None else None)
-    prob.split = {'Es': Es, 'enmax': guard[1:2], 'enmax1': guard[5:6] if T1 is not None else None,
+    Es, e2 = hip.split_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=guard[5:6] if T1 is not None else None)
+    prob.split = {'Es': Es, 'e2pref': e2, 'enmax': guard[1:2], 'enmax1': guard[5:6] if T1 is not None else None,
                   'overflow': guard[2:3]}
     try:
         for eps in (1.0, 1.0 / 16):
@@ -880,14 +881,15 @@ def test_split_prefilter_random_shape_sweep(hip):
             hip.row_sqnorm(T0, max_io=guard[1:2])
             if T1 is not None:
                 hip.row_sqnorm(T1, max_io=guard[5:6])
-            Es = hip.split_rows(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=guard[5:6] if T1 is not None else None)
+            Es, e2 = hip.split_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=guard[5:6] if T1 is not None else None)
         else:
             en = hip.row_sqnorm(T0, max_io=guard[1:2]); qn = hip.row_sqnorm(A0, max_io=guard[0:1])
             prob = hip.LpProblem(hip.LP_L2_EXPAND, A0, T0, qn=qn, en=en)
-            Es = hip.split_rows(T0, aug=en)
+            Es, e2 = hip.split_table(T0, aug=en)
         st = prob.pair_scores(t)
         exact = prob.count_ge(st)
-        prob.split = {'Es': Es, 'enmax': guard[1:2], 'enmax1': guard[5:6] if T1 is not None else None,
+        prob.split = {'Es': Es, 'e2pref': e2 if trial % 3 else None, 'enmax': guard[1:2],   # (every third trial: the plain band)
+                      'enmax1': guard[5:6] if T1 is not None else None,
                       'overflow': guard[2:3]}
         got = prob.count_ge(st)
         assert float(guard[2]) == 0.0, (trial, B, N, K, K1)
@@ -1011,7 +1013,8 @@ def test_split_prefilter_projection_modes_counts_equal_exact_counts(hip, mode_na
     st = prob.pair_scores(t)
     exact = prob.count_ge(st)
     hip.absmax(X, guard[3:4]); hip.absmax(ycb, guard[4:5])
-    prob.split = {'Es': hip.split_rows(dT, aug=en), 'enmax': guard[1:2], 'overflow': guard[2:3],
+    Es, e2 = hip.split_table(dT, aug=en)
+    prob.split = {'Es': Es, 'e2pref': e2, 'enmax': guard[1:2], 'overflow': guard[2:3],
                   'xabsmax': guard[3:4], 'yabsmax': guard[4:5] if mode_name == 'D' else None}
     try:
         for eps in (1.0, 1.0 / 16):
@@ -1076,7 +1079,7 @@ def test_query_pipeline_equals_separate_kernels(hip, B, N, d, side):
     true = t if side == 'tail' else h
     guard = torch.zeros(8, device='cuda')
     en = hip.row_sqnorm(E, max_io=guard[1:2])
-    Es = hip.split_rows(E, aug=en)
+    Es, e2 = hip.split_table(E, aug=en)
 
     # the separate kernels
     Q0 = hip.lp_prep(hip.TRANSE_L2, sd, [E, R], d, d, h, t, r)[0]
@@ -1085,13 +1088,13 @@ def test_query_pipeline_equals_separate_kernels(hip, B, N, d, side):
     ref = hip.LpProblem(hip.LP_L2_EXPAND, Q0, E, qn=qn, en=en)
     st = ref.pair_scores(true)
     exact = ref.count_ge(st)
-    ref.split = {'Es': Es, 'enmax': g_ref[1:2], 'overflow': g_ref[2:3]}
+    ref.split = {'Es': Es, 'e2pref': e2, 'enmax': g_ref[1:2], 'overflow': g_ref[2:3]}
     prep_ref = ref.split_prepare()
     raw_ref = torch.zeros(B, dtype=torch.int32, device='cuda')
     ref.split_count(prep_ref, st, raw_ref)
 
     # the fused launch
-    pre = hip.lp_query_pipeline(sd, E, R, h, t, r, en, guard[1:2], guard[0:1])
+    pre = hip.lp_query_pipeline(sd, E, R, h, t, r, en, guard[1:2], guard[0:1], e2pref=e2)
     assert torch.equal(pre['Q'], Q0)
     assert torch.equal(pre['qn'].view(torch.int32), qn.view(torch.int32))
     assert torch.equal(pre['s_true'].view(torch.int32), st.view(torch.int32))
@@ -1102,7 +1105,7 @@ def test_query_pipeline_equals_separate_kernels(hip, B, N, d, side):
 
     pre['true_idx'] = true
     prob = hip.LpProblem(hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
-    prob.split = {'Es': Es, 'enmax': guard[1:2], 'overflow': guard[2:3]}
+    prob.split = {'Es': Es, 'e2pref': e2, 'enmax': guard[1:2], 'overflow': guard[2:3]}
     prob.pre = pre
     st2 = prob.pair_scores(true)
     assert st2 is pre['s_true']

@@ -15,7 +15,8 @@ en = _hip.row_sqnorm(E, max_io=guard[1:2])
 qn = _hip.row_sqnorm(q, max_io=guard[0:1])
 prob = _hip.LpProblem(_hip.LP_L2_EXPAND, q, E, qn=qn, en=en)
 st = prob.pair_scores(t)
-prob.split = {'Es': _hip.split_rows(E, aug=en), 'enmax': guard[1:2], 'overflow': guard[2:3]}
+_Es, _e2 = _hip.split_table(E, aug=en)
+prob.split = {'Es': _Es, 'e2pref': None if os.environ.get('NO_PREF') else _e2, 'enmax': guard[1:2], 'overflow': guard[2:3]}
 _hip.SPLIT_EPS_SCALE = float(os.environ.get('EPS', '1'))
 prep = prob.split_prepare()
 raw = torch.zeros(B, dtype=torch.int32, device='cuda')

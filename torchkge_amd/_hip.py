@@ -44,7 +44,7 @@ class SplitArgs(ctypes.Structure):
     _fields_ = [
         ('Qs', _vp), ('Es', _vp), ('qn0', _vp), ('qn1', _vp), ('qmax0', _vp), ('qmax1', _vp),
         ('emax0', _vp), ('emax1', _vp), ('xabsmax', _vp), ('yabsmax', _vp), ('accum_model', ctypes.c_int32),
-        ('eps_scale', ctypes.c_float), ('thr_ready', ctypes.c_int32),
+        ('eps_scale', ctypes.c_float), ('thr_ready', ctypes.c_int32), ('q_cell_ss', _vp), ('e2pref', _vp),
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
     ]
 
@@ -68,12 +68,13 @@ _SIGNATURES = {
     'kge_lp_count_ge': [ctypes.POINTER(LpDesc), _vp, _vp, _vp],
     'kge_lp_split_units': [_int, _int],
     'kge_lp_split_rows': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _int, _vp, ctypes.c_float, _vp, _vp, _vp,
-                          _vp],
+                          _vp, _vp],
+    'kge_lp_split_prefix_max': [_vp, _i64, _int, _int, _vp, _vp],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
-                              _vp, _vp, _vp, _vp, _vp],
+                              _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
@@ -117,7 +118,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 10:
+    if lib.kge_abi_version() != 11:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -310,7 +311,8 @@ SPLIT_EPS_SCALE = 1.0          # multiplies the proven error band of the f16-spl
 SPLIT_LIST_PER_QUERY = 64      # capacity of the uncertain-pair list per query of the batch (floor; grows with N)
 
 
-def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None):
+def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None,
+               cell_ss=False):
     """f16 hi/lo split operand of kge_lp_split_count (uint8 tensor holding
     [rows_p][units_p][64 bytes]) of [X | X1].  L2 mode (dot=False): candidates
     carry -||e||^2/2 in the extra column (aug = ||e||^2), queries carry 1, fixed
@@ -335,13 +337,27 @@ def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False,
     units_p = int(lib.kge_lp_split_units(K + K1, 1))
     rows_p = int(lib.kge_lp_split_rows_padded(rows, 1 if is_query else 0))
     out = torch.empty(max(rows_p, 1) * units_p * 64, dtype=torch.uint8, device=X.device)
+    css = torch.empty(units_p, max(rows_p, 1), dtype=torch.float32, device=X.device) if cell_ss else None
     with _on(X.device):
         _check(lib.kge_lp_split_rows(_p(X), ld, K, _p(X1), ld1, K1, rows, 1 if is_query else 0, aug_mode, _p(aug),
-                                     aug_mul, _p(nmax0), _p(nmax1), _p(out), _stream()), 'kge_lp_split_rows')
-    return out
+                                     aug_mul, _p(nmax0), _p(nmax1), _p(out), _p(css), _stream()), 'kge_lp_split_rows')
+    return (out, css) if cell_ss else out
 
 
-def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io):
+def split_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None):
+    """Candidate operand of the split prefilter + the prefix squared-norm maxima that tighten its error
+    band (kge_lp_split_rows with cell sums, kge_lp_split_prefix_max): (Es, e2pref)."""
+    lib = load_library()
+    Es, css = split_rows(X, K=K, aug=aug, X1=X1, K1=K1, dot=dot, nmax0=nmax0, nmax1=nmax1, cell_ss=True)
+    units_p = css.shape[0]
+    e2 = torch.zeros(units_p, dtype=torch.float32, device=X.device)
+    with _on(X.device):
+        _check(lib.kge_lp_split_prefix_max(_p(css), X.shape[0], 0, units_p, _p(e2), _stream()),
+               'kge_lp_split_prefix_max')
+    return Es, e2
+
+
+def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None):
     """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
     s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
     the threshold kernel."""
@@ -362,7 +378,7 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io):
         _check(lib.kge_lp_query_pipeline(side, _p(E), _p(R), d, _p(h), _p(t), _p(r), B, _p(en), _p(emax), _p(qmax_io),
                                          split_accum_model(), SPLIT_EPS_SCALE, _p(out['Q']), _p(out['qn']),
                                          _p(out['s_true']), _p(out['Qs']), _p(out['thr']), _p(out['n_list']),
-                                         _stream()), 'kge_lp_query_pipeline')
+                                         _p(e2pref), _stream()), 'kge_lp_query_pipeline')
     return out
 
 
@@ -504,6 +520,7 @@ class LpProblem(object):
         K = int(self.desc.K0)
         A0, A1 = self.keep[0], self.keep[2]
         extra = {}
+        want_ss = self.split.get('e2pref') is not None     # prefix-norm magnitude bound of the error band
         if self.pre is not None:
             Qs, extra = self.pre['Qs'], {'thr_pre': self.pre['thr'], 'n_list_pre': self.pre['n_list'],
                                          's_true_pre': self.pre['s_true']}
@@ -513,10 +530,12 @@ class LpProblem(object):
             qn1 = row_sqnorm(A1, max_io=qmax[1:2]) if A1 is not None else None
             qn = qn0 if qn1 is None else qn0 + qn1
             Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
-                            nmax1=qmax[1:2] if A1 is not None else None)
+                            nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
             extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
         else:
-            Qs = split_rows(A0, K=K, is_query=True)
+            Qs = split_rows(A0, K=K, is_query=True, cell_ss=want_ss)
+        if isinstance(Qs, tuple):
+            Qs, extra['q_cell_ss'] = Qs
         Bp = int(lib.kge_lp_split_rows_padded(self.B, 1))
         thr = extra['thr_pre'] if 'thr_pre' in extra else torch.empty(4 * Bp, dtype=torch.float32, device=self.device)
         # the band holds ~1e-3 of a query's candidates for an untrained model (far fewer for a trained one)
@@ -543,6 +562,7 @@ class LpProblem(object):
         a.accum_model = split_accum_model()
         a.eps_scale = SPLIT_EPS_SCALE
         # thresholds written by the fused query pipeline are valid for its own true scores, once
+        a.q_cell_ss, a.e2pref = _p(prep.get('q_cell_ss')), _p(sp.get('e2pref') if prep.get('q_cell_ss') is not None else None)
         a.thr_ready = 1 if (prep.get('s_true_pre') is s_true and not prep.get('thr_used')) else 0
         prep['thr_used'] = True
         a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']

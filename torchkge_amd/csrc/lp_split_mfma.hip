@@ -119,6 +119,7 @@ struct SplitRowsParams {
     const float *nmax0, *nmax1;   // device scalars: squared-norm maxima -> scale (NULL: 2^12)
     int units_p;
     uint4 *out;
+    float *cell_ss;           // optional [units_p][rows_p]: sum of squares of the cell's 16 data values (unscaled)
 };
 
 __global__ void split_rows_kernel(const SplitRowsParams p)
@@ -135,6 +136,7 @@ __global__ void split_rows_kernel(const SplitRowsParams p)
         const int64_t row = idx / p.units_p;
         const int u = (int)(idx % p.units_p);
         union { _Float16 h[16]; uint4 v[2]; } hi, lo;
+        float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int k = u * 16 + e;
@@ -142,6 +144,7 @@ __global__ void split_rows_kernel(const SplitRowsParams p)
             if (row < p.rows) {
                 if (k < p.K0) x = p.X0[row * p.ld0 + k];
                 else if (k < K) x = p.X1[row * p.ld1 + (k - p.K0)];
+                if (k < K) ss = fmaf(x, x, ss);
                 else if (k == K && p.aug_mode == 1) x = p.aug[row] * p.aug_mul;
                 else if (k == K && p.aug_mode == 2) x = p.aug_mul;
                 else if (k == K && p.aug_mode == 3) x = 0.25f * (sqrtf(p.aug[row]) + sqrtf(nmax) * 0.00390625f);
@@ -162,7 +165,37 @@ __global__ void split_rows_kernel(const SplitRowsParams p)
         }
         uint4 *o = p.out + idx * 4;
         o[0] = hi.v[0]; o[1] = hi.v[1]; o[2] = lo.v[0]; o[3] = lo.v[1];
+        if (p.cell_ss) p.cell_ss[(int64_t)u * p.rows_p + row] = ss;
     }
+}
+
+// e2pref[u] = max over rows of the squared norm of the row's first (u+1)*16 data columns: with the
+// same prefix norms of a query, || q[:k] || * sqrt(e2pref) bounds every partial sum the MFMA
+// accumulator holds while it works through unit u (Cauchy-Schwarz on the prefix) -- the error band
+// then charges each unit with ITS magnitude instead of the full ||q|| ||e|| (about half of it).
+__global__ void prefix_max_kernel(const float *__restrict__ cell_ss, int64_t rows_p, int64_t rows, int units_p,
+                                  float *e2pref)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; r0 < rows;
+         r0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = r0 + lane;
+        float prefix = 0.f;
+        for (int u = 0; u < units_p; ++u) {
+            if (r < rows) prefix += cell_ss[(int64_t)u * rows_p + r];
+            unsigned m = __float_as_uint(prefix);       // sums of squares: >= 0, ordered like their bit patterns
+            for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+            if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned *>(e2pref) + u, m);
+        }
+    }
+}
+
+// One step of the per-query magnitude sum (shared by split_thr_kernel and the fused query pipeline, which
+// must agree bit for bit): prefix += cell sum;  amag += sqrt(prefix * e2pref[u])
+__device__ __forceinline__ void split_amag_step(float &prefix, float &amag, float ss, float e2u)
+{
+    prefix = prefix + ss;
+    amag = amag + sqrtf(prefix * e2u);
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, float *max_io)
@@ -232,6 +265,9 @@ struct SplitThrParams {
     const float *xabsmax, *yabsmax; // device scalars >= max |X|, max |y_c|
     float4 *thr4;
     float c_acc;                    // accumulation-error coefficient per product (2: any adder; 1.25: measured model)
+    const float *q_cell_ss;         // optional [units_p][Bp] cell sums of the queries (kge_lp_split_rows) ...
+    const float *e2pref;            // ... and prefix squared-norm maxima of the candidates (kge_lp_split_prefix_max)
+    int units_p;
 };
 
 // (a_lo, a_hi) of the plain L2 expansion, unscaled half-width logic shared by split_thr_kernel and the fused
@@ -240,15 +276,26 @@ struct SplitThrParams {
 // a zero threshold is moved down to the next normal number (widening the band is always safe).
 __device__ __forceinline__ float split_nonzero_lo(float lo) { return lo == 0.f ? -1.17549435e-38f : lo; }
 
-__device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int K, int units, float c_acc, float eps_scale)
+// amag: the sum over the k16 units of the bound on the accumulator's magnitude in that unit (split_amag_step,
+// times 1.003 for the cross terms and f16 roundings), or < 0 when the prefix norms are not at hand: every unit is
+// then charged with the full ||q|| ||e||.
+__device__ __forceinline__ float split_acc_err(float amag, float aug_mag, float mag, int units, float c_acc)
+{
+    const float two24 = 5.9604645e-8f;
+    const float sum_mag = amag >= 0.f ? amag * 1.003f + aug_mag : (float)units * mag;
+    return c_acc * 48.0f * two24 * sum_mag;          // 48 additions per unit, each within c_acc * 2^-24 of the magnitude
+}
+
+__device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int K, int units, float c_acc, float eps_scale,
+                                               float amag)
 {
     const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
-    const float eps_rel = (c_acc * (float)(48 * units) + 1.01f * (float)K) * two24 + 3.01f * two22;
+    const float eps_rel = (1.01f * (float)K) * two24 + 3.01f * two22;    // exact chain (gamma_K) + split residual
     const float enrm = sqrtf(em) * 1.000001f, qnrm = sqrtf(q) * 1.000001f;
     const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
     const float u = -st;                             // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
     const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
-    const float eps_dot = eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
+    const float eps_dot = split_acc_err(amag, 0.5f * em, mag, units, c_acc) + eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
     const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
     const float mid = 0.5f * (q - u);
     const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
@@ -269,8 +316,9 @@ __global__ void split_thr_kernel(const SplitThrParams p)
     // accumulation: 48*units fp32 additions, c_acc = 2 (adders that truncate instead of rounding, any order)
     // or 1.25 when kge_mfma_f16_selftest confirmed the measured behaviour (<= 9/8 per product, see below);
     // exact chain: K fmaf roundings (gamma_K <= 1.01 K u); split residual 3 * 2^-22 * (1 + 2^-10)
-    const float eps_rel = (p.c_acc * (float)(48 * p.units) + 1.01f * (float)p.K) * two24 + 3.01f * two22;
+    const float eps_rel = (1.01f * (float)p.K) * two24 + 3.01f * two22;
     const float enrm = sqrtf(em) * 1.000001f;
+    const bool have_pref = p.q_cell_ss && p.e2pref;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.Bp; i += (int64_t)gridDim.x * blockDim.x) {
         if (i >= p.B) {
             if (p.mode >= KGE_LP_L2_PROJH) p.thr4[i] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
@@ -279,13 +327,20 @@ __global__ void split_thr_kernel(const SplitThrParams p)
         }
         const float q = p.qn0[i] + (p.qn1 ? p.qn1[i] : 0.f);
         const float qnrm = sqrtf(q) * 1.000001f;
+        float amag = -1.0f;
+        if (have_pref) {
+            float prefix = 0.f;
+            amag = 0.f;
+            for (int u = 0; u < p.units; ++u) split_amag_step(prefix, amag, p.q_cell_ss[(int64_t)u * p.Bp + i], p.e2pref[u]);
+        }
         if (p.mode == KGE_LP_L2_EXPAND) {
-            p.thr[i] = split_thr_l2(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale);
+            p.thr[i] = split_thr_l2(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale, amag);
         } else if (p.mode >= KGE_LP_L2_PROJH) {
             const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
             const float u = -p.s_true[i];                    // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
             const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
-            const float eps_dot = eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
+            const float eps_dot = split_acc_err(amag, 0.5f * em, mag, p.units, p.c_acc) + eps_rel * mag +
+                                  2.5e-7f * (qnrm + enrm) + 4e-9f;
             const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * p.eps_scale;
             const float mid = 0.5f * (q - u);
             float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
@@ -307,7 +362,8 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float st = p.s_true[i];
             const float sqk = sqrtf((float)p.K);
             const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
-            const float eps_dot = (eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
+            const float eps_dot = (split_acc_err(amag, 0.f, qnrm * enrm, p.units, p.c_acc) + eps_rel * qnrm * enrm +
+                                   eps_abs) * p.eps_scale;
             const float hw = eps_dot + two22 * fabsf(st);
             p.thr[i] = make_float2(split_nonzero_lo((st - hw) * out_scale), (st + hw) * out_scale);
         }
@@ -336,6 +392,7 @@ struct QueryPipeParams {
     float2 *thr;
     _Float16 *Qs;
     int32_t *list_count;
+    const float *e2pref;            // optional: prefix squared-norm maxima of the entity table (tighter error band)
 };
 
 template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
@@ -362,6 +419,7 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
         const int64_t src = tl ? p.h[fi] : p.t[fi], tru = tl ? p.t[fi] : p.h[fi], ri = p.r[fi];
         const int tli = tl ? 1 : 0;
         float qn = 0.f, acc = 0.f;
+        float ss = 0.f, prefix = 0.f, amag = 0.f;               // split_rows' cell sums / split_thr's magnitude sum
         for (int k0 = 0; k0 < kpad; k0 += KC) {
             const int kc = max(0, min(KC, d - k0));              // data columns of this chunk
             const int pieces = kc >> 2;
@@ -389,6 +447,15 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
             if (kc > 0 && lane < QPW) {
                 const float *x = qs + lane * LD;
                 for (int k = 0; k < kc; ++k) qn = fmaf(x[k], x[k], qn);         // row_sqnorm_kernel's chain
+                if (p.e2pref) {
+                    for (int k = 0; k < kc; ++k) {
+                        ss = fmaf(x[k], x[k], ss);
+                        if (((k0 + k) & 15) == 15 || k0 + k == d - 1) {         // end of a k16 cell (or of the data)
+                            split_amag_step(prefix, amag, ss, p.e2pref[(k0 + k) >> 4]);
+                            ss = 0.f;
+                        }
+                    }
+                }
                 acc = lp_chain_dot(x, ts + lane * LD, kc, acc);                 // the pair kernel's chain
             }
             // split cells of this chunk: 8 consecutive k of one row per lane and pass
@@ -419,7 +486,12 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
                 const float st = lp_epilogue(KGE_LP_L2_EXPAND, acc, qn, p.en[tru]);
                 p.qn[i] = qn;
                 p.s_true[i] = st;
-                p.thr[i] = split_thr_l2(qn, st, em, d, p.units, p.c_acc, p.eps_scale);
+                if (p.e2pref) {     // units past the data (the augmentation column alone in its unit)
+                    for (int u = (d + 15) >> 4; u < p.units; ++u) split_amag_step(prefix, amag, 0.f, p.e2pref[u]);
+                } else {
+                    amag = -1.0f;
+                }
+                p.thr[i] = split_thr_l2(qn, st, em, d, p.units, p.c_acc, p.eps_scale, amag);
                 qbig = __uint_as_float(max(__float_as_uint(qbig), __float_as_uint(qn)));
             } else {
                 p.thr[i] = make_float2(INFINITY, INFINITY);
@@ -865,7 +937,8 @@ extern "C" int64_t kge_lp_split_rows_padded(int64_t rows, int is_query) { return
 
 extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1,
                                  int64_t rows, int is_query, int aug_mode, const float *aug, float aug_mul,
-                                 const float *norm2max0, const float *norm2max1, void *out, kge_stream_t stream)
+                                 const float *norm2max0, const float *norm2max1, void *out, float *cell_ss,
+                                 kge_stream_t stream)
 {
     if (rows < 0 || K0 <= 0 || K1 < 0 || ld0 < K0 || (K1 > 0 && ld1 < K1) || aug_mode < 0 || aug_mode > 4)
         return KGE_EINVAL;
@@ -880,10 +953,25 @@ extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const flo
     p.nmax0 = norm2max0; p.nmax1 = norm2max1;
     p.units_p = kge_lp_split_units(K0 + K1, aug_mode != 0);
     p.out = reinterpret_cast<uint4 *>(out);
+    p.cell_ss = cell_ss;
     const int64_t total = p.rows_p * p.units_p;
     if (total == 0) return 0;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_lp_split_prefix_max(const float *cell_ss, int64_t rows, int is_query, int units_p, float *e2pref,
+                                       kge_stream_t stream)
+{
+    if (rows < 0 || units_p <= 0) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!cell_ss || !e2pref) return KGE_EINVAL;
+    const int64_t rows_p = kge_lp_split_rows_padded(rows, is_query);
+    const int64_t want = (rows + 255) / 256;
+    hipLaunchKernelGGL(prefix_max_kernel, dim3((int)(want < 2048 ? want : 2048)), dim3(256), 0, kge_s(stream), cell_ss,
+                       rows_p, rows, units_p, e2pref);
     KGE_CHECK_LAUNCH();
     return 0;
 }
@@ -924,6 +1012,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.pz = d->Wq; t.ldw = d->ldw;
     t.xabsmax = a->xabsmax; t.yabsmax = a->yabsmax;
     t.c_acc = a->accum_model == 1 ? 1.25f : 2.0f;
+    t.q_cell_ss = a->q_cell_ss; t.e2pref = a->e2pref; t.units_p = units_p;
     t.list_count = a->list_count;
     t.overflow = a->overflow;
     if (!a->thr_ready) {    // (the fused query pipeline has already written thr and zeroed list_count)
@@ -1050,7 +1139,7 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
                                      const int64_t *t, const int64_t *r, int64_t B, const float *en,
                                      const float *emax, float *qmax_io, int accum_model, float eps_scale, float *Q,
                                      float *qn, float *s_true, void *Qs, float *thr, int32_t *list_count,
-                                     kge_stream_t stream)
+                                     const float *e2pref, kge_stream_t stream)
 {
     const bool both = side == KGE_SIDE_BOTH;
     if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD && !both) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
@@ -1068,6 +1157,7 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     p.thr = reinterpret_cast<float2 *>(thr);
     p.Qs = reinterpret_cast<_Float16 *>(Qs);
     p.list_count = list_count;
+    p.e2pref = e2pref;
     if (d % 4 != 0 || !kge_aligned16(E) || !kge_aligned16(R)) return KGE_EINVAL;   // float4 staging
     const int qpw = kge_env_int("KGE_QPIPE_QPW", 32);
     const int64_t groups = (p.Bp + qpw - 1) / qpw;

@@ -164,9 +164,10 @@ class Model(Module):
             if T1 is not None:
                 _hip.row_sqnorm(T1, max_io=g[5:6])
             del en0
-            return _hip.split_rows(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=g[5:6] if T1 is not None else None)
-        Es = self._cache.get('esd_' + key, [T0] + ([T1] if T1 is not None else []), build)
-        prob.split = {'Es': Es, 'enmax': g[1:2], 'enmax1': g[5:6] if T1 is not None else None, 'overflow': g[2:3]}
+            return _hip.split_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=g[5:6] if T1 is not None else None)
+        Es, e2 = self._cache.get('esd_' + key, [T0] + ([T1] if T1 is not None else []), build)
+        prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'enmax1': g[5:6] if T1 is not None else None,
+                      'overflow': g[2:3]}
         return prob
 
     def lp_problem_both(self, h_idx, t_idx, r_idx):
@@ -304,11 +305,11 @@ class TranslationModel(Model):
         g = self._lp_guard
         key = '%d_%d' % (prob.desc.c_base, table.shape[0])
         Kq = table.shape[1] if K0 is None else K0
-        Es = self._cache.get('es_' + key, [table], lambda: _hip.split_rows(table, K=Kq, aug=en))
+        Es, e2 = self._cache.get('es_' + key, [table], lambda: _hip.split_table(table, K=Kq, aug=en))
         self._cache.get('xmax_' + key, [X], lambda: _hip.absmax(X, g[3:4]))
         if yc is not None:
             self._cache.get('ymax_' + key, [yc], lambda: _hip.absmax(yc, g[4:5]))
-        prob.split = {'Es': Es, 'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': g[3:4],
+        prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': g[3:4],
                       'yabsmax': g[4:5] if yc is not None else None}
         return prob
 
@@ -335,9 +336,9 @@ class TranslationModel(Model):
                 if guarded and self.split_filter and self._split_ok:
                     # rank counts through the certified f16-split prefilter (16x MFMA rate)
                     Kq = q.shape[1] if K0 is None else K0
-                    Es = self._cache.get('es_%d_%d' % (c_base, table.shape[0]), [table],
-                                         lambda: _hip.split_rows(table, K=Kq, aug=en))
-                    prob.split = {'Es': Es, 'enmax': ge, 'overflow': self._lp_guard[2:3]}
+                    Es, e2 = self._cache.get('es_%d_%d' % (c_base, table.shape[0]), [table],
+                                             lambda: _hip.split_table(table, K=Kq, aug=en))
+                    prob.split = {'Es': Es, 'e2pref': e2, 'enmax': ge, 'overflow': self._lp_guard[2:3]}
                 return prob
         if callable(scal):          # built only when the broadcast-subtract kernel is really taken
             scal = scal()

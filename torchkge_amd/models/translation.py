@@ -92,12 +92,12 @@ class TransEModel(TranslationModel):
         g = self._lp_guard
         key = '0_%d' % E.shape[0]
         en = self._cache.get('en_' + key, [E], lambda: _hip.row_sqnorm(E, max_io=g[1:2]))
-        Es = self._cache.get('es_' + key, [E], lambda: _hip.split_rows(E, aug=en))
-        pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1])
+        Es, e2 = self._cache.get('es_' + key, [E], lambda: _hip.split_table(E, aug=en))
+        pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2)
         # (SIDE_BOTH: the evaluator fills in the concatenated true indices it gets from the filter lookup)
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
-        prob.split = {'Es': Es, 'enmax': g[1:2], 'overflow': g[2:3]}
+        prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'overflow': g[2:3]}
         prob.pre = pre
         return prob
 
