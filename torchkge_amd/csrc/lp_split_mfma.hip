@@ -285,17 +285,26 @@ __device__ __forceinline__ float split_acc_err(float amag, float aug_mag, float 
     const float sum_mag = amag >= 0.f ? amag * 1.003f + aug_mag : (float)units * mag;
     return c_acc * 48.0f * two24 * sum_mag;          // 48 additions per unit, each within c_acc * 2^-24 of the magnitude
 }
+// Rounding error of the exact fp32 chain the counts are defined by: one fmaf rounding per element, each within
+// 2^-24 of the partial sum it produces (running error bound) -- 16 per unit against the same prefix magnitudes,
+// or gamma_K * ||q|| ||e|| without them.
+__device__ __forceinline__ float split_chain_err(float amag, float mag, int K)
+{
+    const float two24 = 5.9604645e-8f;
+    return amag >= 0.f ? 16.16f * two24 * amag * 1.003f : 1.01f * (float)K * two24 * mag;
+}
 
 __device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int K, int units, float c_acc, float eps_scale,
                                                float amag)
 {
-    const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
-    const float eps_rel = (1.01f * (float)K) * two24 + 3.01f * two22;    // exact chain (gamma_K) + split residual
+    const float two22 = 2.3841858e-7f;
+    const float eps_rel = 3.01f * two22;             // split residual
     const float enrm = sqrtf(em) * 1.000001f, qnrm = sqrtf(q) * 1.000001f;
     const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
     const float u = -st;                             // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
     const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
-    const float eps_dot = split_acc_err(amag, 0.5f * em, mag, units, c_acc) + eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
+    const float eps_dot = split_acc_err(amag, 0.5f * em, mag, units, c_acc) + split_chain_err(amag, mag, K) + eps_rel * mag +
+                          2.5e-7f * (qnrm + enrm) + 4e-9f;
     const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
     const float mid = 0.5f * (q - u);
     const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
@@ -304,7 +313,7 @@ __device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int 
 
 __global__ void split_thr_kernel(const SplitThrParams p)
 {
-    const float two24 = 5.9604645e-8f, two22 = 2.3841858e-7f;
+    const float two22 = 2.3841858e-7f;
     const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *p.list_count = 0;
@@ -316,7 +325,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
     // accumulation: 48*units fp32 additions, c_acc = 2 (adders that truncate instead of rounding, any order)
     // or 1.25 when kge_mfma_f16_selftest confirmed the measured behaviour (<= 9/8 per product, see below);
     // exact chain: K fmaf roundings (gamma_K <= 1.01 K u); split residual 3 * 2^-22 * (1 + 2^-10)
-    const float eps_rel = (1.01f * (float)p.K) * two24 + 3.01f * two22;
+    const float eps_rel = 3.01f * two22;             // split residual
     const float enrm = sqrtf(em) * 1.000001f;
     const bool have_pref = p.q_cell_ss && p.e2pref;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.Bp; i += (int64_t)gridDim.x * blockDim.x) {
@@ -339,8 +348,8 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
             const float u = -p.s_true[i];                    // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
             const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
-            const float eps_dot = split_acc_err(amag, 0.5f * em, mag, p.units, p.c_acc) + eps_rel * mag +
-                                  2.5e-7f * (qnrm + enrm) + 4e-9f;
+            const float eps_dot = split_acc_err(amag, 0.5f * em, mag, p.units, p.c_acc) + split_chain_err(amag, mag, p.K) +
+                                  eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
             const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * p.eps_scale;
             const float mid = 0.5f * (q - u);
             float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
@@ -362,8 +371,8 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float st = p.s_true[i];
             const float sqk = sqrtf((float)p.K);
             const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
-            const float eps_dot = (split_acc_err(amag, 0.f, qnrm * enrm, p.units, p.c_acc) + eps_rel * qnrm * enrm +
-                                   eps_abs) * p.eps_scale;
+            const float eps_dot = (split_acc_err(amag, 0.f, qnrm * enrm, p.units, p.c_acc) +
+                                   split_chain_err(amag, qnrm * enrm, p.K) + eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
             const float hw = eps_dot + two22 * fabsf(st);
             p.thr[i] = make_float2(split_nonzero_lo((st - hw) * out_scale), (st + hw) * out_scale);
         }
