@@ -1100,7 +1100,14 @@ def test_query_pipeline_equals_separate_kernels(hip, B, N, d, side):
     assert torch.equal(pre['s_true'].view(torch.int32), st.view(torch.int32))
     assert torch.equal(pre['Qs'], prep_ref['Qs'])
     Bp = pre['thr'].numel() // 4
-    assert torch.equal(pre['thr'][:2 * Bp].view(torch.int32), prep_ref['thr'][:2 * Bp].view(torch.int32))
+    # thresholds: same formula; the magnitude sum of the band comes from the chain's running value here and from
+    # cell sums there (equal up to rounding; both inside the band's safety factor)
+    thr_a, thr_b = pre['thr'][:2 * Bp].view(-1, 2), prep_ref['thr'][:2 * Bp].view(-1, 2)
+    assert torch.equal(torch.isinf(thr_a), torch.isinf(thr_b))
+    fin = ~torch.isinf(thr_a)
+    assert torch.allclose(thr_a[fin], thr_b[fin], rtol=1e-5, atol=0.0)
+    mid_a, mid_b = thr_a[:B].sum(1), thr_b[:B].sum(1)           # band centres agree to rounding
+    assert torch.allclose(mid_a, mid_b, rtol=1e-6, atol=1e-3)
     assert float(guard[0]) == float(g_ref[0])                # max ||q||^2 folded into the guard
 
     pre['true_idx'] = true

@@ -20,6 +20,14 @@ static inline hipStream_t kge_s(kge_stream_t s) { return reinterpret_cast<hipStr
 
 static inline bool kge_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Running maximum in a device scalar (non-negative floats compared as bit patterns).  Same-address atomics
+// serialise at ~12 ns each on this part (they are resolved past the per-XCD L2s), so a wave first LOOKS:
+// the scalar only grows, a stale (smaller) reading merely costs the atomic it would have saved.
+__device__ __forceinline__ void kge_atomic_max_u32(unsigned *addr, unsigned v)
+{
+    if (v > __builtin_nontemporal_load(addr)) atomicMax(addr, v);
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

@@ -130,7 +130,7 @@ __global__ void row_sqnorm_kernel(const float *__restrict__ X, int64_t ld, int64
     if (max_io) {
         unsigned m = __float_as_uint(big);
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-        if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned *>(max_io), m);
+        if ((threadIdx.x & 63) == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), m);
     }
 }
 // The same chains with the rows fetched cooperatively: a wavefront owns 64 rows,
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void row_sqnorm_staged_kernel(const float *__re
     if (max_io) {
         unsigned m = __float_as_uint(big);
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-        if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned *>(max_io), m);
+        if (lane == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), m);
     }
 }
 __global__ void row_dot_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t ld,

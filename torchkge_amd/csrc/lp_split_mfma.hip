@@ -173,10 +173,14 @@ __global__ void split_rows_kernel(const SplitRowsParams p)
 // same prefix norms of a query, || q[:k] || * sqrt(e2pref) bounds every partial sum the MFMA
 // accumulator holds while it works through unit u (Cauchy-Schwarz on the prefix) -- the error band
 // then charges each unit with ITS magnitude instead of the full ||q|| ||e|| (about half of it).
-__global__ void prefix_max_kernel(const float *__restrict__ cell_ss, int64_t rows_p, int64_t rows, int units_p,
-                                  float *e2pref)
+__global__ __launch_bounds__(1024) void prefix_max_kernel(const float *__restrict__ cell_ss, int64_t rows_p, int64_t rows,
+                                                          int units_p, float *e2pref)
 {
+    // block maxima in LDS, ONE global atomic per (block, unit): same-line atomics serialise at ~12 ns each
+    __shared__ unsigned smax[128];
     const int lane = threadIdx.x & 63;
+    for (int u = threadIdx.x; u < units_p; u += blockDim.x) smax[u] = 0u;
+    __syncthreads();
     for (int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; r0 < rows;
          r0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = r0 + lane;
@@ -185,13 +189,14 @@ __global__ void prefix_max_kernel(const float *__restrict__ cell_ss, int64_t row
             if (r < rows) prefix += cell_ss[(int64_t)u * rows_p + r];
             unsigned m = __float_as_uint(prefix);       // sums of squares: >= 0, ordered like their bit patterns
             for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-            if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned *>(e2pref) + u, m);
+            if (lane == 0) atomicMax(&smax[u], m);
         }
     }
+    __syncthreads();
+    for (int u = threadIdx.x; u < units_p; u += blockDim.x) kge_atomic_max_u32(reinterpret_cast<unsigned *>(e2pref) + u, smax[u]);
 }
 
-// One step of the per-query magnitude sum (shared by split_thr_kernel and the fused query pipeline, which
-// must agree bit for bit): prefix += cell sum;  amag += sqrt(prefix * e2pref[u])
+// One step of the per-query magnitude sum: prefix += cell sum;  amag += sqrt(prefix * e2pref[u])
 __device__ __forceinline__ void split_amag_step(float &prefix, float &amag, float ss, float e2u)
 {
     prefix = prefix + ss;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     __syncthreads();
     if (threadIdx.x == 0) {
         u = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-        if (u) atomicMax(reinterpret_cast<unsigned *>(max_io), u);
+        kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), u);
     }
 }
 
@@ -405,21 +410,24 @@ struct QueryPipeParams {
 };
 
 template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
-__global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParams p)
+__global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipeParams p)
 {
     // rows staged cooperatively 48 k at a time (row stride 52 floats: conflict-free b128), the two
     // sequential chains run one lane per query; few queries per wavefront = many wavefronts in flight
     // (the chains are latency bound)
     constexpr int KC = 48, LD = 52;
-    __shared__ __attribute__((aligned(16))) float qs[QPW * LD];
-    __shared__ __attribute__((aligned(16))) float ts[QPW * LD];
-    const int lane = threadIdx.x;
+    // (4 independent wavefronts per block, each on its own LDS slice: they only share the final atomic)
+    __shared__ __attribute__((aligned(16))) float qs_all[4 * QPW * LD];
+    __shared__ __attribute__((aligned(16))) float ts_all[4 * QPW * LD];
+    __shared__ unsigned wmax[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *qs = qs_all + wv * QPW * LD, *ts = ts_all + wv * QPW * LD;
     const int d = p.d, kpad = p.units_p * 16;
-    if (blockIdx.x == 0 && lane == 0) *p.list_count = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
     const float em = *p.emax;
     float qbig = 0.f;
     const int64_t ngroups = (p.Bp + QPW - 1) / QPW;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
         const int64_t i = grp * QPW + lane;
         const bool valid = lane < QPW && i < p.B;
         const int64_t ic = valid ? i : 0;
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
         const int64_t src = tl ? p.h[fi] : p.t[fi], tru = tl ? p.t[fi] : p.h[fi], ri = p.r[fi];
         const int tli = tl ? 1 : 0;
         float qn = 0.f, acc = 0.f;
-        float ss = 0.f, prefix = 0.f, amag = 0.f;               // split_rows' cell sums / split_thr's magnitude sum
+        float amag = 0.f;                                        // split_thr's magnitude sum
         for (int k0 = 0; k0 < kpad; k0 += KC) {
             const int kc = max(0, min(KC, d - k0));              // data columns of this chunk
             const int pieces = kc >> 2;
@@ -455,15 +463,13 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (kc > 0 && lane < QPW) {
                 const float *x = qs + lane * LD;
-                for (int k = 0; k < kc; ++k) qn = fmaf(x[k], x[k], qn);         // row_sqnorm_kernel's chain
-                if (p.e2pref) {
-                    for (int k = 0; k < kc; ++k) {
-                        ss = fmaf(x[k], x[k], ss);
-                        if (((k0 + k) & 15) == 15 || k0 + k == d - 1) {         // end of a k16 cell (or of the data)
-                            split_amag_step(prefix, amag, ss, p.e2pref[(k0 + k) >> 4]);
-                            ss = 0.f;
-                        }
-                    }
+                // row_sqnorm_kernel's chain; its value at the end of every k16 cell is the prefix squared norm
+                // of the magnitude sum (split_thr_kernel adds up cell sums instead: equal up to rounding, and
+                // the band carries a 1.003 factor)
+                for (int k = 0; k < kc; ++k) {
+                    qn = fmaf(x[k], x[k], qn);
+                    if (p.e2pref && (((k0 + k) & 15) == 15 || k0 + k == d - 1))
+                        amag = amag + sqrtf(qn * p.e2pref[(k0 + k) >> 4]);
                 }
                 acc = lp_chain_dot(x, ts + lane * LD, kc, acc);                 // the pair kernel's chain
             }
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
                 p.qn[i] = qn;
                 p.s_true[i] = st;
                 if (p.e2pref) {     // units past the data (the augmentation column alone in its unit)
-                    for (int u = (d + 15) >> 4; u < p.units; ++u) split_amag_step(prefix, amag, 0.f, p.e2pref[u]);
+                    for (int u = (d + 15) >> 4; u < p.units; ++u) amag = amag + sqrtf(qn * p.e2pref[u]);
                 } else {
                     amag = -1.0f;
                 }
@@ -507,10 +513,13 @@ __global__ __launch_bounds__(64) void query_pipeline_kernel(const QueryPipeParam
             }
         }
     }
-    if (p.qmax_io) {
+    if (p.qmax_io) {    // one atomic per block (same-address atomics serialise at ~12 ns each)
         unsigned m = __float_as_uint(qbig);
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-        if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned *>(p.qmax_io), m);
+        if (lane == 0) wmax[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.qmax_io), max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
     }
 }
 
@@ -978,8 +987,9 @@ extern "C" int kge_lp_split_prefix_max(const float *cell_ss, int64_t rows, int i
     if (rows == 0) return 0;
     if (!cell_ss || !e2pref) return KGE_EINVAL;
     const int64_t rows_p = kge_lp_split_rows_padded(rows, is_query);
-    const int64_t want = (rows + 255) / 256;
-    hipLaunchKernelGGL(prefix_max_kernel, dim3((int)(want < 2048 ? want : 2048)), dim3(256), 0, kge_s(stream), cell_ss,
+    if (units_p > 128) return KGE_EINVAL;       // (K <= 2031)
+    const int64_t want = (rows + 1023) / 1024;
+    hipLaunchKernelGGL(prefix_max_kernel, dim3((int)(want < 512 ? want : 512)), dim3(1024), 0, kge_s(stream), cell_ss,
                        rows_p, rows, units_p, e2pref);
     KGE_CHECK_LAUNCH();
     return 0;
@@ -1169,12 +1179,10 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     p.e2pref = e2pref;
     if (d % 4 != 0 || !kge_aligned16(E) || !kge_aligned16(R)) return KGE_EINVAL;   // float4 staging
     const int qpw = kge_env_int("KGE_QPIPE_QPW", 32);
-    const int64_t groups = (p.Bp + qpw - 1) / qpw;
-    const int grid = (int)(groups < 256 * 16 ? groups : 256 * 16);
-    if (qpw == 64) hipLaunchKernelGGL(query_pipeline_kernel<64>, dim3(grid), dim3(64), 0, kge_s(stream), p);
-    else if (qpw == 32) hipLaunchKernelGGL(query_pipeline_kernel<32>, dim3(grid), dim3(64), 0, kge_s(stream), p);
-    else if (qpw == 8) hipLaunchKernelGGL(query_pipeline_kernel<8>, dim3(grid), dim3(64), 0, kge_s(stream), p);
-    else hipLaunchKernelGGL(query_pipeline_kernel<16>, dim3(grid), dim3(64), 0, kge_s(stream), p);
+    const int64_t groups = (p.Bp + qpw - 1) / qpw, blocks = (groups + 3) / 4;
+    const int grid = (int)(blocks < 256 * 8 ? blocks : 256 * 8);
+    if (qpw == 16) hipLaunchKernelGGL(query_pipeline_kernel<16>, dim3(grid), dim3(256), 0, kge_s(stream), p);
+    else hipLaunchKernelGGL(query_pipeline_kernel<32>, dim3(grid), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
 }
