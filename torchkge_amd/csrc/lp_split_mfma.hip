@@ -1178,11 +1178,12 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     p.list_count = list_count;
     p.e2pref = e2pref;
     if (d % 4 != 0 || !kge_aligned16(E) || !kge_aligned16(R)) return KGE_EINVAL;   // float4 staging
-    const int qpw = kge_env_int("KGE_QPIPE_QPW", 32);
+    const int qpw = kge_env_int("KGE_QPIPE_QPW", 16);
     const int64_t groups = (p.Bp + qpw - 1) / qpw, blocks = (groups + 3) / 4;
-    const int grid = (int)(blocks < 256 * 8 ? blocks : 256 * 8);
-    if (qpw == 16) hipLaunchKernelGGL(query_pipeline_kernel<16>, dim3(grid), dim3(256), 0, kge_s(stream), p);
-    else hipLaunchKernelGGL(query_pipeline_kernel<32>, dim3(grid), dim3(256), 0, kge_s(stream), p);
+    const int grid = (int)(blocks < 256 * 16 ? blocks : 256 * 16);
+    if (qpw == 8) hipLaunchKernelGGL(query_pipeline_kernel<8>, dim3(grid), dim3(256), 0, kge_s(stream), p);
+    else if (qpw == 32) hipLaunchKernelGGL(query_pipeline_kernel<32>, dim3(grid), dim3(256), 0, kge_s(stream), p);
+    else hipLaunchKernelGGL(query_pipeline_kernel<16>, dim3(grid), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
 }
