@@ -103,6 +103,17 @@ class HipRankEngine(object):
         return _hip.filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets)
 
 
+def _to_host(t):
+    """Device -> host through a pinned buffer of torch's caching host allocator (a pageable
+    destination is staged by the runtime in chunks: several times slower for the ~1 MB of ranks)."""
+    if not t.is_cuda:
+        return t
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host
+
+
 class _GraphSegments(object):
     """evaluate() of one entity shard as hipGraph segments with the collectives between them:
     the short launches of a batch replay without host gaps, the RCCL calls stay ordinary
@@ -409,7 +420,7 @@ class LinkPredictionEvaluator(object):
                 kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
                 worst, overflow = flags.tolist()
             else:   # one device-to-host transfer for the ranks and the two flags (8 bytes = one int64)
-                packed = flat.cpu()
+                packed = _to_host(flat)
                 worst, overflow = packed[-1:].view(torch.float32).tolist()
                 res = packed[:-1].view(4, n_local)
             redo = False
@@ -428,7 +439,7 @@ class LinkPredictionEvaluator(object):
         if self.shard == 'queries' and kdist.multi(world):
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
         if res is None:
-            res = out.cpu()
+            res = _to_host(out)
         self.rank_true_heads, self.rank_true_tails = res[0], res[1]
         self.filt_rank_true_heads, self.filt_rank_true_tails = res[2], res[3]
         self.evaluated = True
