@@ -261,6 +261,7 @@ __global__ __launch_bounds__(64) void filter_sub_staged_kernel(const kge_lp_desc
                     else score = true;
                 }
             }
+            if (__ballot(score) == 0ull) continue;      // this round lists only true entities / other shards' candidates
             const float sc = lp_pair_score_staged<VEC4>(d, score ? (int)i : 0, score ? (int)c : 0, qs, es);
             if (score) sub += ((sc >= tv) ? 1 : 0) - neg_inf_counts;
         }
