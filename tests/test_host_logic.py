@@ -43,6 +43,52 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert names == [f[0] for f in _hip.LpDesc._fields_]
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/kge_hip.h against the ctypes argtypes of _hip._SIGNATURES: same number of
+    parameters, pointers bound as void*, int / int32_t as c_int, int64_t as c_int64, float as c_float; and
+    struct kge_split_args field for field (a drifted binding would corrupt arguments silently)."""
+    import ctypes
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'kge_hip.h')).read(), flags=re.S)
+    protos = dict(re.findall(r'\bint\s+(kge_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', hdr, flags=re.S))
+
+    def kind(param):
+        param = param.strip()
+        if '*' in param:
+            return ctypes.c_void_p
+        t = param.split()
+        if 'kge_stream_t' in t:
+            return ctypes.c_void_p
+        if 'int64_t' in t:
+            return ctypes.c_int64
+        if 'float' in t:
+            return ctypes.c_float
+        if 'int' in t or 'int32_t' in t:
+            return ctypes.c_int
+        raise AssertionError('unparsed parameter: %r' % param)
+    checked = 0
+    for name, args in _hip._SIGNATURES.items():
+        assert name in protos, name
+        params = [] if protos[name].strip() in ('', 'void') else protos[name].split(',')
+        assert len(params) == len(args), (name, len(params), len(args))
+        for prm, a in zip(params, args):
+            k = kind(prm)
+            if k is ctypes.c_void_p:    # pointers are bound as void* or as POINTER(struct)
+                assert a is ctypes.c_void_p or issubclass(a, ctypes._Pointer), (name, prm)
+            elif k is ctypes.c_int:
+                assert a in (ctypes.c_int, ctypes.c_int32), (name, prm)
+            else:
+                assert a is k, (name, prm)
+        checked += 1
+    assert checked == len(_hip._SIGNATURES) >= 30
+    fields = re.search(r'typedef struct kge_split_args \{(.*?)\} kge_split_args;', hdr, re.S).group(1)
+    names = []
+    for decl in fields.split(';'):
+        decl = decl.strip()
+        if decl:
+            names += [re.sub(r'[\s\*]', '', x).split(' ')[-1] for x in re.sub(r'^(const\s+)?\w+\s+', '', decl).split(',')]
+    assert names == [f[0] for f in _hip.SplitArgs._fields_]
+
+
 def test_no_cpu_fallback():
     m = tk.TransEModel(8, 10, 3)
     i = torch.tensor([0, 1])
