@@ -270,6 +270,7 @@ struct SplitThrParams {
     const float *xabsmax, *yabsmax; // device scalars >= max |X|, max |y_c|
     float4 *thr4;
     float c_acc;                    // accumulation-error coefficient per product (2: any adder; 1.25: measured model)
+    int K0;                         // columns of the first K-segment (K - K0 of the second)
     const float *q_cell_ss;         // optional [units_p][Bp] cell sums of the queries (kge_lp_split_rows) ...
     const float *e2pref;            // ... and prefix squared-norm maxima of the candidates (kge_lp_split_prefix_max)
     int units_p;
@@ -318,6 +319,7 @@ __device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int 
 
 __global__ void split_thr_kernel(const SplitThrParams p)
 {
+    const float two24_c = 5.9604645e-8f;
     const float two22 = 2.3841858e-7f;
     const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -333,6 +335,10 @@ __global__ void split_thr_kernel(const SplitThrParams p)
     const float eps_rel = 3.01f * two22;             // split residual
     const float enrm = sqrtf(em) * 1.000001f;
     const bool have_pref = p.q_cell_ss && p.e2pref;
+    // two K-segments whose first is not a multiple of 8 long: the exact chain's 8-blocks of the second segment
+    // straddle the k16 cells, a partial sum may reach one cell ahead of its own -- one more full magnitude
+    // covers the 16 roundings per unit that are then charged to the earlier (smaller) prefix
+    const float straddle = (have_pref && p.K0 % 8 != 0 && p.K0 < p.K) ? 16.16f * two24_c : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.Bp; i += (int64_t)gridDim.x * blockDim.x) {
         if (i >= p.B) {
             if (p.mode >= KGE_LP_L2_PROJH) p.thr4[i] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
@@ -377,7 +383,8 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float sqk = sqrtf((float)p.K);
             const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
             const float eps_dot = (split_acc_err(amag, 0.f, qnrm * enrm, p.units, p.c_acc) +
-                                   split_chain_err(amag, qnrm * enrm, p.K) + eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
+                                   split_chain_err(amag, qnrm * enrm, p.K) + straddle * qnrm * enrm +
+                                   eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
             const float hw = eps_dot + two22 * fabsf(st);
             p.thr[i] = make_float2(split_nonzero_lo((st - hw) * out_scale), (st + hw) * out_scale);
         }
@@ -1031,7 +1038,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.pz = d->Wq; t.ldw = d->ldw;
     t.xabsmax = a->xabsmax; t.yabsmax = a->yabsmax;
     t.c_acc = a->accum_model == 1 ? 1.25f : 2.0f;
-    t.q_cell_ss = a->q_cell_ss; t.e2pref = a->e2pref; t.units_p = units_p;
+    t.q_cell_ss = a->q_cell_ss; t.e2pref = a->e2pref; t.units_p = units_p; t.K0 = d->K0;
     t.list_count = a->list_count;
     t.overflow = a->overflow;
     if (!a->thr_ready) {    // (the fused query pipeline has already written thr and zeroed list_count)
