@@ -191,6 +191,15 @@ int kge_lp_prep(int kind, int side, const float *t0, const float *t1, const floa
                 const int64_t *r, int64_t B, float *Q0, float *Q1, float *qn, float *Wq,
                 kge_stream_t stream);
 
+/* Relation candidates of the projection models (relation prediction, `entities=False`;
+ * TransH translation.py:252-256, TransD :621-626, scored as interfaces.py:261-272):
+ *   out[i*ldo + rho] = -|| p_rho(h_i) + R[rho] - p_rho(t_i) ||^2  for every relation rho < n_rel,
+ * p_rho as in kge_lp_prep (raw tables; Wt = W for KGE_TRANSH, Rp for KGE_TRANSD; Ep only TransD).
+ * Replaces two (b, n_rel, d) gathers from the reference's (n_rel, n_ent, d) projection cache. */
+int kge_relation_scores_proj(int kind, const float *E, const float *R, const float *Wt, const float *Ep,
+                             int d_ent, int d_rel, const int64_t *h, const int64_t *t, int64_t B,
+                             int64_t n_rel, float *out, int64_t ldo, kge_stream_t stream);
+
 /* out = op(a, b[, c, d]) elementwise over n floats (separate mul / add roundings,
  * as the reference's (re_h * re_r - im_h * im_r) etc., bilinear.py:514-522). */
 int kge_ewise(int op, const float *a, const float *b, const float *c, const float *d, int64_t n,
@@ -230,6 +239,19 @@ int kge_lp_count_ge(const kge_lp_desc *d, const float *s_true, int32_t *raw_coun
 int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
                       const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
                       int32_t *sub, int32_t *found, kge_stream_t stream);
+
+/* The same sub / found for a whole batch of link-prediction queries, load-balanced for heavy-tailed
+ * filter lists.  PRECONDITION: queries whose segments start at the same position have identical
+ * query rows (true for link prediction: the key (h, r) / (t, r) fixes both the filter list,
+ * utils/modeling.py:78, and the query vector) -- each distinct list is then scored once, all
+ * (list, target) pairs flattened over the grid, and every query only compares its true score with
+ * its list's scores; total scoring work <= n_targets whatever the skew.  n_targets = length of
+ * `targets`; ws = kge_lp_filter_sub_ws_bytes(B, n_targets) bytes of scratch. */
+int64_t kge_lp_filter_sub_ws_bytes(int64_t B, int64_t n_targets);
+int kge_lp_filter_sub_grouped(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
+                              const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                              int64_t n_targets, int32_t *sub, int32_t *found, void *ws, int64_t ws_bytes,
+                              kge_stream_t stream);
 
 /* rank[i] = raw[i]; filt_rank[i] = found[i] ? raw[i] - sub[i] : raw[i]  (int64 out) */
 int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,

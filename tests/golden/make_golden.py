@@ -93,6 +93,7 @@ def tables_of(kind, m):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. `relpred`: rewrite only ref_relpred.npz
     kg = make_kg(1234)
     kg_test = sub_kg(kg, N_TEST)
     common = dict(heads=kg.head_idx.numpy(), tails=kg.tail_idx.numpy(), rels=kg.relations.numpy(),
@@ -100,6 +101,8 @@ def main():
 
     for kind, p in [('transe', 2), ('transe', 1), ('transh', 2), ('transd', 2),
                     ('distmult', 2), ('complex', 2)]:
+        if only is not None:
+            break
         m = build_model(kind, p)
         # perturb tables a little so they are NOT exactly normalised: exercises
         # the on-the-fly normalisation of scoring_function vs raw tables at inference
@@ -142,7 +145,7 @@ def main():
 
     # ---- relation prediction (evaluation.py:16-204) + relation-candidate scores ----
     rp = dict(common)
-    for kind in ('transe', 'distmult', 'complex'):
+    for kind in ('transe', 'distmult', 'complex', 'transh', 'transd'):
         m = build_model(kind, 2)
         tabs = tables_of(kind, m)
         for i, tb in enumerate(tabs):
@@ -160,6 +163,9 @@ def main():
                 rp[tag + '_mrr'] = np.array(ev.mrr())
                 rp[tag + '_hit3'] = np.array(ev.hit_at_k(3))
     np.savez_compressed(os.path.join(HERE, 'ref_relpred.npz'), **rp)
+    if only is not None:
+        print('done (only %s)' % only)
+        return
 
     # ---- sampler ---------------------------------------------------------
     samp = BernoulliNegativeSampler(kg, n_neg=3)

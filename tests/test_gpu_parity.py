@@ -525,7 +525,7 @@ def test_dissimilarities_known_answers(hip):
 def _relpred_setup(kind):
     import torchkge_amd as tk
     z = np.load(GOLDEN + '/ref_relpred.npz')
-    ntab = 4 if kind == 'complex' else 2
+    ntab = {'complex': 4, 'transd': 4, 'transh': 3}.get(kind, 2)
     tables = [torch.from_numpy(z['%s_table%d' % (kind, i)]) for i in range(ntab)]
     n_ent, n_rel = int(z['n_ent']), int(z['n_rel'])
     m = build_model(kind, 2, tables, n_ent, n_rel)
@@ -537,7 +537,7 @@ def _relpred_setup(kind):
     return z, tables, m, kg, kg_test
 
 
-@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex'])
+@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex', 'transh', 'transd'])
 def test_relation_prediction_vs_reference(hip, kind):
     import torchkge_amd as tk
     z, tables, m, kg, kg_test = _relpred_setup(kind)
@@ -546,6 +546,15 @@ def test_relation_prediction_vs_reference(hip, kind):
     h_e, t_e, r_e, cand = m.inference_prepare_candidates(h, t, r, entities=False)
     s = m.inference_scoring_function(h_e, t_e, cand)
     assert np.abs(s.cpu().numpy() - z['%s_s_rel' % kind]).max() < TOL
+    if kind in ('transh', 'transd'):
+        # the handles stand for real (b, n_rel, d) tensors: the generic 3-D path gives the same scores
+        ph, pt = h_e.materialize(), t_e.materialize()
+        assert tuple(ph.shape) == tuple(h_e.shape) == (B, m.n_rel, cand.shape[2])
+        s2 = m.inference_scoring_function(ph, pt, cand.contiguous())
+        assert (s2 - s).abs().max().item() < TOL
+        P = orc.transh_projected_entities(tables[0], tables[2]) if kind == 'transh' else \
+            orc.transd_projected_entities(tables[0], tables[2], tables[3])
+        assert (ph.cpu() - P[:, h.cpu()].transpose(0, 1)).abs().max().item() < TOL
     for directed, tag in ((True, 'dir'), (False, 'undir')):
         ev = tk.RelationPredictionEvaluator(m, kg_test, directed=directed)
         with pytest.raises(tk.NotYetEvaluatedError):

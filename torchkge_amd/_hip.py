@@ -58,6 +58,7 @@ _SIGNATURES = {
     'kge_key_scatter': [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     'kge_lp_prep': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp,
                     _vp, _vp, _vp],
+    'kge_relation_scores_proj': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     'kge_row_dot': [_vp, _vp, _i64, _i64, _int, ctypes.c_float, _vp, _vp],
@@ -77,6 +78,7 @@ _SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
@@ -90,7 +92,7 @@ _SIGNATURES = {
 }
 # every symbol include/kge_hip.h declares
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version', 'kge_lp_split_rows_padded',
-                                               'kge_build_arch'])
+                                               'kge_build_arch', 'kge_lp_filter_sub_ws_bytes'])
 
 _lib = None
 
@@ -114,11 +116,13 @@ def load_library():
     lib.kge_corrupt_ws_elems.restype = _i64
     lib.kge_lp_split_rows_padded.argtypes = [_i64, _int]
     lib.kge_lp_split_rows_padded.restype = _i64
+    lib.kge_lp_filter_sub_ws_bytes.argtypes = [_i64, _i64]
+    lib.kge_lp_filter_sub_ws_bytes.restype = _i64
     lib.kge_abi_version.argtypes = []
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 11:
+    if lib.kge_abi_version() != 12:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -277,6 +281,22 @@ def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=Fal
                                d_ent, d_rel, _p(h), _p(t), _p(r), n_facts, _p(Q0), _p(Q1), _p(qn),
                                _p(Wq), _stream()), 'kge_lp_prep')
     return Q0, Q1, qn, Wq
+
+
+def relation_scores_proj(kind, E, R, Wt, Ep, d_ent, d_rel, h, t):
+    """(B, n_rel) scores of every relation for (h_i, ?, t_i) under the relation-specific projections of
+    TransH / TransD (kge_relation_scores_proj)."""
+    lib = load_library()
+    require_cuda(E, R, Wt, Ep, h, t)
+    E, R, Wt = f32c(E), f32c(R), f32c(Wt)
+    Ep = None if Ep is None else f32c(Ep)
+    h, t = i64c(h), i64c(t)
+    B, n_rel = h.shape[0], R.shape[0]
+    out = torch.empty(B, n_rel, dtype=torch.float32, device=E.device)
+    with _on(E.device):
+        _check(lib.kge_relation_scores_proj(kind, _p(E), _p(R), _p(Wt), _p(Ep), d_ent, d_rel, _p(h), _p(t), B, n_rel,
+                                            _p(out), out.stride(0), _stream()), 'kge_relation_scores_proj')
+    return out
 
 
 def ewise(op, a, b, c=None, d=None):
@@ -590,12 +610,24 @@ class LpProblem(object):
         self.last_split = (prep['n_list'], prep)     # kept alive until the launches have run; tests read n_list
         return raw
 
-    def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None):
+    def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None, grouped=False):
+        """Filter correction of every query.  ``grouped=True`` (link-prediction batches: queries that
+        share a filter segment share their query row): kge_lp_filter_sub_grouped -- each distinct
+        list scored once, pairs flattened over the grid (heavy-tailed lists stay cheap)."""
         lib = load_library()
         if sub is None:
             sub = torch.empty(self.B, dtype=torch.int32, device=self.device)
         if found is None:
             found = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        if grouped and self.B > 0:
+            n_t = int(targets.shape[0])
+            nb = int(lib.kge_lp_filter_sub_ws_bytes(self.B, n_t))
+            ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=self.device)
+            with _on(self.device):
+                _check(lib.kge_lp_filter_sub_grouped(ctypes.byref(self.desc), _p(s_true), _p(true_idx), _p(seg_lo),
+                                                     _p(seg_hi), _p(targets), n_t, _p(sub), _p(found), _p(ws), nb,
+                                                     _stream()), 'kge_lp_filter_sub_grouped')
+            return sub, found
         with _on(self.device):
             _check(lib.kge_lp_filter_sub(ctypes.byref(self.desc), _p(s_true), _p(true_idx),
                                          _p(seg_lo), _p(seg_hi), _p(targets), _p(sub), _p(found),

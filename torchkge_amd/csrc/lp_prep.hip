@@ -112,6 +112,51 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
     }
 }
 
+// Relation candidates of the projection models (relation prediction, `entities=False`):
+//   out[i, rho] = -|| p_rho(h_i) + R[rho] - p_rho(t_i) ||^2   for EVERY relation rho
+//   TransH  p_rho(e) = E[e] - (E[e].W[rho]) W[rho]                    translation.py:252-256, :270-282
+//   TransD  p_rho(e) = (Ep[e].E[e]) Rp[rho] + E[e, :d_r]             translation.py:621-626, :639-650
+// scored as interfaces.py:261-272 does (-dissimilarity(proj_h + r, proj_t)).  The reference gathers
+// two (b, n_rel, d) slices of its (n_rel, n_ent, d) projection cache; here one wavefront per
+// (fact, relation) pair forms both projections in registers: the rank-1 form, no cache.
+// Block = 4 waves = 4 consecutive relations of one fact (h, t rows shared through the L1/L2).
+__global__ __launch_bounds__(WPB * 64) void rel_proj_scores_kernel(int kind, const float *__restrict__ E,
+                                                                   const float *__restrict__ R,
+                                                                   const float *__restrict__ Wt, /* W or Rp */
+                                                                   const float *__restrict__ Ep, int de, int dr,
+                                                                   const int64_t *__restrict__ h,
+                                                                   const int64_t *__restrict__ t, int64_t B,
+                                                                   int64_t n_rel, float *out, int64_t ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB, total = B * n_rel;
+    for (int64_t pi = wave; pi < total; pi += nwaves) {
+        const int64_t i = pi / n_rel, rho = pi - i * n_rel;
+        const float *eh = E + h[i] * de, *et = E + t[i] * de;
+        const float *r = R + rho * dr, *w = Wt + rho * dr;
+        float ah = 0.f, at = 0.f;
+        if (kind == KGE_TRANSH) {
+            for (int k = lane; k < dr; k += 64) { ah = fmaf(eh[k], w[k], ah); at = fmaf(et[k], w[k], at); }
+        } else {
+            const float *ph = Ep + h[i] * de, *pt = Ep + t[i] * de;
+            for (int k = lane; k < de; k += 64) { ah = fmaf(ph[k], eh[k], ah); at = fmaf(pt[k], et[k], at); }
+        }
+        ah = wave_sum(ah);
+        at = wave_sum(at);
+        float acc = 0.f;
+        for (int k = lane; k < dr; k += 64) {
+            float pjh, pjt;
+            if (kind == KGE_TRANSH) { pjh = eh[k] - ah * w[k]; pjt = et[k] - at * w[k]; }
+            else { pjh = ah * w[k] + eh[k]; pjt = at * w[k] + et[k]; }
+            const float diff = (pjh + r[k]) - pjt;
+            acc = fmaf(diff, diff, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[i * ldo + rho] = -acc;
+    }
+}
+
 // serial single-accumulator chains (one thread per row): these feed
 // L2_EXPAND's qn / en and must match oracle orc_row_sqnorm_chain bit for bit.
 __global__ void row_sqnorm_kernel(const float *__restrict__ X, int64_t ld, int64_t rows, int K, float *out,
@@ -373,5 +418,21 @@ extern "C" int kge_lp_prep(int kind, int side, const float *t0, const float *t1,
     hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(nq)), dim3(WPB * 64), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     if (qn) return kge_row_sqnorm(Q0, d_rel, nq, d_rel, qn, nullptr, stream);
+    return 0;
+}
+
+extern "C" int kge_relation_scores_proj(int kind, const float *E, const float *R, const float *Wt, const float *Ep,
+                                        int d_ent, int d_rel, const int64_t *h, const int64_t *t, int64_t B,
+                                        int64_t n_rel, float *out, int64_t ldo, kge_stream_t stream)
+{
+    if (kind != KGE_TRANSH && kind != KGE_TRANSD) return KGE_EINVAL;
+    if (!E || !R || !Wt || d_ent <= 0 || d_rel <= 0 || B < 0 || n_rel < 0 || ldo < n_rel) return KGE_EINVAL;
+    if (kind == KGE_TRANSD && (!Ep || d_ent < d_rel)) return KGE_EINVAL;
+    if (kind == KGE_TRANSH && d_ent != d_rel) return KGE_EINVAL;
+    if (B == 0 || n_rel == 0) return 0;
+    if (!h || !t || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(rel_proj_scores_kernel, dim3(grid_rows(B * n_rel)), dim3(WPB * 64), 0, kge_s(stream), kind, E, R,
+                       Wt, Ep, d_ent, d_rel, h, t, B, n_rel, out, ldo);
+    KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -861,13 +861,16 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                 const int nc = min(n, UNC_CAP);
                 if (n > 0) {
                     int base = 0;
-                    if (lane == 0) base = atomicAdd(p.list_count, nc);
+                    // saturating: once the list is full the counter is left alone (it only ever grows), so it
+                    // stays below cap + #blocks * UNC_CAP and cannot wrap (cap <= INT32_MAX - 2^22, host side)
+                    if (lane == 0)
+                        base = (__builtin_nontemporal_load(p.list_count) >= p.cap) ? p.cap : atomicAdd(p.list_count, nc);
                     base = __shfl(base, 0, 64);
                     if (n > UNC_CAP && lane == 0) *p.overflow = 1.0f;
                     for (int i = lane; i < nc; i += 64) {
                         const unsigned e = unc_list[i];
                         const int pos = base + i;
-                        if (pos < p.cap) {
+                        if ((unsigned)pos < (unsigned)p.cap) {
                             p.list[2 * pos] = (int32_t)(cur_q0 + (e & 255u));
                             p.list[2 * pos + 1] = (int32_t)(c0 + (e >> 8));
                         } else {
@@ -908,7 +911,7 @@ __global__ __launch_bounds__(64) void split_recheck_kernel(const kge_lp_desc d, 
     __shared__ __attribute__((aligned(16))) float qs[64 * KGE_PS_LD];
     __shared__ __attribute__((aligned(16))) float es[64 * KGE_PS_LD];
     const int lane = threadIdx.x;
-    const int n = min(*list_count, cap);
+    const int n = (int)min((unsigned)*list_count, (unsigned)cap);   // (a count past the capacity means overflow: the caller redoes the count)
     const int ngroups = (n + 63) >> 6;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int pi = grp * 64 + lane;
@@ -1049,7 +1052,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     const void *Es = a->Es, *Qs = a->Qs;
     float *thr = a->thr, *overflow = a->overflow;
     int32_t *list = a->list, *list_count = a->list_count;
-    const int32_t cap = a->cap;
+    const int32_t cap = a->cap < INT32_MAX - (1 << 22) ? a->cap : INT32_MAX - (1 << 22);   // see the list flush: no wrap
     SplitParams p;
     p.Es = reinterpret_cast<const char *>(Es);
     p.Qs = reinterpret_cast<const char *>(Qs);

@@ -274,6 +274,138 @@ __global__ __launch_bounds__(64) void filter_sub_staged_kernel(const kge_lp_desc
     }
 }
 
+// ---- filter correction, grouped and flattened (kge_lp_filter_sub_grouped) ----------------------
+// Real link-prediction test splits are heavy-tailed: many queries share a key -- (h, r) on the tail
+// side, (t, r) on the head side -- and a hub key's filter list holds thousands of entities (FB15k-237:
+// gender / nationality / profession).  A key fixes BOTH the filter list and the query row, so the
+// exact scores of a list are the same for every query of that key.  Instead of walking each query's
+// list (8 lanes per query, the wavefront looping to its longest list: the r01 kernel), the lists the
+// batch touches are scored ONCE per key into fs[] (indexed like targets[]), all (key, target) pairs
+// flattened over the whole grid, and every query then only COMPARES its true score with its list's
+// scores.  Work is bounded by the size of the target array, whatever the skew.
+//   claim[T]  : smallest query index whose segment starts at that target position (0xffffffff: none)
+//   woff[B+1] : exclusive prefix sum of the claimed segments' lengths (the flattened work list)
+__global__ void fsub_claim_kernel(const int64_t *__restrict__ seg_lo, const int64_t *__restrict__ seg_hi, int64_t B,
+                                  unsigned *claim)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x)
+        if (seg_hi[i] > seg_lo[i]) atomicMin(&claim[seg_lo[i]], (unsigned)i);
+}
+
+constexpr int FS_SCAN_T = 1024, FS_SCAN_PER = 8;
+__global__ __launch_bounds__(FS_SCAN_T) void fsub_scan_kernel(const int64_t *__restrict__ seg_lo,
+                                                              const int64_t *__restrict__ seg_hi, int64_t B,
+                                                              const unsigned *__restrict__ claim, int64_t *woff)
+{
+    __shared__ int64_t wsum[FS_SCAN_T / 64];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < B; base += (int64_t)FS_SCAN_T * FS_SCAN_PER) {
+        int64_t len[FS_SCAN_PER], tot = 0;
+        const int64_t i0 = base + (int64_t)threadIdx.x * FS_SCAN_PER;
+#pragma unroll
+        for (int k = 0; k < FS_SCAN_PER; ++k) {
+            const int64_t i = i0 + k;
+            int64_t l = 0;
+            if (i < B) {
+                const int64_t lo = seg_lo[i], hi = seg_hi[i];
+                if (hi > lo && claim[lo] == (unsigned)i) l = hi - lo;
+            }
+            len[k] = l;
+            tot += l;
+        }
+        int64_t inc = tot; // inclusive scan over the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int64_t before = carry_s;
+        for (int w = 0; w < wv; ++w) before += wsum[w];
+        int64_t run = before + inc - tot;
+#pragma unroll
+        for (int k = 0; k < FS_SCAN_PER; ++k) {
+            const int64_t i = i0 + k;
+            if (i < B) woff[i] = run;
+            run += len[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == FS_SCAN_T - 1) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) woff[B] = carry_s;
+}
+
+// scores of the flattened (claimed key, target) pairs: one lane per pair, 64 pairs per wavefront round
+template <bool STAGED, bool VEC4>
+__global__ __launch_bounds__(64) void fsub_score_kernel(const kge_lp_desc d, const int64_t *__restrict__ seg_lo,
+                                                        const int32_t *__restrict__ targets,
+                                                        const int64_t *__restrict__ woff, float *fs)
+{
+    __shared__ __attribute__((aligned(16))) float qs[STAGED ? 64 * KGE_PS_LD : 4];
+    __shared__ __attribute__((aligned(16))) float es[STAGED ? 64 * KGE_PS_LD : 4];
+    const int lane = threadIdx.x;
+    const int64_t W = woff[d.B];
+    for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < W; w0 += (int64_t)gridDim.x * 64) {
+        const int64_t w = w0 + lane;
+        const bool valid = w < W;
+        int64_t lo = 0, hi = d.B; // first index with woff[idx] > w, minus one (zero-length entries are skipped)
+        if (valid) {
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (woff[mid + 1] <= w) lo = mid + 1; else hi = mid;
+            }
+        }
+        const int64_t i = lo;
+        int64_t j = 0, c = -1;
+        if (valid) {
+            j = seg_lo[i] + (w - woff[i]);
+            c = (int64_t)targets[j] - d.c_base;
+        }
+        const bool ok = valid && c >= 0 && c < d.N;
+        float sc;
+        if (STAGED) sc = lp_pair_score_staged<VEC4>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
+        else sc = ok ? lp_pair_score(d, i, c) : 0.f;
+        if (ok) fs[j] = sc;
+    }
+}
+
+// one wavefront per query: compare the true score with the scores of its list
+__global__ __launch_bounds__(256) void fsub_count_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                         const int64_t *__restrict__ true_idx,
+                                                         const int64_t *__restrict__ seg_lo,
+                                                         const int64_t *__restrict__ seg_hi,
+                                                         const int32_t *__restrict__ targets,
+                                                         const float *__restrict__ fs, int32_t *sub_out,
+                                                         int32_t *found_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = wave; i < d.B; i += nwaves) {
+        const int64_t lo = seg_lo[i], hi = seg_hi[i];
+        int sub = 0, found = 0;
+        if (hi > lo) {
+            const float tv = s_true[i];
+            const int64_t ti = true_idx[i];
+            const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+            for (int64_t j = lo + lane; j < hi; j += 64) {
+                const int64_t cg = targets[j];
+                const int64_t c = cg - d.c_base;
+                if (c < 0 || c >= d.N) continue;
+                if (cg == ti) { found = 1; continue; }
+                sub += ((fs[j] >= tv) ? 1 : 0) - neg_inf_counts;
+            }
+            sub = wave_sum_i(sub);
+            found = wave_sum_i(found);
+        }
+        if (lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
+    }
+}
+
 __global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
                                      const int32_t *__restrict__ found, int64_t B, int64_t *rank, int64_t *filt)
 {
@@ -511,6 +643,52 @@ extern "C" int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, cons
     return 0;
 }
 
+static inline int64_t fsub_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern "C" int64_t kge_lp_filter_sub_ws_bytes(int64_t B, int64_t n_targets)
+{
+    if (B < 0 || n_targets < 0) return 0;
+    return fsub_align(n_targets * 4) * 2 + fsub_align((B + 1) * 8);
+}
+
+extern "C" int kge_lp_filter_sub_grouped(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
+                                         const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                                         int64_t n_targets, int32_t *sub, int32_t *found, void *ws, int64_t ws_bytes,
+                                         kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0) return 0;
+    if (!s_true || !true_idx || !seg_lo || !seg_hi || !sub || !found || n_targets < 0) return KGE_EINVAL;
+    if (n_targets > 0 && (!targets || !ws || ws_bytes < kge_lp_filter_sub_ws_bytes(d->B, n_targets))) return KGE_EINVAL;
+    if (d->B > INT32_MAX || d->N > INT32_MAX) return KGE_EINVAL;
+    hipStream_t st = kge_s(stream);
+    char *w8 = static_cast<char *>(ws);
+    unsigned *claim = reinterpret_cast<unsigned *>(w8);
+    float *fs = reinterpret_cast<float *>(w8 + fsub_align(n_targets * 4));
+    int64_t *woff = reinterpret_cast<int64_t *>(w8 + 2 * fsub_align(n_targets * 4));
+    if (n_targets > 0 && d->N > 0) {
+        hipError_t e = hipMemsetAsync(claim, 0xff, (size_t)n_targets * 4, st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(fsub_claim_kernel, dim3(grid1d(d->B, 256)), dim3(256), 0, st, seg_lo, seg_hi, d->B, claim);
+        hipLaunchKernelGGL(fsub_scan_kernel, dim3(1), dim3(FS_SCAN_T), 0, st, seg_lo, seg_hi, d->B, claim, woff);
+        const int64_t groups = (n_targets + 63) / 64;     // upper bound of the flattened work (read on the device)
+        const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
+        if (KGE_LP_IS_MFMA(d->mode)) {
+            if (kge_lp_vec4(*d))
+                hipLaunchKernelGGL((fsub_score_kernel<true, true>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+            else
+                hipLaunchKernelGGL((fsub_score_kernel<true, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+        } else {
+            hipLaunchKernelGGL((fsub_score_kernel<false, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+        }
+    }
+    hipLaunchKernelGGL(fsub_count_kernel, dim3(grid1d(d->B, 4)), dim3(256), 0, st, *d, s_true, true_idx, seg_lo, seg_hi,
+                       targets, fs, sub, found);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
                                  int64_t *rank, int64_t *filt_rank, kge_stream_t stream)
 {
@@ -560,5 +738,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 11; }
+extern "C" int kge_abi_version(void) { return 12; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -82,7 +82,7 @@ class HipRankEngine(object):
         """int32 (3, B): raw >= counts, filter correction, found-true flag for this shard."""
         out = torch.zeros(3, prob.B, dtype=torch.int32, device=s_true.device)
         prob.count_ge(s_true, out[0])
-        prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2])
+        prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True)
         return out
 
     @staticmethod
@@ -158,14 +158,18 @@ class LinkPredictionEvaluator(object):
     shard: None | 'entities' | 'queries' -- multi-GPU partitioning (needs an
         initialised torch.distributed process group, one rank per GPU).
     exchange: 'counts' | 'scores' -- what entity shards exchange.
-    graph: bool -- capture one evaluate() into a hipGraph and replay it on later
-        calls with the same shapes (removes the host launch gaps between the
-        ~20 short kernels of a batch).
+    graph: None | bool -- replay evaluate() as a hipGraph (removes the host launch
+        gaps between the ~20 short kernels of a batch).  True: capture on the first
+        call.  None (default, 'auto'): the first call with given shapes runs eagerly
+        and serves as the warm-up, the second one captures, later ones replay -- a
+        single evaluation never pays for a capture, a validation loop gets the graph.
+        False: always eager.  A capture that fails (e.g. a user model that syncs)
+        falls back to eager for good.
     group: torch.distributed process group (default: WORLD).
     """
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
-                 group=None, engine=None, graph=False, overlap=False, both_sides=True):
+                 group=None, engine=None, graph=None, overlap=False, both_sides=True):
         self.model = model
         self.kg = knowledge_graph
         n = knowledge_graph.n_facts
@@ -178,8 +182,8 @@ class LinkPredictionEvaluator(object):
         assert exchange in ('counts', 'scores')
         self.fused, self.shard, self.exchange, self.group = fused, shard, exchange, group
         self.engine = engine if engine is not None else HipRankEngine()
-        self.graph = graph and engine is None       # replay evaluate() as one hipGraph (single GPU)
-        self._graph = self._graph_static = self._graph_key = self._graph_src = None
+        self.graph = graph if engine is None else False   # replay evaluate() as one hipGraph (see above)
+        self._graph = self._graph_static = self._graph_key = self._graph_src = self._graph_seen = None
         self.overlap = overlap                      # two-stream overlap of the short kernels (single GPU, fused)
         self._aux_stream = None
         # both sides of a batch as ONE 2B-query problem (single GPU, fused): every latency-bound short
@@ -321,121 +325,150 @@ class LinkPredictionEvaluator(object):
             guard = self.model.lp_guard_begin(device)   # TransE-L2: optimistic MFMA norm expansion
         session = self.model.lp_session() if hasattr(self.model, 'lp_session') else _NullCtx()
 
-        overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
-                   isinstance(self.engine, HipRankEngine) and device.type == 'cuda')
+        try:
+            overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
+                       isinstance(self.engine, HipRankEngine) and device.type == 'cuda')
 
-        both = (self.both_sides and self.fused and not self._generic_model and not overlap and
-                not (sharded and self.exchange == 'scores') and hasattr(self.engine, 'lookup_both'))
+            both = (self.both_sides and self.fused and not self._generic_model and not overlap and
+                    not (sharded and self.exchange == 'scores') and hasattr(self.engine, 'lookup_both'))
 
-        def alloc_out():
-            # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
-            flat = torch.empty(4 * n_local + 1, dtype=torch.int64, device=device)
-            return flat, flat[:4 * n_local].view(4, n_local), flat[4 * n_local:].view(torch.float32)
+            def alloc_out():
+                # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
+                flat = torch.empty(4 * n_local + 1, dtype=torch.int64, device=device)
+                return flat, flat[:4 * n_local].view(4, n_local), flat[4 * n_local:].view(torch.float32)
 
-        def run(heads, tails, rels, out, fl):
-            with session, torch.no_grad():
-                if guard is not None and self.model._expand_ok is None:
-                    guard.zero_()
-                n_batches = get_n_batches(n_local, b_size)
-                for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
-                              desc='Link prediction evaluation'):
-                    sl = slice(i * b_size, (i + 1) * b_size)
-                    h, t, r = heads[sl], tails[sl], rels[sl]
-                    if overlap:
-                        out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
-                            self._rank_batch_overlapped(h, t, r, index_t, index_h)
-                        continue
-                    if both:
-                        self._rank_batch_both(h, t, r, index_t, index_h, out, i * b_size, lo, hi, sharded)
-                        continue
-                    out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
-                    out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
-                if guard is not None:   # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks
-                    torch.add(guard[0:1], guard[1:2], out=fl[0:1])
-                    fl[1:2].copy_(guard[2:3])
+            def run(heads, tails, rels, out, fl):
+                with session, torch.no_grad():
+                    if guard is not None and self.model._expand_ok is None:
+                        guard.zero_()
+                    n_batches = get_n_batches(n_local, b_size)
+                    for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
+                                  desc='Link prediction evaluation'):
+                        sl = slice(i * b_size, (i + 1) * b_size)
+                        h, t, r = heads[sl], tails[sl], rels[sl]
+                        if overlap:
+                            out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
+                                self._rank_batch_overlapped(h, t, r, index_t, index_h)
+                            continue
+                        if both:
+                            self._rank_batch_both(h, t, r, index_t, index_h, out, i * b_size, lo, hi, sharded)
+                            continue
+                        out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
+                        out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
+                    if guard is not None:   # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks
+                        torch.add(guard[0:1], guard[1:2], out=fl[0:1])
+                        fl[1:2].copy_(guard[2:3])
 
-        # one hipGraph when run() contains no collective (single GPU, query shards); graph segments with
-        # the collectives between them for entity shards exchanging counts; eager otherwise
-        multi = kdist.multi(world)
-        segmented = multi and sharded and both
-        use_graph = (self.graph and device.type == 'cuda' and n_local > 0 and
-                     (not multi or self.shard == 'queries' or segmented))
-        if not use_graph:
-            heads = kg.head_idx[f_lo:f_hi].to(device)
-            tails = kg.tail_idx[f_lo:f_hi].to(device)
-            rels = kg.relations[f_lo:f_hi].to(device)
-            flat, out, fl = alloc_out()
-            run(heads, tails, rels, out, fl)
-        else:
-            # the whole evaluate() as ONE hipGraph: ~20 short launches per batch
-            # replayed without host launch gaps (capture is keyed on everything
-            # that fixes shapes and addresses; table VALUES may change freely)
-            key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, lo, hi, f_lo, f_hi,
-                   getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                   tuple(p_.data_ptr() for p_ in self.model.parameters()))
-            if self._graph_key != key:
-                st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
-                      'r': kg.relations[f_lo:f_hi].to(device).clone(),
-                      'out': alloc_out()}
-                side = torch.cuda.Stream(device)
-                side.wait_stream(torch.cuda.current_stream(device))
-                with torch.cuda.stream(side):            # warm-up outside capture (lazy inits, attribute sets)
-                    run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
-                torch.cuda.current_stream(device).wait_stream(side)
-                if segmented:
-                    g = _GraphSegments()
-                    self._cut = g.cut
-                    g.begin()
-                    try:
-                        run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
-                    except BaseException:
-                        import sys
-                        g.end(sys.exc_info())
-                        raise
-                    finally:
-                        self._cut = None
-                    g.end()
-                else:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
-                self._graph, self._graph_static, self._graph_key = g, st, key
-                self._graph_src = None
-            st = self._graph_static
-            src = tuple((x.data_ptr(), x._version, f_lo, f_hi) for x in (kg.head_idx, kg.tail_idx, kg.relations))
-            if src != self._graph_src:      # refresh the graph's static inputs only when the facts changed
-                st['h'].copy_(kg.head_idx[f_lo:f_hi], non_blocking=True)
-                st['t'].copy_(kg.tail_idx[f_lo:f_hi], non_blocking=True)
-                st['r'].copy_(kg.relations[f_lo:f_hi], non_blocking=True)
-                self._graph_src = src
-            self._graph.replay()
-            flat, out, fl = st['out']
-
-        res = None
-        if guard is not None:
-            # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
-            # cancellation error could exceed the score tolerance -> redo on the VALU kernel
-            if kdist.multi(world):
-                flags = fl.clone()
-                kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
-                worst, overflow = flags.tolist()
-            else:   # one device-to-host transfer for the ranks and the two flags (8 bytes = one int64)
-                packed = _to_host(flat)
-                worst, overflow = packed[-1:].view(torch.float32).tolist()
-                res = packed[:-1].view(4, n_local)
-            redo = False
-            if not worst <= self.model.L2_EXPAND_LIMIT:
-                self.model._expand_ok = False
-                redo = True
-            elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
-                self.model._split_ok = False
-                redo = True
-            if redo:
-                res = None
+            # one hipGraph when run() contains no collective (single GPU, query shards); graph segments with
+            # the collectives between them for entity shards exchanging counts; eager otherwise
+            multi = kdist.multi(world)
+            segmented = multi and sharded and both
+            use_graph = (self.graph is not False and device.type == 'cuda' and n_local > 0 and
+                         not self._generic_model and
+                         (not multi or self.shard == 'queries' or segmented))
+            key = None
+            if use_graph:
+                # capture is keyed on everything that fixes shapes and ADDRESSES (tables, filter index); table
+                # VALUES may change freely.  The filter indices are kept alive with the graph (their pointers
+                # are baked into it).
+                key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, lo, hi, f_lo, f_hi,
+                       getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
+                       tuple(p_.data_ptr() for p_ in self.model.parameters()),
+                       tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
+                             for x in (ix.keys, ix.offsets, ix.targets)))
+                if self.graph is None and self._graph_key != key and self._graph_seen != key:
+                    self._graph_seen = key      # 'auto': this eager call is the warm-up, the next one captures
+                    use_graph = False
+            if not use_graph:
+                heads = kg.head_idx[f_lo:f_hi].to(device)
+                tails = kg.tail_idx[f_lo:f_hi].to(device)
+                rels = kg.relations[f_lo:f_hi].to(device)
                 flat, out, fl = alloc_out()
-                run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
-                    kg.relations[f_lo:f_hi].to(device), out, fl)
-            self.model.lp_guard_end()
+                run(heads, tails, rels, out, fl)
+            else:
+                # the whole evaluate() as ONE hipGraph: ~20 short launches per batch replayed without host gaps
+                if self._graph_key != key:
+                    st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
+                          'r': kg.relations[f_lo:f_hi].to(device).clone(),
+                          'out': alloc_out(), 'index': (index_h, index_t), 'engine': self.engine}
+                    try:
+                        if self.graph is not None or self._graph_seen != key:
+                            side = torch.cuda.Stream(device)
+                            side.wait_stream(torch.cuda.current_stream(device))
+                            with torch.cuda.stream(side):            # warm-up outside capture (lazy inits, attribute sets)
+                                run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
+                            torch.cuda.current_stream(device).wait_stream(side)
+                        if segmented:
+                            g = _GraphSegments()
+                            self._cut = g.cut
+                            g.begin()
+                            try:
+                                run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
+                            except BaseException:
+                                import sys
+                                g.end(sys.exc_info())
+                                raise
+                            finally:
+                                self._cut = None
+                            g.end()
+                        else:
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g):
+                                run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
+                    except Exception as exc:
+                        if self.graph is True:
+                            raise
+                        import warnings
+                        warnings.warn('torchkge_amd: hipGraph capture of evaluate() failed (%s); running eagerly' % (exc,))
+                        self.graph = False
+                        self._graph = self._graph_static = self._graph_key = None
+                        torch.cuda.synchronize(device)
+                        flat, out, fl = alloc_out()
+                        run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
+                            kg.relations[f_lo:f_hi].to(device), out, fl)
+                        g = None
+                    if g is not None:
+                        st['targets_cat'] = getattr(self.engine, '_targets_cat', None)   # baked into the graph too
+                        self._graph, self._graph_static, self._graph_key = g, st, key
+                        self._graph_src = None
+                if self._graph_key == key:
+                    st = self._graph_static
+                    src = tuple((x.data_ptr(), x._version, f_lo, f_hi) for x in (kg.head_idx, kg.tail_idx, kg.relations))
+                    if src != self._graph_src:      # refresh the graph's static inputs only when the facts changed
+                        st['h'].copy_(kg.head_idx[f_lo:f_hi], non_blocking=True)
+                        st['t'].copy_(kg.tail_idx[f_lo:f_hi], non_blocking=True)
+                        st['r'].copy_(kg.relations[f_lo:f_hi], non_blocking=True)
+                        self._graph_src = src
+                    self._graph.replay()
+                    flat, out, fl = st['out']
+
+            res = None
+            if guard is not None:
+                # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
+                # cancellation error could exceed the score tolerance -> redo on the VALU kernel
+                if kdist.multi(world):
+                    flags = fl.clone()
+                    kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
+                    worst, overflow = flags.tolist()
+                else:   # one device-to-host transfer for the ranks and the two flags (8 bytes = one int64)
+                    packed = _to_host(flat)
+                    worst, overflow = packed[-1:].view(torch.float32).tolist()
+                    res = packed[:-1].view(4, n_local)
+                redo = False
+                if not worst <= self.model.L2_EXPAND_LIMIT:
+                    self.model._expand_ok = False
+                    redo = True
+                elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
+                    self.model._split_ok = False
+                    redo = True
+                if redo:
+                    res = None
+                    flat, out, fl = alloc_out()
+                    run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
+                        kg.relations[f_lo:f_hi].to(device), out, fl)
+        finally:
+            if guard is not None:      # never leave the model in guarded mode (exceptions included)
+                self.model.lp_guard_end()
         if self.shard == 'queries' and kdist.multi(world):
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
         if res is None:

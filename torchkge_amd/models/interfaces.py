@@ -87,6 +87,31 @@ class EntityCandidates(object):
         return 3
 
 
+class RelationProjections(object):
+    """Light handle standing for the reference's (b, n_rel, d) ``proj_h`` / ``proj_t`` of relation
+    prediction with relation-specific projections (TransH / TransD:
+    ``projected_entities[:, idx].transpose(0, 1)``, translation.py:253-254, :622-623): the
+    projection of each entity of ``idx`` under EVERY relation.  It names the entities instead of
+    gathering b * n_rel * d floats from an (n_rel, n_ent, d) cache the engine never builds;
+    ``materialize()`` gives the tensor itself."""
+
+    def __init__(self, model, idx, side):
+        self.model, self.idx, self.side = model, idx, side
+        self.shape = (idx.shape[0], model.n_rel, model._d_rel)
+
+    def dim(self):
+        return 3
+
+    def materialize(self):
+        m = self.model
+        b, n_rel, dr = self.shape
+        tabs = [x.data for x in m._tables()]
+        e = self.idx.repeat_interleave(n_rel)
+        r = torch.arange(n_rel, device=self.idx.device).repeat(b)
+        q = _hip.lp_prep(m._kind, self.side, tabs, m._d_ent, dr, e, e, r, want_w=True)[0]
+        return q.view(b, n_rel, dr)
+
+
 def _is_cand(x):
     if isinstance(x, EntityCandidates):
         return True
@@ -350,11 +375,19 @@ class TranslationModel(Model):
         argument (or EntityCandidates handle) is the candidate set
         (interfaces.py:240-272)."""
         if torch.is_tensor(r) and r.dim() == 3:
-            # relation prediction: -diss(h + r_c, t) = -diss(r_c, t - h)
-            if not (torch.is_tensor(proj_h) and proj_h.dim() == 2 and proj_t.dim() == 2):
-                raise NotYetImplementedError('relation candidates with relation-specific '
-                                             'projections (TransH/TransD) are not on the hot path')
-            return self._score_against(_hip.ewise(_hip.EW_SUB, proj_t, proj_h), r)
+            if torch.is_tensor(proj_h) and proj_h.dim() == 2 and torch.is_tensor(proj_t) and proj_t.dim() == 2:
+                # relation prediction without projections: -diss(h + r_c, t) = -diss(r_c, t - h)
+                return self._score_against(_hip.ewise(_hip.EW_SUB, proj_t, proj_h), r)
+            # relation-specific projections (interfaces.py:261-272): -diss(proj_h + r, proj_t) over (b, n_rel, d)
+            if isinstance(proj_h, RelationProjections) and isinstance(proj_t, RelationProjections):
+                fused = self._relation_scores_proj(proj_h, proj_t, r)
+                if fused is not None:
+                    return fused
+            ph = proj_h.materialize() if isinstance(proj_h, RelationProjections) else proj_h
+            pt = proj_t.materialize() if isinstance(proj_t, RelationProjections) else proj_t
+            ph, pt = ph.view(ph.shape[0], -1, r.shape[2]), pt.view(pt.shape[0], -1, r.shape[2])
+            ph, rr = torch.broadcast_tensors(ph, r)
+            return - self.dissimilarity(_hip.ewise(_hip.EW_ADD, ph.contiguous(), rr.contiguous()), pt)
         assert r.dim() == 2
         if _is_cand(proj_t):
             assert torch.is_tensor(proj_h) and proj_h.dim() == 2   # tail completion
@@ -373,6 +406,11 @@ class TranslationModel(Model):
 
     def _handle_problem(self, q, cand):
         raise NotImplementedError
+
+    def _relation_scores_proj(self, proj_h, proj_t, r):
+        """Fused relation-candidate scores when ``r`` is the (stride-0 expanded) relation table
+        itself -- what inference_prepare_candidates(entities=False) returns; else None."""
+        return None
 
 
 class BilinearModel(Model):

@@ -13,7 +13,7 @@ import torch
 from .. import _hip
 from ..exceptions import NotYetImplementedError
 from ..utils.modeling import init_embedding
-from .interfaces import TranslationModel, EntityCandidates
+from .interfaces import TranslationModel, EntityCandidates, RelationProjections, _table_of
 
 
 def _projections(kind, tabs, d_ent, d_rel, h_idx, t_idx, r_idx):
@@ -183,13 +183,24 @@ class TransHModel(TranslationModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(proj_h, proj_t, r, candidates) (translation.py:234-258); candidates
         is an EntityCandidates handle, not a (b, N, d) copy."""
-        if not entities:
-            raise NotYetImplementedError('TransH relation candidates are not on the hot path')
         tabs = [x.data for x in self._tables()]
         d = self.emb_dim
+        if not entities:    # translation.py:252-256: every entity projected under EVERY relation
+            r = _hip.gather_rows(tabs[1], r_idx)
+            cand = tabs[1].view(1, self.n_rel, d).expand(h_idx.shape[0], self.n_rel, d)
+            return (RelationProjections(self, _hip.i64c(h_idx), _hip.SIDE_PROJ_H),
+                    RelationProjections(self, _hip.i64c(t_idx), _hip.SIDE_PROJ_T), r, cand)
         proj_h, proj_t = _projections(_hip.TRANSH, tabs, d, d, h_idx, t_idx, r_idx)
         r = _hip.gather_rows(tabs[1], r_idx)
         return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), max(h_idx.shape[0], t_idx.shape[0]))
+
+    def _relation_scores_proj(self, proj_h, proj_t, r):
+        R = self.rel_emb.weight.data
+        tab = _table_of(r)
+        if tab is None or tab.data_ptr() != R.data_ptr() or tab.shape != R.shape:
+            return None
+        return _hip.relation_scores_proj(_hip.TRANSH, self.ent_emb.weight.data, R, self.norm_vect.weight.data, None,
+                                         self.emb_dim, self.emb_dim, proj_h.idx, proj_t.idx)
 
     def _handle_problem(self, q, cand, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
@@ -260,13 +271,25 @@ class TransDModel(TranslationModel):
 
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(proj_h, proj_t, r, candidates) (translation.py:603-627)."""
-        if not entities:
-            raise NotYetImplementedError('TransD relation candidates are not on the hot path')
         tabs = [x.data for x in self._tables()]
         de, dr = self.ent_emb_dim, self.rel_emb_dim
+        if not entities:    # translation.py:621-626
+            r = _hip.gather_rows(tabs[1], r_idx)
+            cand = tabs[1].view(1, self.n_rel, dr).expand(h_idx.shape[0], self.n_rel, dr)
+            return (RelationProjections(self, _hip.i64c(h_idx), _hip.SIDE_PROJ_H),
+                    RelationProjections(self, _hip.i64c(t_idx), _hip.SIDE_PROJ_T), r, cand)
         proj_h, proj_t = _projections(_hip.TRANSD, tabs, de, dr, h_idx, t_idx, r_idx)
         r = _hip.gather_rows(tabs[1], r_idx)
         return proj_h, proj_t, r, EntityCandidates(self, _hip.i64c(r_idx), max(h_idx.shape[0], t_idx.shape[0]))
+
+    def _relation_scores_proj(self, proj_h, proj_t, r):
+        R = self.rel_emb.weight.data
+        tab = _table_of(r)
+        if tab is None or tab.data_ptr() != R.data_ptr() or tab.shape != R.shape:
+            return None
+        return _hip.relation_scores_proj(_hip.TRANSD, self.ent_emb.weight.data, R, self.rel_proj_vect.weight.data,
+                                         self.ent_proj_vect.weight.data, self.ent_emb_dim, self.rel_emb_dim,
+                                         proj_h.idx, proj_t.idx)
 
     def _problem(self, q, Wq, ent_lo, ent_hi, r_idx=None):
         E = _hip.f32c(self.ent_emb.weight.data)

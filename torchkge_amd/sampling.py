@@ -133,10 +133,12 @@ class PositionalNegativeSampler(BernoulliNegativeSampler):
     """Socher et al. 2013: the head (or tail, Bernoulli choice of Wang et al. 2014) is
     replaced by an entity that already occupies that position for the same relation
     (sampling.py:330-505).  Same attributes as the reference (``possible_heads``,
-    ``possible_tails``, ``n_poss_heads``, ``n_poss_tails``) and the same random draws in
-    the same order (bernoulli, rand(n_heads), rand(n_tails), one randint per sample of a
-    relation without candidates); the per-sample Python loop of the reference
-    (:480-503) is a gather from a per-relation CSR on the device."""
+    ``possible_tails``, ``n_poss_heads``, ``n_poss_tails``) and the same KIND of random
+    draws in the same order (bernoulli, rand(n_heads), rand(n_tails), one randint per sample
+    of a relation without candidates) -- but issued on the DEVICE generator (the reference
+    draws ``rand`` / ``randint`` on the CPU generator, :470-503), so the samples are equally
+    distributed, not seed-identical to the reference's; the per-sample Python loop of the
+    reference (:480-503) is a gather from a per-relation CSR on the device."""
 
     def __init__(self, kg, kg_val=None, kg_test=None):
         super().__init__(kg, kg_val, kg_test, 1)
