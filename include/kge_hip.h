@@ -191,6 +191,16 @@ int kge_lp_prep(int kind, int side, const float *t0, const float *t1, const floa
                 const int64_t *r, int64_t B, float *Q0, float *Q1, float *qn, float *Wq,
                 kge_stream_t stream);
 
+/* The same with ROW-SHARDED entity tables (one shard per GPU): t0 (and t2 of TransD, t1 of
+ * ComplEx) hold only the rows [ent_lo, ent_lo + ent_n) of the entity tables, h / t stay GLOBAL ids.  The rank
+ * that owns the query's entity writes the row, every other rank writes zeros: an all-reduce SUM of Q0 (/Q1)
+ * over the shards (x + 0 is exact) gives every rank the full query matrix.  Relation tables are replicated,
+ * so Wq is complete on every rank.  qn (if requested) is only meaningful after that sum.  ent_n < 0: whole tables. */
+int kge_lp_prep_sharded(int kind, int side, const float *t0, const float *t1, const float *t2,
+                        const float *t3, int d_ent, int d_rel, const int64_t *h, const int64_t *t,
+                        const int64_t *r, int64_t B, int64_t ent_lo, int64_t ent_n, float *Q0, float *Q1,
+                        float *qn, float *Wq, kge_stream_t stream);
+
 /* Relation candidates of the projection models (relation prediction, `entities=False`;
  * TransH translation.py:252-256, TransD :621-626, scored as interfaces.py:261-272):
  *   out[i*ldo + rho] = -|| p_rho(h_i) + R[rho] - p_rho(t_i) ||^2  for every relation rho < n_rel,

@@ -82,7 +82,7 @@ class OracleRankEngine(object):
                 torch.cat([hi_t, torch.where(found, hi_h + base, hi_h)]),
                 torch.cat([t, h]), torch.cat([index_t.targets, index_h.targets]))
 
-    def problem(self, model, h, t, r, side, lo, hi):
+    def problem(self, model, h, t, r, side, lo, hi, exchange=None):
         from oracle import kge_oracle as orc
         if side == 'both':      # 2B queries: tail side first
             full = torch.cat([orc.lp_scores(self.kind, self.tables, h, t, r, 'tail', self.p),
@@ -148,3 +148,88 @@ class OracleRankEngine(object):
             else:
                 frk[i] = raw
         return rk, frk
+
+
+class ShardedOracleEngine(OracleRankEngine):
+    """CPU stand-in for the HIP engine on a ROW-SHARDED model (TEST ONLY): it reads the entity
+    tables from the model itself -- which holds only rows [lo, hi) after distributed.shard_model_ --
+    builds the rows of the queries whose entity it owns (zeros elsewhere), has the evaluator's
+    exchange sum them over the ranks, and scores its own candidates with the reference's formulas
+    (oracle.lp_scores, restated on explicit rows).  TransE / DistMult / ComplEx."""
+
+    name = 'oracle-sharded'
+
+    def __init__(self, kind, p=2):
+        self.kind, self.p = kind, p
+
+    @staticmethod
+    def _rows(table, idx, lo, hi):
+        own = (idx >= lo) & (idx < hi)
+        out = torch.zeros(idx.shape[0], table.shape[1])
+        out[own] = table[idx[own] - lo]
+        return out
+
+    def problem(self, model, h, t, r, side, lo, hi, exchange=None):
+        from oracle import kge_oracle as orc
+        assert model._row_shard == (lo, hi) and exchange is not None
+        tabs = [x.data for x in model._tables()]
+        n_et = 2 if self.kind == 'complex' else 1
+        ent, rel = tabs[:n_et], tabs[n_et:]
+        assert all(x.shape[0] == hi - lo for x in ent)
+        rows_h = [self._rows(x, h, lo, hi) for x in ent]
+        rows_t = [self._rows(x, t, lo, hi) for x in ent]
+        exchange(rows_h + rows_t)                   # one SUM all-reduce per matrix: x + 0 is exact
+        b = h.shape[0]
+        rr = [x[r] for x in rel]
+
+        def tile(sd):
+            if self.kind == 'transe':               # oracle._translation_inference
+                cand = ent[0].view(1, hi - lo, -1).expand(b, -1, -1)
+                if sd == 'tail':
+                    return orc._translation_inference(self.p, rows_h[0], cand, rr[0])
+                return orc._translation_inference(self.p, cand, rows_t[0], rr[0])
+            if self.kind == 'distmult':
+                d = ent[0].shape[1]
+                cand = ent[0].view(1, hi - lo, d).expand(b, -1, -1)
+                if sd == 'tail':
+                    return ((rows_h[0] * rr[0]).view(b, 1, d) * cand).sum(dim=2)
+                return (cand * (rr[0] * rows_t[0]).view(b, 1, d)).sum(dim=2)
+            d = ent[0].shape[1]
+            re_c = ent[0].view(1, -1, d).expand(b, -1, -1)
+            im_c = ent[1].view(1, -1, d).expand(b, -1, -1)
+            (re_h, im_h), (re_t, im_t), (re_r, im_r) = rows_h, rows_t, rr
+            if sd == 'tail':
+                return ((re_h * re_r - im_h * im_r).view(b, 1, d) * re_c
+                        + (re_h * im_r + im_h * re_r).view(b, 1, d) * im_c).sum(dim=2)
+            return (re_c * (re_r * re_t + im_r * im_t).view(b, 1, d)
+                    + im_c * (re_r * im_t - im_r * re_t).view(b, 1, d)).sum(dim=2)
+
+        class P(object):
+            pass
+        pr = P()
+        pr.local = torch.cat([tile('tail'), tile('head')]) if side == 'both' else tile(side)
+        pr.B, pr.lo, pr.hi = pr.local.shape[0], lo, hi
+        return pr
+
+    def true_scores(self, prob, true_idx):
+        own = (true_idx >= prob.lo) & (true_idx < prob.hi)
+        st = prob.local.gather(1, (true_idx - prob.lo).clamp(0, prob.hi - prob.lo - 1).view(-1, 1)).view(-1)
+        return torch.where(own, st, torch.zeros_like(st))
+
+    def partial_counts(self, prob, s_true, true_idx, seg_lo, seg_hi, targets):
+        out = torch.zeros(3, prob.B, dtype=torch.int32)
+        out[0] = (prob.local >= s_true.view(-1, 1)).sum(1).int()
+        for i in range(prob.B):
+            tv = s_true[i]
+            neg = 1 if (-float('inf') >= tv) else 0
+            for c in targets[int(seg_lo[i]):int(seg_hi[i])].tolist():
+                if c < prob.lo or c >= prob.hi:
+                    continue
+                if c == int(true_idx[i]):
+                    out[2, i] = 1
+                    continue
+                out[1, i] += int(prob.local[i, c - prob.lo] >= tv) - neg
+        return out
+
+    def local_scores(self, prob):
+        return prob.local.contiguous()

@@ -52,7 +52,10 @@ def test_full_test_split_vs_gpu_resident_reference(hip, workload, weights):
              par['filt_hits10_ref_hip'][0], par['filt_hits10_ref_hip'][1], par['median_filt_rank_ref']))
     assert par['ranks_compared'] == 4 * info['n_test']
     assert par['within_reference_tie_interval_2e-5'], par
-    assert par['abs_diff_filt_mrr'] < 1e-5 and par['abs_diff_filt_hits10'] < 1e-5, par
+    # Hits@10 is a step function of the ranks: ONE near-tie flip across rank 10 (inside the tie interval, checked
+    # above) moves it by 0.5 / n_test (8.5e-6 at cfg4) -- allow exactly the flips that were counted, nothing else
+    assert par['abs_diff_filt_mrr'] < 1e-5, par
+    assert par['abs_diff_filt_hits10'] < 1e-5 + par['filtered_ranks_across_the_hits10_boundary'] * 0.5 / info['n_test'], par
     assert abs(par['mrr_ref_hip'][0] - par['mrr_ref_hip'][1]) < 1e-5
     if weights == 'trained':
         assert par['filt_hits10_ref_hip'][0] > 0.02, 'the trained-like model should rank its facts high'

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     out = subprocess.check_output(['nm', '-D', '--defined-only', _hip.LIB_PATH], text=True)
     assert declared <= set(re.findall(r' T (kge_[a-z0-9_]+)', out))
-    assert lib.kge_abi_version() == 12 and lib.kge_build_arch() == b'gfx950'
+    assert lib.kge_abi_version() == 13 and lib.kge_build_arch() == b'gfx950'
     # the descriptor struct mirrors the header field for field
     fields = re.search(r'typedef struct kge_lp_desc \{(.*?)\} kge_lp_desc;', hdr, re.S).group(1)
     names = re.findall(r'\b(\w+)\s*(?:;|,)', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
@@ -262,6 +262,31 @@ for shard, exchange, fused in [('entities', 'counts', True), ('entities', 'score
         ok = ok and same
         if not same:
             print('MISMATCH', rank, shard, exchange, fused, nm, flush=True)
+# ROW-SHARDED entity tables (SURVEY 8e): each rank keeps only its rows of every entity-indexed table,
+# query rows are built by the owner rank and summed over the ranks; the ranks must still be the reference's
+from torchkge_amd import distributed as kd
+from tests.helpers import ShardedOracleEngine
+names = ['ent_emb', 'rel_emb'] if kind == 'transe' else ['re_ent_emb', 'im_ent_emb', 're_rel_emb', 'im_rel_emb']
+m.load_state_dict({n + '.weight': t.clone() for n, t in zip(names, tables)})
+full_bytes = m.entity_table_bytes()
+lo, hi = kd.shard_model_(m)
+assert (lo, hi) == kd.shard_range(n_ent, world, rank) and m.n_ent == n_ent
+assert m.entity_table_bytes() * world <= full_bytes + 4 * world * tables[0].shape[1] * (2 if kind == 'complex' else 1)
+assert all(getattr(m, nm).weight.shape[0] == hi - lo for nm in m._ENT_TABLES)
+for exchange, fused in [('counts', True), ('scores', True), ('scores', False)]:
+    ev = tk.LinkPredictionEvaluator(m, kg_test, fused=fused, shard='entities', exchange=exchange,
+                                    engine=ShardedOracleEngine(kind))
+    ev.evaluate(b_size=13, verbose=False)
+    for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
+        same = np.array_equal(getattr(ev, nm).numpy(), z[nm])
+        ok = ok and same
+        if not same:
+            print('MISMATCH row-sharded', rank, exchange, fused, nm, flush=True)
+try:        # a row-sharded model refuses anything that needs the whole tables
+    tk.LinkPredictionEvaluator(m, kg_test, engine=ShardedOracleEngine(kind)).evaluate(b_size=13, verbose=False)
+    ok = False
+except RuntimeError:
+    pass
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)

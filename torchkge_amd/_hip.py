@@ -58,6 +58,8 @@ _SIGNATURES = {
     'kge_key_scatter': [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     'kge_lp_prep': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp,
                     _vp, _vp, _vp],
+    'kge_lp_prep_sharded': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                            _vp, _vp, _vp],
     'kge_relation_scores_proj': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
@@ -122,7 +124,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 12:
+    if lib.kge_abi_version() != 13:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -262,7 +264,9 @@ def side_code(side):
 
 
 def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=False,
-            want_q1=False):
+            want_q1=False, ent_lo=0, ent_n=-1):
+    """kge_lp_prep; ent_n >= 0: the entity tables hold only rows [ent_lo, ent_lo + ent_n) (kge_lp_prep_sharded:
+    rows of entities this shard does not own come back as zeros, to be summed over the shards)."""
     lib = load_library()
     require_cuda(h, t, r, *tables)
     tabs = [f32c(x) for x in tables] + [None] * (4 - len(tables))
@@ -277,9 +281,9 @@ def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=Fal
     qn = torch.empty(B, dtype=torch.float32, device=dev) if want_qn else None
     Wq = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_w else None
     with _on(dev):
-        _check(lib.kge_lp_prep(kind, side, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
-                               d_ent, d_rel, _p(h), _p(t), _p(r), n_facts, _p(Q0), _p(Q1), _p(qn),
-                               _p(Wq), _stream()), 'kge_lp_prep')
+        _check(lib.kge_lp_prep_sharded(kind, side, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
+                                       d_ent, d_rel, _p(h), _p(t), _p(r), n_facts, ent_lo, ent_n, _p(Q0), _p(Q1),
+                                       _p(qn), _p(Wq), _stream()), 'kge_lp_prep_sharded')
     return Q0, Q1, qn, Wq
 
 

@@ -33,6 +33,7 @@ struct PrepParams {
     const int64_t *h, *t, *r;
     int64_t B;
     float *Q0, *Q1, *Wq;
+    int64_t ent_lo, ent_n;  // row-sharded entity tables: this rank holds rows [ent_lo, ent_lo + ent_n); ent_n < 0: whole tables
 };
 
 __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
@@ -48,9 +49,28 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
         const bool tail = both ? i < p.B : p.side == KGE_SIDE_TAIL;
         const bool use_h = tail || p.side == KGE_SIDE_PROJ_H;
         const int64_t f = (both && i >= p.B) ? i - p.B : i;   // the fact this query belongs to
-        const int64_t ei = use_h ? p.h[f] : p.t[f]; // the entity that stays in the query
+        int64_t ei = use_h ? p.h[f] : p.t[f]; // the entity that stays in the query
         const int64_t ri = p.r[f];
         float *q0 = p.Q0 + i * dr;
+        if (p.ent_n >= 0) {
+            // row-sharded tables (one shard per GPU): only the OWNER of entity ei can build this query row; every
+            // other rank writes zeros, and the sum over ranks (x + 0 is exact) hands the row to all of them.
+            // Relation-side outputs (Wq) come from replicated tables and are complete on every rank.
+            const bool owned = ei >= p.ent_lo && ei < p.ent_lo + p.ent_n;
+            ei -= p.ent_lo;
+            if (!owned) {
+                for (int k = lane; k < dr; k += 64) q0[k] = 0.f;
+                if (p.kind == KGE_COMPLEX) {
+                    float *q1 = p.Q1 + i * dr;
+                    for (int k = lane; k < dr; k += 64) q1[k] = 0.f;
+                } else if (p.kind == KGE_TRANSH || p.kind == KGE_TRANSD) {
+                    const float *w = (p.kind == KGE_TRANSH ? p.t2 : p.t3) + ri * dr;
+                    float *wq = p.Wq + i * dr;
+                    for (int k = lane; k < dr; k += 64) wq[k] = w[k];
+                }
+                continue;
+            }
+        }
         switch (p.kind) {
         case KGE_TRANSE_L1:
         case KGE_TRANSE_L2: {
@@ -404,7 +424,16 @@ extern "C" int kge_lp_prep(int kind, int side, const float *t0, const float *t1,
                            const int64_t *r, int64_t B, float *Q0, float *Q1, float *qn, float *Wq,
                            kge_stream_t stream)
 {
+    return kge_lp_prep_sharded(kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, 0, -1, Q0, Q1, qn, Wq, stream);
+}
+
+extern "C" int kge_lp_prep_sharded(int kind, int side, const float *t0, const float *t1, const float *t2,
+                                   const float *t3, int d_ent, int d_rel, const int64_t *h, const int64_t *t,
+                                   const int64_t *r, int64_t B, int64_t ent_lo, int64_t ent_n, float *Q0, float *Q1,
+                                   float *qn, float *Wq, kge_stream_t stream)
+{
     if (kind < KGE_TRANSE_L1 || kind > KGE_COMPLEX) return KGE_EINVAL;
+    if (ent_n >= 0 && ent_lo < 0) return KGE_EINVAL;
     if (side < KGE_SIDE_TAIL || side > KGE_SIDE_BOTH) return KGE_EINVAL;
     if (!t0 || !t1 || d_ent <= 0 || d_rel <= 0 || B < 0) return KGE_EINVAL;
     if (B == 0) return 0;
@@ -413,7 +442,7 @@ extern "C" int kge_lp_prep(int kind, int side, const float *t0, const float *t1,
     if (kind == KGE_TRANSH && (!t2 || !Wq)) return KGE_EINVAL;
     if (kind == KGE_TRANSD && (!t2 || !t3 || !Wq || d_ent < d_rel)) return KGE_EINVAL;
     if (kind != KGE_TRANSD && d_ent != d_rel) return KGE_EINVAL;
-    PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq};
+    PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq, ent_lo, ent_n};
     const int64_t nq = side == KGE_SIDE_BOTH ? 2 * B : B;
     hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(nq)), dim3(WPB * 64), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();

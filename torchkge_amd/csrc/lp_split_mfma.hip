@@ -861,10 +861,10 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                 const int nc = min(n, UNC_CAP);
                 if (n > 0) {
                     int base = 0;
-                    // saturating: once the list is full the counter is left alone (it only ever grows), so it
-                    // stays below cap + #blocks * UNC_CAP and cannot wrap (cap <= INT32_MAX - 2^22, host side)
-                    if (lane == 0)
-                        base = (__builtin_nontemporal_load(p.list_count) >= p.cap) ? p.cap : atomicAdd(p.list_count, nc);
+                    // (a degenerate all-tied model can push the counter past 2^31: positions are compared as
+                    // unsigned, so nothing is ever written outside the list, and the sticky overflow flag makes
+                    // the caller redo the count on the exact kernel)
+                    if (lane == 0) base = atomicAdd(p.list_count, nc);
                     base = __shfl(base, 0, 64);
                     if (n > UNC_CAP && lane == 0) *p.overflow = 1.0f;
                     for (int i = lane; i < nc; i += 64) {
@@ -1052,7 +1052,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     const void *Es = a->Es, *Qs = a->Qs;
     float *thr = a->thr, *overflow = a->overflow;
     int32_t *list = a->list, *list_count = a->list_count;
-    const int32_t cap = a->cap < INT32_MAX - (1 << 22) ? a->cap : INT32_MAX - (1 << 22);   // see the list flush: no wrap
+    const int32_t cap = a->cap;
     SplitParams p;
     p.Es = reinterpret_cast<const char *>(Es);
     p.Qs = reinterpret_cast<const char *>(Qs);

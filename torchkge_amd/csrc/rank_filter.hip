@@ -285,6 +285,13 @@ __global__ __launch_bounds__(64) void filter_sub_staged_kernel(const kge_lp_desc
 // scores.  Work is bounded by the size of the target array, whatever the skew.
 //   claim[T]  : smallest query index whose segment starts at that target position (0xffffffff: none)
 //   woff[B+1] : exclusive prefix sum of the claimed segments' lengths (the flattened work list)
+// (only the entries the batch touches are reset: O(B), not O(n_targets), and no memset node in a captured graph)
+__global__ void fsub_reset_kernel(const int64_t *__restrict__ seg_lo, const int64_t *__restrict__ seg_hi, int64_t B,
+                                  unsigned *claim)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x)
+        if (seg_hi[i] > seg_lo[i]) claim[seg_lo[i]] = 0xffffffffu;
+}
 __global__ void fsub_claim_kernel(const int64_t *__restrict__ seg_lo, const int64_t *__restrict__ seg_hi, int64_t B,
                                   unsigned *claim)
 {
@@ -316,11 +323,12 @@ __global__ __launch_bounds__(FS_SCAN_T) void fsub_scan_kernel(const int64_t *__r
             len[k] = l;
             tot += l;
         }
-        int64_t inc = tot; // inclusive scan over the wavefront
+        int64_t inc = tot; // inclusive scan over the wavefront (64-bit values as two 32-bit shuffles)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int64_t v = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += v;
+            const unsigned vlo = __shfl_up((unsigned)(inc & 0xffffffffll), o, 64);
+            const unsigned vhi = __shfl_up((unsigned)((uint64_t)inc >> 32), o, 64);
+            if (lane >= o) inc += (int64_t)(((uint64_t)vhi << 32) | vlo);
         }
         if (lane == 63) wsum[wv] = inc;
         __syncthreads();
@@ -668,8 +676,7 @@ extern "C" int kge_lp_filter_sub_grouped(const kge_lp_desc *d, const float *s_tr
     float *fs = reinterpret_cast<float *>(w8 + fsub_align(n_targets * 4));
     int64_t *woff = reinterpret_cast<int64_t *>(w8 + 2 * fsub_align(n_targets * 4));
     if (n_targets > 0 && d->N > 0) {
-        hipError_t e = hipMemsetAsync(claim, 0xff, (size_t)n_targets * 4, st);
-        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(fsub_reset_kernel, dim3(grid1d(d->B, 256)), dim3(256), 0, st, seg_lo, seg_hi, d->B, claim);
         hipLaunchKernelGGL(fsub_claim_kernel, dim3(grid1d(d->B, 256)), dim3(256), 0, st, seg_lo, seg_hi, d->B, claim);
         hipLaunchKernelGGL(fsub_scan_kernel, dim3(1), dim3(FS_SCAN_T), 0, st, seg_lo, seg_hi, d->B, claim, woff);
         const int64_t groups = (n_targets + 63) / 64;     // upper bound of the flattened work (read on the device)
@@ -738,5 +745,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 12; }
+extern "C" int kge_abi_version(void) { return 13; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -5,7 +5,10 @@ tests).  The reference has no distributed code at all; the
 partitioning below is the one BASELINE.json's north star names:
 
   * the entity table is row-sharded: rank p scores candidates
-    [p*ceil(N/P), min(N, (p+1)*ceil(N/P)));
+    [p*ceil(N/P), min(N, (p+1)*ceil(N/P))) -- and, after `shard_model_`, HOLDS only those rows of
+    every entity-indexed table (relation tables stay replicated); the (2B, K) query rows of a batch
+    are then built by the rank that owns each query's entity and summed over the ranks
+    (zeros elsewhere: exact), one all-reduce per query matrix;
   * exchange='scores': every rank all-gathers the partial score tiles
     S_p (B, N/P) into S (B, N) and ranks on the full matrix;
   * exchange='counts': ranks are sums over candidates, so each rank counts
@@ -45,6 +48,16 @@ def shard_range(n, world, rank):
     per = shard_size(n, world)
     lo = min(n, rank * per)
     return lo, min(n, lo + per)
+
+
+def shard_model_(model, group=None):
+    """Row-shard `model`'s entity tables over the process group, in place: this rank keeps rows
+    shard_range(n_ent, world, rank) of every entity-indexed table.  Every rank must hold the same
+    tables before the call (e.g. broadcast from rank 0).  Returns (lo, hi)."""
+    world, rank = world_and_rank(group)
+    lo, hi = shard_range(model.n_ent, world, rank)
+    model.shard_entities_(lo, hi)
+    return lo, hi
 
 
 def all_reduce_sum(t, group=None):

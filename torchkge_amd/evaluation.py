@@ -68,7 +68,10 @@ class HipRankEngine(object):
         return seg_lo, seg_hi, true_idx, self._targets_cat[1]
 
     @staticmethod
-    def problem(model, h, t, r, side, lo, hi):
+    def problem(model, h, t, r, side, lo, hi, exchange=None):
+        """`exchange`: completes the query rows of a ROW-SHARDED model (sum over the shards)."""
+        if exchange is not None and getattr(model, '_row_shard', None) is not None:
+            return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, exchange=exchange)
         return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi)
 
     @staticmethod
@@ -205,7 +208,7 @@ class LinkPredictionEvaluator(object):
         seg_lo, seg_hi = eng.lookup(index, key1, r)
         if self._generic_model:
             return self._rank_side_generic(h, t, r, side, index, true_idx, key1)
-        prob = eng.problem(self.model, h, t, r, side, lo, hi)
+        prob = eng.problem(self.model, h, t, r, side, lo, hi, **self._xkw(sharded))
         if self.fused and not (sharded and self.exchange == 'scores'):
             s_true = eng.true_scores(prob, true_idx)
             if sharded:
@@ -228,7 +231,7 @@ class LinkPredictionEvaluator(object):
         x + 0 is exact) and the (3, 2B) partial rank counts."""
         eng = self.engine
         seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
-        prob = eng.problem(self.model, h, t, r, 'both', lo, hi)
+        prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **self._xkw(sharded))
         s_true = eng.true_scores(prob, true_idx)
         if sharded:
             self._collective(lambda: kdist.all_reduce_sum(s_true, self.group))
@@ -236,6 +239,15 @@ class LinkPredictionEvaluator(object):
         if sharded:
             self._collective(lambda: kdist.all_reduce_sum(counts, self.group))
         eng.finalize_both(counts, out, off)
+
+    def _xkw(self, sharded):
+        """Engine keyword for the query exchange of row-sharded entity tables: every rank builds the
+        query rows whose entity it owns (zeros elsewhere) and ONE all-reduce SUM per query matrix
+        hands the (2B, K) rows to every rank (x + 0 is exact)."""
+        if not sharded:
+            return {}
+        return {'exchange': lambda tensors: self._collective(
+            lambda: [kdist.all_reduce_sum(x, self.group) for x in tensors])}
 
     def _collective(self, fn):
         """Run a collective now -- or, while evaluate() is being captured, close the current
@@ -313,6 +325,10 @@ class LinkPredictionEvaluator(object):
         world, rank = kdist.world_and_rank(self.group) if self.shard else (1, 0)
         sharded = self.shard == 'entities' and kdist.multi(world)
         lo, hi = kdist.shard_range(self.model.n_ent, world, rank) if sharded else (0, self.model.n_ent)
+        row_shard = getattr(self.model, '_row_shard', None)
+        if row_shard is not None and (not sharded or row_shard != (lo, hi)):
+            raise RuntimeError('torchkge_amd: the model holds only entity rows [%d, %d): evaluate it with '
+                               "shard='entities' on the process group it was sharded over" % row_shard)
         if self.shard == 'queries' and kdist.multi(world):
             f_lo, f_hi = kdist.shard_range(kg.n_facts, world, rank)
         else:

@@ -8,7 +8,7 @@ import torch
 from .. import _hip
 from ..utils.modeling import init_embedding
 from .interfaces import BilinearModel, _table_of
-from .translation import _shard
+from .translation import _ent_range
 
 
 class DistMultModel(BilinearModel):
@@ -16,6 +16,7 @@ class DistMultModel(BilinearModel):
     n_relations)``; parameters ``ent_emb`` (L2-normalised rows), ``rel_emb``."""
 
     _kind = _hip.DISTMULT
+    _ENT_TABLES = ('ent_emb',)
 
     def __init__(self, emb_dim, n_entities, n_relations):
         super().__init__(emb_dim, n_entities, n_relations)
@@ -54,6 +55,7 @@ class DistMultModel(BilinearModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(h, t, r, candidates) with a stride-0 (b, N, d) candidates view
         (bilinear.py:247-267)."""
+        self._check_unsharded('inference_prepare_candidates')
         b_size = max(h_idx.shape[0], t_idx.shape[0], r_idx.shape[0])   # inference passes one empty index
         E, R = self.ent_emb.weight.data, self.rel_emb.weight.data
         h, t, r = _hip.gather_rows(E, h_idx), _hip.gather_rows(E, t_idx), _hip.gather_rows(R, r_idx)
@@ -63,12 +65,12 @@ class DistMultModel(BilinearModel):
             candidates = R.view(1, self.n_rel, self.emb_dim).expand(b_size, self.n_rel, self.emb_dim)
         return h, t, r, candidates
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
-        ent_hi = self.n_ent if ent_hi is None else ent_hi
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+        ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
-        Q0 = _hip.lp_prep(_hip.DISTMULT, sd, tabs, self.emb_dim, self.emb_dim, h_idx, t_idx, r_idx)[0]
-        T0 = _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi)
+        Q0 = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange)[0]
+        T0 = self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi)
         return self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, c_base=ent_lo), T0, c_base=ent_lo)
 
 
@@ -78,6 +80,7 @@ class ComplExModel(BilinearModel):
     ``im_rel_emb``; never normalised (:475-480)."""
 
     _kind = _hip.COMPLEX
+    _ENT_TABLES = ('re_ent_emb', 'im_ent_emb')
 
     def __init__(self, emb_dim, n_entities, n_relations):
         super().__init__(emb_dim, n_entities, n_relations)
@@ -133,6 +136,7 @@ class ComplExModel(BilinearModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """((re_h, im_h), (re_t, im_t), (re_r, im_r), (re_cand, im_cand))
         (bilinear.py:530-556)."""
+        self._check_unsharded('inference_prepare_candidates')
         b_size = max(h_idx.shape[0], t_idx.shape[0], r_idx.shape[0])   # inference passes one empty index
         Ere, Eim, Rre, Rim = [x.data for x in self._tables()]
         g = _hip.gather_rows
@@ -149,12 +153,11 @@ class ComplExModel(BilinearModel):
                     Rim.view(1, self.n_rel, self.emb_dim).expand(*shape))
         return h, t, r, cand
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
-        ent_hi = self.n_ent if ent_hi is None else ent_hi
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+        ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
-        Q0, Q1, _, _ = _hip.lp_prep(_hip.COMPLEX, sd, tabs, self.emb_dim, self.emb_dim, h_idx, t_idx,
-                                    r_idx, want_q1=True)
-        T0, T1 = _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), _shard(_hip.f32c(tabs[1]), ent_lo, ent_hi)
+        Q0, Q1, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, want_q1=True)
+        T0, T1 = self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), self._cand_rows(_hip.f32c(tabs[1]), ent_lo, ent_hi)
         return self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, A1=Q1, T1=T1, c_base=ent_lo), T0, T1,
                                       c_base=ent_lo)

@@ -133,12 +133,14 @@ class Model(Module):
     """Base interface (interfaces.py:13-174)."""
 
     _kind = None          # kge_hip.h model kind
+    _ENT_TABLES = ()      # names of the entity-indexed nn.Embedding tables (row-sharded across GPUs)
 
     def __init__(self, n_entities, n_relations):
         super().__init__()
         self.n_ent = n_entities
         self.n_rel = n_relations
         self._cache = _SessionCache()
+        self._row_shard = None      # (lo, hi): the entity tables hold only these rows (one shard per GPU)
         # evaluation-time guard scalars (device, float32 x 8): [0] max ||q||^2 (L2 norm guard),
         # [1] max ||e||^2 (segment 0), [2] split-list overflow flag, [3] max |X|, [4] max |y_c| (projection
         # modes), [5] max ||e||^2 (segment 1)
@@ -151,6 +153,62 @@ class Model(Module):
     # ---- engine hooks (overridden by concrete models) ---------------------
     def _tables(self):
         raise NotImplementedError
+
+    # ---- row-sharded entity tables (N/P rows per GPU, relation tables replicated) ----
+    def shard_entities_(self, lo, hi):
+        """Keep only rows [lo, hi) of every entity-indexed table (in place; ``n_ent`` stays the
+        GLOBAL entity count).  From then on the model can only serve an entity-sharded
+        LinkPredictionEvaluator (shard='entities'): query rows are built by the rank that owns
+        the query's entity and summed over the ranks, each rank scores its own candidates."""
+        assert self._row_shard is None, 'already sharded'
+        assert 0 <= lo <= hi <= self.n_ent
+        for name in self._ENT_TABLES:
+            emb = getattr(self, name)
+            w = emb.weight.data[lo:hi].clone()
+            emb.weight = torch.nn.Parameter(w, requires_grad=emb.weight.requires_grad)
+            emb.num_embeddings = hi - lo
+        self._row_shard = (lo, hi)
+        return self
+
+    def as_entity_shard_(self, n_total, lo, hi):
+        """Declare a model that was CONSTRUCTED with n_entities = hi - lo to be the shard
+        [lo, hi) of an n_total-entity model (tables too large to ever exist on one GPU)."""
+        assert self._row_shard is None and self.n_ent == hi - lo and 0 <= lo <= hi <= n_total
+        self.n_ent = n_total
+        self._row_shard = (lo, hi)
+        return self
+
+    def entity_table_bytes(self):
+        return sum(getattr(self, n).weight.numel() * 4 for n in self._ENT_TABLES)
+
+    def _check_unsharded(self, what):
+        if self._row_shard is not None:
+            raise RuntimeError('torchkge_amd: %s needs the whole entity tables; this model holds only rows '
+                               '[%d, %d) (use LinkPredictionEvaluator(shard=\'entities\'))' % ((what,) + self._row_shard))
+
+    def _cand_rows(self, table, lo, hi):
+        """Rows [lo, hi) of an entity-indexed table as candidates."""
+        if self._row_shard is not None:
+            if (lo, hi) != self._row_shard:
+                raise RuntimeError('torchkge_amd: candidate range [%d, %d) requested from a model that holds rows '
+                                   '[%d, %d)' % ((lo, hi) + self._row_shard))
+            return table
+        return table if (lo == 0 and hi == table.shape[0]) else table[lo:hi]
+
+    def _lp_prep(self, side, h_idx, t_idx, r_idx, exchange=None, **want):
+        """kge_lp_prep on this model's tables.  Row-sharded tables: rows of entities another rank owns
+        come back as zeros and ``exchange`` (the evaluator's all-reduce SUM over the shards) completes
+        the entity-derived outputs Q0 (/Q1); x + 0 is exact, so every rank ends up with the rows the
+        owner computed."""
+        tabs = [x.data for x in self._tables()]
+        lo, n = (self._row_shard[0], self._row_shard[1] - self._row_shard[0]) if self._row_shard is not None else (0, -1)
+        out = _hip.lp_prep(self._hip_kind(), side, tabs, self._d_ent, self._d_rel, h_idx, t_idx, r_idx,
+                           ent_lo=lo, ent_n=n, **want)
+        if self._row_shard is not None:
+            if exchange is None:
+                raise RuntimeError('torchkge_amd: a row-sharded model needs the evaluator\'s query exchange')
+            exchange([x for x in (out[0], out[1]) if x is not None])
+        return out
 
     L2_EXPAND_LIMIT = float('inf')      # TranslationModel: bound on ||q||^2 + ||e||^2 for the norm expansion
 
@@ -241,6 +299,7 @@ class Model(Module):
 
     def scoring_function(self, h_idx, t_idx, r_idx):
         """Score of each triplet, one fused HIP kernel (K1), differentiable."""
+        self._check_unsharded('scoring_function')
         tables = self._tables()
         _hip.require_cuda(h_idx, t_idx, r_idx, *tables)
         return _ScoreTriples.apply(self._hip_kind(), self._d_ent, self._d_rel, h_idx, t_idx,
@@ -265,9 +324,9 @@ class Model(Module):
     def lp_prep_cands(self, h_idx, t_idx, r_idx, entities=True):
         return self.inference_prepare_candidates(h_idx, t_idx, r_idx, entities=entities)
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
         """kge_lp_desc owner for scoring every entity in [ent_lo, ent_hi) as the
-        tail (side='tail') or head (side='head') of each (h, r, t)."""
+        tail (side='tail') or head (side='head') of each (h, r, t).  ``exchange``: see _lp_prep."""
         raise NotImplementedError
 
     @staticmethod

@@ -32,6 +32,13 @@ def _shard(table, lo, hi):
     return table if (lo == 0 and hi == table.shape[0]) else table[lo:hi]
 
 
+def _ent_range(model, ent_lo, ent_hi):
+    """Default candidate range: the whole table -- or, for a row-sharded model, its own rows."""
+    if ent_hi is None:
+        return model._row_shard if model._row_shard is not None else (0, model.n_ent)
+    return ent_lo, ent_hi
+
+
 class TransEModel(TranslationModel):
     """TransE (translation.py:18-125).  ``TransEModel(emb_dim, n_entities,
     n_relations, dissimilarity_type='L2')``; parameters ``ent_emb``, ``rel_emb``."""
@@ -44,6 +51,8 @@ class TransEModel(TranslationModel):
         # translation.py:66-67: entities and (once) relations L2-normalised
         self.ent_emb.weight.data = torch.nn.functional.normalize(self.ent_emb.weight.data, p=2, dim=1)
         self.rel_emb.weight.data = torch.nn.functional.normalize(self.rel_emb.weight.data, p=2, dim=1)
+
+    _ENT_TABLES = ('ent_emb',)
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight]
@@ -62,6 +71,7 @@ class TransEModel(TranslationModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(h, t, r, candidates); candidates is a stride-0 (b, N, d) view of the
         table, as in the reference (translation.py:105-125)."""
+        self._check_unsharded('inference_prepare_candidates')
         b_size = max(h_idx.shape[0], t_idx.shape[0], r_idx.shape[0])   # inference passes one empty index
         E, R = self.ent_emb.weight.data, self.rel_emb.weight.data
         h, t, r = _hip.gather_rows(E, h_idx), _hip.gather_rows(E, t_idx), _hip.gather_rows(R, r_idx)
@@ -71,17 +81,16 @@ class TransEModel(TranslationModel):
             candidates = R.view(1, self.n_rel, self.emb_dim).expand(b_size, self.n_rel, self.emb_dim)
         return h, t, r, candidates
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
-        ent_hi = self.n_ent if ent_hi is None else ent_hi
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+        ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
         if (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
                 and self.split_filter and self._split_ok and ent_lo == 0 and ent_hi == self.n_ent
-                and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
+                and self._row_shard is None and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
             return self._fused_query_problem(h_idx, t_idx, r_idx, sd, tabs)
-        Q0, _, _, _ = _hip.lp_prep(self._hip_kind(), sd, tabs, self.emb_dim, self.emb_dim,
-                                   h_idx, t_idx, r_idx)
-        return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi),
+        Q0, _, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange)
+        return self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
 
     def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs):
@@ -122,6 +131,7 @@ class TransHModel(TranslationModel):
         self.evaluated_projections = False
 
     _kind = _hip.TRANSH
+    _ENT_TABLES = ('ent_emb',)
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight, self.norm_vect.weight]
@@ -155,7 +165,7 @@ class TransHModel(TranslationModel):
         """a[c, r] = E[c].W[r] for c in [lo, hi): the only thing the
         reference's projected_entities cache is needed for (translation.py:272-281)."""
         E, W = _hip.f32c(self.ent_emb.weight.data), _hip.f32c(self.norm_vect.weight.data)
-        Es = _shard(E, lo, hi)
+        Es = self._cand_rows(E, lo, hi)
         return self._cache.get('transh_a_%d_%d' % (lo, hi), [E, W],
                                lambda: _hip.LpProblem(_hip.LP_DOT, Es, W).scores())
 
@@ -183,6 +193,7 @@ class TransHModel(TranslationModel):
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(proj_h, proj_t, r, candidates) (translation.py:234-258); candidates
         is an EntityCandidates handle, not a (b, N, d) copy."""
+        self._check_unsharded('inference_prepare_candidates')
         tabs = [x.data for x in self._tables()]
         d = self.emb_dim
         if not entities:    # translation.py:252-256: every entity projected under EVERY relation
@@ -206,17 +217,16 @@ class TransHModel(TranslationModel):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
         E, W = _hip.f32c(self.ent_emb.weight.data), self.norm_vect.weight.data
         Wq = _hip.gather_rows(W, cand.r_idx)
-        return self._translational_problem(q, _shard(E, ent_lo, ent_hi), Wq=Wq,
+        return self._translational_problem(q, self._cand_rows(E, ent_lo, ent_hi), Wq=Wq,
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi), r_idx=cand.r_idx,
                                            c_base=ent_lo)
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
-        ent_hi = self.n_ent if ent_hi is None else ent_hi
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+        ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
-        d = self.emb_dim
-        Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSH, sd, tabs, d, d, h_idx, t_idx, r_idx, want_w=True)
-        return self._translational_problem(Q0, _shard(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
+        Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, want_w=True)
+        return self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi),
                                            r_idx=_both_r(r_idx, sd), c_base=ent_lo)
 
@@ -228,6 +238,7 @@ class TransDModel(TranslationModel):
     (the reference's ``ent[:, :rel_emb_dim]`` slice, :568)."""
 
     _kind = _hip.TRANSD
+    _ENT_TABLES = ('ent_emb', 'ent_proj_vect')
 
     def __init__(self, ent_emb_dim, rel_emb_dim, n_entities, n_relations):
         super().__init__(n_entities, n_relations, 'L2')
@@ -261,7 +272,7 @@ class TransDModel(TranslationModel):
         cache depends on per entity (translation.py:641-646)."""
         E, Ep = _hip.f32c(self.ent_emb.weight.data), _hip.f32c(self.ent_proj_vect.weight.data)
         return self._cache.get('transd_s_%d_%d' % (lo, hi), [E, Ep],
-                               lambda: _hip.row_dot(_shard(Ep, lo, hi), _shard(E, lo, hi), scale=-1.0))
+                               lambda: _hip.row_dot(self._cand_rows(Ep, lo, hi), self._cand_rows(E, lo, hi), scale=-1.0))
 
     def evaluate_projectionss(self):
         """Kept for API compatibility (translation.py:629-652, reference spelling)."""
@@ -271,6 +282,7 @@ class TransDModel(TranslationModel):
 
     def inference_prepare_candidates(self, h_idx, t_idx, r_idx, entities=True):
         """(proj_h, proj_t, r, candidates) (translation.py:603-627)."""
+        self._check_unsharded('inference_prepare_candidates')
         tabs = [x.data for x in self._tables()]
         de, dr = self.ent_emb_dim, self.rel_emb_dim
         if not entities:    # translation.py:621-626
@@ -294,7 +306,7 @@ class TransDModel(TranslationModel):
     def _problem(self, q, Wq, ent_lo, ent_hi, r_idx=None):
         E = _hip.f32c(self.ent_emb.weight.data)
         # candidates use E[c, :d_r]: same rows, inner dim K0 = d_r, leading dim d_e
-        return self._translational_problem(q, _shard(E, ent_lo, ent_hi), Wq=Wq,
+        return self._translational_problem(q, self._cand_rows(E, ent_lo, ent_hi), Wq=Wq,
                                            scal=lambda: self._neg_sigma(ent_lo, ent_hi), c_base=ent_lo,
                                            K0=self.rel_emb_dim, r_idx=r_idx)
 
@@ -313,7 +325,7 @@ class TransDModel(TranslationModel):
 
         def build_s():
             buf = torch.zeros(_hip.padded_cols(n), dtype=torch.float32, device=table.device)
-            buf[:n] = _hip.row_dot(_shard(Ep, lo, hi), table, scale=1.0)
+            buf[:n] = _hip.row_dot(self._cand_rows(Ep, lo, hi), table, scale=1.0)
             return buf[:n]
         GT = self._cache.get('transd_gT_%d_%d' % (lo, hi), [table, Rp], build_g)
         sigma = self._cache.get('transd_sp_%d_%d' % (lo, hi), [table, Ep], build_s)
@@ -327,10 +339,8 @@ class TransDModel(TranslationModel):
         Wq = _hip.gather_rows(self.rel_proj_vect.weight.data, cand.r_idx)
         return self._problem(q, Wq, ent_lo, ent_hi, r_idx=cand.r_idx)
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None):
-        ent_hi = self.n_ent if ent_hi is None else ent_hi
-        tabs = [x.data for x in self._tables()]
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+        ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         sd = _hip.side_code(side)
-        Q0, _, _, Wq = _hip.lp_prep(_hip.TRANSD, sd, tabs, self.ent_emb_dim, self.rel_emb_dim,
-                                    h_idx, t_idx, r_idx, want_w=True)
+        Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, want_w=True)
         return self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_both_r(r_idx, sd))
