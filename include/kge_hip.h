@@ -263,6 +263,20 @@ int kge_lp_filter_sub_grouped(const kge_lp_desc *d, const float *s_true, const i
                               int64_t n_targets, int32_t *sub, int32_t *found, void *ws, int64_t ws_bytes,
                               kge_stream_t stream);
 
+/* The same with a PLAN: the grouping of a batch (which query scores which list, the flattened work
+ * offsets) depends only on the test facts and the filter index, not on the model, so an evaluator builds it
+ * once per batch and reuses it for every evaluate() call.
+ *   woff[B+1]: exclusive prefix sum over the queries of (segment length if the query is the FIRST of the batch
+ *              with that segment, else 0); n_pairs = woff[B] (host copy: sizes the launch)
+ *   long_q[n_long]: the queries whose segment is longer than 512 entries (one 256-thread block compares
+ *              each; may be NULL when n_long == 0: every query is then taken by a wavefront)
+ *   fs: n_targets floats of scratch (scores per target position). */
+int kge_lp_filter_sub_planned(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
+                              const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                              int64_t n_targets, const int64_t *woff, int64_t n_pairs,
+                              const int64_t *long_q, int64_t n_long, float *fs, int32_t *sub, int32_t *found,
+                              kge_stream_t stream);
+
 /* rank[i] = raw[i]; filt_rank[i] = found[i] ? raw[i] - sub[i] : raw[i]  (int64 out) */
 int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
                       int64_t *rank, int64_t *filt_rank, kge_stream_t stream);

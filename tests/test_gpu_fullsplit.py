@@ -104,6 +104,13 @@ def test_grouped_filter_correction_with_hub_keys_bit_exact(hip, kind, p):
     sub_g, found_g = prob.filter_sub(s_true, T, seg_lo, seg_hi, idx.targets, grouped=True)
     sub_w, found_w = prob.filter_sub(s_true, T, seg_lo, seg_hi, idx.targets, grouped=False)
     assert torch.equal(sub_g, sub_w) and torch.equal(found_g, found_w)
+    # ... and with the grouping precomputed once (FilterPlan, what the evaluator keeps per batch)
+    from torchkge_amd.filter_index import FilterPlan
+    plan = FilterPlan(seg_lo, seg_hi, T, idx.targets)
+    assert plan.n_long > 0 and plan.n_pairs <= int(idx.targets.shape[0]) and plan.n_pairs < int((seg_hi - seg_lo).sum())
+    for _ in range(2):
+        sub_p, found_p = prob.filter_sub(s_true, T, seg_lo, seg_hi, idx.targets, plan=plan)
+        assert torch.equal(sub_p, sub_w) and torch.equal(found_p, found_w)
     rk, frk = hip.filtered_rank_from_scores(scores, T, seg_lo, seg_hi, idx.targets)
     rk2, frk2 = hip.rank_finalize(raw, sub_g, found_g)
     assert torch.equal(rk, rk2) and torch.equal(frk, frk2)
@@ -123,6 +130,8 @@ def test_grouped_filter_correction_with_hub_keys_bit_exact(hip, kind, p):
             lo, hi = kd.shard_range(n_ent, 3, pidx)
             pp = m.lp_problem(H, T, R, 'tail', ent_lo=lo, ent_hi=hi)
             s_, f_ = pp.filter_sub(s_true, T, seg_lo, seg_hi, idx.targets, grouped=True)
+            s2_, f2_ = pp.filter_sub(s_true, T, seg_lo, seg_hi, idx.targets, plan=plan)
+            assert torch.equal(s_, s2_) and torch.equal(f_, f2_)
             acc[0] += s_; acc[1] += f_
         assert torch.equal(acc[0], sub_g) and torch.equal(acc[1], found_g)
 

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     out = subprocess.check_output(['nm', '-D', '--defined-only', _hip.LIB_PATH], text=True)
     assert declared <= set(re.findall(r' T (kge_[a-z0-9_]+)', out))
-    assert lib.kge_abi_version() == 13 and lib.kge_build_arch() == b'gfx950'
+    assert lib.kge_abi_version() == 14 and lib.kge_build_arch() == b'gfx950'
     # the descriptor struct mirrors the header field for field
     fields = re.search(r'typedef struct kge_lp_desc \{(.*?)\} kge_lp_desc;', hdr, re.S).group(1)
     names = re.findall(r'\b(\w+)\s*(?:;|,)', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
@@ -356,3 +356,17 @@ def test_filter_index_torch_build_and_disk_cache(tmp_path):
     kg2.set_filter_cache(str(tmp_path / 'cache'))
     i2 = kg2.filter_index('tails', 'cpu')
     assert torch.equal(i1.keys, i2.keys) and torch.equal(i1.targets, i2.targets) and torch.equal(i1.keys, a.keys)
+
+
+def test_filter_plan_groups_queries_by_segment():
+    """FilterPlan: only the FIRST query of a distinct (non-empty) segment owns its pairs; woff is the
+    exclusive prefix sum of the owned lengths; long_q lists the queries with more than 512 entries."""
+    from torchkge_amd.filter_index import FilterPlan
+    seg_lo = torch.tensor([0, 0, 10, 0, 10, 700, 0, 5])
+    seg_hi = torch.tensor([5, 5, 700, 0, 700, 701, 0, 10])      # queries 3 and 6: key absent (empty segment)
+    true = torch.arange(8)
+    targets = torch.zeros(701, dtype=torch.int32)
+    p = FilterPlan(seg_lo, seg_hi, true, targets)
+    owned = [5, 0, 690, 0, 0, 1, 0, 5]
+    assert p.woff.tolist() == [0] + list(np.cumsum(owned))
+    assert p.n_pairs == sum(owned) and p.long_q.tolist() == [2, 4] and p.n_long == 2

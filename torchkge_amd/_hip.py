@@ -81,6 +81,8 @@ _SIGNATURES = {
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
+    'kge_lp_filter_sub_planned': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                                  _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
@@ -124,7 +126,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 13:
+    if lib.kge_abi_version() != 14:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -614,15 +616,25 @@ class LpProblem(object):
         self.last_split = (prep['n_list'], prep)     # kept alive until the launches have run; tests read n_list
         return raw
 
-    def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None, grouped=False):
+    def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None, grouped=False, plan=None):
         """Filter correction of every query.  ``grouped=True`` (link-prediction batches: queries that
         share a filter segment share their query row): kge_lp_filter_sub_grouped -- each distinct
-        list scored once, pairs flattened over the grid (heavy-tailed lists stay cheap)."""
+        list scored once, pairs flattened over the grid (heavy-tailed lists stay cheap).  ``plan``
+        (filter_index.FilterPlan): the same with the grouping precomputed (kge_lp_filter_sub_planned)."""
         lib = load_library()
         if sub is None:
             sub = torch.empty(self.B, dtype=torch.int32, device=self.device)
         if found is None:
             found = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        if plan is not None and self.B > 0:
+            n_t = int(targets.shape[0])
+            fs = torch.empty(max(n_t, 1), dtype=torch.float32, device=self.device)
+            with _on(self.device):
+                _check(lib.kge_lp_filter_sub_planned(ctypes.byref(self.desc), _p(s_true), _p(true_idx), _p(seg_lo),
+                                                     _p(seg_hi), _p(targets), n_t, _p(plan.woff), plan.n_pairs,
+                                                     _p(plan.long_q) if plan.n_long else None, plan.n_long, _p(fs),
+                                                     _p(sub), _p(found), _stream()), 'kge_lp_filter_sub_planned')
+            return sub, found
         if grouped and self.B > 0:
             n_t = int(targets.shape[0])
             nb = int(lib.kge_lp_filter_sub_ws_bytes(self.B, n_t))

@@ -299,53 +299,79 @@ __global__ void fsub_claim_kernel(const int64_t *__restrict__ seg_lo, const int6
         if (seg_hi[i] > seg_lo[i]) atomicMin(&claim[seg_lo[i]], (unsigned)i);
 }
 
-constexpr int FS_SCAN_T = 1024, FS_SCAN_PER = 8;
-__global__ __launch_bounds__(FS_SCAN_T) void fsub_scan_kernel(const int64_t *__restrict__ seg_lo,
-                                                              const int64_t *__restrict__ seg_hi, int64_t B,
-                                                              const unsigned *__restrict__ claim, int64_t *woff)
+// exclusive prefix sum of the claimed segments' lengths, reduce-then-scan over blocks of FS_SCAN_T queries:
+//   fsub_len_kernel   len[i] (0 for queries that are not their segment's leader) + one sum per block
+//   fsub_bscan_kernel exclusive scan of the block sums (one block; any number of block sums)
+//   fsub_off_kernel   woff[i] = block base + exclusive scan inside the block;  woff[B] = total
+constexpr int FS_SCAN_T = 1024;
+__device__ __forceinline__ int64_t fsub_shfl_up64(int64_t v, int o)
+{
+    const unsigned vlo = __shfl_up((unsigned)(v & 0xffffffffll), o, 64);
+    const unsigned vhi = __shfl_up((unsigned)((uint64_t)v >> 32), o, 64);
+    return (int64_t)(((uint64_t)vhi << 32) | vlo);
+}
+// inclusive scan of one value per thread over a block of FS_SCAN_T threads; returns (inclusive, block total)
+__device__ __forceinline__ int64_t fsub_block_scan(int64_t v, int64_t *wsum, int64_t &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t u = fsub_shfl_up64(inc, o);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int64_t before = 0, tot = 0;
+    for (int w = 0; w < FS_SCAN_T / 64; ++w) {
+        const int64_t x = wsum[w];
+        if (w < wv) before += x;
+        tot += x;
+    }
+    total = tot;
+    return before + inc;
+}
+__global__ __launch_bounds__(FS_SCAN_T) void fsub_len_kernel(const int64_t *__restrict__ seg_lo,
+                                                             const int64_t *__restrict__ seg_hi, int64_t B,
+                                                             const unsigned *__restrict__ claim, int64_t *woff,
+                                                             int64_t *bsum)
 {
     __shared__ int64_t wsum[FS_SCAN_T / 64];
-    __shared__ int64_t carry_s;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < B; base += (int64_t)FS_SCAN_T * FS_SCAN_PER) {
-        int64_t len[FS_SCAN_PER], tot = 0;
-        const int64_t i0 = base + (int64_t)threadIdx.x * FS_SCAN_PER;
-#pragma unroll
-        for (int k = 0; k < FS_SCAN_PER; ++k) {
-            const int64_t i = i0 + k;
-            int64_t l = 0;
-            if (i < B) {
-                const int64_t lo = seg_lo[i], hi = seg_hi[i];
-                if (hi > lo && claim[lo] == (unsigned)i) l = hi - lo;
-            }
-            len[k] = l;
-            tot += l;
-        }
-        int64_t inc = tot; // inclusive scan over the wavefront (64-bit values as two 32-bit shuffles)
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned vlo = __shfl_up((unsigned)(inc & 0xffffffffll), o, 64);
-            const unsigned vhi = __shfl_up((unsigned)((uint64_t)inc >> 32), o, 64);
-            if (lane >= o) inc += (int64_t)(((uint64_t)vhi << 32) | vlo);
-        }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        int64_t before = carry_s;
-        for (int w = 0; w < wv; ++w) before += wsum[w];
-        int64_t run = before + inc - tot;
-#pragma unroll
-        for (int k = 0; k < FS_SCAN_PER; ++k) {
-            const int64_t i = i0 + k;
-            if (i < B) woff[i] = run;
-            run += len[k];
-        }
-        __syncthreads();
-        if (threadIdx.x == FS_SCAN_T - 1) carry_s = before + inc;
+    const int64_t i = (int64_t)blockIdx.x * FS_SCAN_T + threadIdx.x;
+    int64_t l = 0;
+    if (i < B) {
+        const int64_t lo = seg_lo[i], hi = seg_hi[i];
+        if (hi > lo && claim[lo] == (unsigned)i) l = hi - lo;
+        woff[i] = l;     // (turned into the offset by fsub_off_kernel)
+    }
+    int64_t total;
+    fsub_block_scan(l, wsum, total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(FS_SCAN_T) void fsub_bscan_kernel(int64_t *bsum, int64_t nb, int64_t *woff_total)
+{
+    __shared__ int64_t wsum[FS_SCAN_T / 64];
+    int64_t carry = 0;
+    for (int64_t base = 0; base < nb; base += FS_SCAN_T) {
+        const int64_t b = base + threadIdx.x;
+        const int64_t v = b < nb ? bsum[b] : 0;
+        int64_t total;
+        const int64_t inc = fsub_block_scan(v, wsum, total);
+        if (b < nb) bsum[b] = carry + inc - v;
+        carry += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) woff[B] = carry_s;
+    if (threadIdx.x == 0) *woff_total = carry;
+}
+__global__ __launch_bounds__(FS_SCAN_T) void fsub_off_kernel(int64_t B, int64_t *woff, const int64_t *__restrict__ bsum)
+{
+    __shared__ int64_t wsum[FS_SCAN_T / 64];
+    const int64_t i = (int64_t)blockIdx.x * FS_SCAN_T + threadIdx.x;
+    const int64_t l = i < B ? woff[i] : 0;
+    int64_t total;
+    const int64_t inc = fsub_block_scan(l, wsum, total);
+    if (i < B) woff[i] = bsum[blockIdx.x] + inc - l;
 }
 
 // scores of the flattened (claimed key, target) pairs: one lane per pair, 64 pairs per wavefront round
@@ -382,35 +408,76 @@ __global__ __launch_bounds__(64) void fsub_score_kernel(const kge_lp_desc d, con
     }
 }
 
-// one wavefront per query: compare the true score with the scores of its list
+// Comparison of every query's true score with the scores of its list.  Lists of up to FS_SHORT entries: one
+// wavefront per query, 8 independent loads per lane in flight (a hub list walked 64 entries per dependent
+// round was ~1 us per round).  Longer lists (hub keys: thousands of entities, shared by hundreds of queries):
+// `long_q` names those queries and one 256-thread BLOCK takes each; without it the wavefront loops.
+constexpr int FS_SHORT = 512;
+__device__ __forceinline__ void fsub_cmp(const kge_lp_desc &d, const int32_t *__restrict__ targets,
+                                         const float *__restrict__ fs, int64_t j, int64_t hi, int64_t ti, float tv,
+                                         int neg_inf_counts, int &sub, int &found)
+{
+    if (j >= hi) return;
+    const int64_t cg = targets[j];
+    const int64_t c = cg - d.c_base;
+    if (c < 0 || c >= d.N) return;
+    if (cg == ti) { found = 1; return; }
+    sub += ((fs[j] >= tv) ? 1 : 0) - neg_inf_counts;
+}
 __global__ __launch_bounds__(256) void fsub_count_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
                                                          const int64_t *__restrict__ true_idx,
                                                          const int64_t *__restrict__ seg_lo,
                                                          const int64_t *__restrict__ seg_hi,
                                                          const int32_t *__restrict__ targets,
-                                                         const float *__restrict__ fs, int32_t *sub_out,
-                                                         int32_t *found_out)
+                                                         const float *__restrict__ fs, int skip_long,
+                                                         int32_t *sub_out, int32_t *found_out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t i = wave; i < d.B; i += nwaves) {
         const int64_t lo = seg_lo[i], hi = seg_hi[i];
+        if (skip_long && hi - lo > FS_SHORT) continue;      // fsub_count_long_kernel writes this query
         int sub = 0, found = 0;
         if (hi > lo) {
             const float tv = s_true[i];
             const int64_t ti = true_idx[i];
             const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
-            for (int64_t j = lo + lane; j < hi; j += 64) {
-                const int64_t cg = targets[j];
-                const int64_t c = cg - d.c_base;
-                if (c < 0 || c >= d.N) continue;
-                if (cg == ti) { found = 1; continue; }
-                sub += ((fs[j] >= tv) ? 1 : 0) - neg_inf_counts;
+            for (int64_t j0 = lo; j0 < hi; j0 += FS_SHORT) {
+#pragma unroll
+                for (int u = 0; u < FS_SHORT / 64; ++u)
+                    fsub_cmp(d, targets, fs, j0 + u * 64 + lane, hi, ti, tv, neg_inf_counts, sub, found);
             }
             sub = wave_sum_i(sub);
             found = wave_sum_i(found);
         }
         if (lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
+    }
+}
+__global__ __launch_bounds__(256) void fsub_count_long_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                              const int64_t *__restrict__ true_idx,
+                                                              const int64_t *__restrict__ seg_lo,
+                                                              const int64_t *__restrict__ seg_hi,
+                                                              const int32_t *__restrict__ targets,
+                                                              const float *__restrict__ fs,
+                                                              const int64_t *__restrict__ long_q, int64_t n_long,
+                                                              int32_t *sub_out, int32_t *found_out)
+{
+    __shared__ int sh[4];
+    for (int64_t q = blockIdx.x; q < n_long; q += gridDim.x) {
+        const int64_t i = long_q[q];
+        const int64_t lo = seg_lo[i], hi = seg_hi[i];
+        const float tv = s_true[i];
+        const int64_t ti = true_idx[i];
+        const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+        int sub = 0, found = 0;
+        for (int64_t j0 = lo; j0 < hi; j0 += 1024) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                fsub_cmp(d, targets, fs, j0 + u * 256 + threadIdx.x, hi, ti, tv, neg_inf_counts, sub, found);
+        }
+        sub = block_sum_i(sub, sh);
+        found = block_sum_i(found, sh);
+        if (threadIdx.x == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
     }
 }
 
@@ -652,11 +719,39 @@ extern "C" int kge_lp_filter_sub(const kge_lp_desc *d, const float *s_true, cons
 }
 
 static inline int64_t fsub_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+static inline int64_t fsub_nblocks(int64_t B) { return (B + FS_SCAN_T - 1) / FS_SCAN_T; }
 
 extern "C" int64_t kge_lp_filter_sub_ws_bytes(int64_t B, int64_t n_targets)
 {
     if (B < 0 || n_targets < 0) return 0;
-    return fsub_align(n_targets * 4) * 2 + fsub_align((B + 1) * 8);
+    return fsub_align(n_targets * 4) * 2 + fsub_align((B + 1) * 8) + fsub_align((fsub_nblocks(B) + 1) * 8);
+}
+
+// scoring of the flattened work list + the per-query comparison (shared by the two entry points below)
+static int fsub_score_and_count(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
+                                const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets, int64_t n_pairs_max,
+                                const int64_t *woff, const int64_t *long_q, int64_t n_long, float *fs, int32_t *sub,
+                                int32_t *found, hipStream_t st)
+{
+    if (n_pairs_max > 0 && d->N > 0) {
+        const int64_t groups = (n_pairs_max + 63) / 64;      // upper bound of the flattened work (the exact total is read on the device)
+        const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
+        if (KGE_LP_IS_MFMA(d->mode)) {
+            if (kge_lp_vec4(*d))
+                hipLaunchKernelGGL((fsub_score_kernel<true, true>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+            else
+                hipLaunchKernelGGL((fsub_score_kernel<true, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+        } else {
+            hipLaunchKernelGGL((fsub_score_kernel<false, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+        }
+    }
+    hipLaunchKernelGGL(fsub_count_kernel, dim3(grid1d(d->B, 4)), dim3(256), 0, st, *d, s_true, true_idx, seg_lo, seg_hi,
+                       targets, fs, long_q ? 1 : 0, sub, found);
+    if (long_q && n_long > 0)
+        hipLaunchKernelGGL(fsub_count_long_kernel, dim3((int)(n_long < 256 * 16 ? n_long : 256 * 16)), dim3(256), 0, st, *d,
+                           s_true, true_idx, seg_lo, seg_hi, targets, fs, long_q, n_long, sub, found);
+    KGE_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int kge_lp_filter_sub_grouped(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
@@ -675,25 +770,34 @@ extern "C" int kge_lp_filter_sub_grouped(const kge_lp_desc *d, const float *s_tr
     unsigned *claim = reinterpret_cast<unsigned *>(w8);
     float *fs = reinterpret_cast<float *>(w8 + fsub_align(n_targets * 4));
     int64_t *woff = reinterpret_cast<int64_t *>(w8 + 2 * fsub_align(n_targets * 4));
+    int64_t *bsum = reinterpret_cast<int64_t *>(w8 + 2 * fsub_align(n_targets * 4) + fsub_align((d->B + 1) * 8));
     if (n_targets > 0 && d->N > 0) {
+        const int nb = (int)fsub_nblocks(d->B);
         hipLaunchKernelGGL(fsub_reset_kernel, dim3(grid1d(d->B, 256)), dim3(256), 0, st, seg_lo, seg_hi, d->B, claim);
         hipLaunchKernelGGL(fsub_claim_kernel, dim3(grid1d(d->B, 256)), dim3(256), 0, st, seg_lo, seg_hi, d->B, claim);
-        hipLaunchKernelGGL(fsub_scan_kernel, dim3(1), dim3(FS_SCAN_T), 0, st, seg_lo, seg_hi, d->B, claim, woff);
-        const int64_t groups = (n_targets + 63) / 64;     // upper bound of the flattened work (read on the device)
-        const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
-        if (KGE_LP_IS_MFMA(d->mode)) {
-            if (kge_lp_vec4(*d))
-                hipLaunchKernelGGL((fsub_score_kernel<true, true>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
-            else
-                hipLaunchKernelGGL((fsub_score_kernel<true, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
-        } else {
-            hipLaunchKernelGGL((fsub_score_kernel<false, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
-        }
+        hipLaunchKernelGGL(fsub_len_kernel, dim3(nb), dim3(FS_SCAN_T), 0, st, seg_lo, seg_hi, d->B, claim, woff, bsum);
+        hipLaunchKernelGGL(fsub_bscan_kernel, dim3(1), dim3(FS_SCAN_T), 0, st, bsum, (int64_t)nb, woff + d->B);
+        hipLaunchKernelGGL(fsub_off_kernel, dim3(nb), dim3(FS_SCAN_T), 0, st, d->B, woff, bsum);
     }
-    hipLaunchKernelGGL(fsub_count_kernel, dim3(grid1d(d->B, 4)), dim3(256), 0, st, *d, s_true, true_idx, seg_lo, seg_hi,
-                       targets, fs, sub, found);
-    KGE_CHECK_LAUNCH();
-    return 0;
+    return fsub_score_and_count(d, s_true, true_idx, seg_lo, seg_hi, targets, n_targets, woff, nullptr, 0, fs, sub, found, st);
+}
+
+extern "C" int kge_lp_filter_sub_planned(const kge_lp_desc *d, const float *s_true, const int64_t *true_idx,
+                                         const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                                         int64_t n_targets, const int64_t *woff, int64_t n_pairs,
+                                         const int64_t *long_q, int64_t n_long, float *fs, int32_t *sub, int32_t *found,
+                                         kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0) return 0;
+    if (!s_true || !true_idx || !seg_lo || !seg_hi || !sub || !found || !woff || n_targets < 0 || n_pairs < 0 || n_long < 0)
+        return KGE_EINVAL;
+    if (n_targets > 0 && (!targets || !fs)) return KGE_EINVAL;
+    if (n_long > 0 && !long_q) return KGE_EINVAL;
+    if (d->B > INT32_MAX || d->N > INT32_MAX) return KGE_EINVAL;
+    return fsub_score_and_count(d, s_true, true_idx, seg_lo, seg_hi, targets, n_pairs, woff, long_q, n_long, fs, sub, found,
+                                kge_s(stream));
 }
 
 extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
@@ -745,5 +849,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 13; }
+extern "C" int kge_abi_version(void) { return 14; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -43,13 +43,34 @@ __device__ __forceinline__ int elem_index(int e, int lane)
     return VEC4 ? ((e >> 2) * 64 + lane) * 4 + (e & 3) : e * 64 + lane;
 }
 
+// Wavefront sum on the DPP cross-lane path of the VALU (quad permutes, row mirrors, row broadcasts;
+// the total lands in lane 63 and is read back as a wave-uniform scalar): ~7 dependent full-rate VALU
+// ops instead of 6 ds_bpermute round trips through the LDS crossbar (__shfl_xor).  A triple's score is a
+// chain of up to six such reductions (norms, projections, the final sum), so this kernel is bound by
+// their latency, not by bytes.  (Summation order differs from wave_sum(): this file only.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v += dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xf>(v);   // row_mirror: every lane holds its row's 16-lane sum
+    v += dpp_mov<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <int NE>
 __device__ __forceinline__ float sumsq(const float (&x)[NE])
 {
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < NE; ++e) s = fmaf(x[e], x[e], s);
-    return wave_sum(s);
+    return wave_sum_dpp(s);
 }
 template <int NE>
 __device__ __forceinline__ float dotp(const float (&x)[NE], const float (&y)[NE])
@@ -57,15 +78,23 @@ __device__ __forceinline__ float dotp(const float (&x)[NE], const float (&y)[NE]
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < NE; ++e) s = fmaf(x[e], y[e], s);
-    return wave_sum(s);
+    return wave_sum_dpp(s);
 }
-// F.normalize: x / max(||x||, eps)
-template <int NE>
+// F.normalize: x / max(||x||, eps).  EXACT = true keeps the IEEE division per element (the backward, whose two
+// reduction modes are compared bit for bit); the forward multiplies by the reciprocal (one division per row,
+// <= 1 ulp per element: far inside the 1e-5 score tolerance, ~40 VALU ops per row cheaper).
+template <int NE, bool EXACT = true>
 __device__ __forceinline__ float normalize_inplace(float (&x)[NE])
 {
     const float n = fmaxf(sqrtf(sumsq<NE>(x)), 1e-12f);
+    if (EXACT) {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) x[e] = x[e] / n;
+        for (int e = 0; e < NE; ++e) x[e] = x[e] / n;
+    } else {
+        const float rn = 1.0f / n;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) x[e] = x[e] * rn;
+    }
     return n;
 }
 
@@ -94,15 +123,15 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const S
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
             load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
             load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
-            normalize_inplace<NE>(h);
-            normalize_inplace<NE>(t);
+            normalize_inplace<NE, false>(h);
+            normalize_inplace<NE, false>(t);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const float diff = (h[e] + r[e]) - t[e];
                 s = (p.kind == KGE_TRANSE_L1) ? s + fabsf(diff) : fmaf(diff, diff, s);
             }
-            s = wave_sum(s);
+            s = wave_sum_dpp(s);
             if (p.kind == KGE_TRANSE_L2) { const float n = sqrtf(s); s = n * n; } // norm(p=2)**2
             score = -s;
         } else if (p.kind == KGE_DISTMULT) {
@@ -110,12 +139,12 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const S
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
             load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
             load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
-            normalize_inplace<NE>(h);
-            normalize_inplace<NE>(t);
+            normalize_inplace<NE, false>(h);
+            normalize_inplace<NE, false>(t);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < NE; ++e) s += (h[e] * r[e]) * t[e];
-            score = wave_sum(s);
+            score = wave_sum_dpp(s);
         } else if (p.kind == KGE_COMPLEX) {
             float reh[NE], imh[NE], ret[NE], imt[NE], rer[NE], imr[NE];
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, reh);
@@ -128,16 +157,16 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const S
 #pragma unroll
             for (int e = 0; e < NE; ++e)
                 s += reh[e] * (rer[e] * ret[e] + imr[e] * imt[e]) + imh[e] * (rer[e] * imt[e] - imr[e] * ret[e]);
-            score = wave_sum(s);
+            score = wave_sum_dpp(s);
         } else if (p.kind == KGE_TRANSH) {
             float h[NE], t[NE], r[NE], w[NE];
             load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
             load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
             load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
             load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, w);
-            normalize_inplace<NE>(h);
-            normalize_inplace<NE>(t);
-            normalize_inplace<NE>(w);
+            normalize_inplace<NE, false>(h);
+            normalize_inplace<NE, false>(t);
+            normalize_inplace<NE, false>(w);
             const float hw = dotp<NE>(h, w), tw = dotp<NE>(t, w);
             float s = 0.f;
 #pragma unroll
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const S
                 const float diff = (ph + r[e]) - pt;
                 s = fmaf(diff, diff, s);
             }
-            s = wave_sum(s);
+            s = wave_sum_dpp(s);
             const float n = sqrtf(s);
             score = -(n * n);
         } else { // KGE_TRANSD
@@ -158,12 +187,12 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const S
             load_row<VEC4, NE>(p.t2 + ti * de, de, lane, tp);
             load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
             load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, rp);
-            normalize_inplace<NE>(h);
-            normalize_inplace<NE>(t);
-            normalize_inplace<NE>(hp);
-            normalize_inplace<NE>(tp);
-            normalize_inplace<NE>(r);
-            normalize_inplace<NE>(rp);
+            normalize_inplace<NE, false>(h);
+            normalize_inplace<NE, false>(t);
+            normalize_inplace<NE, false>(hp);
+            normalize_inplace<NE, false>(tp);
+            normalize_inplace<NE, false>(r);
+            normalize_inplace<NE, false>(rp);
             const float sh = dotp<NE>(h, hp), st = dotp<NE>(t, tp);
             float s = 0.f;
 #pragma unroll
@@ -174,7 +203,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const S
                 const float diff = (ph + r[e]) - pt;
                 s = fmaf(diff, diff, s);
             }
-            s = wave_sum(s);
+            s = wave_sum_dpp(s);
             const float n = sqrtf(s);
             score = -(n * n);
         }

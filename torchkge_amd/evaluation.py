@@ -32,7 +32,7 @@ from tqdm.autonotebook import tqdm
 from . import _hip
 from . import distributed as kdist
 from .exceptions import NotYetEvaluatedError
-from .filter_index import filter_index_for, KEY2_SPAN
+from .filter_index import filter_index_for, KEY2_SPAN, FilterPlan
 from .utils.data import get_n_batches
 from .utils.modeling import filter_scores
 from .utils.operations import get_rank
@@ -80,12 +80,19 @@ class HipRankEngine(object):
             prob.pre['true_idx'] = true_idx     # both-sides batch: the fused query pipeline scored exactly these pairs
         return prob.pair_scores(true_idx)
 
+    uses_plans = True       # per-batch FilterPlan (segments + grouping), built once per evaluator
+
+    def plan_both(self, index_t, index_h, h, t, r):
+        """FilterPlan of one both-sides batch: the filter lookup and the grouping of its 2B queries."""
+        seg_lo, seg_hi, true_idx, targets = self.lookup_both(index_t, index_h, h, t, r)
+        return FilterPlan(seg_lo, seg_hi, true_idx, targets)
+
     @staticmethod
-    def partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets):
+    def partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, plan=None):
         """int32 (3, B): raw >= counts, filter correction, found-true flag for this shard."""
         out = torch.zeros(3, prob.B, dtype=torch.int32, device=s_true.device)
         prob.count_ge(s_true, out[0])
-        prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True)
+        prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
         return out
 
     @staticmethod
@@ -193,6 +200,27 @@ class LinkPredictionEvaluator(object):
         # kernel of a batch runs once instead of twice, the all-candidates count kernel sees 2B queries
         self.both_sides = both_sides
         self._cut = None        # set while evaluate() is being captured as graph segments (see _GraphSegments)
+        # per-batch FilterPlans (filter segments, true ids, grouping): a function of the test facts and the filter
+        # index only, kept across evaluate() calls; _plan_stamp tells when they went stale
+        self._plans = None
+        self._plan_stamp = None
+        self._plan_gen = 0
+
+    def _ensure_plans(self, kg, f_lo, f_hi, b_size, index_t, index_h, device):
+        """Build (or keep) the FilterPlans of every batch of this evaluation, OUTSIDE any graph capture."""
+        stamp = (b_size, f_lo, f_hi, str(device),
+                 tuple((x.data_ptr(), x._version, x.shape[0]) for x in (kg.head_idx, kg.tail_idx, kg.relations)),
+                 tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t) for x in (ix.keys, ix.offsets, ix.targets)))
+        if self._plans is not None and self._plan_stamp == stamp:
+            return
+        heads, tails, rels = (kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
+                              kg.relations[f_lo:f_hi].to(device))
+        plans = {}
+        for i in range(get_n_batches(f_hi - f_lo, b_size)):
+            sl = slice(i * b_size, (i + 1) * b_size)
+            plans[(i * b_size, heads[sl].shape[0])] = self.engine.plan_both(index_t, index_h, heads[sl], tails[sl], rels[sl])
+        self._plans, self._plan_stamp = plans, stamp
+        self._plan_gen += 1
 
     # -- filter indices ------------------------------------------------------
     def _filter_indices(self, device):
@@ -230,12 +258,19 @@ class LinkPredictionEvaluator(object):
         per batch -- the (2B) true scores (the owner shard holds the value, the others 0;
         x + 0 is exact) and the (3, 2B) partial rank counts."""
         eng = self.engine
-        seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
+        plan = self._plans.get((off, h.shape[0])) if self._plans is not None else None
+        if plan is not None:    # filter segments, true ids and the grouping of the batch: precomputed (FilterPlan)
+            seg_lo, seg_hi, true_idx, targets = plan.seg_lo, plan.seg_hi, plan.true_idx, plan.targets
+        else:
+            seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **self._xkw(sharded))
         s_true = eng.true_scores(prob, true_idx)
         if sharded:
             self._collective(lambda: kdist.all_reduce_sum(s_true, self.group))
-        counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets)
+        if plan is not None:
+            counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, plan=plan)
+        else:
+            counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets)
         if sharded:
             self._collective(lambda: kdist.all_reduce_sum(counts, self.group))
         eng.finalize_both(counts, out, off)
@@ -347,6 +382,10 @@ class LinkPredictionEvaluator(object):
 
             both = (self.both_sides and self.fused and not self._generic_model and not overlap and
                     not (sharded and self.exchange == 'scores') and hasattr(self.engine, 'lookup_both'))
+            if both and getattr(self.engine, 'uses_plans', False) and n_local > 0:
+                self._ensure_plans(kg, f_lo, f_hi, b_size, index_t, index_h, device)
+            else:
+                self._plans = None
 
             def alloc_out():
                 # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
@@ -389,7 +428,7 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                       tuple(p_.data_ptr() for p_ in self.model.parameters()),
+                       tuple(p_.data_ptr() for p_ in self.model.parameters()), self._plan_gen,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))
                 if self.graph is None and self._graph_key != key and self._graph_seen != key:
@@ -406,7 +445,7 @@ class LinkPredictionEvaluator(object):
                 if self._graph_key != key:
                     st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
                           'r': kg.relations[f_lo:f_hi].to(device).clone(),
-                          'out': alloc_out(), 'index': (index_h, index_t), 'engine': self.engine}
+                          'out': alloc_out(), 'index': (index_h, index_t), 'engine': self.engine, 'plans': self._plans}
                     try:
                         if self.graph is not None or self._graph_seen != key:
                             side = torch.cuda.Stream(device)

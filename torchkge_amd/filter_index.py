@@ -114,6 +114,39 @@ class FilterIndex(object):
         return _hip.filter_lookup(self.keys, self.offsets, key1, key2, KEY2_SPAN)
 
 
+class FilterPlan(object):
+    """What one batch of link-prediction queries needs from the filter index, computed ONCE: the
+    filter segments and true ids of its 2B queries (tail side first), and the grouping that lets
+    every distinct filter list be scored once (kge_lp_filter_sub_planned): queries that share a key
+    share the list AND the query row, so only the first query of a key 'owns' the list's pairs.
+    A pure function of the test facts and the index -- not of the model -- so an evaluator keeps it
+    across evaluate() calls (like the index itself, built once per graph).
+
+    seg_lo / seg_hi / true_idx: (2B) int64;  woff: (2B + 1) exclusive prefix sum of the owned lengths;
+    n_pairs = woff[-1] (host int);  long_q: queries with more than 512 list entries."""
+
+    LONG = 512
+
+    def __init__(self, seg_lo, seg_hi, true_idx, targets):
+        self.seg_lo, self.seg_hi, self.true_idx, self.targets = seg_lo, seg_hi, true_idx, targets
+        n = seg_lo.shape[0]
+        dev = seg_lo.device
+        ln = seg_hi - seg_lo
+        nonempty = ln > 0
+        # first query of every distinct segment start (segments of one index are disjoint: the start names the key)
+        first = torch.full((int(targets.shape[0]) + 1,), n, dtype=torch.int64, device=dev)
+        q = torch.arange(n, dtype=torch.int64, device=dev)
+        first.scatter_reduce_(0, torch.where(nonempty, seg_lo, torch.full_like(seg_lo, targets.shape[0])), q,
+                              reduce='amin', include_self=True)
+        owner = nonempty & (first[seg_lo.clamp(max=targets.shape[0])] == q)
+        owned = torch.where(owner, ln, torch.zeros_like(ln))
+        self.woff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        self.woff[1:] = torch.cumsum(owned, 0)
+        self.long_q = torch.nonzero(ln > self.LONG).view(-1).contiguous()
+        self.n_pairs = int(self.woff[-1].item())       # (one host sync, at plan build only)
+        self.n_long = int(self.long_q.shape[0])
+
+
 _CACHE = []          # [(dictionary, len, device, FilterIndex)] -- small LRU
 _CACHE_MAX = 8
 
