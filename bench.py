@@ -528,19 +528,32 @@ def main():
     cpu = None
     ev_ranks = [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and tables is not None:
-        torch.set_num_threads(os.cpu_count())
         th, tt_, tr = kg_test.head_idx.cpu(), kg_test.tail_idx.cpu(), kg_test.relations.cpu()
         dh, dtl = kg.dict_of_heads, kg.dict_of_tails
-        orc.lp_evaluate(kind, tables, th[:8], tt_[:8], tr[:8], dh, dtl, 8, p)     # warms the allocator / threads
+
+        def cpu_run(off, bs, ties=False):
+            c0 = time.perf_counter()
+            o = orc.lp_evaluate(kind, tables, th[off:off + bs], tt_[off:off + bs], tr[off:off + bs], dh, dtl, bs, p,
+                                tie_tol=2e-5 if ties else None)
+            return time.perf_counter() - c0, o
+        # thread count: all host cores is not always the fastest for these memory-bound (b, N, d) temporaries
+        thread_sweep, best_thr = {}, None
+        for nthr in sorted({os.cpu_count(), min(os.cpu_count(), 64), min(os.cpu_count(), 16)}, reverse=True):
+            torch.set_num_threads(nthr)
+            cpu_run(0, 32)                              # warms the allocator / threads (first touch is page-fault bound)
+            dt_, _ = cpu_run(0, 32)
+            thread_sweep[nthr] = round(32 * 2 * n_ent_full / dt_, 1)
+            if best_thr is None or thread_sweep[nthr] > thread_sweep[best_thr]:
+                best_thr = nthr
+        torch.set_num_threads(best_thr)
         sweep, best, off = {}, None, 0
         cpu_r, gpu_r, ties_all = [], [], []
         for bs in (32, 64, 128, 256):           # the reference is strongly non-monotonic in b
             if off + bs > n_test:
                 break
-            c0 = time.perf_counter()
-            rh, rt, frh, frt, ties = orc.lp_evaluate(kind, tables, th[off:off + bs], tt_[off:off + bs], tr[off:off + bs],
-                                                     dh, dtl, bs, p, tie_tol=2e-5)
-            dt_ = time.perf_counter() - c0
+            if bs > 32:
+                cpu_run(off, bs)                        # untimed first touch of this size's temporaries
+            dt_, (rh, rt, frh, frt, ties) = cpu_run(off, bs, ties=True)
             sweep[bs] = round(bs * 2 * n_ent_full / dt_, 1)
             if best is None or sweep[bs] > sweep[best]:
                 best = bs
@@ -554,10 +567,12 @@ def main():
         mo = orc.lp_metrics(*cpu_r, 10)
         mg = orc.lp_metrics(*gpu_r, 10)
         cpu = {'value': sweep[best], 'unit': 'triples_scored/s',
-               'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': 'one batch per b_size in {32,64,128,256} (%d of %d test triples), oracle.lp_evaluate = the '
-                         'reference algorithm on torch CPU ops; value = the best b_size (%d)' % (off, n_test, best),
-               'b_size_sweep': sweep,
+               'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'port',
+               'sample': 'one batch per b_size in {32,64,128,256} (%d of %d test triples; each size run twice, the second timed), '
+                         'oracle.lp_evaluate = the reference algorithm on torch CPU ops (no autograd graph: measured 1.27x '
+                         'faster than the real reference in the build container, BASELINE.md); value = the best b_size (%d) '
+                         'at the best thread count (%d)' % (off, n_test, best, best_thr),
+               'b_size_sweep': sweep, 'thread_sweep_b32': thread_sweep,
                'ranks_equal_to_gpu': n_diff == 0, 'ranks_differing': n_diff, 'ranks_compared': int(cpu_r.numel()),
                'gpu_ranks_within_reference_tie_interval_2e-5': in_tie,
                'filt_hits10_cpu_gpu': [mo['hit_at_k'][1], mg['hit_at_k'][1]],
