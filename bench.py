@@ -96,6 +96,8 @@ def parse():
     ap.add_argument('--weights', default='trained', choices=['trained', 'xavier'],
                     help="model weights: 'trained' = a few hundred engine training steps before the timed region")
     ap.add_argument('--train-steps', type=int, default=None)
+    ap.add_argument('--only-timed', action='store_true',
+                    help='profiling aid: nothing but the warm-up and the timed loop (no roofline / f32 / cpu / parity legs)')
     ap.add_argument('--no-full-parity', action='store_true',
                     help='skip the full-test-split comparison against the GPU-resident reference algorithm')
     return ap.parse_args()
@@ -246,6 +248,8 @@ def _flush_c_stdio():
 
 def main():
     args = parse()
+    if args.only_timed:
+        args.no_cpu_baseline = args.no_secondary = args.no_full_parity = True
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -377,7 +381,7 @@ def main():
 
     # the same evaluation with the rank counts on the fp32 MFMA kernel only (reported beside the headline)
     f32_only_ms = None
-    if getattr(model, 'split_filter', False) and rank == 0 and not multi:
+    if getattr(model, 'split_filter', False) and rank == 0 and not multi and not args.only_timed:
         model.split_filter = False
         for _ in range(2):
             ev.evaluate(args.batch, verbose=False)
@@ -410,7 +414,7 @@ def main():
 
     # ---- roofline of the dominant kernel (the all-candidates count kernel) ----
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.only_timed:
         B = min(args.batch, n_test)
         h, t, r = kg_test.head_idx[:B], kg_test.tail_idx[:B], kg_test.relations[:B]
         guard_on = hasattr(model, 'lp_guard_begin') and model.lp_guard_begin(device) is not None

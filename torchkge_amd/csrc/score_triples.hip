@@ -107,107 +107,149 @@ struct ScoreParams {
     float *out;
 };
 
-template <bool VEC4, int NE>
+// Rows a triple gathers, per model kind: table and index of row j (0: h, 1: t, 2: r)
+//   TransE / DistMult: E[h] E[t] R[r]            TransH: E[h] E[t] R[r] W[r]
+//   ComplEx: Re[h] Im[h] Re[t] Im[t] Rre[r] Rim[r]   TransD: E[h] E[t] Ep[h] Ep[t] R[r] Rp[r]
+template <int KIND> struct RowSet;
+template <> struct RowSet<KGE_TRANSE_L1> { static constexpr int NR = 3; };
+template <> struct RowSet<KGE_TRANSE_L2> { static constexpr int NR = 3; };
+template <> struct RowSet<KGE_DISTMULT> { static constexpr int NR = 3; };
+template <> struct RowSet<KGE_TRANSH> { static constexpr int NR = 4; };
+template <> struct RowSet<KGE_COMPLEX> { static constexpr int NR = 6; };
+template <> struct RowSet<KGE_TRANSD> { static constexpr int NR = 6; };
+
+template <int KIND, bool VEC4, int NE>
+__device__ __forceinline__ void gather_rows(const ScoreParams &p, int64_t hi, int64_t ti, int64_t ri, int lane,
+                                            float (&x)[RowSet<KIND>::NR][NE])
+{
+    const int de = p.d_ent, dr = p.d_rel;
+    if (KIND == KGE_COMPLEX) {
+        load_row<VEC4, NE>(p.t0 + hi * de, de, lane, x[0]);
+        load_row<VEC4, NE>(p.t1 + hi * de, de, lane, x[1]);
+        load_row<VEC4, NE>(p.t0 + ti * de, de, lane, x[2]);
+        load_row<VEC4, NE>(p.t1 + ti * de, de, lane, x[3]);
+        load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, x[4]);
+        load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, x[5]);
+    } else if (KIND == KGE_TRANSD) {
+        load_row<VEC4, NE>(p.t0 + hi * de, de, lane, x[0]);
+        load_row<VEC4, NE>(p.t0 + ti * de, de, lane, x[1]);
+        load_row<VEC4, NE>(p.t2 + hi * de, de, lane, x[2]);
+        load_row<VEC4, NE>(p.t2 + ti * de, de, lane, x[3]);
+        load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, x[4]);
+        load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, x[5]);
+    } else {
+        load_row<VEC4, NE>(p.t0 + hi * de, de, lane, x[0]);
+        load_row<VEC4, NE>(p.t0 + ti * de, de, lane, x[1]);
+        load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, x[2]);
+        if (KIND == KGE_TRANSH) load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, x[RowSet<KIND>::NR - 1]);
+    }
+}
+
+template <int KIND, bool VEC4, int NE>
+__device__ __forceinline__ float score_rows(const ScoreParams &p, int lane, float (&x)[RowSet<KIND>::NR][NE])
+{
+    if (KIND == KGE_TRANSE_L1 || KIND == KGE_TRANSE_L2) {
+        float (&h)[NE] = x[0], (&t)[NE] = x[1], (&r)[NE] = x[2];
+        normalize_inplace<NE, false>(h);
+        normalize_inplace<NE, false>(t);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const float diff = (h[e] + r[e]) - t[e];
+            s = (KIND == KGE_TRANSE_L1) ? s + fabsf(diff) : fmaf(diff, diff, s);
+        }
+        s = wave_sum_dpp(s);
+        if (KIND == KGE_TRANSE_L2) { const float n = sqrtf(s); s = n * n; } // norm(p=2)**2
+        return -s;
+    } else if (KIND == KGE_DISTMULT) {
+        float (&h)[NE] = x[0], (&t)[NE] = x[1], (&r)[NE] = x[2];
+        normalize_inplace<NE, false>(h);
+        normalize_inplace<NE, false>(t);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) s += (h[e] * r[e]) * t[e];
+        return wave_sum_dpp(s);
+    } else if (KIND == KGE_COMPLEX) {
+        float (&reh)[NE] = x[0], (&imh)[NE] = x[1], (&ret)[NE] = x[2], (&imt)[NE] = x[3], (&rer)[NE] = x[4], (&imr)[NE] = x[5];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            s += reh[e] * (rer[e] * ret[e] + imr[e] * imt[e]) + imh[e] * (rer[e] * imt[e] - imr[e] * ret[e]);
+        return wave_sum_dpp(s);
+    } else if (KIND == KGE_TRANSH) {
+        float (&h)[NE] = x[0], (&t)[NE] = x[1], (&r)[NE] = x[2], (&w)[NE] = x[3];
+        normalize_inplace<NE, false>(h);
+        normalize_inplace<NE, false>(t);
+        normalize_inplace<NE, false>(w);
+        const float hw = dotp<NE>(h, w), tw = dotp<NE>(t, w);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const float ph = h[e] - hw * w[e];
+            const float pt = t[e] - tw * w[e];
+            const float diff = (ph + r[e]) - pt;
+            s = fmaf(diff, diff, s);
+        }
+        s = wave_sum_dpp(s);
+        const float n = sqrtf(s);
+        return -(n * n);
+    } else { // KGE_TRANSD
+        float (&h)[NE] = x[0], (&t)[NE] = x[1], (&hp)[NE] = x[2], (&tp)[NE] = x[3], (&r)[NE] = x[4], (&rp)[NE] = x[5];
+        normalize_inplace<NE, false>(h);
+        normalize_inplace<NE, false>(t);
+        normalize_inplace<NE, false>(hp);
+        normalize_inplace<NE, false>(tp);
+        normalize_inplace<NE, false>(r);
+        normalize_inplace<NE, false>(rp);
+        const float sh = dotp<NE>(h, hp), st = dotp<NE>(t, tp);
+        const int dr = p.d_rel;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const bool in = elem_index<VEC4, NE>(e, lane) < dr; // ent[:, :rel_emb_dim]
+            const float ph = rp[e] * sh + (in ? h[e] : 0.f);
+            const float pt = rp[e] * st + (in ? t[e] : 0.f);
+            const float diff = (ph + r[e]) - pt;
+            s = fmaf(diff, diff, s);
+        }
+        s = wave_sum_dpp(s);
+        const float n = sqrtf(s);
+        return -(n * n);
+    }
+}
+
+// One wavefront per triple, specialised per model kind, software-pipelined over the wavefront's triples
+// (PF): the rows of triple i + nwaves are in flight while triple i is normalised / reduced -- a triple is a
+// dependent chain  index load -> row gathers -> up to eight wave reductions, and with a handful of triples
+// per wavefront nothing else hides that chain.
+template <int KIND, bool VEC4, int NE, bool PF>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void score_fwd_kernel(const ScoreParams p)
 {
+    constexpr int NR = RowSet<KIND>::NR;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
-    const int de = p.d_ent, dr = p.d_rel;
-
-    for (int64_t i = wave; i < p.B; i += nwaves) {
-        const int64_t hi = p.h[i], ti = p.t[i], ri = p.r[i];
-        float score;
-        if (p.kind == KGE_TRANSE_L1 || p.kind == KGE_TRANSE_L2) {
-            float h[NE], t[NE], r[NE];
-            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
-            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
-            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
-            normalize_inplace<NE, false>(h);
-            normalize_inplace<NE, false>(t);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const float diff = (h[e] + r[e]) - t[e];
-                s = (p.kind == KGE_TRANSE_L1) ? s + fabsf(diff) : fmaf(diff, diff, s);
-            }
-            s = wave_sum_dpp(s);
-            if (p.kind == KGE_TRANSE_L2) { const float n = sqrtf(s); s = n * n; } // norm(p=2)**2
-            score = -s;
-        } else if (p.kind == KGE_DISTMULT) {
-            float h[NE], t[NE], r[NE];
-            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
-            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
-            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
-            normalize_inplace<NE, false>(h);
-            normalize_inplace<NE, false>(t);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < NE; ++e) s += (h[e] * r[e]) * t[e];
-            score = wave_sum_dpp(s);
-        } else if (p.kind == KGE_COMPLEX) {
-            float reh[NE], imh[NE], ret[NE], imt[NE], rer[NE], imr[NE];
-            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, reh);
-            load_row<VEC4, NE>(p.t1 + hi * de, de, lane, imh);
-            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, ret);
-            load_row<VEC4, NE>(p.t1 + ti * de, de, lane, imt);
-            load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, rer);
-            load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, imr);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < NE; ++e)
-                s += reh[e] * (rer[e] * ret[e] + imr[e] * imt[e]) + imh[e] * (rer[e] * imt[e] - imr[e] * ret[e]);
-            score = wave_sum_dpp(s);
-        } else if (p.kind == KGE_TRANSH) {
-            float h[NE], t[NE], r[NE], w[NE];
-            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
-            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
-            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
-            load_row<VEC4, NE>(p.t2 + ri * dr, dr, lane, w);
-            normalize_inplace<NE, false>(h);
-            normalize_inplace<NE, false>(t);
-            normalize_inplace<NE, false>(w);
-            const float hw = dotp<NE>(h, w), tw = dotp<NE>(t, w);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const float ph = h[e] - hw * w[e];
-                const float pt = t[e] - tw * w[e];
-                const float diff = (ph + r[e]) - pt;
-                s = fmaf(diff, diff, s);
-            }
-            s = wave_sum_dpp(s);
-            const float n = sqrtf(s);
-            score = -(n * n);
-        } else { // KGE_TRANSD
-            float h[NE], t[NE], hp[NE], tp[NE], r[NE], rp[NE];
-            load_row<VEC4, NE>(p.t0 + hi * de, de, lane, h);
-            load_row<VEC4, NE>(p.t0 + ti * de, de, lane, t);
-            load_row<VEC4, NE>(p.t2 + hi * de, de, lane, hp);
-            load_row<VEC4, NE>(p.t2 + ti * de, de, lane, tp);
-            load_row<VEC4, NE>(p.t1 + ri * dr, dr, lane, r);
-            load_row<VEC4, NE>(p.t3 + ri * dr, dr, lane, rp);
-            normalize_inplace<NE, false>(h);
-            normalize_inplace<NE, false>(t);
-            normalize_inplace<NE, false>(hp);
-            normalize_inplace<NE, false>(tp);
-            normalize_inplace<NE, false>(r);
-            normalize_inplace<NE, false>(rp);
-            const float sh = dotp<NE>(h, hp), st = dotp<NE>(t, tp);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const bool in = elem_index<VEC4, NE>(e, lane) < dr; // ent[:, :rel_emb_dim]
-                const float ph = rp[e] * sh + (in ? h[e] : 0.f);
-                const float pt = rp[e] * st + (in ? t[e] : 0.f);
-                const float diff = (ph + r[e]) - pt;
-                s = fmaf(diff, diff, s);
-            }
-            s = wave_sum_dpp(s);
-            const float n = sqrtf(s);
-            score = -(n * n);
+    if (wave >= p.B) return;
+    if (!PF) {
+        for (int64_t i = wave; i < p.B; i += nwaves) {
+            float x[NR][NE];
+            gather_rows<KIND, VEC4, NE>(p, p.h[i], p.t[i], p.r[i], lane, x);
+            const float score = score_rows<KIND, VEC4, NE>(p, lane, x);
+            if (lane == 0) p.out[i] = score;
         }
-        if (lane == 0) p.out[i] = score;
+        return;
+    }
+    float a[NR][NE], b[NR][NE];
+    gather_rows<KIND, VEC4, NE>(p, p.h[wave], p.t[wave], p.r[wave], lane, a);
+    for (int64_t i = wave; i < p.B; i += 2 * nwaves) {
+        const int64_t i1 = i + nwaves, i2 = i1 + nwaves;
+        if (i1 < p.B) gather_rows<KIND, VEC4, NE>(p, p.h[i1], p.t[i1], p.r[i1], lane, b);
+        const float sa = score_rows<KIND, VEC4, NE>(p, lane, a);
+        if (lane == 0) p.out[i] = sa;
+        if (i1 >= p.B) break;
+        if (i2 < p.B) gather_rows<KIND, VEC4, NE>(p, p.h[i2], p.t[i2], p.r[i2], lane, a);
+        const float sb = score_rows<KIND, VEC4, NE>(p, lane, b);
+        if (lane == 0) p.out[i1] = sb;
     }
 }
 
@@ -490,19 +532,55 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restric
     }
 }
 
-// counting sort of small-integer keys (entity / relation ids): histogram, (host: cumsum), scatter
+// counting sort of small-integer keys (entity / relation ids): histogram, (host: cumsum), scatter.
+// Atomics are aggregated per wavefront: one atomic per DISTINCT key among a wavefront's 64 keys.  Real
+// graphs are heavy-tailed (a hub entity / relation owns 10% of a batch) and same-address atomics
+// serialise at ~12 ns each past the L2s: 100 us per launch at B = 32768 on a Zipf batch before this.
+__device__ __forceinline__ int64_t readlane64(int64_t v, int src)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), src);
+    const unsigned hi = __builtin_amdgcn_readlane((int)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 __global__ void key_hist_kernel(const int64_t *__restrict__ k0, int64_t n0, const int64_t *__restrict__ k1, int64_t n1,
                                 int32_t *hist)
 {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0 + n1; j += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&hist[j < n0 ? k0[j] : k1[j - n0]], 1);
+    const int lane = threadIdx.x & 63;
+    const int64_t n = n0 + n1, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t jb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; jb < n; jb += stride) {   // wave-uniform trip count
+        const int64_t j = jb + lane;
+        const bool act = j < n;
+        const int64_t key = act ? (j < n0 ? k0[j] : k1[j - n0]) : -1;
+        unsigned long long todo = __ballot(act);
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int64_t kl = readlane64(key, lead);
+            const unsigned long long same = __ballot(act && key == kl);
+            if (lane == lead) atomicAdd(&hist[kl], (int)__popcll(same));
+            todo &= ~same;
+        }
+    }
 }
 __global__ void key_scatter_kernel(const int64_t *__restrict__ k0, int64_t n0, const int64_t *__restrict__ k1,
                                    int64_t n1, const int64_t *__restrict__ offsets, int32_t *cursor, int64_t *perm)
 {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0 + n1; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t key = j < n0 ? k0[j] : k1[j - n0];
-        perm[offsets[key] + atomicAdd(&cursor[key], 1)] = j;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = n0 + n1, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t jb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; jb < n; jb += stride) {
+        const int64_t j = jb + lane;
+        const bool act = j < n;
+        const int64_t key = act ? (j < n0 ? k0[j] : k1[j - n0]) : -1;
+        unsigned long long todo = __ballot(act);
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int64_t kl = readlane64(key, lead);
+            const unsigned long long same = __ballot(act && key == kl);
+            int base = 0;
+            if (lane == lead) base = atomicAdd(&cursor[kl], (int)__popcll(same));
+            base = __builtin_amdgcn_readlane(base, lead);
+            if (act && key == kl) perm[offsets[kl] + base + (int)__popcll(same & ((1ull << lane) - 1ull))] = j;
+            todo &= ~same;
+        }
     }
 }
 
@@ -559,8 +637,23 @@ extern "C" int kge_score_triples(int kind, const float *t0, const float *t1, con
     const bool vec4 = tables_vec4(t0, t1, t2, t3, d_ent, d_rel);
     auto sel = [](const ScoreParams &pp, auto ne, bool v4, int64_t b, hipStream_t s) -> int {
         constexpr int NE = decltype(ne)::value;
-        if (v4) hipLaunchKernelGGL((score_fwd_kernel<true, NE>), dim3(grid_for(b)), dim3(WAVES_PER_BLOCK * 64), 0, s, pp);
-        else hipLaunchKernelGGL((score_fwd_kernel<false, NE>), dim3(grid_for(b)), dim3(WAVES_PER_BLOCK * 64), 0, s, pp);
+        constexpr bool PF = NE <= 8;    // two row sets in registers (6 rows x 16 floats x 2 would not fit)
+        const dim3 grid(grid_for(b)), block(WAVES_PER_BLOCK * 64);
+#define KGE_FWD_CASE(K)                                                                                   \
+    case K:                                                                                               \
+        if (v4) hipLaunchKernelGGL((score_fwd_kernel<K, true, NE, PF>), grid, block, 0, s, pp);           \
+        else hipLaunchKernelGGL((score_fwd_kernel<K, false, NE, PF>), grid, block, 0, s, pp);             \
+        break;
+        switch (pp.kind) {
+            KGE_FWD_CASE(KGE_TRANSE_L1)
+            KGE_FWD_CASE(KGE_TRANSE_L2)
+            KGE_FWD_CASE(KGE_TRANSH)
+            KGE_FWD_CASE(KGE_TRANSD)
+            KGE_FWD_CASE(KGE_DISTMULT)
+            KGE_FWD_CASE(KGE_COMPLEX)
+        default: return KGE_EINVAL;
+        }
+#undef KGE_FWD_CASE
         KGE_CHECK_LAUNCH();
         return 0;
     };
