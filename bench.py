@@ -637,6 +637,10 @@ def main():
                                 'filter_lists': flt_stats},
             'roofline': roof, 'cpu_baseline': cpu, 'parity_full_split': parity, 'secondary': sec,
             'entity_tables': None if not multi else {
+                'query_rows': (None if getattr(model, '_row_shard', None) is None else
+                               ('rows of the %d distinct entities of the test facts summed over the ranks once per evaluate()'
+                                % int(ev._qmap['uniq'].shape[0]) if getattr(ev, '_qmap', None) is not None and ev.query_exchange == 'evaluate'
+                                else '(2B, K) query rows summed over the ranks per batch')),
                 'layout': ('row-sharded: N/P rows per GPU, relation tables replicated' if (shard == 'entities' and args.tables == 'sharded')
                            else 'replicated'),
                 'bytes_full': table_bytes_full, 'bytes_this_rank': model.entity_table_bytes()},

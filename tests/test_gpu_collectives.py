@@ -72,15 +72,16 @@ full = m.entity_table_bytes()
 lo, hi = kd.shard_model_(m)
 assert m.entity_table_bytes() <= full // world + 4 * 2 * d * 2
 ok = True
-for exchange, graph in (('counts', False), ('counts', True), ('scores', False)):
-    ev = tk.LinkPredictionEvaluator(m, kg_test, shard='entities', exchange=exchange, graph=graph)
+for exchange, graph, qx in (('counts', False, 'evaluate'), ('counts', True, 'evaluate'), ('counts', False, 'batch'),
+                            ('counts', True, 'batch'), ('scores', False, 'evaluate')):
+    ev = tk.LinkPredictionEvaluator(m, kg_test, shard='entities', exchange=exchange, graph=graph, query_exchange=qx)
     for _ in range(2):
         ev.evaluate(b_size=256, verbose=False)
     got = [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]
     for a, b in zip(want, got):
         if not torch.equal(a, b):
             ok = False
-            print('MISMATCH', rank, kind, exchange, graph, int((a != b).sum()), flush=True)
+            print('MISMATCH', rank, kind, exchange, graph, qx, int((a != b).sum()), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 open(out_path, 'w').write('ok' if ok else 'bad')

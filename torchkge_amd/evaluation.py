@@ -68,10 +68,14 @@ class HipRankEngine(object):
         return seg_lo, seg_hi, true_idx, self._targets_cat[1]
 
     @staticmethod
-    def problem(model, h, t, r, side, lo, hi, exchange=None):
-        """`exchange`: completes the query rows of a ROW-SHARDED model (sum over the shards)."""
-        if exchange is not None and getattr(model, '_row_shard', None) is not None:
-            return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, exchange=exchange)
+    def problem(model, h, t, r, side, lo, hi, exchange=None, qctx=None):
+        """ROW-SHARDED model: `qctx` = (replicas of the query entities' rows, h and t as indices into them),
+        exchanged once per evaluate(); or `exchange`: completes the query rows of this batch (sum over the shards)."""
+        if getattr(model, '_row_shard', None) is not None:
+            if qctx is not None:
+                return model.lp_problem(qctx[1], qctx[2], r, side, ent_lo=lo, ent_hi=hi, qtabs=qctx[0])
+            if exchange is not None:
+                return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, exchange=exchange)
         return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi)
 
     @staticmethod
@@ -176,10 +180,16 @@ class LinkPredictionEvaluator(object):
         False: always eager.  A capture that fails (e.g. a user model that syncs)
         falls back to eager for good.
     group: torch.distributed process group (default: WORLD).
+    query_exchange: 'evaluate' | 'batch' -- models whose entity tables are ROW-SHARDED
+        (distributed.shard_model_): how the query rows reach every rank.  'evaluate'
+        (default): the rows of the distinct entities the test facts mention are summed
+        over the ranks once per evaluate() (owner contributes the row, the others zeros)
+        and every batch builds its queries locally from those replicas; 'batch': each
+        batch's (2B, K) query matrix is built by the owners and summed.  Same ranks.
     """
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
-                 group=None, engine=None, graph=None, overlap=False, both_sides=True):
+                 group=None, engine=None, graph=None, overlap=False, both_sides=True, query_exchange='evaluate'):
         self.model = model
         self.kg = knowledge_graph
         n = knowledge_graph.n_facts
@@ -205,6 +215,12 @@ class LinkPredictionEvaluator(object):
         self._plans = None
         self._plan_stamp = None
         self._plan_gen = 0
+        # row-sharded models: the distinct entities of the test facts and the facts re-indexed into that list
+        # (static like the plans); their rows are exchanged ONCE per evaluate() (query_exchange='evaluate') instead
+        # of the (2B, K) query rows of every batch ('batch')
+        self.query_exchange = query_exchange
+        self._qmap = None
+        self._qb = None
 
     def _ensure_plans(self, kg, f_lo, f_hi, b_size, index_t, index_h, device):
         """Build (or keep) the FilterPlans of every batch of this evaluation, OUTSIDE any graph capture."""
@@ -215,6 +231,9 @@ class LinkPredictionEvaluator(object):
             return
         heads, tails, rels = (kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                               kg.relations[f_lo:f_hi].to(device))
+        uniq, inv = torch.unique(torch.cat([heads, tails]), return_inverse=True)
+        n = heads.shape[0]
+        self._qmap = {'uniq': uniq.contiguous(), 'hq': inv[:n].contiguous(), 'tq': inv[n:].contiguous()}
         plans = {}
         for i in range(get_n_batches(f_hi - f_lo, b_size)):
             sl = slice(i * b_size, (i + 1) * b_size)
@@ -281,8 +300,11 @@ class LinkPredictionEvaluator(object):
         hands the (2B, K) rows to every rank (x + 0 is exact)."""
         if not sharded:
             return {}
-        return {'exchange': lambda tensors: self._collective(
+        kw = {'exchange': lambda tensors: self._collective(
             lambda: [kdist.all_reduce_sum(x, self.group) for x in tensors])}
+        if self._qb is not None:
+            kw['qctx'] = self._qb
+        return kw
 
     def _collective(self, fn):
         """Run a collective now -- or, while evaluate() is being captured, close the current
@@ -385,7 +407,9 @@ class LinkPredictionEvaluator(object):
             if both and getattr(self.engine, 'uses_plans', False) and n_local > 0:
                 self._ensure_plans(kg, f_lo, f_hi, b_size, index_t, index_h, device)
             else:
-                self._plans = None
+                self._plans = self._qmap = None
+            use_qmap = (row_shard is not None and self._qmap is not None and self.query_exchange == 'evaluate')
+            self._qb = None
 
             def alloc_out():
                 # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
@@ -397,10 +421,14 @@ class LinkPredictionEvaluator(object):
                     if guard is not None and self.model._expand_ok is None:
                         guard.zero_()
                     n_batches = get_n_batches(n_local, b_size)
+                    qt = None
+                    if use_qmap:    # row-sharded tables: replicas of the rows of the query entities, once per evaluate()
+                        qt = self.model.lp_query_tables(self._qmap['uniq'], self._xkw(True)['exchange'])
                     for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
                                   desc='Link prediction evaluation'):
                         sl = slice(i * b_size, (i + 1) * b_size)
                         h, t, r = heads[sl], tails[sl], rels[sl]
+                        self._qb = (qt, self._qmap['hq'][sl], self._qmap['tq'][sl]) if qt is not None else None
                         if overlap:
                             out[1, sl], out[3, sl], out[0, sl], out[2, sl] = \
                                 self._rank_batch_overlapped(h, t, r, index_t, index_h)
@@ -428,7 +456,7 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                       tuple(p_.data_ptr() for p_ in self.model.parameters()), self._plan_gen,
+                       tuple(p_.data_ptr() for p_ in self.model.parameters()), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))
                 if self.graph is None and self._graph_key != key and self._graph_seen != key:
@@ -445,7 +473,8 @@ class LinkPredictionEvaluator(object):
                 if self._graph_key != key:
                     st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
                           'r': kg.relations[f_lo:f_hi].to(device).clone(),
-                          'out': alloc_out(), 'index': (index_h, index_t), 'engine': self.engine, 'plans': self._plans}
+                          'out': alloc_out(), 'index': (index_h, index_t), 'engine': self.engine, 'plans': self._plans,
+                          'qmap': self._qmap}
                     try:
                         if self.graph is not None or self._graph_seen != key:
                             side = torch.cuda.Stream(device)
@@ -522,6 +551,7 @@ class LinkPredictionEvaluator(object):
                     run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                         kg.relations[f_lo:f_hi].to(device), out, fl)
         finally:
+            self._qb = None
             if guard is not None:      # never leave the model in guarded mode (exceptions included)
                 self.model.lp_guard_end()
         if self.shard == 'queries' and kdist.multi(world):

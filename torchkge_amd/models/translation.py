@@ -81,7 +81,7 @@ class TransEModel(TranslationModel):
             candidates = R.view(1, self.n_rel, self.emb_dim).expand(b_size, self.n_rel, self.emb_dim)
         return h, t, r, candidates
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
@@ -89,7 +89,7 @@ class TransEModel(TranslationModel):
                 and self.split_filter and self._split_ok and ent_lo == 0 and ent_hi == self.n_ent
                 and self._row_shard is None and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
             return self._fused_query_problem(h_idx, t_idx, r_idx, sd, tabs)
-        Q0, _, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange)
+        Q0, _, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)
         return self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
 
@@ -221,11 +221,11 @@ class TransHModel(TranslationModel):
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi), r_idx=cand.r_idx,
                                            c_base=ent_lo)
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
-        Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, want_w=True)
+        Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_w=True)
         return self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi),
                                            r_idx=_both_r(r_idx, sd), c_base=ent_lo)
@@ -239,6 +239,7 @@ class TransDModel(TranslationModel):
 
     _kind = _hip.TRANSD
     _ENT_TABLES = ('ent_emb', 'ent_proj_vect')
+    _ENT_POS = (0, 2)
 
     def __init__(self, ent_emb_dim, rel_emb_dim, n_entities, n_relations):
         super().__init__(n_entities, n_relations, 'L2')
@@ -339,8 +340,8 @@ class TransDModel(TranslationModel):
         Wq = _hip.gather_rows(self.rel_proj_vect.weight.data, cand.r_idx)
         return self._problem(q, Wq, ent_lo, ent_hi, r_idx=cand.r_idx)
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         sd = _hip.side_code(side)
-        Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, want_w=True)
+        Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_w=True)
         return self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_both_r(r_idx, sd))
