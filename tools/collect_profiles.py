@@ -22,6 +22,9 @@ def main(tag):
     shutil.copy(os.path.join(src, 'SUMMARY.md'), dst)
     shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'),
                 os.path.join(dst, 'kernel_stats_bench_transe_fb15k237.csv'))
+    if os.path.exists(os.path.join(src, 'trace_eval', 'bench_kernel_stats.csv')):
+        shutil.copy(os.path.join(src, 'trace_eval', 'bench_kernel_stats.csv'),
+                    os.path.join(dst, 'kernel_stats_evaluate_only_transe_fb15k237.csv'))
     rows = []
     for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
         if not os.path.isdir(d):
@@ -60,4 +63,4 @@ def main(tag):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'r01')
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r02')

@@ -27,18 +27,26 @@ def main(out):
                   os.path.basename(f), j['value'], j['unit'], j['ms_per_step'], j['filtered_hits_at_10'],
                   j['filtered_mrr'], r.get('kernel'), r.get('achieved', 0), r.get('unit'), 100 * r.get('frac', 0),
                   r.get('kernel_ms', 0)))
+        if j.get('workload_detail'):
+            print('  * workload: %s' % json.dumps(j['workload_detail']))
         if j.get('cpu_baseline'):
             print('  * cpu_baseline: %s' % json.dumps(j['cpu_baseline']))
+        if j.get('parity_full_split'):
+            print('  * parity_full_split: %s' % json.dumps(j['parity_full_split']))
+        if j.get('f32_mfma_only'):
+            print('  * f32_mfma_only: %s' % json.dumps(j['f32_mfma_only']))
         if j.get('secondary'):
             print('  * secondary: %s' % json.dumps(j['secondary']))
-    stats = glob.glob(os.path.join(out, 'trace', '*kernel_stats.csv')) + glob.glob(os.path.join(out, 'trace', '*', '*kernel_stats.csv'))
-    if stats:
-        print('\n## kernel-trace --stats (bench.py --steps 10 --warmup 3)\n')
-        print('| kernel | calls | total ms | avg us | % |')
-        print('|---|---|---|---|---|')
-        for r in csv.DictReader(open(stats[0])):
-            print('| %s | %s | %.3f | %.2f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
-                                                      float(r['AverageNs']) / 1e3, r['Percentage']))
+    for sub, title in (('trace', 'bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-parity (incl. the 500-step set-up training)'),
+                       ('trace_eval', 'bench.py --steps 20 --warmup 5 --only-timed --weights xavier (the evaluate() replays alone)')):
+        stats = glob.glob(os.path.join(out, sub, '*kernel_stats.csv')) + glob.glob(os.path.join(out, sub, '*', '*kernel_stats.csv'))
+        if stats:
+            print('\n## kernel-trace --stats: %s\n' % title)
+            print('| kernel | calls | total ms | avg us | % |')
+            print('|---|---|---|---|---|')
+            for r in list(csv.DictReader(open(stats[0])))[:40]:
+                print('| %s | %s | %.3f | %.2f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                                          float(r['AverageNs']) / 1e3, r['Percentage']))
     print('\n## PMC counters, mean per launch of the dominant kernels\n')
     print('| counter | kernel | launches | mean per launch |')
     print('|---|---|---|---|')
@@ -49,7 +57,7 @@ def main(out):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 k = short(r['Kernel_Name'])
-                if 'lp_gemm' in k or 'lp_direct' in k or 'score_fwd' in k or 'lp_split' in k or 'recheck' in k:
+                if 'lp_gemm' in k or 'lp_direct' in k or 'score_fwd' in k or 'lp_split' in k or 'recheck' in k or 'fsub' in k or 'query_pipeline' in k:
                     agg[(r['Counter_Name'], k)].append(float(r['Counter_Value']))
             for (c, k), v in sorted(agg.items()):
                 print('| %s | %s | %d | %.6g |' % (c, k, len(v), sum(v) / len(v)))
