@@ -475,6 +475,14 @@ class LinkPredictionEvaluator(object):
                           'r': kg.relations[f_lo:f_hi].to(device).clone(),
                           'out': alloc_out(), 'index': (index_h, index_t), 'engine': self.engine, 'plans': self._plans,
                           'qmap': self._qmap}
+                    # A hipGraph must not be DESTROYED while a stream is capturing (hipErrorStreamCaptureUnsupported, and
+                    # ~CUDAGraph throwing takes the process down): garbage that holds old graphs -- e.g. a previous
+                    # evaluator, which sits in a reference cycle with its graph segments -- is collected now, and the
+                    # cyclic collector stays off until the capture is over.
+                    import gc
+                    gc_was_on = gc.isenabled()
+                    gc.collect()
+                    gc.disable()
                     try:
                         if self.graph is not None or self._graph_seen != key:
                             side = torch.cuda.Stream(device)
@@ -511,6 +519,9 @@ class LinkPredictionEvaluator(object):
                         run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                             kg.relations[f_lo:f_hi].to(device), out, fl)
                         g = None
+                    finally:
+                        if gc_was_on:
+                            gc.enable()
                     if g is not None:
                         st['targets_cat'] = getattr(self.engine, '_targets_cat', None)   # baked into the graph too
                         self._graph, self._graph_static, self._graph_key = g, st, key
