@@ -128,16 +128,16 @@ __device__ __forceinline__ float lp_pair_score(const kge_lp_desc &d, int64_t i, 
 // ---- wave-cooperative exact pair scores (MFMA modes) ------------------------------
 // One lane per (query, candidate) pair runs the scalar chain above -- one
 // accumulator in a fixed order, it cannot be split across lanes -- but the two
-// rows of each of the wavefront's 64 pairs are fetched COOPERATIVELY, 40 k at a
-// time, as 160-byte row segments (10 lanes x float4 per row, all of a chunk's
-// loads in flight together) and handed to their lane through LDS (row stride 44
+// rows of each of the wavefront's 64 pairs are fetched COOPERATIVELY, 32 k at a
+// time, as 128-byte row segments (8 lanes x float4 per row, all of a chunk's
+// loads in flight together) and handed to their lane through LDS (row stride 36
 // floats: conflict-free b128 stores and loads).  A lane-per-row gather touches 64
 // different cache lines per load instruction and is ~5x slower.
 // Every lane of the wavefront must call; `qs`/`es` are this wavefront's own
 // 64 x KGE_PS_LD floats of LDS.  Bit-identical to lp_pair_score.
 #ifndef KGE_PS_KC_V
-#define KGE_PS_KC_V 40
-#define KGE_PS_LD_V 44
+#define KGE_PS_KC_V 32      /* 8 float4 pieces per row: the piece -> (row, column) split is shifts, and hipcc keeps */
+#define KGE_PS_LD_V 36      /* the pipelined loop at 88 VGPRs (40 / 44 hoisted 80 address registers and spilled)   */
 #endif
 constexpr int KGE_PS_KC = KGE_PS_KC_V, KGE_PS_LD = KGE_PS_LD_V;
 
@@ -149,30 +149,50 @@ static inline bool kge_lp_vec4(const kge_lp_desc &d)
     return v;
 }
 
+// cooperative fetch of one full KGE_PS_KC-column chunk of the wavefront's 64 (query, candidate) rows into registers
+__device__ __forceinline__ void lp_staged_fetch(const float *__restrict__ A, int64_t lda, const float *__restrict__ T,
+                                                int64_t ldt, int k0, int qi, int ci, float4 (&qv)[KGE_PS_KC / 4],
+                                                float4 (&ev)[KGE_PS_KC / 4])
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < KGE_PS_KC / 4; ++it) {
+        const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
+        const int rq = __shfl(qi, rr, 64), rc = __shfl(ci, rr, 64);
+        qv[it] = *reinterpret_cast<const float4 *>(A + (int64_t)rq * lda + k0 + pc * 4);
+        ev[it] = *reinterpret_cast<const float4 *>(T + (int64_t)rc * ldt + k0 + pc * 4);
+    }
+}
+
 template <bool VEC4>
 __device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ T, int64_t ldt, int K, int qi, int ci,
                                                    float *qs, float *es, float acc)
 {
     const int lane = threadIdx.x & 63;
-    for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {
-        const int kc = min(KGE_PS_KC, K - k0);
-        if (VEC4 && kc == KGE_PS_KC) {
-            float4 qv[KGE_PS_KC / 4], ev[KGE_PS_KC / 4];
-#pragma unroll
-            for (int it = 0; it < KGE_PS_KC / 4; ++it) {
-                const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
-                const int rq = __shfl(qi, rr, 64), rc = __shfl(ci, rr, 64);
-                qv[it] = *reinterpret_cast<const float4 *>(A + (int64_t)rq * lda + k0 + pc * 4);
-                ev[it] = *reinterpret_cast<const float4 *>(T + (int64_t)rc * ldt + k0 + pc * 4);
-            }
+    // Full chunks (16-byte aligned rows): software-pipelined -- the NEXT chunk's 20 row loads are issued before
+    // the current chunk's sequential chain runs, so the chain (40 dependent FMAs fed from LDS) hides under the
+    // loads' latency instead of following it: a pair costs one load latency plus the chains, not one per chunk.
+    int k0 = 0;
+    if (VEC4 && K >= KGE_PS_KC) {
+        float4 qv[KGE_PS_KC / 4], ev[KGE_PS_KC / 4];
+        lp_staged_fetch(A, lda, T, ldt, 0, qi, ci, qv, ev);
+        for (; k0 + KGE_PS_KC <= K; k0 += KGE_PS_KC) {
 #pragma unroll
             for (int it = 0; it < KGE_PS_KC / 4; ++it) {
                 const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
                 *reinterpret_cast<float4 *>(qs + rr * KGE_PS_LD + pc * 4) = qv[it];
                 *reinterpret_cast<float4 *>(es + rr * KGE_PS_LD + pc * 4) = ev[it];
             }
-        } else {
+            if (k0 + 2 * KGE_PS_KC <= K) lp_staged_fetch(A, lda, T, ldt, k0 + KGE_PS_KC, qi, ci, qv, ev);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same wave: LDS executes in order
+            acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, KGE_PS_KC, acc);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    }
+    for (; k0 < K; k0 += KGE_PS_KC) {      // the last, partial chunk (and everything when rows are not 16-byte aligned)
+        const int kc = min(KGE_PS_KC, K - k0);
+        {
             const int pieces = (kc + 3) >> 2;
             for (int idx = lane; idx < 64 * pieces; idx += 64) { // uniform trip count
                 const int rr = idx / pieces, pc = idx - rr * pieces;
@@ -189,7 +209,7 @@ __device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, 
                 *reinterpret_cast<float4 *>(es + rr * KGE_PS_LD + pc * 4) = ev;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same wave: LDS executes in order
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, kc, acc);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }

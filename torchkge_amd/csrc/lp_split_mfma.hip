@@ -904,7 +904,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 // Exact re-scoring of the listed pairs: one lane per pair, rows staged cooperatively
 // (kge_common.h: lp_pair_score_staged).
 template <bool VEC4>
-__global__ __launch_bounds__(64) void split_recheck_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+__global__ __launch_bounds__(64, 2) void split_recheck_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
                                                            const int32_t *__restrict__ list, int32_t cap,
                                                            const int32_t *__restrict__ list_count, int32_t *raw_count)
 {

@@ -167,7 +167,7 @@ __global__ void pair_scores_kernel(const kge_lp_desc d, const int64_t *__restric
 
 // MFMA modes: one wavefront per block, rows staged cooperatively (lp_pair_score_staged)
 template <bool VEC4>
-__global__ __launch_bounds__(64) void pair_scores_staged_kernel(const kge_lp_desc d, const int64_t *__restrict__ qi,
+__global__ __launch_bounds__(64, 2) void pair_scores_staged_kernel(const kge_lp_desc d, const int64_t *__restrict__ qi,
                                                                 const int64_t *__restrict__ ci, int64_t P, float *out)
 {
     __shared__ __attribute__((aligned(16))) float qs[64 * KGE_PS_LD];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void filter_sub_kernel(const kge_lp_desc d, co
 // MFMA modes: the same 8-lanes-per-query walk, but every round's 64 (query, candidate)
 // pairs are scored through the cooperative row staging (one wavefront per block)
 template <bool VEC4>
-__global__ __launch_bounds__(64) void filter_sub_staged_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+__global__ __launch_bounds__(64, 2) void filter_sub_staged_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
                                                                const int64_t *__restrict__ true_idx,
                                                                const int64_t *__restrict__ seg_lo,
                                                                const int64_t *__restrict__ seg_hi,
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(FS_SCAN_T) void fsub_off_kernel(int64_t B, int64_t 
 
 // scores of the flattened (claimed key, target) pairs: one lane per pair, 64 pairs per wavefront round
 template <bool STAGED, bool VEC4>
-__global__ __launch_bounds__(64) void fsub_score_kernel(const kge_lp_desc d, const int64_t *__restrict__ seg_lo,
+__global__ __launch_bounds__(64, 2) void fsub_score_kernel(const kge_lp_desc d, const int64_t *__restrict__ seg_lo,
                                                         const int32_t *__restrict__ targets,
                                                         const int64_t *__restrict__ woff, float *fs)
 {
