@@ -149,46 +149,47 @@ static inline bool kge_lp_vec4(const kge_lp_desc &d)
     return v;
 }
 
-// cooperative fetch of one full KGE_PS_KC-column chunk of the wavefront's 64 (query, candidate) rows into registers
-__device__ __forceinline__ void lp_staged_fetch(const float *__restrict__ A, int64_t lda, const float *__restrict__ T,
-                                                int64_t ldt, int k0, int qi, int ci, float4 (&qv)[KGE_PS_KC / 4],
-                                                float4 (&ev)[KGE_PS_KC / 4])
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int it = 0; it < KGE_PS_KC / 4; ++it) {
-        const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
-        const int rq = __shfl(qi, rr, 64), rc = __shfl(ci, rr, 64);
-        qv[it] = *reinterpret_cast<const float4 *>(A + (int64_t)rq * lda + k0 + pc * 4);
-        ev[it] = *reinterpret_cast<const float4 *>(T + (int64_t)rc * ldt + k0 + pc * 4);
-    }
-}
-
 template <bool VEC4>
 __device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ T, int64_t ldt, int K, int qi, int ci,
                                                    float *qs, float *es, float acc)
 {
     const int lane = threadIdx.x & 63;
-    // Full chunks (16-byte aligned rows): software-pipelined -- the NEXT chunk's 20 row loads are issued before
-    // the current chunk's sequential chain runs, so the chain (40 dependent FMAs fed from LDS) hides under the
+    // Full chunks (16-byte aligned rows): software-pipelined -- the NEXT chunk's 16 row loads are issued before
+    // the current chunk's sequential chain runs, so the chain (32 dependent FMAs fed from LDS) hides under the
     // loads' latency instead of following it: a pair costs one load latency plus the chains, not one per chunk.
+    // The 16 in-flight float4 are NAMED scalars (macro-expanded): as arrays carried around the chunk loop hipcc
+    // left them in scratch memory (272 B of private segment, 3.5x slower than no pipelining at all).
+    static_assert(KGE_PS_KC == 32, "the fetch / store macros below are written out for 8 float4 pieces per row");
     int k0 = 0;
     if (VEC4 && K >= KGE_PS_KC) {
-        float4 qv[KGE_PS_KC / 4], ev[KGE_PS_KC / 4];
-        lp_staged_fetch(A, lda, T, ldt, 0, qi, ci, qv, ev);
+        float4 q0, q1, q2, q3, q4, q5, q6, q7, e0, e1, e2, e3, e4, e5, e6, e7;
+#define KGE_PS_FETCH(IT, KK)                                                                                  \
+    {                                                                                                         \
+        const int idx_ = lane + 64 * IT, rr_ = idx_ >> 3, pc_ = idx_ & 7;                                     \
+        const int rq_ = __shfl(qi, rr_, 64), rc_ = __shfl(ci, rr_, 64);                                      \
+        q##IT = *reinterpret_cast<const float4 *>(A + (int64_t)rq_ * lda + (KK) + pc_ * 4);                   \
+        e##IT = *reinterpret_cast<const float4 *>(T + (int64_t)rc_ * ldt + (KK) + pc_ * 4);                   \
+    }
+#define KGE_PS_STORE(IT)                                                                                      \
+    {                                                                                                         \
+        const int idx_ = lane + 64 * IT, rr_ = idx_ >> 3, pc_ = idx_ & 7;                                     \
+        *reinterpret_cast<float4 *>(qs + rr_ * KGE_PS_LD + pc_ * 4) = q##IT;                                  \
+        *reinterpret_cast<float4 *>(es + rr_ * KGE_PS_LD + pc_ * 4) = e##IT;                                  \
+    }
+#define KGE_PS_ALL(M, ...) M(0, ##__VA_ARGS__) M(1, ##__VA_ARGS__) M(2, ##__VA_ARGS__) M(3, ##__VA_ARGS__) \
+                           M(4, ##__VA_ARGS__) M(5, ##__VA_ARGS__) M(6, ##__VA_ARGS__) M(7, ##__VA_ARGS__)
+        KGE_PS_ALL(KGE_PS_FETCH, 0)
         for (; k0 + KGE_PS_KC <= K; k0 += KGE_PS_KC) {
-#pragma unroll
-            for (int it = 0; it < KGE_PS_KC / 4; ++it) {
-                const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
-                *reinterpret_cast<float4 *>(qs + rr * KGE_PS_LD + pc * 4) = qv[it];
-                *reinterpret_cast<float4 *>(es + rr * KGE_PS_LD + pc * 4) = ev[it];
-            }
-            if (k0 + 2 * KGE_PS_KC <= K) lp_staged_fetch(A, lda, T, ldt, k0 + KGE_PS_KC, qi, ci, qv, ev);
+            KGE_PS_ALL(KGE_PS_STORE)
+            if (k0 + 2 * KGE_PS_KC <= K) { KGE_PS_ALL(KGE_PS_FETCH, k0 + KGE_PS_KC) }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same wave: LDS executes in order
             acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, KGE_PS_KC, acc);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
+#undef KGE_PS_ALL
+#undef KGE_PS_STORE
+#undef KGE_PS_FETCH
     }
     for (; k0 < K; k0 += KGE_PS_KC) {      // the last, partial chunk (and everything when rows are not 16-byte aligned)
         const int kc = min(KGE_PS_KC, K - k0);
