@@ -70,7 +70,7 @@ ref.evaluate(b_size=256, verbose=False)                            # the unshard
 want = [ref.rank_true_heads, ref.rank_true_tails, ref.filt_rank_true_heads, ref.filt_rank_true_tails]
 full = m.entity_table_bytes()
 lo, hi = kd.shard_model_(m)
-assert m.entity_table_bytes() <= full // world + 4 * 2 * d * 2
+assert m.entity_table_bytes() <= full // world + 4 * 2 * d * 2 * world
 ok = True
 for exchange, graph, qx in (('counts', False, 'evaluate'), ('counts', True, 'evaluate'), ('counts', False, 'batch'),
                             ('counts', True, 'batch'), ('scores', False, 'evaluate')):
@@ -89,18 +89,21 @@ sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize('kind', ['transe', 'transe_l1', 'transh', 'transd', 'distmult', 'complex'])
-def test_row_sharded_entity_tables_two_ranks_on_one_gpu(kind, tmp_path):
+@pytest.mark.parametrize('kind,world', [('transe', 2), ('transe_l1', 2), ('transh', 2), ('transd', 2), ('distmult', 2),
+                                        ('complex', 2), ('transe', 3), ('complex', 3)])
+def test_row_sharded_entity_tables_two_ranks_on_one_gpu(kind, world, tmp_path):
     """Two ranks (gloo) sharing the one GPU: each keeps HALF of every entity-indexed table
     (distributed.shard_model_), query rows are built by the owner rank (kge_lp_prep_sharded) and
     summed over the ranks, each rank counts its own candidates -- the four rank vectors equal the
-    unsharded single-GPU ones position by position, for both exchanges and the hipGraph segments."""
+    unsharded single-GPU ones position by position, for both exchanges and the hipGraph segments.
+    (world = 3: uneven shards, the replica all-gather with padded blocks.)"""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'root': ROOT})
-    port = str(29900 + (os.getpid() % 50) * 7 + ['transe', 'transe_l1', 'transh', 'transd', 'distmult', 'complex'].index(kind))
+    port = str(29900 + (os.getpid() % 50) * 13 + ['transe', 'transe_l1', 'transh', 'transd', 'distmult', 'complex'].index(kind)
+               + 6 * (world - 2))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('KGE_FORCE_COLLECTIVES', None)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', port, kind, str(tmp_path / ('r%d' % r))],
-                              env=env, cwd=ROOT) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), port, kind, str(tmp_path / ('r%d' % r))],
+                              env=env, cwd=ROOT) for r in range(world)]
     codes = [p.wait(timeout=600) for p in procs]
-    assert codes == [0, 0]
+    assert codes == [0] * world

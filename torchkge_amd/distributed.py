@@ -93,6 +93,16 @@ def all_gather_columns(local, n_total, group=None):
     return full[:, :n_total].contiguous()
 
 
+def all_gather_blocks(block, out, group=None):
+    """Equal-size row blocks (m, d) of every rank -> out (P * m, d), rank-major: ONE all-gather."""
+    world, rank = world_and_rank(group)
+    if not multi(world):
+        out.copy_(block)
+        return out
+    dist.all_gather_into_tensor(out, block.contiguous(), group=group)
+    return out
+
+
 def all_gather_facts(local, n_total, group=None):
     """(4, n_p) rank rows of every query shard -> (4, n_total)."""
     world, rank = world_and_rank(group)

@@ -91,10 +91,12 @@ class HipRankEngine(object):
         seg_lo, seg_hi, true_idx, targets = self.lookup_both(index_t, index_h, h, t, r)
         return FilterPlan(seg_lo, seg_hi, true_idx, targets)
 
+    flag_columns = True     # partial_counts(pad=k) appends k spare int32 columns (the guard flags ride the counts exchange)
+
     @staticmethod
-    def partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, plan=None):
-        """int32 (3, B): raw >= counts, filter correction, found-true flag for this shard."""
-        out = torch.zeros(3, prob.B, dtype=torch.int32, device=s_true.device)
+    def partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, plan=None, pad=0):
+        """int32 (3, B [+ pad]): raw >= counts, filter correction, found-true flag for this shard."""
+        out = torch.zeros(3, prob.B + pad, dtype=torch.int32, device=s_true.device)
         prob.count_ge(s_true, out[0])
         prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
         return out
@@ -221,6 +223,7 @@ class LinkPredictionEvaluator(object):
         self.query_exchange = query_exchange
         self._qmap = None
         self._qb = None
+        self._shard_flags = None
 
     def _ensure_plans(self, kg, f_lo, f_hi, b_size, index_t, index_h, device):
         """Build (or keep) the FilterPlans of every batch of this evaluation, OUTSIDE any graph capture."""
@@ -234,6 +237,20 @@ class LinkPredictionEvaluator(object):
         uniq, inv = torch.unique(torch.cat([heads, tails]), return_inverse=True)
         n = heads.shape[0]
         self._qmap = {'uniq': uniq.contiguous(), 'hq': inv[:n].contiguous(), 'tq': inv[n:].contiguous()}
+        world, rank = kdist.world_and_rank(self.group) if self.shard else (1, 0)
+        if self.shard == 'entities' and kdist.multi(world):
+            # uniq is sorted and the shards are contiguous id ranges: rank p owns ONE slice [a_p, b_p) of uniq
+            per = kdist.shard_size(self.model.n_ent, world)
+            cuts = torch.searchsorted(uniq, torch.arange(world + 1, device=device, dtype=uniq.dtype) * per).tolist()
+            cuts[-1] = int(uniq.shape[0])
+            maxc = max(1, max(b - a for a, b in zip(cuts[:-1], cuts[1:])))
+            owner = torch.div(uniq, per, rounding_mode='floor')
+            first = torch.tensor(cuts[:-1], device=device, dtype=torch.int64)
+            self._qmap.update({
+                'maxc': maxc,
+                'mine_local': (uniq[cuts[rank]:cuts[rank + 1]] - rank * per).contiguous(),
+                # row of uniq[u] in the gathered (P * maxc, d) layout: its owner's block, its position in the slice
+                'sel': (owner * maxc + (torch.arange(uniq.shape[0], device=device) - first[owner])).contiguous()})
         plans = {}
         for i in range(get_n_batches(f_hi - f_lo, b_size)):
             sl = slice(i * b_size, (i + 1) * b_size)
@@ -269,13 +286,14 @@ class LinkPredictionEvaluator(object):
             scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
         return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
 
-    def _rank_batch_both(self, h, t, r, index_t, index_h, out, off, lo, hi, sharded):
+    def _rank_batch_both(self, h, t, r, index_t, index_h, out, off, lo, hi, sharded, last=False, guard=None):
         """Both sides of one batch through one problem of 2B queries (tail side first):
         one filter lookup, one query-side launch, one count (+ recheck), one filter
         correction, one finalize into columns off.. of the (4, n) result matrix.  Ranks
-        are per query: identical to two _rank_side calls.  Entity-sharded: TWO collectives
-        per batch -- the (2B) true scores (the owner shard holds the value, the others 0;
-        x + 0 is exact) and the (3, 2B) partial rank counts."""
+        are per query: identical to two _rank_side calls.  Entity-sharded: ONE collective per
+        batch -- the (3, 2B) partial rank counts (+ the guard flags on the last batch); the (2B) true
+        scores need a second one only when no query-entity replicas are at hand (the owner shard holds
+        the value, the others 0; x + 0 is exact)."""
         eng = self.engine
         plan = self._plans.get((off, h.shape[0])) if self._plans is not None else None
         if plan is not None:    # filter segments, true ids and the grouping of the batch: precomputed (FilterPlan)
@@ -283,15 +301,33 @@ class LinkPredictionEvaluator(object):
         else:
             seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **self._xkw(sharded))
-        s_true = eng.true_scores(prob, true_idx)
-        if sharded:
-            self._collective(lambda: kdist.all_reduce_sum(s_true, self.group))
-        if plan is not None:
-            counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, plan=plan)
-        else:
-            counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets)
+        s_true = None
+        if sharded and self._qb is not None and hasattr(self.model, 'lp_true_scores_replica'):
+            # row-sharded tables: the true entities' rows are in the query-entity replicas, so every rank scores
+            # the (query, true entity) pairs itself -- same rows, same chain, same bits: no collective
+            s_true = self.model.lp_true_scores_replica(prob, self._qb)
+        if s_true is None:
+            s_true = eng.true_scores(prob, true_idx)
+            if sharded:
+                self._collective(lambda: kdist.all_reduce_sum(s_true, self.group))
+        n2 = s_true.shape[0]
+        # entity shards, last batch: the two guard decisions ride the counts exchange as 0 / 1 columns (a SUM > 0
+        # means "some rank says so"; max ||q||^2 is the same on every rank, so "max_q + max_e_p > limit on some
+        # rank p" IS "max_q + max_p max_e_p > limit") -- no separate MAX all-reduce, no extra host sync
+        ride = sharded and last and guard is not None and getattr(eng, 'flag_columns', False)
+        kw = {'plan': plan} if plan is not None else {}
+        if ride:
+            kw['pad'] = 2
+        counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, **kw)
+        if ride:
+            lim = float(self.model.L2_EXPAND_LIMIT)
+            counts[0, n2:n2 + 1] = ((guard[0:1] + guard[1:2]) > lim).to(torch.int32) if lim != float('inf') else 0
+            counts[0, n2 + 1:n2 + 2] = (guard[2:3] > 0).to(torch.int32)
         if sharded:
             self._collective(lambda: kdist.all_reduce_sum(counts, self.group))
+        if ride:
+            self._shard_flags = counts[0, n2:n2 + 2]
+            counts = counts[:, :n2]
         eng.finalize_both(counts, out, off)
 
     def _xkw(self, sharded):
@@ -305,6 +341,16 @@ class LinkPredictionEvaluator(object):
         if self._qb is not None:
             kw['qctx'] = self._qb
         return kw
+
+    def _collective_value(self, fn, shape, like):
+        """A collective that RETURNS a tensor: run it now -- or, while evaluate() is being captured, allocate the
+        result in the graph's pool, cut the capture, and record a call that fills that buffer at replay."""
+        buf = like.new_empty(shape)
+        if self._cut is None:
+            fn(buf)
+        else:
+            self._cut(lambda: fn(buf))
+        return buf
 
     def _collective(self, fn):
         """Run a collective now -- or, while evaluate() is being captured, close the current
@@ -380,6 +426,7 @@ class LinkPredictionEvaluator(object):
         self._generic_model = impl is None or impl is _BaseModel.lp_problem
 
         world, rank = kdist.world_and_rank(self.group) if self.shard else (1, 0)
+        world_n = world
         sharded = self.shard == 'entities' and kdist.multi(world)
         lo, hi = kdist.shard_range(self.model.n_ent, world, rank) if sharded else (0, self.model.n_ent)
         row_shard = getattr(self.model, '_row_shard', None)
@@ -421,9 +468,15 @@ class LinkPredictionEvaluator(object):
                     if guard is not None and self.model._expand_ok is None:
                         guard.zero_()
                     n_batches = get_n_batches(n_local, b_size)
+                    self._shard_flags = None
                     qt = None
                     if use_qmap:    # row-sharded tables: replicas of the rows of the query entities, once per evaluate()
-                        qt = self.model.lp_query_tables(self._qmap['uniq'], self._xkw(True)['exchange'])
+                        gather = None
+                        if getattr(self.engine, 'uses_plans', False):
+                            gather = lambda blk: self._collective_value(
+                                lambda out_: kdist.all_gather_blocks(blk, out_, self.group),
+                                (blk.shape[0] * world_n, blk.shape[1]), blk)
+                        qt = self.model.lp_query_tables(self._qmap, self._xkw(True)['exchange'], gather)
                     for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
                                   desc='Link prediction evaluation'):
                         sl = slice(i * b_size, (i + 1) * b_size)
@@ -434,11 +487,16 @@ class LinkPredictionEvaluator(object):
                                 self._rank_batch_overlapped(h, t, r, index_t, index_h)
                             continue
                         if both:
-                            self._rank_batch_both(h, t, r, index_t, index_h, out, i * b_size, lo, hi, sharded)
+                            self._rank_batch_both(h, t, r, index_t, index_h, out, i * b_size, lo, hi, sharded,
+                                                  last=(i == n_batches - 1), guard=guard)
                             continue
                         out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                         out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
-                    if guard is not None:   # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks
+                    if guard is not None and self._shard_flags is not None:
+                        # entity shards: the flags came back summed over the ranks with the last batch's counts
+                        fl[0:1].copy_(torch.where(self._shard_flags[0:1] > 0, float('inf'), 0.0))
+                        fl[1:2].copy_(self._shard_flags[1:2].to(torch.float32))
+                    elif guard is not None:   # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks
                         torch.add(guard[0:1], guard[1:2], out=fl[0:1])
                         fl[1:2].copy_(guard[2:3])
 
@@ -541,7 +599,7 @@ class LinkPredictionEvaluator(object):
             if guard is not None:
                 # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
                 # cancellation error could exceed the score tolerance -> redo on the VALU kernel
-                if kdist.multi(world):
+                if kdist.multi(world) and self._shard_flags is None:
                     flags = fl.clone()
                     kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
                     worst, overflow = flags.tolist()

@@ -196,18 +196,32 @@ class Model(Module):
             return table
         return table if (lo == 0 and hi == table.shape[0]) else table[lo:hi]
 
-    def lp_query_tables(self, ent_ids, exchange):
-        """Row-sharded model: compact replicas of the entity-table rows ``ent_ids`` (the distinct entities
-        the test queries mention) on EVERY rank -- each rank contributes the rows it owns (zeros elsewhere,
-        kge_lp_prep_sharded as a gather) and ``exchange`` sums them over the ranks (x + 0 is exact).  One
-        collective per entity table and per evaluate(); the batches then build their query rows locally
-        from the replicas (``lp_problem(..., qtabs=...)`` with indices into ``ent_ids``).  At FB15k-237
-        shape that moves ~12 k rows instead of the 2 x 20,466 query rows of every evaluation."""
+    def lp_query_tables(self, qmap, exchange, gather=None):
+        """Row-sharded model: compact replicas of the entity-table rows ``qmap['uniq']`` (the distinct entities
+        the test queries mention, sorted) on EVERY rank, once per evaluate(); the batches then build their
+        query rows locally from the replicas (``lp_problem(..., qtabs=...)`` with indices into ``uniq``).
+        At FB15k-237 shape that moves ~12 k rows instead of the 2 x 20,466 query rows of every evaluation.
+
+        ``gather`` (all-gather of equal-size row blocks) + ``qmap['sel']``: shards are contiguous id ranges and
+        ``uniq`` is sorted, so the rows a rank owns are ONE slice of ``uniq`` -- every rank gathers its slice
+        (padded to the longest), one all-gather per entity table, and a static index puts the blocks back
+        in ``uniq`` order: (P - 1) / P of the replica's bytes received per rank.  Without it: every rank
+        contributes the rows it owns to a zero matrix (kge_lp_prep_sharded as a gather) and ``exchange``
+        sums them (x + 0 is exact) -- twice the bytes, any engine."""
         assert self._row_shard is not None
         lo, hi = self._row_shard
         tabs = [x.data for x in self._tables()]
-        zr = torch.zeros_like(ent_ids)
         out = []
+        if gather is not None and qmap.get('sel') is not None:
+            for pos in self._ENT_POS:
+                T = _hip.f32c(tabs[pos])
+                block = torch.zeros(qmap['maxc'], T.shape[1], dtype=torch.float32, device=T.device)
+                if qmap['mine_local'].shape[0]:
+                    block[:qmap['mine_local'].shape[0]] = _hip.gather_rows(T, qmap['mine_local'])
+                out.append(_hip.gather_rows(gather(block), qmap['sel']))
+            return out
+        ent_ids = qmap['uniq']
+        zr = torch.zeros_like(ent_ids)
         for pos in self._ENT_POS:
             T = _hip.f32c(tabs[pos])
             d = T.shape[1]
@@ -215,6 +229,31 @@ class Model(Module):
                                     ent_lo=lo, ent_n=hi - lo)[0])
         exchange(out)
         return out
+
+    def lp_true_scores_replica(self, prob, qctx):
+        """Row-sharded model, both-sides batch: the (2B) true scores computed by EVERY rank from the
+        query-entity replicas ``qctx = (replica tables, h, t as indices into them)`` -- the true entity of a
+        tail-side query is the fact's tail, of a head-side query its head, and both are rows of the
+        replicas.  Same rows, same sequential chain (kge_lp_pair_scores) as the owner shard would run on
+        its own table: identical bits, no collective.  None: this problem's mode needs per-candidate
+        side tables (projection modes) -- the caller falls back to the owner's value summed over ranks."""
+        A0, _, A1, _, qn, _, Wq, _, _, _ = prob.keep
+        if Wq is not None:
+            return None
+        qt, hq, tq = qctx
+        rep = [_hip.f32c(x) for x in qt]
+        mode, K0 = int(prob.desc.mode), int(prob.desc.K0)
+        true_q = torch.cat([tq, hq])
+        if mode == _hip.LP_L2_EXPAND:
+            en = self._cache.get('en_replica', rep, lambda: _hip.row_sqnorm(rep[0], K=K0))
+            P = _hip.LpProblem(mode, A0, rep[0], qn=qn, en=en, K0=K0)
+        elif mode == _hip.LP_DOT:
+            P = _hip.LpProblem(mode, A0, rep[0], A1=A1, T1=rep[1] if A1 is not None else None, K0=K0)
+        elif mode in (_hip.LP_L1_DIRECT, _hip.LP_L2_DIRECT):
+            P = _hip.LpProblem(mode, A0, rep[0], K0=K0)
+        else:
+            return None
+        return P.pair_scores(true_q)
 
     def _lp_prep(self, side, h_idx, t_idx, r_idx, exchange=None, qtabs=None, **want):
         """kge_lp_prep on this model's tables.  Row-sharded tables: rows of entities another rank owns
