@@ -309,7 +309,7 @@ class LinkPredictionEvaluator(object):
         if s_true is None:
             s_true = eng.true_scores(prob, true_idx)
             if sharded:
-                self._collective(lambda: kdist.all_reduce_sum(s_true, self.group))
+                self._collective(lambda s_=s_true: kdist.all_reduce_sum(s_, self.group))
         n2 = s_true.shape[0]
         # entity shards, last batch: the two guard decisions ride the counts exchange as 0 / 1 columns (a SUM > 0
         # means "some rank says so"; max ||q||^2 is the same on every rank, so "max_q + max_e_p > limit on some
@@ -323,12 +323,11 @@ class LinkPredictionEvaluator(object):
             lim = float(self.model.L2_EXPAND_LIMIT)
             counts[0, n2:n2 + 1] = ((guard[0:1] + guard[1:2]) > lim).to(torch.int32) if lim != float('inf') else 0
             counts[0, n2 + 1:n2 + 2] = (guard[2:3] > 0).to(torch.int32)
-        if sharded:
-            self._collective(lambda: kdist.all_reduce_sum(counts, self.group))
+        if sharded:     # (the recorded call runs again at every graph replay: bind the tensor, not the name)
+            self._collective(lambda c_=counts: kdist.all_reduce_sum(c_, self.group))
         if ride:
             self._shard_flags = counts[0, n2:n2 + 2]
-            counts = counts[:, :n2]
-        eng.finalize_both(counts, out, off)
+        eng.finalize_both(counts[:, :n2] if ride else counts, out, off)
 
     def _xkw(self, sharded):
         """Engine keyword for the query exchange of row-sharded entity tables: every rank builds the
