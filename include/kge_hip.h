@@ -282,9 +282,11 @@ int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *fou
                       int64_t *rank, int64_t *filt_rank, kge_stream_t stream);
 /* The same for a 2B-query batch (tail-side queries first), written straight into a (4, ld) result
  * matrix whose rows are [head raw, tail raw, head filtered, tail filtered] (the four rank vectors of
- * evaluation.py:294-300), at columns off .. off + B - 1. */
+ * evaluation.py:294-300), at columns off .. off + B - 1 (or pos[off .. off + B - 1]). */
 int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
-                           int64_t *out, int64_t ld, int64_t off, kge_stream_t stream);
+                           int64_t *out, int64_t ld, int64_t off, const int64_t *pos /* optional: fact j of the
+                           evaluation goes to column pos[j] (facts processed in another order, e.g. sorted by relation) */,
+                           kge_stream_t stream);
 
 /* generic: every query has its own candidate matrix cand[i] (N,K) at
  * cand + i*stride_b (stride_b = 0: shared), rows at stride_n.

@@ -495,11 +495,12 @@ __global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int3
 // [head raw, tail raw, head filtered, tail filtered] at column off + fact
 __global__ void rank_finalize_both_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
                                           const int32_t *__restrict__ found, int64_t B, int64_t *out, int64_t ld,
-                                          int64_t off)
+                                          int64_t off, const int64_t *__restrict__ pos)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
         const bool tail = i < B;
-        const int64_t f = off + (tail ? i : i - B);
+        const int64_t j = off + (tail ? i : i - B);
+        const int64_t f = pos ? pos[j] : j;        // facts processed in another order (e.g. sorted by relation)
         const int64_t r = raw[i];
         out[(tail ? 1 : 0) * ld + f] = r;
         out[(tail ? 3 : 2) * ld + f] = found[i] ? r - sub[i] : r;
@@ -813,13 +814,13 @@ extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const i
 }
 
 extern "C" int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
-                                      int64_t *out, int64_t ld, int64_t off, kge_stream_t stream)
+                                      int64_t *out, int64_t ld, int64_t off, const int64_t *pos, kge_stream_t stream)
 {
     if (B < 0 || off < 0 || ld < off + B) return KGE_EINVAL;
     if (B == 0) return 0;
     if (!raw || !sub || !found || !out) return KGE_EINVAL;
     hipLaunchKernelGGL(rank_finalize_both_kernel, dim3(grid1d(2 * B, 256)), dim3(256), 0, kge_s(stream), raw, sub,
-                       found, B, out, ld, off);
+                       found, B, out, ld, off, pos);
     KGE_CHECK_LAUNCH();
     return 0;
 }
@@ -849,5 +850,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 14; }
+extern "C" int kge_abi_version(void) { return 15; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

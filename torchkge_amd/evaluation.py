@@ -106,9 +106,9 @@ class HipRankEngine(object):
         return _hip.rank_finalize(counts[0], counts[1], counts[2])
 
     @staticmethod
-    def finalize_both(counts, out, off):
-        """Ranks of a 2B-query batch into the (4, n) result matrix at columns off..off+B-1."""
-        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off)
+    def finalize_both(counts, out, off, pos=None):
+        """Ranks of a 2B-query batch into the (4, n) result matrix at columns off..off+B-1 (or pos[off..])."""
+        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off, pos)
 
     @staticmethod
     def local_scores(prob):
@@ -224,16 +224,28 @@ class LinkPredictionEvaluator(object):
         self._qmap = None
         self._qb = None
         self._shard_flags = None
+        # models whose count kernel gathers a per-(relation, candidate) table in its epilogue (TransH / TransD) ask for
+        # the facts of a batch to be PROCESSED sorted by relation: the queries of a wavefront then share one or two
+        # relation rows of that table instead of 32 different ones.  _perm[j] = original position of the j-th processed
+        # fact (the ranks are written straight to it); static like the plans.
+        self._perm = None
 
     def _ensure_plans(self, kg, f_lo, f_hi, b_size, index_t, index_h, device):
         """Build (or keep) the FilterPlans of every batch of this evaluation, OUTSIDE any graph capture."""
-        stamp = (b_size, f_lo, f_hi, str(device),
+        want_sort = bool(getattr(self.model, 'lp_sort_queries_by_relation', False))
+        stamp = (b_size, f_lo, f_hi, str(device), want_sort,
                  tuple((x.data_ptr(), x._version, x.shape[0]) for x in (kg.head_idx, kg.tail_idx, kg.relations)),
                  tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t) for x in (ix.keys, ix.offsets, ix.targets)))
         if self._plans is not None and self._plan_stamp == stamp:
             return
         heads, tails, rels = (kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                               kg.relations[f_lo:f_hi].to(device))
+        self._perm = None
+        if want_sort and rels.shape[0] > 0:
+            # stable sort by relation INSIDE every batch (batch membership is unchanged)
+            batch_of = torch.div(torch.arange(rels.shape[0], device=device), b_size, rounding_mode='floor')
+            self._perm = torch.argsort(batch_of * (int(rels.max()) + 1) + rels, stable=True).contiguous()
+            heads, tails, rels = heads[self._perm], tails[self._perm], rels[self._perm]
         uniq, inv = torch.unique(torch.cat([heads, tails]), return_inverse=True)
         n = heads.shape[0]
         self._qmap = {'uniq': uniq.contiguous(), 'hq': inv[:n].contiguous(), 'tq': inv[n:].contiguous()}
@@ -327,7 +339,10 @@ class LinkPredictionEvaluator(object):
             self._collective(lambda c_=counts: kdist.all_reduce_sum(c_, self.group))
         if ride:
             self._shard_flags = counts[0, n2:n2 + 2]
-        eng.finalize_both(counts[:, :n2] if ride else counts, out, off)
+        if self._perm is not None:
+            eng.finalize_both(counts[:, :n2] if ride else counts, out, off, self._perm)
+        else:
+            eng.finalize_both(counts[:, :n2] if ride else counts, out, off)
 
     def _xkw(self, sharded):
         """Engine keyword for the query exchange of row-sharded entity tables: every rank builds the
@@ -453,9 +468,17 @@ class LinkPredictionEvaluator(object):
             if both and getattr(self.engine, 'uses_plans', False) and n_local > 0:
                 self._ensure_plans(kg, f_lo, f_hi, b_size, index_t, index_h, device)
             else:
-                self._plans = self._qmap = None
+                self._plans = self._qmap = self._perm = None
             use_qmap = (row_shard is not None and self._qmap is not None and self.query_exchange == 'evaluate')
             self._qb = None
+
+            def facts():
+                """The facts of this evaluation on the device, in processing order."""
+                hh, tt, rr = (kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
+                              kg.relations[f_lo:f_hi].to(device))
+                if self._perm is not None:
+                    hh, tt, rr = hh[self._perm], tt[self._perm], rr[self._perm]
+                return hh, tt, rr
 
             def alloc_out():
                 # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
@@ -520,16 +543,14 @@ class LinkPredictionEvaluator(object):
                     self._graph_seen = key      # 'auto': this eager call is the warm-up, the next one captures
                     use_graph = False
             if not use_graph:
-                heads = kg.head_idx[f_lo:f_hi].to(device)
-                tails = kg.tail_idx[f_lo:f_hi].to(device)
-                rels = kg.relations[f_lo:f_hi].to(device)
+                heads, tails, rels = facts()
                 flat, out, fl = alloc_out()
                 run(heads, tails, rels, out, fl)
             else:
                 # the whole evaluate() as ONE hipGraph: ~20 short launches per batch replayed without host gaps
                 if self._graph_key != key:
-                    st = {'h': kg.head_idx[f_lo:f_hi].to(device).clone(), 't': kg.tail_idx[f_lo:f_hi].to(device).clone(),
-                          'r': kg.relations[f_lo:f_hi].to(device).clone(),
+                    hh_, tt_, rr_ = facts()
+                    st = {'h': hh_.clone(), 't': tt_.clone(), 'r': rr_.clone(),
                           'out': alloc_out(), 'index': (index_h, index_t), 'engine': self.engine, 'plans': self._plans,
                           'qmap': self._qmap}
                     # A hipGraph must not be DESTROYED while a stream is capturing (hipErrorStreamCaptureUnsupported, and
@@ -573,8 +594,7 @@ class LinkPredictionEvaluator(object):
                         self._graph = self._graph_static = self._graph_key = None
                         torch.cuda.synchronize(device)
                         flat, out, fl = alloc_out()
-                        run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
-                            kg.relations[f_lo:f_hi].to(device), out, fl)
+                        run(*facts(), out, fl)
                         g = None
                     finally:
                         if gc_was_on:
@@ -587,9 +607,10 @@ class LinkPredictionEvaluator(object):
                     st = self._graph_static
                     src = tuple((x.data_ptr(), x._version, f_lo, f_hi) for x in (kg.head_idx, kg.tail_idx, kg.relations))
                     if src != self._graph_src:      # refresh the graph's static inputs only when the facts changed
-                        st['h'].copy_(kg.head_idx[f_lo:f_hi], non_blocking=True)
-                        st['t'].copy_(kg.tail_idx[f_lo:f_hi], non_blocking=True)
-                        st['r'].copy_(kg.relations[f_lo:f_hi], non_blocking=True)
+                        hh_, tt_, rr_ = facts()
+                        st['h'].copy_(hh_, non_blocking=True)
+                        st['t'].copy_(tt_, non_blocking=True)
+                        st['r'].copy_(rr_, non_blocking=True)
                         self._graph_src = src
                     self._graph.replay()
                     flat, out, fl = st['out']
@@ -616,8 +637,7 @@ class LinkPredictionEvaluator(object):
                 if redo:
                     res = None
                     flat, out, fl = alloc_out()
-                    run(kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
-                        kg.relations[f_lo:f_hi].to(device), out, fl)
+                    run(*facts(), out, fl)
         finally:
             self._qb = None
             if guard is not None:      # never leave the model in guarded mode (exceptions included)

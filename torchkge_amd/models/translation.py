@@ -132,6 +132,8 @@ class TransHModel(TranslationModel):
 
     _kind = _hip.TRANSH
     _ENT_TABLES = ('ent_emb',)
+    # the count kernel's epilogue gathers X[r_i, c]: queries processed in relation order share those rows
+    lp_sort_queries_by_relation = True
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight, self.norm_vect.weight]
@@ -240,6 +242,7 @@ class TransDModel(TranslationModel):
     _kind = _hip.TRANSD
     _ENT_TABLES = ('ent_emb', 'ent_proj_vect')
     _ENT_POS = (0, 2)
+    lp_sort_queries_by_relation = True     # (as TransH: the epilogue gathers G[r_i, c])
 
     def __init__(self, ent_emb_dim, rel_emb_dim, n_entities, n_relations):
         super().__init__(n_entities, n_relations, 'L2')
