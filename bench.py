@@ -417,6 +417,8 @@ def main():
     if rank == 0 and not args.only_timed:
         B = min(args.batch, n_test)
         h, t, r = kg_test.head_idx[:B], kg_test.tail_idx[:B], kg_test.relations[:B]
+        if getattr(ev, '_perm', None) is not None and B == n_test:    # the order evaluate() processes the facts in
+            h, t, r = h[ev._perm], t[ev._perm], r[ev._perm]
         guard_on = hasattr(model, 'lp_guard_begin') and model.lp_guard_begin(device) is not None
         with model.lp_session():
             prob = None
