@@ -444,19 +444,38 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
         const int tli = tl ? 1 : 0;
         float qn = 0.f, acc = 0.f;
         float amag = 0.f;                                        // split_thr's magnitude sum
+        // Software-pipelined staging: the three row loads of the NEXT chunk are issued before this chunk's two
+        // sequential chains run (they are the latency of this kernel: 48 dependent FMA pairs per chunk), so a
+        // group of queries costs one load latency plus its chains instead of one load latency per chunk.
+        constexpr int NP = KC / 4, ITS = (QPW * NP + 63) / 64;     // 16-byte pieces per full row chunk; passes per chunk
+        float4 pe[ITS], pr[ITS], pt[ITS];
+#define KGE_QP_FETCH(K0)                                                                                     \
+    {                                                                                                        \
+        const int pcs_ = max(0, min(KC, d - (K0))) >> 2;                                                     \
+        _Pragma("unroll") for (int it = 0; it < ITS; ++it) {                                                 \
+            const int idx = it * 64 + lane;                                                                  \
+            const bool act = idx < QPW * pcs_;                                                               \
+            const int rr = act ? idx / pcs_ : 0, pc = act ? idx - rr * pcs_ : 0;                             \
+            const int64_t s_ = __shfl(src, rr, 64), r_ = __shfl(ri, rr, 64), t_ = __shfl(tru, rr, 64);       \
+            if (act) {                                                                                       \
+                pe[it] = *reinterpret_cast<const float4 *>(p.E + s_ * d + (K0) + pc * 4);                    \
+                pr[it] = *reinterpret_cast<const float4 *>(p.R + r_ * d + (K0) + pc * 4);                    \
+                pt[it] = *reinterpret_cast<const float4 *>(p.E + t_ * d + (K0) + pc * 4);                    \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+        KGE_QP_FETCH(0)
         for (int k0 = 0; k0 < kpad; k0 += KC) {
             const int kc = max(0, min(KC, d - k0));              // data columns of this chunk
             const int pieces = kc >> 2;
-            for (int idx0 = 0; idx0 < QPW * pieces; idx0 += 64) { // uniform trip count (shuffles inside)
-                const int idx = idx0 + lane;
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {                   // uniform trip count (shuffles inside)
+                const int idx = it * 64 + lane;
                 const bool act = idx < QPW * pieces;
                 const int rr = act ? idx / pieces : 0, pc = act ? idx - rr * pieces : 0;
-                const int64_t s_ = __shfl(src, rr, 64), r_ = __shfl(ri, rr, 64), t_ = __shfl(tru, rr, 64);
                 const bool tl_ = __shfl(tli, rr, 64) != 0;
                 if (!act) continue;
-                const float4 e4 = *reinterpret_cast<const float4 *>(p.E + s_ * d + k0 + pc * 4);
-                const float4 r4 = *reinterpret_cast<const float4 *>(p.R + r_ * d + k0 + pc * 4);
-                const float4 t4 = *reinterpret_cast<const float4 *>(p.E + t_ * d + k0 + pc * 4);
+                const float4 e4 = pe[it], r4 = pr[it], t4 = pt[it];
                 float4 q4;                                       // lp_prep_kernel, translation.py:105-125
                 q4.x = tl_ ? e4.x + r4.x : e4.x - r4.x;
                 q4.y = tl_ ? e4.y + r4.y : e4.y - r4.y;
@@ -467,6 +486,7 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 *reinterpret_cast<float4 *>(qs + rr * LD + pc * 4) = q4;
                 *reinterpret_cast<float4 *>(ts + rr * LD + pc * 4) = t4;
             }
+            if (k0 + KC < kpad) KGE_QP_FETCH(k0 + KC)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (kc > 0 && lane < QPW) {
                 const float *x = qs + lane * LD;
@@ -503,6 +523,7 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
+#undef KGE_QP_FETCH
         if (lane < QPW && i < p.Bp) {
             if (valid) {
                 const float st = lp_epilogue(KGE_LP_L2_EXPAND, acc, qn, p.en[tru]);
