@@ -493,12 +493,40 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 // row_sqnorm_kernel's chain; its value at the end of every k16 cell is the prefix squared norm
                 // of the magnitude sum (split_thr_kernel adds up cell sums instead: equal up to rounding, and
                 // the band carries a 1.003 factor)
-                for (int k = 0; k < kc; ++k) {
+                // Whole k16 cells: the cell's 16 query and 16 true-entity values come in with 8 b128 LDS reads, then the
+                // two dependent chains run side by side (||q||^2 in ascending k; the true score in the tile kernel's
+                // order, 8-blocks ascending and k = 0,4,1,5,2,6,3,7 inside) -- one LDS round trip per cell instead of
+                // one per element / per 8-block and chain.  Same operations in the same order: same bits.
+                const float *tt = ts + lane * LD;
+                int k = 0;
+                for (; k + 16 <= kc; k += 16) {
+                    float xv[16], tv[16];
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const float4 v = *reinterpret_cast<const float4 *>(x + k + 4 * j4);
+                        const float4 w = *reinterpret_cast<const float4 *>(tt + k + 4 * j4);
+                        xv[4 * j4] = v.x; xv[4 * j4 + 1] = v.y; xv[4 * j4 + 2] = v.z; xv[4 * j4 + 3] = v.w;
+                        tv[4 * j4] = w.x; tv[4 * j4 + 1] = w.y; tv[4 * j4 + 2] = w.z; tv[4 * j4 + 3] = w.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) qn = fmaf(xv[j], xv[j], qn);
+#pragma unroll
+                    for (int b8 = 0; b8 < 16; b8 += 8) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc = fmaf(xv[b8 + j], tv[b8 + j], acc);
+                            acc = fmaf(xv[b8 + 4 + j], tv[b8 + 4 + j], acc);
+                        }
+                    }
+                    if (p.e2pref) amag = amag + sqrtf(qn * p.e2pref[(k0 + k) >> 4]);
+                }
+                const int ktail = k;
+                for (; k < kc; ++k) {
                     qn = fmaf(x[k], x[k], qn);
                     if (p.e2pref && (((k0 + k) & 15) == 15 || k0 + k == d - 1))
                         amag = amag + sqrtf(qn * p.e2pref[(k0 + k) >> 4]);
                 }
-                acc = lp_chain_dot(x, ts + lane * LD, kc, acc);                 // the pair kernel's chain
+                if (ktail < kc) acc = lp_chain_dot(x + ktail, tt + ktail, kc - ktail, acc);   // the pair kernel's chain
             }
             // split cells of this chunk: 8 consecutive k of one row per lane and pass
             const int ngr = min(KC, kpad - k0) >> 3;
