@@ -621,7 +621,39 @@ def main():
             opt.step()
         t_tr = ev_time(train_step, reps=10)
         sec['train_step'] = {'triples_per_s': round(Bt / t_tr, 1), 'batch': Bt, 'ms': round(t_tr * 1e3, 4),
-                             'what': 'corrupt_batch + Model.forward(pos,neg) + MarginLoss + backward + SGD step'}
+                             'what': 'corrupt_batch + Model.forward(pos,neg) + MarginLoss + backward + SGD step',
+                             'note': 'eager: ~30 launches per step, host bound at this batch size'}
+        # the same step as ONE hipGraph (sampler in its sync-free form: no host read of the mask sum): device time
+        try:
+            samp.sync_free = True
+            for prm in model.parameters():
+                prm.grad = torch.zeros_like(prm)
+
+            def graph_step():
+                nh, nt = samp.corrupt_batch(h2, t2, r2)
+                pos, neg = model(h2, t2, r2, nh, nt)
+                loss = crit(pos, neg)
+                for prm in model.parameters():
+                    prm.grad.zero_()
+                loss.backward()
+                opt.step()
+            sside = torch.cuda.Stream(device)
+            sside.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(sside):
+                for _ in range(3):
+                    graph_step()
+            torch.cuda.current_stream(device).wait_stream(sside)
+            gtr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gtr):
+                graph_step()
+            t_gr = ev_time(gtr.replay, reps=20)
+            sec['train_step_hipgraph'] = {'triples_per_s': round(Bt / t_gr, 1), 'batch': Bt, 'ms': round(t_gr * 1e3, 4),
+                                          'what': 'the same step captured once and replayed as one hipGraph '
+                                                  '(sync-free sampler), device time'}
+        except Exception as exc:      # a capture problem must not cost the bench line
+            sec['train_step_hipgraph'] = {'error': str(exc)[:200]}
+        finally:
+            samp.sync_free = False
 
     if rank == 0:
         if not multi:
