@@ -20,6 +20,10 @@ HEADERS = ['kge_common.h', os.path.join('..', '..', 'include', 'kge_hip.h')]
 LIB = os.path.join(HERE, 'libkge_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-Wall', '-Wno-unused-function']
+# per-file extras.  lp_direct.hip: the SLP vectoriser turns the L1 inner loop (sub, then add |.|) into v_pk_add_f32
+# pairs -- which issue at HALF rate on gfx950 (tools/probe/valu_rate_probe.hip: 34 T vs 63 T lane-ops/s) and have no
+# abs modifier, so every element pays an extra v_and: 3 issue slots per element instead of 2.
+EXTRA_FLAGS = {'lp_direct.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -49,7 +53,8 @@ def build(force=False, verbose=False):
         o = os.path.join(bdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs + [os.path.abspath(__file__)]):
-            jobs.append([hipcc] + FLAGS + os.environ.get('KGE_HIPCC_EXTRA', '').split() + ['-c', s, '-o', o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + os.environ.get('KGE_HIPCC_EXTRA', '').split() +
+                        ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:
