@@ -422,6 +422,36 @@ int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
                          const int32_t *list_count, int32_t *raw_count, kge_stream_t stream);
 
+/* ---- certified integer prefilter of the fused rank count, TransE-L1 (torchkge_amd/csrc/lp_l1_sad.hip) ----------
+ * kge_lp_sad_count + kge_lp_sad_recheck leave in raw_count exactly what kge_lp_count_ge leaves there for a plain
+ * KGE_LP_L1_DIRECT problem (no rank-1 term; interfaces.py:253-260 with l1_dissimilarity): the sum of absolute
+ * differences is evaluated on 16-bit fixed-point copies of the operands (v_sad_u16, exact integer accumulation)
+ * with a proven error band, the pairs inside the band are re-scored by the exact fp32 chain.
+ * Operands: kge_lp_sad_rows turns fp32 rows into (rows, kge_lp_sad_cols_padded(K)) uint16, X = rint(x * s) + 32768,
+ * s = 32700 / (*emax + *rmax): device scalars with max |x| of the entity table and of the relation table (every
+ * query element is e +- r; see kge_absmax).  *overflow is set to 1.0f if more than cap pairs (or more than 2048 in
+ * one 128 x 128 tile) fell inside the band, or if the maxima are not finite / zero -- raw_count is then invalid and
+ * the caller redoes the count with kge_lp_count_ge. */
+typedef struct kge_sad_args {
+    const void *Qi, *Ei;          /* fixed-point operands (kge_lp_sad_rows) */
+    const float *emax, *rmax;     /* the device scalars the operands were scaled with */
+    float eps_scale;              /* multiplies the error band (1.0 = the proven bound; tests shrink it) */
+    int32_t *thr;                 /* scratch: 2 * B int32 */
+    int32_t *list;                /* scratch: cap x 2 int32 (query, local candidate) */
+    int32_t cap;
+    int32_t *list_count;          /* device int32 */
+    float *overflow;              /* device float, set to 1.0f on overflow (see above) */
+} kge_sad_args;
+int64_t kge_lp_sad_cols_padded(int K);
+int kge_lp_sad_rows(const float *X, int64_t ld, int64_t rows, int K, const float *emax, const float *rmax,
+                    void *out, kge_stream_t stream);
+int kge_lp_sad_count(const kge_lp_desc *d, const kge_sad_args *a, const float *s_true, int32_t *raw_count,
+                     kge_stream_t stream);
+/* exact re-scoring of a (query, local candidate) pair list for plain KGE_LP_L1_DIRECT / _L2_DIRECT problems:
+ * raw_count[q] -= 1 for every listed pair whose score is below s_true[q] */
+int kge_lp_sad_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
+                       const int32_t *list_count, int32_t *raw_count, kge_stream_t stream);
+
 int kge_abi_version(void);
 const char *kge_build_arch(void);
 

@@ -1158,3 +1158,100 @@ def test_filter_lookup_both_equals_two_lookups(hip):
     cat = torch.cat([it.targets, ih.targets])
     for i in (0, 17, 332):
         assert torch.equal(cat[lo[333 + i]:hi[333 + i]], ih.targets[lo_h[i]:hi_h[i]])
+
+
+# ---------------------------------------------------------------------------
+# TransE-L1: certified 16-bit sum-of-absolute-differences prefilter (lp_l1_sad.hip)
+# ---------------------------------------------------------------------------
+def _sad_problem(hip, Q, E):
+    prob = hip.LpProblem(hip.LP_L1_DIRECT, Q, E)
+    bounds = torch.zeros(3, dtype=torch.float32, device='cuda')
+    hip.absmax(torch.cat([Q.reshape(-1), E.reshape(-1)]), bounds[0:1])     # rmax = 0: the bound is max |x| itself
+    prob.sad = {'Ei': hip.sad_rows(E, bounds[0:1], bounds[1:2]), 'emax': bounds[0:1], 'rmax': bounds[1:2],
+                'overflow': bounds[2:3]}
+    return prob, bounds
+
+
+@pytest.mark.parametrize('B,N,K', [(64, 300, 32), (1000, 3000, 200), (193, 257, 17), (5, 2, 1), (700, 1500, 203), (129, 129, 8)])
+def test_l1_sad_prefilter_counts_equal_exact_counts(hip, B, N, K):
+    """kge_lp_sad_count + kge_lp_sad_recheck == kge_lp_count_ge (lp_direct_kernel) for plain L1 problems: random
+    operands, exact ties (duplicate candidates, the true candidate itself), thresholds from real pair scores; also
+    with the error band shrunk 16x (the proven bound has slack) -- and the prefilter really decides most pairs."""
+    g = torch.Generator().manual_seed(B * 7 + N + K)
+    E = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.3).cuda()
+    Q = ((torch.rand(B, K, generator=g) * 2 - 1) * 0.45).cuda()
+    if N > 10:
+        E[5] = E[3]                      # exact duplicates: ties
+        E[N - 1] = E[N // 2]
+    ci = torch.randint(0, N, (B,), generator=g).cuda()
+    if B > 3:
+        Q[1] = E[int(ci[1])]             # distance 0 to its true candidate
+    exact = hip.LpProblem(hip.LP_L1_DIRECT, Q, E)
+    s_true = exact.pair_scores(ci)
+    if B > 4:
+        s_true[2] = -float('inf')        # everything counts
+        s_true[3] = float('nan')         # nothing counts
+    want = exact.count_ge(s_true)
+    for eps in (1.0, 1.0 / 16):
+        old = hip.SPLIT_EPS_SCALE
+        hip.SPLIT_EPS_SCALE = eps
+        try:
+            prob, bounds = _sad_problem(hip, Q, E)
+            got = prob.count_ge(s_true)
+        finally:
+            hip.SPLIT_EPS_SCALE = old
+        assert float(bounds[2]) == 0.0
+        assert torch.equal(got, want), (eps, int((got != want).sum()))
+        n_unc = int(prob.last_split[0])
+        assert n_unc <= max(64, 0.05 * B * N), n_unc       # most pairs never reach the exact chain
+
+
+def test_l1_sad_prefilter_overflow_and_degenerate_tables_fall_back(hip):
+    """All candidates identical -> every pair is tied with the true score -> the uncertain list overflows: the flag
+    is raised (the evaluator then redoes the count exactly); all-zero tables raise it too."""
+    B, N, K = 300, 2000, 64
+    E = torch.full((N, K), 0.25, device='cuda')
+    Q = torch.full((B, K), 0.5, device='cuda')
+    prob, bounds = _sad_problem(hip, Q, E)
+    s_true = prob.pair_scores(torch.zeros(B, dtype=torch.long, device='cuda'))
+    hip.SPLIT_LIST_PER_QUERY, old = 4, hip.SPLIT_LIST_PER_QUERY
+    try:
+        prob.count_ge(s_true)
+    finally:
+        hip.SPLIT_LIST_PER_QUERY = old
+    assert float(bounds[2]) == 1.0
+    Z = torch.zeros(8, K, device='cuda')
+    prob, bounds = _sad_problem(hip, Z, Z.clone())
+    prob.count_ge(prob.pair_scores(torch.zeros(8, dtype=torch.long, device='cuda')))
+    assert float(bounds[2]) == 1.0
+
+
+def test_l1_evaluator_uses_the_prefilter_and_matches_exact_counts(hip):
+    """TransE-L1 evaluate(): the SAD prefilter is what runs by default; ranks equal the all-exact evaluation."""
+    import torchkge_amd as tk
+    n_ent, n_rel, d = 3000, 9, 100
+    tables = orc.init_tables('transe', n_ent, n_rel, d, seed=5)
+    m = build_model('transe', 1, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 20000, 31, hubs=((500, 'head'),))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(18000, 2000))
+    res = []
+    for split in (True, False):
+        m.split_filter = split
+        ev = tk.LinkPredictionEvaluator(m, kg_test, graph=True)
+        ev.evaluate(b_size=1024, verbose=False)
+        ev.evaluate(b_size=1024, verbose=False)
+        res.append([ev.rank_true_heads.clone(), ev.rank_true_tails.clone(), ev.filt_rank_true_heads.clone(),
+                    ev.filt_rank_true_tails.clone()])
+    m.split_filter = True
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    prob = None
+    guard = m.lp_guard_begin(torch.device('cuda', 0))
+    try:
+        with m.lp_session():
+            prob = m.lp_problem(kg_test.head_idx[:64].cuda(), kg_test.tail_idx[:64].cuda(), kg_test.relations[:64].cuda(), 'both')
+            assert prob.sad is not None and guard is not None
+    finally:
+        m.lp_guard_end()

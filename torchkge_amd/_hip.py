@@ -49,6 +49,14 @@ class SplitArgs(ctypes.Structure):
     ]
 
 
+class SadArgs(ctypes.Structure):
+    """struct kge_sad_args (include/kge_hip.h)."""
+    _fields_ = [
+        ('Qi', _vp), ('Ei', _vp), ('emax', _vp), ('rmax', _vp), ('eps_scale', ctypes.c_float),
+        ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
+    ]
+
+
 _SIGNATURES = {
     'kge_score_triples': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp],
     'kge_score_triples_bwd': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp,
@@ -76,6 +84,9 @@ _SIGNATURES = {
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
+    'kge_lp_sad_rows': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp],
+    'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
+    'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
@@ -96,7 +107,7 @@ _SIGNATURES = {
 }
 # every symbol include/kge_hip.h declares
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version', 'kge_lp_split_rows_padded',
-                                               'kge_build_arch', 'kge_lp_filter_sub_ws_bytes'])
+                                               'kge_build_arch', 'kge_lp_filter_sub_ws_bytes', 'kge_lp_sad_cols_padded'])
 
 _lib = None
 
@@ -122,11 +133,13 @@ def load_library():
     lib.kge_lp_split_rows_padded.restype = _i64
     lib.kge_lp_filter_sub_ws_bytes.argtypes = [_i64, _i64]
     lib.kge_lp_filter_sub_ws_bytes.restype = _i64
+    lib.kge_lp_sad_cols_padded.argtypes = [_int]
+    lib.kge_lp_sad_cols_padded.restype = _i64
     lib.kge_abi_version.argtypes = []
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 15:
+    if lib.kge_abi_version() != 16:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -408,6 +421,21 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None):
     return out
 
 
+def sad_rows(X, emax, rmax, K=None):
+    """16-bit fixed-point operand of the L1 prefilter (kge_lp_sad_rows): (rows, K padded to 8) uint16, scaled by
+    32700 / (*emax + *rmax) (device scalars: max |x| of the entity and of the relation table)."""
+    lib = load_library()
+    require_cuda(X, emax, rmax)
+    X = f32c(X)
+    rows, ld = X.shape[0], X.stride(0)
+    K = X.shape[1] if K is None else K
+    Kp = int(lib.kge_lp_sad_cols_padded(K))
+    out = torch.empty(max(rows, 1), Kp, dtype=torch.int16, device=X.device)
+    with _on(X.device):
+        _check(lib.kge_lp_sad_rows(_p(X), ld, rows, K, _p(emax), _p(rmax), _p(out), _stream()), 'kge_lp_sad_rows')
+    return out
+
+
 def absmax(x, max_io):
     """max_io[0] = max(max_io[0], max |x|) on the device (no sync)."""
     lib = load_library()
@@ -505,6 +533,7 @@ class LpProblem(object):
         self.desc = d
         self.B, self.N = int(d.B), int(d.N)
         self.split = None
+        self.sad = None         # TransE-L1: {'Ei', 'emax', 'rmax', 'overflow'} -> counts via the u16 SAD prefilter
         self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
 
     def scores(self, out=None):
@@ -534,6 +563,8 @@ class LpProblem(object):
             raw = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         if self.split is not None and self.B > 0 and self.N > 0:
             return self._count_ge_split(s_true, raw)
+        if self.sad is not None and self.B > 0 and self.N > 0:
+            return self._count_ge_sad(s_true, raw)
         with _on(self.device):
             _check(lib.kge_lp_count_ge(ctypes.byref(self.desc), _p(s_true), _p(raw), _stream()),
                    'kge_lp_count_ge')
@@ -604,6 +635,29 @@ class LpProblem(object):
         with _on(self.device):
             _check(lib.kge_lp_split_recheck(ctypes.byref(self.desc), _p(s_true), _p(prep['list']), prep['cap'],
                                             _p(prep['n_list']), _p(raw), _stream()), 'kge_lp_split_recheck')
+        return raw
+
+    def _count_ge_sad(self, s_true, raw):
+        """Same counts as kge_lp_count_ge for a plain L1 problem through the certified 16-bit
+        sum-of-absolute-differences prefilter + exact recheck of the pairs inside the error band
+        (kge_lp_sad_count / kge_lp_sad_recheck); self.sad is set by the model."""
+        lib = load_library()
+        sd = self.sad
+        Qi = sad_rows(self.keep[0], sd['emax'], sd['rmax'], K=int(self.desc.K0))
+        cap = int(min(max(SPLIT_LIST_PER_QUERY, self.N // 50) * self.B, 2 ** 31 - 1))
+        a = SadArgs()
+        thr = torch.empty(2 * self.B, dtype=torch.int32, device=self.device)
+        lst = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
+        n_list = torch.empty(1, dtype=torch.int32, device=self.device)
+        a.Qi, a.Ei, a.emax, a.rmax = _p(Qi), _p(sd['Ei']), _p(sd['emax']), _p(sd['rmax'])
+        a.eps_scale = SPLIT_EPS_SCALE
+        a.thr, a.list, a.cap, a.list_count, a.overflow = _p(thr), _p(lst), cap, _p(n_list), _p(sd['overflow'])
+        with _on(self.device):
+            _check(lib.kge_lp_sad_count(ctypes.byref(self.desc), ctypes.byref(a), _p(s_true), _p(raw), _stream()),
+                   'kge_lp_sad_count')
+            _check(lib.kge_lp_sad_recheck(ctypes.byref(self.desc), _p(s_true), _p(lst), cap, _p(n_list), _p(raw),
+                                          _stream()), 'kge_lp_sad_recheck')
+        self.last_split = (n_list, (Qi, thr, lst))      # kept alive until the launches have run; tests read n_list
         return raw
 
     def _count_ge_split(self, s_true, raw):

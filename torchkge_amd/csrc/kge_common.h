@@ -149,7 +149,19 @@ static inline bool kge_lp_vec4(const kge_lp_desc &d)
     return v;
 }
 
-template <bool VEC4>
+// the direct modes' chains (lp_pair_score without the rank-1 term): ascending k, one accumulator
+template <bool L1>
+__device__ __forceinline__ float lp_chain_direct(const float *__restrict__ a, const float *__restrict__ t, int K, float acc)
+{
+    for (int k = 0; k < K; ++k) {
+        const float diff = a[k] - t[k];
+        acc = L1 ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+    }
+    return acc;
+}
+
+// CH: 0 = the MFMA modes' dot chain (lp_chain_dot), 1 = L1 direct, 2 = L2 direct
+template <bool VEC4, int CH = 0>
 __device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ T, int64_t ldt, int K, int qi, int ci,
                                                    float *qs, float *es, float acc)
@@ -184,7 +196,8 @@ __device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, 
             KGE_PS_ALL(KGE_PS_STORE)
             if (k0 + 2 * KGE_PS_KC <= K) { KGE_PS_ALL(KGE_PS_FETCH, k0 + KGE_PS_KC) }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same wave: LDS executes in order
-            acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, KGE_PS_KC, acc);
+            if (CH == 0) acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, KGE_PS_KC, acc);
+            else acc = lp_chain_direct<CH == 1>(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, KGE_PS_KC, acc);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
 #undef KGE_PS_ALL
@@ -211,10 +224,18 @@ __device__ __forceinline__ float lp_staged_segment(const float *__restrict__ A, 
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, kc, acc);
+        if (CH == 0) acc = lp_chain_dot(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, kc, acc);
+        else acc = lp_chain_direct<CH == 1>(qs + lane * KGE_PS_LD, es + lane * KGE_PS_LD, kc, acc);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
     return acc;
+}
+
+// plain direct modes (no rank-1 term): -sum_k |q - t| resp. -sum_k (q - t)^2, bit-identical to lp_pair_score
+template <bool VEC4, bool L1>
+__device__ __forceinline__ float lp_pair_score_staged_direct(const kge_lp_desc &d, int qi, int ci, float *qs, float *es)
+{
+    return -lp_staged_segment<VEC4, L1 ? 1 : 2>(d.A0, d.lda0, d.T0, d.ldt0, d.K0, qi, ci, qs, es, 0.0f);
 }
 
 // MFMA modes only (KGE_LP_IS_MFMA); (qi, ci) must be valid rows on every lane

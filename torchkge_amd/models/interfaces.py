@@ -422,6 +422,7 @@ class TranslationModel(Model):
         # are small enough for the cancellation error to stay inside the 1e-5 score
         # tolerance (||q||^2 + ||e||^2 <= L2_EXPAND_LIMIT), direct otherwise.
         self.l2_mode = 'auto'
+        self._sad_bounds = None     # TransE-L1: callable giving the device scalars (max |E|, max |R|) of an evaluation
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # reference TransH/TransD state_dicts carry the (n_rel, n_ent, d)
@@ -436,8 +437,10 @@ class TranslationModel(Model):
     L2_EXPAND_LIMIT = 16.0
 
     def _uses_guard(self):
-        # the L2 models take the norm expansion (TransE: + the split prefilter) optimistically
-        return self.dissimilarity_type == 'L2' and self.l2_mode == 'auto'
+        # the L2 models take the norm expansion (TransE: + the split prefilter) optimistically; TransE-L1's integer
+        # prefilter needs the overflow flag of the guard vector
+        return (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto') or \
+            (self.dissimilarity_type == 'L1' and bool(self.split_filter))
 
     def _proj_problem(self, q, table, Wq, r_idx, c_base, K0, qn, en):
         """TransH / TransD: the expansion around u.e with the per-pair projection term
@@ -491,8 +494,18 @@ class TranslationModel(Model):
                 return prob
         if callable(scal):          # built only when the broadcast-subtract kernel is really taken
             scal = scal()
-        return _hip.LpProblem(self._direct_mode(), q, table, Wq=Wq, scal=scal, r_idx=r_idx,
+        prob = _hip.LpProblem(self._direct_mode(), q, table, Wq=Wq, scal=scal, r_idx=r_idx,
                               c_base=c_base, K0=K0)
+        if (self.dissimilarity_type == 'L1' and Wq is None and self._guard_on and self.split_filter and self._split_ok
+                and self._sad_bounds is not None and K0 is None and self._row_shard is None
+                and c_base == 0 and table.shape[0] == self.n_ent):     # (whole table: the bounds are taken over it)
+            # TransE-L1 inside an evaluation: rank counts through the certified 16-bit SAD prefilter (lp_l1_sad.hip).
+            # Every query element is e +- r, so max|e| + max|r| (device scalars in the guard vector) bounds both operands.
+            g = self._lp_guard
+            emax, rmax = self._sad_bounds()
+            Ei = self._cache.get('sad_%d_%d' % (c_base, table.shape[0]), [table], lambda: _hip.sad_rows(table, emax, rmax))
+            prob.sad = {'Ei': Ei, 'emax': emax, 'rmax': rmax, 'overflow': g[2:3]}
+        return prob
 
     def inference_scoring_function(self, proj_h, proj_t, r):
         """-dissimilarity(proj_h + r, proj_t) against every candidate; the 3-D

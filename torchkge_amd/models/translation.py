@@ -51,11 +51,21 @@ class TransEModel(TranslationModel):
         # translation.py:66-67: entities and (once) relations L2-normalised
         self.ent_emb.weight.data = torch.nn.functional.normalize(self.ent_emb.weight.data, p=2, dim=1)
         self.rel_emb.weight.data = torch.nn.functional.normalize(self.rel_emb.weight.data, p=2, dim=1)
+        self._sad_bounds = self._abs_bounds
 
     _ENT_TABLES = ('ent_emb',)
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight]
+
+    def _abs_bounds(self):
+        """Device scalars (max |E|, max |R|) of this evaluation (guard slots 3 / 4, cached per session): every query
+        element of TransE is e +- r, so their sum bounds both operands of the L1 prefilter."""
+        g = self._lp_guard
+        E, R = _hip.f32c(self.ent_emb.weight.data), _hip.f32c(self.rel_emb.weight.data)
+        self._cache.get('sad_emax', [E], lambda: _hip.absmax(E, g[3:4]))
+        self._cache.get('sad_rmax', [R], lambda: _hip.absmax(R, g[4:5]))
+        return g[3:4], g[4:5]
 
     def _hip_kind(self):
         return _hip.TRANSE_L1 if self.dissimilarity_type == 'L1' else _hip.TRANSE_L2
