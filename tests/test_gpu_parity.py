@@ -1176,7 +1176,8 @@ def _sad_problem(hip, Q, E):
 def test_l1_sad_prefilter_counts_equal_exact_counts(hip, B, N, K):
     """kge_lp_sad_count + kge_lp_sad_recheck == kge_lp_count_ge (lp_direct_kernel) for plain L1 problems: random
     operands, exact ties (duplicate candidates, the true candidate itself), thresholds from real pair scores; also
-    with the error band shrunk 16x (the proven bound has slack) -- and the prefilter really decides most pairs."""
+    with the error band halved (the proven bound K is a worst case; the typical error grows like sqrt(K / 6), so
+    small K leave little slack) -- and the prefilter really decides most pairs."""
     g = torch.Generator().manual_seed(B * 7 + N + K)
     E = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.3).cuda()
     Q = ((torch.rand(B, K, generator=g) * 2 - 1) * 0.45).cuda()
@@ -1192,7 +1193,7 @@ def test_l1_sad_prefilter_counts_equal_exact_counts(hip, B, N, K):
         s_true[2] = -float('inf')        # everything counts
         s_true[3] = float('nan')         # nothing counts
     want = exact.count_ge(s_true)
-    for eps in (1.0, 1.0 / 16):
+    for eps in (1.0, 0.5):
         old = hip.SPLIT_EPS_SCALE
         hip.SPLIT_EPS_SCALE = eps
         try:
