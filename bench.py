@@ -481,6 +481,13 @@ def main():
             flops_per_pair = 2 * K           # one fp32 MFMA FMA per (pair, k)
             kname = 'lp_gemm_kernel (fp32 MFMA 32x32x2%s)' % (
                 ', per-pair projection gather' if mode >= _hip.LP_L2_PROJH else '')
+        elif getattr(prob, 'sad', None) is not None and not args.materialize:
+            flops_per_pair = 3 * K           # the fp32 work of the same pairs: sub, abs, add per (pair, k)
+            kname = 'lp_l1_sad_count_kernel (+ thresholds + exact recheck): v_sad_u16 on 16-bit fixed-point operands'
+            extra = {'note': 'ranks are bit-identical to the fp32 VALU path (pairs inside the proven error band are re-scored '
+                             'exactly by kge_lp_sad_recheck); achieved = 3K fp32-equivalent flop per pair over the time of '
+                             'the whole count (thresholds + SAD kernel + recheck), peak = fp32 VALU; the SAD kernel itself '
+                             'issues K/2 half-rate integer ops per pair'}
         else:
             flops_per_pair = 3 * K           # sub, mul, add on the VALU
             kname = 'lp_direct_kernel (fp32 VALU)'
@@ -493,7 +500,8 @@ def main():
                 traffic = (json.load(open(tfile)).get(args.workload + ('' if split else ':no-split')) or {}).get('bytes_per_launch')
             except Exception:
                 traffic = None
-        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+        roof = {'bound': 'mfma' if mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND, _hip.LP_L2_PROJH, _hip.LP_L2_PROJD) else 'valu',
+                'achieved': round(achieved, 2), 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4),
                 'pairs_per_launch': B * n_ent, 'flops_per_pair': flops_per_pair}
@@ -667,7 +675,8 @@ def main():
             par = 'query-shards-%d' % world
         used_split = bool(roof and 'fp32_equivalent_TFLOPs' in roof)
         dtype = 'f32 (f16 hi/lo-split MFMA prefilter + exact f32 recheck; ranks bit-identical to f32)' \
-            if used_split else 'f32'
+            if used_split else ('f32 (u16 fixed-point SAD prefilter + exact f32 recheck; ranks bit-identical to f32)'
+                                if roof and 'lp_l1_sad' in roof.get('kernel', '') else 'f32')
         line = {
             'metric': 'link-prediction triples scored/sec (filtered LP eval, both sides)',
             'value': round(value, 1), 'unit': 'triples_scored/s', 'n_gpus': world, 'steps': args.steps,
