@@ -195,24 +195,26 @@ __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams 
         const int nk8 = min(SK / 8, (Kp - s * SK + 7) >> 3);
         const char *Qb = smem + buf * STAGE_BYTES + ty * SROW;
         const char *Tb = smem + buf * STAGE_BYTES + BM * SROW + tx * SROW;
-#pragma unroll 2
         for (int k8 = 0; k8 < nk8; ++k8) {
             uint4 q[TM], t[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) q[i] = *reinterpret_cast<const uint4 *>(Qb + 16 * i * SROW + k8 * 16);
 #pragma unroll
             for (int j = 0; j < TN; ++j) t[j] = *reinterpret_cast<const uint4 *>(Tb + 16 * j * SROW + k8 * 16);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    unsigned v = acc[i][j];
-                    v = __builtin_amdgcn_sad_u16(q[i].x, t[j].x, v);
-                    v = __builtin_amdgcn_sad_u16(q[i].y, t[j].y, v);
-                    v = __builtin_amdgcn_sad_u16(q[i].z, t[j].z, v);
-                    v = __builtin_amdgcn_sad_u16(q[i].w, t[j].w, v);
-                    acc[i][j] = v;
-                }
+            // component-outer: 64 independent SADs between two updates of the same accumulator (a pair's four SADs
+            // written back to back form a dependent chain that the two waves of a SIMD cannot hide)
+#define KGE_SAD_COMP(C)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
+            acc[i][j] = __builtin_amdgcn_sad_u16(q[i].C, t[j].C, acc[i][j]);
+            KGE_SAD_COMP(x)
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_SAD_COMP(y)
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_SAD_COMP(z)
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_SAD_COMP(w)
+#undef KGE_SAD_COMP
         }
 
         const bool tile_done = s == S - 1;

@@ -166,7 +166,7 @@ __global__ void pair_scores_kernel(const kge_lp_desc d, const int64_t *__restric
 }
 
 // MFMA modes: one wavefront per block, rows staged cooperatively (lp_pair_score_staged)
-template <bool VEC4>
+template <bool VEC4, int DIRECT = 0>
 __global__ __launch_bounds__(64, 2) void pair_scores_staged_kernel(const kge_lp_desc d, const int64_t *__restrict__ qi,
                                                                 const int64_t *__restrict__ ci, int64_t P, float *out)
 {
@@ -179,7 +179,9 @@ __global__ __launch_bounds__(64, 2) void pair_scores_staged_kernel(const kge_lp_
         int64_t i = 0, c = -1;
         if (p < P) { i = qi ? qi[p] : p; c = ci[p] - d.c_base; }
         const bool ok = p < P && c >= 0 && c < d.N;
-        const float sc = lp_pair_score_staged<VEC4>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
+        float sc;
+        if (DIRECT) sc = lp_pair_score_staged_direct<VEC4, DIRECT == 1>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
+        else sc = lp_pair_score_staged<VEC4>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
         if (p < P) out[p] = ok ? sc : 0.f;
     }
 }
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(FS_SCAN_T) void fsub_off_kernel(int64_t B, int64_t 
 }
 
 // scores of the flattened (claimed key, target) pairs: one lane per pair, 64 pairs per wavefront round
-template <bool STAGED, bool VEC4>
+template <bool STAGED, bool VEC4, int DIRECT = 0>   // DIRECT: 0 MFMA modes / scalar; 1 plain L1 direct, 2 plain L2 direct (staged)
 __global__ __launch_bounds__(64, 2) void fsub_score_kernel(const kge_lp_desc d, const int64_t *__restrict__ seg_lo,
                                                         const int32_t *__restrict__ targets,
                                                         const int64_t *__restrict__ woff, float *fs)
@@ -402,7 +404,8 @@ __global__ __launch_bounds__(64, 2) void fsub_score_kernel(const kge_lp_desc d, 
         }
         const bool ok = valid && c >= 0 && c < d.N;
         float sc;
-        if (STAGED) sc = lp_pair_score_staged<VEC4>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
+        if (STAGED && DIRECT) sc = lp_pair_score_staged_direct<VEC4, DIRECT == 1>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
+        else if (STAGED) sc = lp_pair_score_staged<VEC4>(d, ok ? (int)i : 0, ok ? (int)c : 0, qs, es);
         else sc = ok ? lp_pair_score(d, i, c) : 0.f;
         if (ok) fs[j] = sc;
     }
@@ -687,6 +690,14 @@ extern "C" int kge_lp_pair_scores(const kge_lp_desc *d, const int64_t *qi, const
             hipLaunchKernelGGL(pair_scores_staged_kernel<true>, dim3(grid), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
         else
             hipLaunchKernelGGL(pair_scores_staged_kernel<false>, dim3(grid), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
+    } else if (!KGE_LP_IS_MFMA(d->mode) && !d->Wq && kge_lp_vec4(*d) && d->B > 0 && d->N > 0 && d->B <= INT32_MAX &&
+               d->N <= INT32_MAX) {        // plain L1 / L2 direct: staged rows, the ascending-k chain of lp_pair_score
+        const int64_t groups = (P + 63) / 64;
+        const int grid = (int)(groups < 256 * 14 ? groups : 256 * 14);
+        if (d->mode == KGE_LP_L1_DIRECT)
+            hipLaunchKernelGGL((pair_scores_staged_kernel<true, 1>), dim3(grid), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
+        else
+            hipLaunchKernelGGL((pair_scores_staged_kernel<true, 2>), dim3(grid), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
     } else {
         hipLaunchKernelGGL(pair_scores_kernel, dim3(grid1d(P, 64)), dim3(64), 0, kge_s(stream), *d, qi, ci, P, out);
     }
@@ -742,6 +753,11 @@ static int fsub_score_and_count(const kge_lp_desc *d, const float *s_true, const
                 hipLaunchKernelGGL((fsub_score_kernel<true, true>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
             else
                 hipLaunchKernelGGL((fsub_score_kernel<true, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+        } else if (!d->Wq && kge_lp_vec4(*d)) {   // plain L1 / L2 direct: the same cooperative row staging, ascending-k chain
+            if (d->mode == KGE_LP_L1_DIRECT)
+                hipLaunchKernelGGL((fsub_score_kernel<true, true, 1>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
+            else
+                hipLaunchKernelGGL((fsub_score_kernel<true, true, 2>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
         } else {
             hipLaunchKernelGGL((fsub_score_kernel<false, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
         }
