@@ -24,6 +24,10 @@
 // per (pair, 8 k).  Uncertain pairs are buffered in LDS per tile and handed to the global list by one atomic.
 #include "kge_common.h"
 
+#ifndef KGE_SAD_UNROLL
+#define KGE_SAD_UNROLL 1
+#endif
+
 namespace {
 
 constexpr int SK = 32;                 // k per stage
@@ -195,6 +199,9 @@ __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams 
         const int nk8 = min(SK / 8, (Kp - s * SK + 7) >> 3);
         const char *Qb = smem + buf * STAGE_BYTES + ty * SROW;
         const char *Tb = smem + buf * STAGE_BYTES + BM * SROW + tx * SROW;
+#if KGE_SAD_UNROLL > 1
+#pragma unroll KGE_SAD_UNROLL
+#endif
         for (int k8 = 0; k8 < nk8; ++k8) {
             uint4 q[TM], t[TN];
 #pragma unroll
