@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(autouse=True)
+def _literal_batches():
+    """Tests pass small b_size values to drive the multi-batch logic (short last batch, plans per batch, graph segments):
+    the evaluator's internal batch coalescing (evaluation.COALESCE_BATCH) is switched off for them;
+    test_batch_coalescing_gives_identical_ranks switches it back on."""
+    import torchkge_amd.evaluation as ev
+    old = ev.COALESCE_BATCH
+    ev.COALESCE_BATCH = 0
+    yield
+    ev.COALESCE_BATCH = old

@@ -294,6 +294,12 @@ def test_evaluator_vs_reference(hip, kind, p):
     ev7.evaluate(b_size=5, verbose=False)
     for nm in names:
         assert torch.equal(getattr(ev, nm), getattr(ev7, nm))
+    # a reference-style small b_size is coalesced into large internal batches (evaluation._internal_batch): same ranks
+    ev8 = tk.LinkPredictionEvaluator(m, kg_test, coalesce=32768)
+    ev8.evaluate(b_size=3, verbose=False)
+    assert ev8._internal_batch(3, nt) == nt and ev._internal_batch(3, nt) == 3    # (conftest switches the default off)
+    for nm in names:
+        assert torch.equal(getattr(ev, nm), getattr(ev8, nm))
     # hipGraph replay of the whole evaluate(): capture call and two replays, tables changed in between
     ev4 = tk.LinkPredictionEvaluator(m, kg_test, graph=True)
     ev4.evaluate(b_size=B, verbose=False)

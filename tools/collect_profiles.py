@@ -25,6 +25,11 @@ def main(tag):
     if os.path.exists(os.path.join(src, 'trace_eval', 'bench_kernel_stats.csv')):
         shutil.copy(os.path.join(src, 'trace_eval', 'bench_kernel_stats.csv'),
                     os.path.join(dst, 'kernel_stats_evaluate_only_transe_fb15k237.csv'))
+    if os.path.exists(os.path.join(src, 'trace_l1', 'bench_kernel_stats.csv')):
+        shutil.copy(os.path.join(src, 'trace_l1', 'bench_kernel_stats.csv'),
+                    os.path.join(dst, 'kernel_stats_evaluate_only_transe_l1_fb15k237.csv'))
+    if os.path.exists(os.path.join(src, 'power_probe.txt')):
+        shutil.copy(os.path.join(src, 'power_probe.txt'), os.path.join(dst, 'power_probe_round_end.txt'))
     rows = []
     for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
         if not os.path.isdir(d):

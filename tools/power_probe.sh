@@ -1,8 +1,9 @@
 #!/bin/bash
-# Power / clock while the split count kernel runs back to back:  bash tools/power_probe.sh [sched]
+# Power / clock while the split count kernel runs back to back:  bash tools/power_probe.sh [KGE_SPLIT_DBG]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-export KGE_SPLIT_SCHED=${1:-0}
+# (optional first argument: value for KGE_SPLIT_DBG, the timing probes of the kernel)
+export KGE_SPLIT_DBG=${1:-0}
 python - <<'PY' &
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())

@@ -22,10 +22,15 @@ python $R/bench.py --steps 10 --warmup 3 --materialize $Q 2>/dev/null | tail -1 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --steps 20 --warmup 5 $Q > $OUT/trace.log 2>&1
 # ... and of the timed loop alone (no set-up training, no roofline / f32 legs): what one evaluate() consists of
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_eval -o bench -- python $R/bench.py --steps 20 --warmup 5 --only-timed --weights xavier > $OUT/trace_eval.log 2>&1
+# ... and of the TransE-L1 evaluation (SAD prefilter)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_l1 -o bench -- python $R/bench.py --steps 10 --warmup 3 --only-timed --workload transe_l1_fb15k237 --weights xavier > $OUT/trace_l1.log 2>&1
+# power / clock of the dominant kernel running back to back
+bash $R/tools/power_probe.sh 0 2>&1 | grep -E "Power|sclk|launches" > $OUT/power_probe.txt
+cd /tmp
 # HBM-side counters of the same command, one --pmc pass per run (Xavier weights: no 500-step set-up under the counters)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -o bench -- python $R/bench.py --steps 3 --warmup 1 $Q --no-secondary --weights xavier > $OUT/pmc_$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -o bench -- python $R/bench.py --steps 3 --warmup 1 $Q --no-secondary --weights xavier --settle-ms 0 > $OUT/pmc_$tag.log 2>&1
 done
 cd $R
 python tools/summarize_profiles.py $OUT > $OUT/SUMMARY.md 2>&1

@@ -27,6 +27,8 @@ def main(out):
                   os.path.basename(f), j['value'], j['unit'], j['ms_per_step'], j['filtered_hits_at_10'],
                   j['filtered_mrr'], r.get('kernel'), r.get('achieved', 0), r.get('unit'), 100 * r.get('frac', 0),
                   r.get('kernel_ms', 0)))
+        if r.get('package_power'):
+            print('  * package_power (dominant kernel back to back): %s; clock_settle: %s' % (json.dumps(r['package_power']), json.dumps(j.get('clock_settle'))))
         if j.get('workload_detail'):
             print('  * workload: %s' % json.dumps(j['workload_detail']))
         if j.get('cpu_baseline'):
@@ -38,7 +40,8 @@ def main(out):
         if j.get('secondary'):
             print('  * secondary: %s' % json.dumps(j['secondary']))
     for sub, title in (('trace', 'bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-parity (incl. the 500-step set-up training)'),
-                       ('trace_eval', 'bench.py --steps 20 --warmup 5 --only-timed --weights xavier (the evaluate() replays alone)')):
+                       ('trace_eval', 'bench.py --steps 20 --warmup 5 --only-timed --weights xavier (the evaluate() replays alone)'),
+                       ('trace_l1', 'bench.py --steps 10 --warmup 3 --only-timed --workload transe_l1_fb15k237 --weights xavier (TransE-L1 evaluate() replays)')):
         stats = glob.glob(os.path.join(out, sub, '*kernel_stats.csv')) + glob.glob(os.path.join(out, sub, '*', '*kernel_stats.csv'))
         if stats:
             print('\n## kernel-trace --stats: %s\n' % title)

@@ -38,6 +38,11 @@ from .utils.modeling import filter_scores
 from .utils.operations import get_rank
 
 
+# LinkPredictionEvaluator._internal_batch: facts per batch of the fused path / bound on a batch's uncertain-pair list
+COALESCE_BATCH = 32768
+COALESCE_LIST_BYTES = 2 << 30
+
+
 class HipRankEngine(object):
     """Per-batch, per-side ranking on the HIP library (the product path)."""
 
@@ -191,8 +196,11 @@ class LinkPredictionEvaluator(object):
     """
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
-                 group=None, engine=None, graph=None, overlap=False, both_sides=True, query_exchange='evaluate'):
+                 group=None, engine=None, graph=None, overlap=False, both_sides=True, query_exchange='evaluate',
+                 coalesce=None):
         self.model = model
+        # internal batch of the fused path (None: the module default COALESCE_BATCH, 0: exactly b_size)
+        self.coalesce = coalesce
         self.kg = knowledge_graph
         n = knowledge_graph.n_facts
         self.rank_true_heads = torch.empty(size=(n,)).long()
@@ -229,6 +237,21 @@ class LinkPredictionEvaluator(object):
         # relation rows of that table instead of 32 different ones.  _perm[j] = original position of the j-th processed
         # fact (the ranks are written straight to it); static like the plans.
         self._perm = None
+
+    def _internal_batch(self, b_size, n_local):
+        """Batch the fused kernels see.  In the reference ``b_size`` only bounds the (b, N, d) temporaries
+        (evaluation.py:286-300); ranks are per query and do not depend on the batching, and the fused path holds
+        O(b * d) bytes per batch plus the uncertain-pair list of the split prefilter.  A script written for the
+        reference passes b_size = 32 .. 256: taken literally that is hundreds of launches that each fill a fraction
+        of the GPU, so the facts are processed max(b_size, COALESCE_BATCH) at a time -- less when the list of a batch
+        would pass COALESCE_LIST_BYTES (16 B per query and list slot, both sides).  Same formula on every rank."""
+        target = COALESCE_BATCH if self.coalesce is None else int(self.coalesce)
+        if (target <= b_size or not self.fused or self._generic_model or not isinstance(self.engine, HipRankEngine)
+                or (self.shard == 'entities' and self.exchange == 'scores')):
+            return b_size
+        per_query = max(_hip.SPLIT_LIST_PER_QUERY, self.model.n_ent // 50)
+        fit = max(1, int(COALESCE_LIST_BYTES // (16 * per_query)))
+        return max(b_size, min(target, fit, max(n_local, 1)))
 
     def _ensure_plans(self, kg, f_lo, f_hi, b_size, index_t, index_h, device):
         """Build (or keep) the FilterPlans of every batch of this evaluation, OUTSIDE any graph capture."""
@@ -453,6 +476,7 @@ class LinkPredictionEvaluator(object):
             f_lo, f_hi = 0, kg.n_facts
 
         n_local = f_hi - f_lo
+        b_size = self._internal_batch(b_size, n_local)
         index_h, index_t = self._filter_indices(device)
         guard = None
         if hasattr(self.model, 'lp_guard_begin') and not self._generic_model and device.type == 'cuda':
