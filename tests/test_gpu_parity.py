@@ -998,16 +998,23 @@ def test_projection_modes_shards_concatenate_bit_identically(hip, kind):
 
 
 @pytest.mark.parametrize('mode_name,B,N,K,R', [('H', 300, 1000, 64, 7), ('D', 257, 700, 40, 5), ('H', 1000, 3000, 200, 37),
-                                               ('D', 500, 2049, 200, 11)])
+                                               ('D', 500, 2049, 200, 11),
+                                               # queries in relation order (how the evaluator feeds these modes): a 192-query
+                                               # panel then holds <= 8 relation runs and each tile stages their X segments in LDS
+                                               ('H', 1000, 3000, 200, -37), ('D', 900, 2049, 200, -11), ('H', 400, 700, 64, -2),
+                                               ('D', 1500, 1300, 72, -160)])
 def test_split_prefilter_projection_modes_counts_equal_exact_counts(hip, mode_name, B, N, K, R):
     """TransH / TransD projection modes through the f16-split prefilter (the per-pair term
     x(xz+p) resp. y(yz+2g+p) is added to the approximate accumulator in the epilogue):
     counts == exact fp32 counts, also with the band shrunk 16x."""
     mode = hip.LP_L2_PROJH if mode_name == 'H' else hip.LP_L2_PROJD
+    sorted_r, R = R < 0, abs(R)
     g = torch.Generator().manual_seed(B + N + K)
     T = torch.nn.functional.normalize(torch.randn(N, K, generator=g), dim=1)
     W = torch.nn.functional.normalize(torch.randn(R, K, generator=g), dim=1)
     r_idx = torch.randint(0, R, (B,), generator=g)
+    if sorted_r:        # two sorted halves, like a both-sides batch (tail-side queries, then head-side ones)
+        r_idx = torch.cat([r_idx[:B // 2].sort().values, r_idx[B // 2:].sort().values])
     A = T[torch.randint(0, N, (B,), generator=g)] + 0.7 * torch.nn.functional.normalize(torch.randn(B, K, generator=g), dim=1)
     dT, dA, dW = T.cuda(), A.cuda().contiguous(), W.cuda()
     Np = hip.padded_cols(N)
