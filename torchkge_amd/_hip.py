@@ -229,6 +229,9 @@ _BWD_STREAMS = {
 BWD_SORTED_MIN_BATCH = 2048     # below this the plain atomic scatter is as fast
 
 
+BWD_PERM = os.environ.get('KGE_BWD_PERM', 'sort')      # 'sort' | 'count': how score_triples_bwd orders the ids of a large batch
+
+
 def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
     """Returns a list of gradient tensors (or None) matching ``tables``.  Large
     batches take the sorted reduction (per-triple gradient rows, then one atomic
@@ -259,13 +262,18 @@ def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
                 continue
             g = grads[ti]
             k0, n0, k1, n1 = (h, B, t, B) if key == 'ht' else (r, B, None, 0)
-            if key not in perms:    # counting sort of the ids (they index g's rows): hist, cumsum, scatter
-                cnt = torch.zeros(2, g.shape[0], dtype=torch.int32, device=dev)
-                _check(lib.kge_key_hist(_p(k0), n0, _p(k1), n1, _p(cnt[0]), _stream()), 'kge_key_hist')
-                off = torch.cumsum(cnt[0], 0, dtype=torch.int64) - cnt[0]
-                perm = torch.empty(n0 + n1, dtype=torch.int64, device=dev)
-                _check(lib.kge_key_scatter(_p(k0), n0, _p(k1), n1, _p(off), _p(cnt[1]), _p(perm), _stream()),
-                       'kge_key_scatter')
+            if key not in perms:    # the ids (they index g's rows) in sorted order: runs of equal target rows
+                if BWD_PERM == 'sort':
+                    # device radix sort of (id, position): ~3x cheaper than the counting sort below at B = 32768, whose
+                    # wave-aggregated atomics walk up to 64 distinct ids per wavefront one after the other
+                    perm = torch.sort(k0 if k1 is None else torch.cat([k0, k1])).indices
+                else:               # counting sort: hist, cumsum, scatter
+                    cnt = torch.zeros(2, g.shape[0], dtype=torch.int32, device=dev)
+                    _check(lib.kge_key_hist(_p(k0), n0, _p(k1), n1, _p(cnt[0]), _stream()), 'kge_key_hist')
+                    off = torch.cumsum(cnt[0], 0, dtype=torch.int64) - cnt[0]
+                    perm = torch.empty(n0 + n1, dtype=torch.int64, device=dev)
+                    _check(lib.kge_key_scatter(_p(k0), n0, _p(k1), n1, _p(off), _p(cnt[1]), _p(perm), _stream()),
+                           'kge_key_scatter')
                 perms[key] = perm
             _check(lib.kge_segment_sum_rows(rows.data_ptr() + s0 * B * d_ent * 4, d_ent, g.shape[1], _p(k0), n0,
                                             _p(k1), n1, _p(perms[key]), _p(g), g.stride(0), _stream()),
