@@ -88,6 +88,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the scoring_function / sampler / train-step timings')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
+    ap.add_argument('--graph-collectives', action='store_true',
+                    help='entity shards: capture the RCCL collectives inside the one hipGraph of evaluate() (opt-in)')
     ap.add_argument('--overlap', action='store_true', help='two-stream overlap of the short kernels (default: single stream)')
     ap.add_argument('--no-both', action='store_true', help='rank the two sides of a batch one after the other '
                                                           '(default: one 2B-query problem per batch)')
@@ -379,7 +381,7 @@ def main():
         torch.cuda.empty_cache()
     ev = tk.LinkPredictionEvaluator(model, kg_test, fused=not args.materialize, shard=shard,
                                     exchange=args.exchange, graph=not args.no_graph, overlap=args.overlap,
-                                    both_sides=not args.no_both)
+                                    both_sides=not args.no_both, graph_collectives=True if args.graph_collectives else None)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -771,6 +773,7 @@ def main():
                        'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': (not args.no_graph) and (not multi or shard == 'queries' or
                                                                (shard == 'entities' and args.exchange == 'counts'
                                                                 and not args.materialize and not args.no_both)),
+                       'collectives_in_graph': bool(getattr(ev, 'graph_collectives', False)) and multi and shard == 'entities',
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
             'workload_detail': {'kg': args.kg, 'weights': weights, 'train': info.get('train'), 'train_s': info.get('train_s'),

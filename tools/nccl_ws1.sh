@@ -8,3 +8,5 @@ echo strong-entities-scores; run --scaling strong --shard entities --exchange sc
 echo strong-queries; run --scaling strong --shard queries
 echo complex-weak; run --workload complex_wn18rr
 echo transh-strong; run --workload transh_fb15k237 --scaling strong
+echo weak-graph-collectives; run --graph-collectives
+echo transh-strong-graph-collectives; run --workload transh_fb15k237 --scaling strong --graph-collectives

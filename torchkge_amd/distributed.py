@@ -33,6 +33,13 @@ def multi(world):
     return world >= MIN_WORLD and dist.is_available() and dist.is_initialized()
 
 
+def backend_name(group=None):
+    """'nccl' (= RCCL), 'gloo', ... or None without a process group."""
+    if dist.is_available() and dist.is_initialized():
+        return str(dist.get_backend(group))
+    return None
+
+
 def world_and_rank(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)

@@ -26,6 +26,8 @@ north star names) or as rank counts (``exchange='counts'``: one int32
 all-reduce of 3*B values, bit-identical ranks).  ``shard='queries'`` splits the
 facts instead (no data-path collective, ranks all-gathered once at the end).
 """
+import os
+
 import torch
 from tqdm.autonotebook import tqdm
 
@@ -197,8 +199,13 @@ class LinkPredictionEvaluator(object):
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
                  group=None, engine=None, graph=None, overlap=False, both_sides=True, query_exchange='evaluate',
-                 coalesce=None):
+                 coalesce=None, graph_collectives=None):
         self.model = model
+        # entity shards + hipGraph: capture the RCCL collectives INSIDE the one graph of evaluate() (thread-local capture
+        # mode: the process-group watchdog thread keeps querying events) instead of cutting the capture at every
+        # collective.  Opt-in (None: env KGE_GRAPH_COLLECTIVES=1): verified on a world of one RCCL rank only.
+        self.graph_collectives = (os.environ.get('KGE_GRAPH_COLLECTIVES') == '1') if graph_collectives is None \
+            else bool(graph_collectives)
         # internal batch of the fused path (None: the module default COALESCE_BATCH, 0: exactly b_size)
         self.coalesce = coalesce
         self.kg = knowledge_graph
@@ -550,6 +557,7 @@ class LinkPredictionEvaluator(object):
             # the collectives between them for entity shards exchanging counts; eager otherwise
             multi = kdist.multi(world)
             segmented = multi and sharded and both
+            one_graph = segmented and self.graph_collectives and kdist.backend_name(self.group) == 'nccl'
             use_graph = (self.graph is not False and device.type == 'cuda' and n_local > 0 and
                          not self._generic_model and
                          (not multi or self.shard == 'queries' or segmented))
@@ -558,7 +566,7 @@ class LinkPredictionEvaluator(object):
                 # capture is keyed on everything that fixes shapes and ADDRESSES (tables, filter index); table
                 # VALUES may change freely.  The filter indices are kept alive with the graph (their pointers
                 # are baked into it).
-                key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, lo, hi, f_lo, f_hi,
+                key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, one_graph, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
                        tuple(p_.data_ptr() for p_ in self.model.parameters()), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
@@ -592,7 +600,11 @@ class LinkPredictionEvaluator(object):
                             with torch.cuda.stream(side):            # warm-up outside capture (lazy inits, attribute sets)
                                 run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
                             torch.cuda.current_stream(device).wait_stream(side)
-                        if segmented:
+                        if one_graph:       # collectives captured with the kernels (see graph_collectives)
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                                run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
+                        elif segmented:
                             g = _GraphSegments()
                             self._cut = g.cut
                             g.begin()
