@@ -175,6 +175,14 @@ int kge_key_hist(const int64_t *k0, int64_t n0, const int64_t *k1, int64_t n1, i
 int kge_key_scatter(const int64_t *k0, int64_t n0, const int64_t *k1, int64_t n1, const int64_t *offsets,
                     int32_t *cursor, int64_t *perm, kge_stream_t stream);
 
+/* The same ordering by a device radix sort over key_bits bits of (id, position) pairs (ids < 2^key_bits, n0 + n1 < 2^31):
+ * perm[j] = position in [k0 | k1] of the j-th id in ascending order, stable.  ws: kge_key_sort_ws_bytes(n0 + n1, key_bits)
+ * bytes of device scratch.  Replaces the hist / cumsum / scatter triple in the backward of Model.scoring_function
+ * (torchkge/models/interfaces.py:65-82 through autograd) for large batches. */
+int64_t kge_key_sort_ws_bytes(int64_t n, int key_bits);
+int kge_key_sort(const int64_t *k0, int64_t n0, const int64_t *k1, int64_t n1, int key_bits, int64_t *perm, void *ws,
+                 int64_t ws_bytes, kge_stream_t stream);
+
 /* ---- link-prediction query preparation ----------------------------------- */
 /* Fills the query-side operands of a kge_lp_desc for one side:
  *   TransE   Q0 = E[h]+R[r] | E[t]-R[r];  qn = chain ||Q0||^2 (optional)

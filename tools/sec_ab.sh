@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of the backward's id ordering (KGE_BWD_PERM=sort|count) on the secondary bench numbers
-for m in sort count; do
+# A/B of the backward's id ordering (KGE_BWD_PERM=sort|torch|count) on the secondary bench numbers
+for m in sort torch count; do
   echo "== KGE_BWD_PERM=$m"
   KGE_BWD_PERM=$m python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-full-parity --settle-ms 0 2>/dev/null | tail -1 | python -c "
 import sys, json

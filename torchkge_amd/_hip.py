@@ -64,6 +64,7 @@ _SIGNATURES = {
     'kge_segment_sum_rows': [_vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp],
     'kge_key_hist': [_vp, _i64, _vp, _i64, _vp, _vp],
     'kge_key_scatter': [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
+    'kge_key_sort': [_vp, _i64, _vp, _i64, _int, _vp, _vp, _i64, _vp],
     'kge_lp_prep': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp,
                     _vp, _vp, _vp],
     'kge_lp_prep_sharded': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
@@ -107,7 +108,8 @@ _SIGNATURES = {
 }
 # every symbol include/kge_hip.h declares
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version', 'kge_lp_split_rows_padded',
-                                               'kge_build_arch', 'kge_lp_filter_sub_ws_bytes', 'kge_lp_sad_cols_padded'])
+                                               'kge_build_arch', 'kge_lp_filter_sub_ws_bytes', 'kge_lp_sad_cols_padded',
+                                               'kge_key_sort_ws_bytes'])
 
 _lib = None
 
@@ -133,13 +135,15 @@ def load_library():
     lib.kge_lp_split_rows_padded.restype = _i64
     lib.kge_lp_filter_sub_ws_bytes.argtypes = [_i64, _i64]
     lib.kge_lp_filter_sub_ws_bytes.restype = _i64
+    lib.kge_key_sort_ws_bytes.argtypes = [_i64, _int]
+    lib.kge_key_sort_ws_bytes.restype = _i64
     lib.kge_lp_sad_cols_padded.argtypes = [_int]
     lib.kge_lp_sad_cols_padded.restype = _i64
     lib.kge_abi_version.argtypes = []
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 16:
+    if lib.kge_abi_version() != 17:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -229,7 +233,8 @@ _BWD_STREAMS = {
 BWD_SORTED_MIN_BATCH = 2048     # below this the plain atomic scatter is as fast
 
 
-BWD_PERM = os.environ.get('KGE_BWD_PERM', 'sort')      # 'sort' | 'count': how score_triples_bwd orders the ids of a large batch
+_KEY_SORT_WS = {}
+BWD_PERM = os.environ.get('KGE_BWD_PERM', 'sort')      # 'sort' (kge_key_sort) | 'torch' (torch.sort) | 'count' (kge_key_hist / _scatter): how score_triples_bwd orders the ids of a large batch
 
 
 def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
@@ -264,8 +269,16 @@ def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
             k0, n0, k1, n1 = (h, B, t, B) if key == 'ht' else (r, B, None, 0)
             if key not in perms:    # the ids (they index g's rows) in sorted order: runs of equal target rows
                 if BWD_PERM == 'sort':
-                    # device radix sort of (id, position): ~3x cheaper than the counting sort below at B = 32768, whose
-                    # wave-aggregated atomics walk up to 64 distinct ids per wavefront one after the other
+                    # device radix sort of (id, position) over the id's bits (kge_key_sort): ~4x cheaper than the counting
+                    # sort below at B = 32768, whose wave-aggregated atomics walk up to 64 distinct ids per wavefront
+                    bits = max(1, int(g.shape[0] - 1).bit_length())
+                    nb = _KEY_SORT_WS.get((n0 + n1, bits))
+                    if nb is None:      # (the size query walks rocPRIM's host-side configuration: once per shape)
+                        nb = _KEY_SORT_WS[(n0 + n1, bits)] = int(lib.kge_key_sort_ws_bytes(n0 + n1, bits))
+                    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                    perm = torch.empty(n0 + n1, dtype=torch.int64, device=dev)
+                    _check(lib.kge_key_sort(_p(k0), n0, _p(k1), n1, bits, _p(perm), _p(ws), nb, _stream()), 'kge_key_sort')
+                elif BWD_PERM == 'torch':
                     perm = torch.sort(k0 if k1 is None else torch.cat([k0, k1])).indices
                 else:               # counting sort: hist, cumsum, scatter
                     cnt = torch.zeros(2, g.shape[0], dtype=torch.int32, device=dev)
