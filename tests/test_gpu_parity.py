@@ -1049,6 +1049,32 @@ def test_split_prefilter_projection_modes_counts_equal_exact_counts(hip, mode_na
     assert B <= int(prob.last_split[0].item()) <= 64 * B
 
 
+@pytest.mark.parametrize('n0,n1,rows', [(1000, 0, 237), (32768, 32768, 14541), (5, 3, 2), (70000, 1, 1 << 20), (1, 0, 1)])
+def test_key_sort_is_the_stable_ascending_order(hip, n0, n1, rows):
+    """kge_key_sort (radix sort of (id, position) over the id bits): perm == stable argsort of [k0 | k1] -- bit-exact
+    integer work, also with heavy-tailed ids (a hub id owning a tenth of the batch)."""
+    import ctypes
+    g = torch.Generator().manual_seed(n0 + 3 * n1 + rows)
+    k0 = torch.randint(0, rows, (n0,), generator=g)
+    k0[: n0 // 10] = rows // 2
+    k1 = torch.randint(0, rows, (n1,), generator=g) if n1 else None
+    keys = k0 if k1 is None else torch.cat([k0, k1])
+    want = torch.sort(keys, stable=True).indices
+    lib = hip.load_library()
+    bits = max(1, int(rows - 1).bit_length())
+    nb = int(lib.kge_key_sort_ws_bytes(n0 + n1, bits))
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+    perm = torch.empty(n0 + n1, dtype=torch.int64, device='cuda')
+    dk0, dk1 = k0.cuda(), (k1.cuda() if k1 is not None else None)
+    rc = lib.kge_key_sort(hip._p(dk0), n0, hip._p(dk1), n1, bits, hip._p(perm), hip._p(ws), nb, hip._stream())
+    assert rc == 0
+    assert torch.equal(perm.cpu(), want)
+    # argument errors: short workspace, too many bits
+    assert lib.kge_key_sort(hip._p(dk0), n0, hip._p(dk1), n1, bits, hip._p(perm), hip._p(ws), nb - 1, hip._stream()) != 0
+    assert lib.kge_key_sort(hip._p(dk0), n0, hip._p(dk1), n1, 33, hip._p(perm), hip._p(ws), nb, hip._stream()) != 0
+
+
 @pytest.mark.parametrize('kind,p', [('transe', 2), ('transe_l1', 1), ('transh', 2), ('transd', 2), ('distmult', 2), ('complex', 2)])
 def test_backward_sorted_reduction_matches_atomic_scatter(hip, kind, p):
     """Large batches reduce per-triple gradient rows in sorted order (kge_segment_sum_rows)
