@@ -370,3 +370,36 @@ def test_filter_plan_groups_queries_by_segment():
     owned = [5, 0, 690, 0, 0, 1, 0, 5]
     assert p.woff.tolist() == [0] + list(np.cumsum(owned))
     assert p.n_pairs == sum(owned) and p.long_q.tolist() == [2, 4] and p.n_long == 2
+
+
+def test_internal_batch_of_the_fused_evaluator():
+    """LinkPredictionEvaluator._internal_batch: a reference-style small b_size is a lower bound for the batch the fused
+    kernels see; bounded by the facts at hand and by the uncertain-pair list of a batch; literal when coalescing is off,
+    for the score exchange and for engines other than the HIP one."""
+    import torchkge_amd.evaluation as ev
+
+    class _M(object):
+        n_ent = 14541
+
+    class _E(ev.LinkPredictionEvaluator):
+        def __init__(self, **kw):
+            self.coalesce = kw.get('coalesce')
+            self.fused, self._generic_model = kw.get('fused', True), False
+            self.engine = kw.get('engine', ev.HipRankEngine())
+            self.shard, self.exchange, self.model = kw.get('shard'), kw.get('exchange', 'counts'), _M()
+    old = ev.COALESCE_BATCH
+    try:
+        ev.COALESCE_BATCH = 32768
+        e = _E()
+        assert e._internal_batch(256, 20466) == 20466 and e._internal_batch(256, 10 ** 6) == 32768
+        assert e._internal_batch(40000, 10 ** 6) == 40000 and e._internal_batch(7, 0) == 7
+        assert _E(coalesce=0)._internal_batch(256, 20466) == 256
+        assert _E(fused=False)._internal_batch(256, 20466) == 256
+        assert _E(shard='entities', exchange='scores')._internal_batch(256, 20466) == 256
+        assert _E(engine=object())._internal_batch(256, 20466) == 256
+        _M.n_ent = 4594485          # Wikidata5M: the list of a batch would pass 2 GiB long before 32768 facts
+        assert 256 < e._internal_batch(256, 5133) < 5133
+        assert e._internal_batch(8192, 5133) == 8192
+    finally:
+        ev.COALESCE_BATCH = old
+        _M.n_ent = 14541
