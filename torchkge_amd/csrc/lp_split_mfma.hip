@@ -122,50 +122,86 @@ struct SplitRowsParams {
     float *cell_ss;           // optional [units_p][rows_p]: sum of squares of the cell's 16 data values (unscaled)
 };
 
-__global__ void split_rows_kernel(const SplitRowsParams p)
+// A block converts tiles of 16 rows x 16 k16 cells: 16 consecutive threads read one row's 1-KiB run (float4 loads where the
+// cell lies inside one K-segment and is 16-byte aligned) and write its 16 cells; the cells' sums of squares go through
+// LDS so that the unit-major cell_ss array is written in 64-byte runs as well (a thread-per-cell store there touches one
+// cache line per cell: it cost as much as the split table itself).
+__global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p)
 {
-    const int64_t total = p.rows_p * p.units_p;
+    __shared__ float ss_s[16][17];
     float scale = (float)(1 << SPLIT_SCALE_LOG2), nmax = 0.f;
     if (p.nmax0) {
         nmax = *p.nmax0 + (p.nmax1 ? *p.nmax1 : 0.f);
         scale = split_scale(nmax);
     }
     const int K = p.K0 + p.K1;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / p.units_p;
-        const int u = (int)(idx % p.units_p);
-        union { _Float16 h[16]; uint4 v[2]; } hi, lo;
+    const int tiles_u = (p.units_p + 15) / 16;
+    const int64_t n_tiles = (p.rows_p / 16) * tiles_u;          // rows_p is a multiple of the count kernel's tile
+    const int tr_ = threadIdx.x >> 4, tu_ = threadIdx.x & 15;
+    const bool vec0 = (p.ld0 % 4 == 0) && ((size_t)p.X0 & 15) == 0;
+    const bool vec1 = p.X1 && (p.ld1 % 4 == 0) && ((size_t)p.X1 & 15) == 0 && (p.K0 % 4 == 0);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t row = (tile / tiles_u) * 16 + tr_;
+        const int u = (int)(tile % tiles_u) * 16 + tu_;
         float ss = 0.f;
+        if (u < p.units_p) {
+            const int k0 = u * 16;
+            float xs[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int k = u * 16 + e;
-            float x = 0.f;
+            for (int e = 0; e < 16; ++e) xs[e] = 0.f;
             if (row < p.rows) {
-                if (k < p.K0) x = p.X0[row * p.ld0 + k];
-                else if (k < K) x = p.X1[row * p.ld1 + (k - p.K0)];
-                if (k < K) ss = fmaf(x, x, ss);
-                else if (k == K && p.aug_mode == 1) x = p.aug[row] * p.aug_mul;
-                else if (k == K && p.aug_mode == 2) x = p.aug_mul;
-                else if (k == K && p.aug_mode == 3) x = 0.25f * (sqrtf(p.aug[row]) + sqrtf(nmax) * 0.00390625f);
+                if (k0 + 16 <= p.K0 && vec0) {
+                    const float4 *src = reinterpret_cast<const float4 *>(p.X0 + row * p.ld0 + k0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { const float4 t = src[v]; xs[4 * v] = t.x; xs[4 * v + 1] = t.y; xs[4 * v + 2] = t.z; xs[4 * v + 3] = t.w; }
+                } else if (k0 >= p.K0 && k0 + 16 <= K && vec1) {
+                    const float4 *src = reinterpret_cast<const float4 *>(p.X1 + row * p.ld1 + (k0 - p.K0));
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { const float4 t = src[v]; xs[4 * v] = t.x; xs[4 * v + 1] = t.y; xs[4 * v + 2] = t.z; xs[4 * v + 3] = t.w; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = k0 + e;
+                        if (k < p.K0) xs[e] = p.X0[row * p.ld0 + k];
+                        else if (k < K) xs[e] = p.X1[row * p.ld1 + (k - p.K0)];
+                    }
+                }
             }
-            x *= scale;
-            if (row < p.rows && k == K && p.aug_mode == 3) x = fmaxf(x, 1.0f);
-            _Float16 h = (_Float16)x;                   // round to nearest even
-            _Float16 l = (_Float16)(x - (float)h);      // x - hi is exact in fp32
-            if (row >= p.rows && k == K && (p.aug_mode == 1 || p.aug_mode == 4)) {
-                // padding candidate: hi = lo = -65504 in the column that meets the queries' guard
-                // column drives its accumulator below every threshold (L2: <= -2*65504*2^12 against
-                // >= -16*2^24 for norm-guarded queries; DOT: <= -32752*S_q*||q|| against >= -16384*S_q*||q||)
-                h = (_Float16)(-65504.f);
-                l = (_Float16)(-65504.f);
+            union { _Float16 h[16]; uint4 v[2]; } hi, lo;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + e;
+                float x = xs[e];
+                if (row < p.rows) {
+                    if (k < K) ss = fmaf(x, x, ss);
+                    else if (k == K && p.aug_mode == 1) x = p.aug[row] * p.aug_mul;
+                    else if (k == K && p.aug_mode == 2) x = p.aug_mul;
+                    else if (k == K && p.aug_mode == 3) x = 0.25f * (sqrtf(p.aug[row]) + sqrtf(nmax) * 0.00390625f);
+                }
+                x *= scale;
+                if (row < p.rows && k == K && p.aug_mode == 3) x = fmaxf(x, 1.0f);
+                _Float16 h = (_Float16)x;                   // round to nearest even
+                _Float16 l = (_Float16)(x - (float)h);      // x - hi is exact in fp32
+                if (row >= p.rows && k == K && (p.aug_mode == 1 || p.aug_mode == 4)) {
+                    // padding candidate: hi = lo = -65504 in the column that meets the queries' guard
+                    // column drives its accumulator below every threshold (L2: <= -2*65504*2^12 against
+                    // >= -16*2^24 for norm-guarded queries; DOT: <= -32752*S_q*||q|| against >= -16384*S_q*||q||)
+                    h = (_Float16)(-65504.f);
+                    l = (_Float16)(-65504.f);
+                }
+                hi.h[e] = h;
+                lo.h[e] = l;
             }
-            hi.h[e] = h;
-            lo.h[e] = l;
+            uint4 *o = p.out + (row * p.units_p + u) * 4;
+            o[0] = hi.v[0]; o[1] = hi.v[1]; o[2] = lo.v[0]; o[3] = lo.v[1];
         }
-        uint4 *o = p.out + idx * 4;
-        o[0] = hi.v[0]; o[1] = hi.v[1]; o[2] = lo.v[0]; o[3] = lo.v[1];
-        if (p.cell_ss) p.cell_ss[(int64_t)u * p.rows_p + row] = ss;
+        if (p.cell_ss) {        // (block-uniform)
+            ss_s[tu_][tr_] = ss;
+            __syncthreads();
+            const int u2 = (int)(tile % tiles_u) * 16 + tr_;     // this thread now stores unit u2, row tu_ of the tile
+            if (u2 < p.units_p) p.cell_ss[(int64_t)u2 * p.rows_p + (tile / tiles_u) * 16 + tu_] = ss_s[tr_][tu_];
+            __syncthreads();
+        }
     }
 }
 
@@ -1031,9 +1067,9 @@ extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const flo
     p.units_p = kge_lp_split_units(K0 + K1, aug_mode != 0);
     p.out = reinterpret_cast<uint4 *>(out);
     p.cell_ss = cell_ss;
-    const int64_t total = p.rows_p * p.units_p;
+    const int64_t total = (p.rows_p / 16) * ((p.units_p + 15) / 16);     // tiles of 16 rows x 16 cells
     if (total == 0) return 0;
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    const int grid = (int)(total < 65536 ? total : 65536);
     hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
