@@ -173,7 +173,10 @@ void orc_row_sqnorm_chain(const float *X, int64_t ld, int64_t rows, int64_t K, f
 
 /* direct translational all-candidates (broadcast-subtract + L_p reduction):
  *   diff_k = (q[i,k] - e[c,k])            [+ a(i,c) * w[i,k]  when w != NULL]
- *   p==1: acc += |diff_k|     p==2: acc = fmaf(diff_k, diff_k, acc)
+ *   p==2: acc = fmaf(diff_k, diff_k, acc), k ascending
+ *   p==1: one add per aligned group of four k:  acc += (|d0| + |d1|) + (|d2| + |d3|)   (absent k: 0)
+ *         -- the HIP kernels' L1 contract since r03: as many instructions as the plain chain, a quarter of
+ *         its roundings at full magnitude (sigma of a d=200 score 4.4e-6 -> 2.2e-6)
  *   S[i,c] = -acc ;  a(i,c) = scal[c*scal_ld + (scal_ld>1 ? r_idx[i] : 0)] */
 void orc_lp_direct_chain(const float *Q, int64_t ldq, const float *T, int64_t ldt, int64_t K,
                          const float *Wq, int64_t ldw, const float *scal, int64_t scal_ld,
@@ -184,11 +187,25 @@ void orc_lp_direct_chain(const float *Q, int64_t ldq, const float *T, int64_t ld
             float a = 0.0f;
             if (Wq) a = scal[c * scal_ld + (scal_ld > 1 ? r_idx[i] : 0)];
             float acc = 0.0f;
-            for (int64_t k = 0; k < K; ++k) {
-                float diff = Q[i * ldq + k] - T[c * ldt + k];
-                if (Wq) diff = fmaf(a, Wq[i * ldw + k], diff);
-                if (p == 1) acc += fabsf(diff);
-                else        acc = fmaf(diff, diff, acc);
+            if (p == 1) {
+                for (int64_t k = 0; k < K; k += 4) {
+                    float m[4];
+                    for (int e = 0; e < 4; ++e) {
+                        float diff = 0.0f;
+                        if (k + e < K) {
+                            diff = Q[i * ldq + k + e] - T[c * ldt + k + e];
+                            if (Wq) diff = fmaf(a, Wq[i * ldw + k + e], diff);
+                        }
+                        m[e] = fabsf(diff);
+                    }
+                    acc = acc + ((m[0] + m[1]) + (m[2] + m[3]));
+                }
+            } else {
+                for (int64_t k = 0; k < K; ++k) {
+                    float diff = Q[i * ldq + k] - T[c * ldt + k];
+                    if (Wq) diff = fmaf(a, Wq[i * ldw + k], diff);
+                    acc = fmaf(diff, diff, acc);
+                }
             }
             out[i * N + c] = -acc;
         }

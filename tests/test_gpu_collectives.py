@@ -72,9 +72,14 @@ full = m.entity_table_bytes()
 lo, hi = kd.shard_model_(m)
 assert m.entity_table_bytes() <= full // world + 4 * 2 * d * 2 * world
 ok = True
-for exchange, graph, qx in (('counts', False, 'evaluate'), ('counts', True, 'evaluate'), ('counts', False, 'batch'),
-                            ('counts', True, 'batch'), ('scores', False, 'evaluate')):
-    ev = tk.LinkPredictionEvaluator(m, kg_test, shard='entities', exchange=exchange, graph=graph, query_exchange=qx)
+# (this worker runs the SHIPPED coalescing default: b_size 256 -> one internal batch; co = 0 takes b_size literally
+#  and drives the multi-batch sharded flow: 4 batches, short last one)
+for exchange, graph, qx, co in (('counts', False, 'evaluate', None), ('counts', True, 'evaluate', None),
+                                ('counts', False, 'batch', None), ('counts', True, 'batch', None),
+                                ('scores', False, 'evaluate', None), ('counts', True, 'evaluate', 0),
+                                ('counts', False, 'batch', 0)):
+    ev = tk.LinkPredictionEvaluator(m, kg_test, shard='entities', exchange=exchange, graph=graph, query_exchange=qx,
+                                    coalesce=co)
     for _ in range(2):
         ev.evaluate(b_size=256, verbose=False)
     got = [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]

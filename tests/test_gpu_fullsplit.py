@@ -1,7 +1,8 @@
 """GPU parity at BASELINE sizes over the WHOLE test split (run with -m gpu on an MI355X).
 
  * every one of the 4 x n_test ranks of LinkPredictionEvaluator.evaluate (evaluation.py:263-308)
-   for cfg2 / cfg3 / cfg4 against the reference algorithm run on ATen GPU ops
+   for cfg2 / cfg3 / cfg4 and for TransH / TransD / TransE-L1 at cfg2's shape (d = 200; the reference's
+   (R, N, d) projection cache, translation.py:260-284 / :629-652, is 2.76 GB on the device) against the reference algorithm run on ATen GPU ops
    (oracle.lp_evaluate(device='cuda')), on Xavier weights AND on trained-like weights (true ranks
    small, near-ties dense): tie-interval containment, |dMRR|, |dHits@10| < 1e-5, f16-split == fp32;
  * the grouped / flattened filter correction (kge_lp_filter_sub_grouped) on heavy-tailed filter
@@ -33,7 +34,8 @@ def _ranks(ev):
             ev.filt_rank_true_tails.clone()]
 
 
-@pytest.mark.parametrize('workload', ['transe_fb15k237', 'complex_wn18rr', 'distmult_fb15k'])
+@pytest.mark.parametrize('workload', ['transe_fb15k237', 'complex_wn18rr', 'distmult_fb15k',
+                                      'transh_fb15k237', 'transd_fb15k237', 'transe_l1_fb15k237'])
 @pytest.mark.parametrize('weights', ['xavier', 'trained'])
 def test_full_test_split_vs_gpu_resident_reference(hip, workload, weights):
     import bench

@@ -300,6 +300,13 @@ def test_evaluator_vs_reference(hip, kind, p):
     assert ev8._internal_batch(3, nt) == nt and ev._internal_batch(3, nt) == 3    # (conftest switches the default off)
     for nm in names:
         assert torch.equal(getattr(ev, nm), getattr(ev8, nm))
+    # ... and so does the SHIPPED default configuration replayed as a hipGraph (coalesced internal batch: its plan keys,
+    # the per-internal-batch relation sort and list capacity differ from the literal-batch runs above)
+    ev9 = tk.LinkPredictionEvaluator(m, kg_test, coalesce=32768, graph=True)
+    for _ in range(3):
+        ev9.evaluate(b_size=3, verbose=False)
+        for nm in names:
+            assert torch.equal(getattr(ev, nm), getattr(ev9, nm))
     # hipGraph replay of the whole evaluate(): capture call and two replays, tables changed in between
     ev4 = tk.LinkPredictionEvaluator(m, kg_test, graph=True)
     ev4.evaluate(b_size=B, verbose=False)

@@ -75,24 +75,6 @@ def test_training_loop_like_tutorial(toy):
     assert (ent.norm(dim=1) - 1).abs().max().item() < 1e-5
 
 
-def test_trainer_wrapper(toy):
-    """docs/tutorials/transe_wrappers.rst: Trainer(...).run() then evaluate."""
-    tk, kg = toy
-    from torchkge_amd.utils import Trainer, MarginLoss
-    model = tk.DistMultModel(16, kg.n_ent, kg.n_rel)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
-    trainer = Trainer(model, MarginLoss(0.5), kg, n_epochs=5, batch_size=4, optimizer=optimizer,
-                      sampling_type='bern', use_cuda='all')
-    trainer.run()
-    ce = trainer.get_counter_examples()
-    assert ce is not None and len(ce) == len(kg)
-    ev = tk.LinkPredictionEvaluator(model, kg)
-    ev.evaluate(b_size=9, verbose=False)
-    assert 0 < ev.mrr()[1] <= 1
-    with pytest.raises(RuntimeError):
-        Trainer(model, MarginLoss(0.5), kg, 1, 4, optimizer, use_cuda=None).run()
-
-
 @pytest.mark.gpu
 def test_positional_sampler_and_triplet_classification():
     """PositionalNegativeSampler (sampling.py:330-505): a corrupted entity has already occupied

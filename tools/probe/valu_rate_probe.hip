@@ -47,6 +47,31 @@ __global__ void probe_pk(float *out, float a0)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// OP: 0 v_pk_fma_f32 acc += a*a ; 1 v_pk_mul_f32 ; 2 v_fma_f32 (scalar, for reference) ; 3 v_pk_fma_f32 with op_sel broadcast + neg
+template <int OP>
+__global__ void probe_pk2(float *out, float a0)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[8];
+    f2 a = {a0 + threadIdx.x * 1e-9f, a0 - threadIdx.x * 1e-9f};
+    float sacc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[i] = (f2){(float)i, 1.0f}; sacc[i] = (float)i; }
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (OP == 0) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc[i]) : "v"(a));
+            else if (OP == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+            else if (OP == 2) asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(sacc[i]) : "v"(a.x));
+            else if (OP == 3) asm volatile("v_pk_fma_f32 %0, %1, %1, %0 op_sel:[0,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc[i]) : "v"(a));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y + sacc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F>
 static double time_it(F launch)
 {
@@ -74,5 +99,9 @@ int main()
     t = time_it([&] { hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(threads), 0, 0, out, 3u, 5u); }); printf("%-24s %.2f T lane-ops/s\n", names[4], lane_ops / t / 1e12);
     t = time_it([&] { hipLaunchKernelGGL(probe<5>, dim3(blocks), dim3(threads), 0, 0, out, 3u, 5u); }); printf("%-24s %.2f T lane-ops/s\n", names[5], lane_ops / t / 1e12);
     t = time_it([&] { hipLaunchKernelGGL(probe_pk, dim3(blocks), dim3(threads), 0, 0, (float *)out, 1.5f); }); printf("%-24s %.2f T lane-ops/s (2 elem/op)\n", "v_pk_add_f32", lane_ops / t / 1e12);
+    t = time_it([&] { hipLaunchKernelGGL(probe_pk2<0>, dim3(blocks), dim3(threads), 0, 0, (float *)out, 1.0f); }); printf("%-24s %.2f T lane-ops/s (2 fma/op)\n", "v_pk_fma_f32", lane_ops / t / 1e12);
+    t = time_it([&] { hipLaunchKernelGGL(probe_pk2<1>, dim3(blocks), dim3(threads), 0, 0, (float *)out, 1.0f); }); printf("%-24s %.2f T lane-ops/s (2 mul/op)\n", "v_pk_mul_f32", lane_ops / t / 1e12);
+    t = time_it([&] { hipLaunchKernelGGL(probe_pk2<2>, dim3(blocks), dim3(threads), 0, 0, (float *)out, 1.0f); }); printf("%-24s %.2f T lane-ops/s\n", "v_fma_f32", lane_ops / t / 1e12);
+    t = time_it([&] { hipLaunchKernelGGL(probe_pk2<3>, dim3(blocks), dim3(threads), 0, 0, (float *)out, 1.0f); }); printf("%-24s %.2f T lane-ops/s (2 fma/op)\n", "v_pk_fma_f32 op_sel+neg", lane_ops / t / 1e12);
     return 0;
 }

@@ -13,9 +13,9 @@ python $R/bench.py --steps 20 --warmup 5 --kg uniform --weights xavier $Q 2>/dev
 python $R/bench.py --steps 10 --warmup 3 --workload complex_wn18rr --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_complex_wn18rr.json
 python $R/bench.py --steps 5 --warmup 2 --workload distmult_fb15k --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_distmult_fb15k.json
 python $R/bench.py --steps 10 --warmup 3 --no-split $Q 2>/dev/null | tail -1 > $OUT/bench_transe_fb15k237_nosplit.json
-python $R/bench.py --steps 5 --warmup 2 --workload transh_fb15k237 $Q 2>/dev/null | tail -1 > $OUT/bench_transh_fb15k237.json
-python $R/bench.py --steps 5 --warmup 2 --workload transd_fb15k237 $Q 2>/dev/null | tail -1 > $OUT/bench_transd_fb15k237.json
-python $R/bench.py --steps 5 --warmup 2 --workload transe_l1_fb15k237 $Q 2>/dev/null | tail -1 > $OUT/bench_transe_l1_fb15k237.json
+python $R/bench.py --steps 5 --warmup 2 --workload transh_fb15k237 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transh_fb15k237.json
+python $R/bench.py --steps 5 --warmup 2 --workload transd_fb15k237 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transd_fb15k237.json
+python $R/bench.py --steps 5 --warmup 2 --workload transe_l1_fb15k237 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_transe_l1_fb15k237.json
 python $R/bench.py --steps 10 --warmup 3 --l2-mode direct $Q 2>/dev/null | tail -1 > $OUT/bench_transe_fb15k237_l2direct.json
 python $R/bench.py --steps 10 --warmup 3 --materialize $Q 2>/dev/null | tail -1 > $OUT/bench_transe_fb15k237_materialized.json
 # per-kernel time of the bench command (the trained-weights set-up shows up as the score_fwd/bwd, key_* and optimiser rows)

@@ -109,17 +109,28 @@ __device__ __forceinline__ float lp_pair_score(const kge_lp_desc &d, int64_t i, 
     const float *q = d.A0 + i * d.lda0;
     const float *t = d.T0 + c * d.ldt0;
     float acc = 0.0f;
-    if (d.Wq) {
-        const float a = d.scal[c * d.scal_ld + (d.scal_ld > 1 ? d.r_idx[i] : 0)];
-        const float *w = d.Wq + i * d.ldw;
-        for (int k = 0; k < d.K0; ++k) {
-            float diff = fmaf(a, w[k], q[k] - t[k]);
-            acc = (d.mode == KGE_LP_L1_DIRECT) ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+    const bool l1 = d.mode == KGE_LP_L1_DIRECT;
+    const float a = d.Wq ? d.scal[c * d.scal_ld + (d.scal_ld > 1 ? d.r_idx[i] : 0)] : 0.0f;
+    const float *w = d.Wq ? d.Wq + i * d.ldw : nullptr;
+    if (l1) {   // one add per aligned 4-group of k, the group as (|d0|+|d1|)+(|d2|+|d3|), absent k = 0
+        for (int k = 0; k < d.K0; k += 4) {
+            float m[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float diff = 0.0f;
+                if (k + e < d.K0) {
+                    diff = q[k + e] - t[k + e];
+                    if (w) diff = fmaf(a, w[k + e], diff);
+                }
+                m[e] = fabsf(diff);
+            }
+            acc = acc + ((m[0] + m[1]) + (m[2] + m[3]));
         }
     } else {
         for (int k = 0; k < d.K0; ++k) {
             float diff = q[k] - t[k];
-            acc = (d.mode == KGE_LP_L1_DIRECT) ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+            if (w) diff = fmaf(a, w[k], diff);
+            acc = fmaf(diff, diff, acc);
         }
     }
     return -acc;
@@ -149,13 +160,22 @@ static inline bool kge_lp_vec4(const kge_lp_desc &d)
     return v;
 }
 
-// the direct modes' chains (lp_pair_score without the rank-1 term): ascending k, one accumulator
+// the direct modes' chains (lp_pair_score without the rank-1 term), one accumulator: L2 one fmaf per k in
+// ascending order; L1 one add per aligned 4-group of k, the group as (|d0|+|d1|)+(|d2|+|d3|).  `a` / `t` must be
+// readable (zero-filled) up to the next multiple of 4 -- the staged chunks below are.
 template <bool L1>
 __device__ __forceinline__ float lp_chain_direct(const float *__restrict__ a, const float *__restrict__ t, int K, float acc)
 {
-    for (int k = 0; k < K; ++k) {
-        const float diff = a[k] - t[k];
-        acc = L1 ? acc + fabsf(diff) : fmaf(diff, diff, acc);
+    if (L1) {
+        for (int k = 0; k < K; k += 4) {
+            const float4 av = *reinterpret_cast<const float4 *>(a + k), tv = *reinterpret_cast<const float4 *>(t + k);
+            acc = acc + ((fabsf(av.x - tv.x) + fabsf(av.y - tv.y)) + (fabsf(av.z - tv.z) + fabsf(av.w - tv.w)));
+        }
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const float diff = a[k] - t[k];
+            acc = fmaf(diff, diff, acc);
+        }
     }
     return acc;
 }

@@ -10,8 +10,11 @@
 // (R,N,d) projection cache or its (b,N,d) intermediates.
 //
 // Register-tiled: 256 threads as 16(query) x 16(candidate); each thread owns a
-// TM x 8 micro-tile with one fp32 accumulator per pair (ascending-k order =
-// the contract of lp_pair_score), q / e / w tiles staged through
+// TM x 8 micro-tile with one fp32 accumulator per pair (the contract of
+// lp_pair_score: p = 2 one fmaf per k in ascending order; p = 1 one add per
+// aligned group of four k, the group's |diff| summed as (|d0|+|d1|)+(|d2|+|d3|),
+// absent k count as 0 -- the same instruction count as a plain chain, a quarter
+// of its roundings at full magnitude), q / e / w tiles staged through
 // double-buffered LDS in BK = 32 slices (row stride 36: conflict-free b128).
 #include "kge_common.h"
 
@@ -219,8 +222,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectPara
                         dz = fmaf(a, wv.z, dz); dw = fmaf(a, wv.w, dw);
                     }
                     float v = acc[i][j];
-                    v = acc_step<L1>(v, dx); v = acc_step<L1>(v, dy);
-                    v = acc_step<L1>(v, dz); v = acc_step<L1>(v, dw);
+                    if (L1) {   // the L1 contract: one add per aligned 4-group, the group summed as a tree
+                        v = v + ((fabsf(dx) + fabsf(dy)) + (fabsf(dz) + fabsf(dw)));
+                    } else {
+                        v = acc_step<L1>(v, dx); v = acc_step<L1>(v, dy);
+                        v = acc_step<L1>(v, dz); v = acc_step<L1>(v, dw);
+                    }
                     acc[i][j] = v;
                 }
         }

@@ -241,23 +241,26 @@ __device__ __forceinline__ void split_amag_step(float &prefix, float &amag, floa
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, float *max_io)
 {
-    // NaN-free inputs assumed: a NaN element is simply skipped by fmaxf.  One atomic per block (thousands
-    // of same-address atomics serialise in the L2: 96 us for 14 MB when every wave issued its own).
+    // The maximum is taken on the BIT PATTERNS of |x| as unsigned integers: for non-negative floats that is the
+    // float order, +inf sorts above every finite value and every NaN above +inf -- a NaN element therefore
+    // reaches max_io as a NaN (fmaxf would skip it), and the threshold kernels that consume the scalar turn a
+    // non-finite maximum into their overflow flag -> exact path (the SAD prefilter quantised a NaN
+    // element to a finite value).  One atomic per block (thousands of same-address atomics serialise in the L2:
+    // 96 us for 14 MB when every wave issued its own).
     __shared__ unsigned wmax[4];
-    float m = 0.f;
+    unsigned u = 0u;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const int64_t n4 = n >> 2;
-        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
         for (int64_t i = tid; i < n4; i += nth) {
-            const float4 v = x4[i];
-            m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+            const uint4 v = x4[i];
+            u = max(max(u, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
         }
-        for (int64_t i = (n4 << 2) + tid; i < n; i += nth) m = fmaxf(m, fabsf(x[i]));
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nth) u = max(u, __float_as_uint(x[i]) & 0x7fffffffu);
     } else {
-        for (int64_t i = tid; i < n; i += nth) m = fmaxf(m, fabsf(x[i]));
+        for (int64_t i = tid; i < n; i += nth) u = max(u, __float_as_uint(x[i]) & 0x7fffffffu);
     }
-    unsigned u = __float_as_uint(m);
     for (int off = 32; off > 0; off >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, off, 64));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = u;
     __syncthreads();

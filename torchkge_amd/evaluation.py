@@ -195,6 +195,12 @@ class LinkPredictionEvaluator(object):
         over the ranks once per evaluate() (owner contributes the row, the others zeros)
         and every batch builds its queries locally from those replicas; 'batch': each
         batch's (2B, K) query matrix is built by the owners and summed.  Same ranks.
+    coalesce: None | int -- the batch the fused kernels see.  In the reference ``b_size`` bounds the
+        (b, N, d) temporaries; here ranks are per query and a small b_size only means many small
+        launches, so the facts are processed ``max(b_size, coalesce)`` at a time (None: the module
+        default COALESCE_BATCH = 32768), never more than fits in a quarter of the FREE device memory
+        (uncertain-pair list + query buffers; single-GPU evaluators).  ``coalesce=0`` takes
+        ``b_size`` literally -- the opt-out when b_size is the script's memory knob.
     """
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
@@ -231,6 +237,7 @@ class LinkPredictionEvaluator(object):
         # index only, kept across evaluate() calls; _plan_stamp tells when they went stale
         self._plans = None
         self._plan_stamp = None
+        self._plan_refs = None
         self._plan_gen = 0
         # row-sharded models: the distinct entities of the test facts and the facts re-indexed into that list
         # (static like the plans); their rows are exchanged ONCE per evaluate() (query_exchange='evaluate') instead
@@ -258,6 +265,16 @@ class LinkPredictionEvaluator(object):
             return b_size
         per_query = max(_hip.SPLIT_LIST_PER_QUERY, self.model.n_ent // 50)
         fit = max(1, int(COALESCE_LIST_BYTES // (16 * per_query)))
+        if self.shard is None and torch.cuda.is_available():
+            # next to a training job the device may be nearly full: the scratch of one internal batch (list slots of
+            # both sides + ~4 (2B, K) fp32 query-side buffers) stays within a quarter of what is free right now.
+            # (Sharded evaluators keep the rank-independent formula: every rank must cut the same batches.)
+            try:
+                free = torch.cuda.mem_get_info(next(self.model.parameters()).device)[0]
+                k_q = 2 * int(getattr(self.model, 'emb_dim', 0) or 0) + 64
+                fit = min(fit, max(1, int((free // 4) // (16 * per_query + 2 * 4 * 4 * k_q))))
+            except Exception:
+                pass
         return max(b_size, min(target, fit, max(n_local, 1)))
 
     def _ensure_plans(self, kg, f_lo, f_hi, b_size, index_t, index_h, device):
@@ -266,8 +283,14 @@ class LinkPredictionEvaluator(object):
         stamp = (b_size, f_lo, f_hi, str(device), want_sort,
                  tuple((x.data_ptr(), x._version, x.shape[0]) for x in (kg.head_idx, kg.tail_idx, kg.relations)),
                  tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t) for x in (ix.keys, ix.offsets, ix.targets)))
-        if self._plans is not None and self._plan_stamp == stamp:
+        # ... and the stamped tensors themselves (strong references, compared by identity): a data_ptr / shape stamp
+        # alone would accept a swapped kg or a rebuilt filter index that landed on a recycled address
+        refs = (kg.head_idx, kg.tail_idx, kg.relations, index_h.keys, index_h.offsets, index_h.targets,
+                index_t.keys, index_t.offsets, index_t.targets)
+        if (self._plans is not None and self._plan_stamp == stamp and self._plan_refs is not None
+                and len(refs) == len(self._plan_refs) and all(a is b for a, b in zip(refs, self._plan_refs))):
             return
+        self._plan_refs = refs
         heads, tails, rels = (kg.head_idx[f_lo:f_hi].to(device), kg.tail_idx[f_lo:f_hi].to(device),
                               kg.relations[f_lo:f_hi].to(device))
         self._perm = None

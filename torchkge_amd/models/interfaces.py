@@ -163,6 +163,7 @@ class Model(Module):
         the query's entity and summed over the ranks, each rank scores its own candidates."""
         assert self._row_shard is None, 'already sharded'
         assert 0 <= lo <= hi <= self.n_ent
+        self._check_shardable(self.n_ent)
         for name in self._ENT_TABLES:
             emb = getattr(self, name)
             w = emb.weight.data[lo:hi].clone()
@@ -175,9 +176,22 @@ class Model(Module):
         """Declare a model that was CONSTRUCTED with n_entities = hi - lo to be the shard
         [lo, hi) of an n_total-entity model (tables too large to ever exist on one GPU)."""
         assert self._row_shard is None and self.n_ent == hi - lo and 0 <= lo <= hi <= n_total
+        self._check_shardable(hi - lo)
         self.n_ent = n_total
         self._row_shard = (lo, hi)
         return self
+
+    def _check_shardable(self, rows):
+        """A model can only be marked row-sharded when it declares WHICH tables are entity-indexed: with an empty
+        ``_ENT_TABLES`` (the base default, e.g. a user subclass with its own lp_problem) nothing would be sliced and
+        every rank would score all N candidates as 'its shard' -- silently wrong summed counts."""
+        if not self._ENT_TABLES:
+            raise RuntimeError('torchkge_amd: %s declares no entity-indexed tables (_ENT_TABLES is empty); it cannot '
+                               'be row-sharded' % type(self).__name__)
+        for name in self._ENT_TABLES:
+            n = getattr(self, name).weight.shape[0]
+            if n != rows:
+                raise RuntimeError('torchkge_amd: entity table %r has %d rows, expected %d' % (name, n, rows))
 
     def entity_table_bytes(self):
         return sum(getattr(self, n).weight.numel() * 4 for n in self._ENT_TABLES)
