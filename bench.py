@@ -73,14 +73,18 @@ def parse():
                          '(power-capped) state; 0 = none')
     ap.add_argument('--workload', default='transe_fb15k237', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32768, help='evaluate() b_size')
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'],
+                    help='N>1: strong (default) = the ONE dataset-sized job BASELINE.json names, split across the ranks; '
+                         'weak = the entity table grows to N dataset-sized shards (also reported beside a strong run: weak_mode)')
     ap.add_argument('--shard', default='entities', choices=['entities', 'queries'],
                     help='N>1: what is partitioned across ranks (weak+queries = independent replicas)')
-    ap.add_argument('--exchange', default='counts', choices=['counts', 'scores'])
+    ap.add_argument('--exchange', default=None, choices=['counts', 'scores'],
+                    help="entity shards: what the ranks exchange.  Default for N>1: 'scores' = the RCCL all-gather of the "
+                         "partial (B, N/P) score tiles north_star names; the other exchange is timed beside it at the same "
+                         "b_size (other_exchange).  'counts' = one all-reduce of 3 x 2B int32 per batch, bit-identical ranks")
+    ap.add_argument('--no-weak', action='store_true', help='N>1 strong run: skip the secondary weak-scaling measurement')
     ap.add_argument('--tables', default='sharded', choices=['sharded', 'replicated'],
                     help='entity shards: each rank HOLDS only its rows of the entity tables (default) or a full replica')
-    ap.add_argument('--scores-batch', type=int, default=2048,
-                    help="b_size of the secondary exchange='scores' measurement (the (B, N) all-gathered tile must fit)")
     ap.add_argument('--materialize', action='store_true', help='fused=False: write the (B,N) scores')
     ap.add_argument('--l2-mode', default='auto', choices=['auto', 'expand', 'direct'])
     ap.add_argument('--no-split', action='store_true',
@@ -98,11 +102,18 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='(unused; kept for compatibility)')
     ap.add_argument('--kg', default='zipf', choices=['zipf', 'uniform'],
                     help='synthetic KG: Zipf-skewed entities/relations + planted hub keys (default), or uniform draws')
-    ap.add_argument('--weights', default='trained', choices=['trained', 'xavier'],
-                    help="model weights: 'trained' = a few hundred engine training steps before the timed region")
+    ap.add_argument('--weights', default='trained', choices=['trained', 'xavier', 'unit'],
+                    help="model weights: 'trained' = a few hundred engine training steps before the timed region; "
+                         "'unit' = uniform(-0.5, 0.5) tables (scores of unit scale like a fitted model's; what the "
+                         "Wikidata5M-size workload uses instead of 'trained': dense Adam state would triple 18.8 GB)")
+    ap.add_argument('--parity-sample', type=int, default=64,
+                    help='workloads too large for the full-split comparison (cfg5): this many test facts through the '
+                         'reference algorithm on ATen GPU ops at b_size 2 (SURVEY 8d)')
     ap.add_argument('--train-steps', type=int, default=None)
     ap.add_argument('--only-timed', action='store_true',
                     help='profiling aid: nothing but the warm-up and the timed loop (no roofline / f32 / cpu / parity legs)')
+    ap.add_argument('--no-traffic', action='store_true',
+                    help='skip the two rocprofv3 --pmc child passes that measure the dominant kernel\'s HBM-side bytes')
     ap.add_argument('--no-full-parity', action='store_true',
                     help='skip the full-test-split comparison against the GPU-resident reference algorithm')
     return ap.parse_args()
@@ -188,6 +199,8 @@ def build_workload(name, device, weights='trained', kg_kind='zipf', n_ent_mult=1
         # Wikidata5M scale: let the constructor draw the 2 x 9.4 GB tables once (same distribution)
         torch.manual_seed(0)
         model = tk.ComplExModel(d, n_ent, n_rel).to(device)
+        if weights != 'xavier':
+            unit_scale_(model)
         tables = None
     else:
         tables = orc.init_tables(kind, n_ent, n_rel, d, seed=0)
@@ -210,6 +223,77 @@ def build_workload(name, device, weights='trained', kg_kind='zipf', n_ent_mult=1
     return model, tables, kg, kg_test, info
 
 
+def unit_scale_(model, seed=0):
+    """Tables ~ uniform(-0.5, 0.5): ComplEx d = 512 scores then have unit scale (std of a score = sqrt(4 d) sigma^3
+    = 1.1), the scale of a fitted model's -- Xavier at N = 4.6 M gives entries ~1e-3 and scores ~1e-8, where an
+    absolute score tolerance says nothing.  The split prefilter's band is relative: timing does not depend on the scale."""
+    g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
+    for prm in model.parameters():
+        prm.data.uniform_(-0.5, 0.5, generator=g)
+    return model
+
+
+def build_cfg5_sample(device, n_facts=400000, n_test=64, seed=1005):
+    """cfg5's MODEL (ComplEx d = 512 on 4,594,485 entities / 822 relations, unit-scale tables) with a small Zipf graph
+    over those entities: what tests/test_gpu_fullsplit.py compares with the reference algorithm at b_size = 2."""
+    import torchkge_amd as tk
+    from oracle import kge_oracle as orc
+    n_ent, n_rel = orc.DATASET_SHAPES['wikidata5m'][:2]
+    torch.manual_seed(0)
+    model = unit_scale_(tk.ComplExModel(512, n_ent, n_rel).to(device))
+    heads, tails, rels = orc.synthetic_triples_zipf(n_ent, n_rel, n_facts, seed)
+    ident_e, ident_r = {i: i for i in range(n_ent)}, {i: i for i in range(n_rel)}
+    kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels}, ent2ix=ident_e, rel2ix=ident_r)
+    kg_test = tk.KnowledgeGraph(kg={'heads': heads[-n_test:].clone(), 'tails': tails[-n_test:].clone(),
+                                    'relations': rels[-n_test:].clone()}, ent2ix=ident_e, rel2ix=ident_r,
+                                _filter_src=kg._lazy)
+    info = {'kind': 'complex', 'shape': 'wikidata5m', 'd': 512, 'p': 2, 'n_ent': n_ent, 'n_rel': n_rel,
+            'n_test': n_test, 'kg_kind': 'zipf', 'weights': 'unit'}
+    return model, kg, kg_test, info
+
+
+def _parity_summary(ref, ties, got, n_test, what, secs):
+    inside = (got >= ties[..., 0]) & (got <= ties[..., 1])
+    from oracle import kge_oracle as orc
+    mo = orc.lp_metrics(*ref, 10)
+    mg = orc.lp_metrics(*got, 10)
+    # ranks on opposite sides of k = 10 (each such near-tie flip moves Hits@10 by 0.5 / n_test: 8.5e-6 at cfg4)
+    flips10 = int(((ref[2:] <= 10) != (got[2:] <= 10)).sum())
+    return {'filtered_ranks_across_the_hits10_boundary': flips10, 'oracle': what,
+            'ranks_compared': int(ref.numel()), 'ranks_differing': int((ref != got).sum()),
+            'max_abs_rank_diff': int((ref - got).abs().max()) if ref.numel() else 0,
+            'within_reference_tie_interval_2e-5': bool(inside.all()), 'outside_tie_interval': int((~inside).sum()),
+            'filt_mrr_ref_hip': [mo['mrr'][1], mg['mrr'][1]], 'filt_hits10_ref_hip': [mo['hit_at_k'][1], mg['hit_at_k'][1]],
+            'mrr_ref_hip': [mo['mrr'][0], mg['mrr'][0]],
+            'abs_diff_filt_mrr': abs(mo['mrr'][1] - mg['mrr'][1]),
+            'abs_diff_filt_hits10': abs(mo['hit_at_k'][1] - mg['hit_at_k'][1]),
+            'median_filt_rank_ref': float(torch.cat([ref[2], ref[3]]).float().median()), 'oracle_seconds': round(secs, 1)}
+
+
+def sample_parity(model, info, kg, kg_test, ev_ranks, device, n=64, b=2, tol=2e-5):
+    """cfg5-size workloads ("subsample to <= 64 test triples and b <= 2"): the first `n` test facts through
+    the reference algorithm on ATen GPU ops (oracle.lp_evaluate, its (b, N, d) temporaries are 18.8 GB each at b = 2),
+    the model's tables read in place, the filter sets of the FULL graph for the looked-up keys by numpy scans
+    (oracle.filter_dicts_for_facts -- independent of the engine's filter index)."""
+    from oracle import kge_oracle as orc
+    n = min(n, info['n_test'])
+    th, tt, tr = kg_test.head_idx[:n].cpu(), kg_test.tail_idx[:n].cpu(), kg_test.relations[:n].cpu()
+    t0 = time.perf_counter()
+    dh, dt = orc.filter_dicts_for_facts(kg.head_idx, kg.tail_idx, kg.relations, th, tt, tr)
+    tables = [x.data for x in model._tables()]
+    with torch.no_grad():
+        rh, rt, frh, frt, ties = orc.lp_evaluate(info['kind'], tables, th, tt, tr, dh, dt, b, info['p'], tie_tol=tol,
+                                                 device=device)
+    torch.cuda.empty_cache()
+    secs = time.perf_counter() - t0
+    ref = torch.stack([rh, rt, frh, frt])
+    got = torch.stack([x.cpu()[:n] for x in ev_ranks])
+    out = _parity_summary(ref, ties, got, n, 'oracle.lp_evaluate = reference algorithm on ATen GPU ops, b_size=%d, the '
+                          'first %d test facts (SURVEY 8d subsample for this size)' % (b, n), secs)
+    out['filter_list_entries_of_the_sample'] = int(sum(len(v) for v in dh.values()) + sum(len(v) for v in dt.values()))
+    return out
+
+
 def full_split_parity(info, tables, kg, kg_test, ev_ranks, device, b=256, tol=2e-5):
     """Every rank of the whole test split against the reference algorithm on ATen GPU ops
     (oracle.lp_evaluate(device=...), evaluation.py:263-308).  ev_ranks: the engine's four rank
@@ -225,21 +309,8 @@ def full_split_parity(info, tables, kg, kg_test, ev_ranks, device, b=256, tol=2e
     secs = time.perf_counter() - t0
     ref = torch.stack([rh, rt, frh, frt])
     got = torch.stack([x.cpu() for x in ev_ranks])
-    inside = (got >= ties[..., 0]) & (got <= ties[..., 1])
-    mo = orc.lp_metrics(rh, rt, frh, frt, 10)
-    mg = orc.lp_metrics(*[x.cpu() for x in ev_ranks], 10)
-    # ranks on opposite sides of k = 10 (each such near-tie flip moves Hits@10 by 0.5 / n_test: 8.5e-6 at cfg4)
-    flips10 = int(((ref[2:] <= 10) != (got[2:] <= 10)).sum())
-    return {'filtered_ranks_across_the_hits10_boundary': flips10,
-            'oracle': 'oracle.lp_evaluate = reference algorithm on ATen GPU ops, b_size=%d' % b,
-            'ranks_compared': int(ref.numel()), 'ranks_differing': int((ref != got).sum()),
-            'max_abs_rank_diff': int((ref - got).abs().max()) if ref.numel() else 0,
-            'within_reference_tie_interval_2e-5': bool(inside.all()), 'outside_tie_interval': int((~inside).sum()),
-            'filt_mrr_ref_hip': [mo['mrr'][1], mg['mrr'][1]], 'filt_hits10_ref_hip': [mo['hit_at_k'][1], mg['hit_at_k'][1]],
-            'mrr_ref_hip': [mo['mrr'][0], mg['mrr'][0]],
-            'abs_diff_filt_mrr': abs(mo['mrr'][1] - mg['mrr'][1]),
-            'abs_diff_filt_hits10': abs(mo['hit_at_k'][1] - mg['hit_at_k'][1]),
-            'median_filt_rank_ref': float(torch.cat([frh, frt]).float().median()), 'oracle_seconds': round(secs, 1)}
+    return _parity_summary(ref, ties, got, info['n_test'],
+                           'oracle.lp_evaluate = reference algorithm on ATen GPU ops, b_size=%d' % b, secs)
 
 
 def _flush_c_stdio():
@@ -298,10 +369,55 @@ def _sample_power(run, device, seconds=1.6):
     return out
 
 
+def _measure_traffic(args, kernel_sym):
+    """HBM-side bytes per launch of the dominant kernel, measured in THIS run: bench.py re-runs itself (timed loop only,
+    eager launches, Xavier weights: the count kernel's traffic does not depend on the weights) under
+    ``rocprofv3 --pmc <counter> --kernel-trace`` once per counter -- FETCH_SIZE (3 TCC slots) and WRITE_SIZE (2) do
+    not fit one pass -- and averages the counter over the launches of `kernel_sym`.  FETCH_SIZE / WRITE_SIZE are in
+    KB; gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> 2 x FETCH_SIZE.
+    Infinity-Cache hits are counted by these memory-side counters, i.e. this is L2-miss traffic, not DRAM traffic."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rp):
+        return None
+    vals = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='kge_pmc_', dir='/tmp')
+        cmd = [rp, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 't', '--', sys.executable,
+               os.path.abspath(__file__), '--only-timed', '--no-graph', '--no-traffic', '--weights',
+               'xavier' if args.weights == 'trained' else args.weights, '--steps', '3', '--warmup', '0',
+               '--settle-ms', '0', '--workload', args.workload, '--batch', str(args.batch), '--kg', args.kg, '--l2-mode', args.l2_mode]
+        cmd += (['--no-split'] if args.no_split else []) + (['--materialize'] if args.materialize else []) \
+            + (['--no-both'] if args.no_both else [])
+        env = dict(os.environ, TMPDIR='/tmp')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'KGE_FORCE_COLLECTIVES'):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd='/tmp', env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            got = []
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name') == ctr and kernel_sym in r.get('Kernel_Name', ''):
+                        got.append(float(r['Counter_Value']))
+            if got:
+                vals[ctr] = sum(got) / len(got)
+        except Exception:
+            pass
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
+        return None
+    return int((2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
+
+
 def main():
     args = parse()
     if args.only_timed:
-        args.no_cpu_baseline = args.no_secondary = args.no_full_parity = True
+        args.no_cpu_baseline = args.no_secondary = args.no_full_parity = args.no_traffic = True
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -326,17 +442,20 @@ def main():
     kind, shape, d, p = WORKLOADS[args.workload]
     n_ent1, n_rel, n_train, n_valid, n_test = orc.DATASET_SHAPES[shape]
     multi = world > 1 or forced
+    if args.exchange is None:
+        args.exchange = 'scores' if (multi and args.shard == 'entities') else 'counts'
     # weak scaling over entity shards (default for N > 1): the entity table grows to N
     # dataset-sized shards, each GPU scores ITS shard for every test triple and the ranks
     # exchange partial results over RCCL -- per-GPU work is fixed as N grows.
     ent_weak = multi and args.scaling == 'weak' and args.shard == 'entities'
     weights = args.weights
-    if shape == 'wikidata5m':
-        weights = 'xavier'      # cfg5: 18.8 GB tables (dense Adam state would triple that)
+    if shape == 'wikidata5m' and weights == 'trained':
+        weights = 'unit'        # cfg5: 18.8 GB tables (dense Adam state would triple that): unit-scale uniform tables
     train_cfg = {'steps': args.train_steps} if args.train_steps is not None else None
     # N > 1: only rank 0 trains (atomics make training run-to-run different); its tables are broadcast below
     model, tables, kg, kg_test, info = build_workload(args.workload, device, kg_kind=args.kg,
-                                                      weights=(weights if rank == 0 or not multi else 'xavier'),
+                                                      weights=(weights if rank == 0 or not multi or weights != 'trained'
+                                                               else 'xavier'),
                                                       n_ent_mult=(world if ent_weak else 1), train_cfg=train_cfg)
     info['weights'] = weights
     n_ent = info['n_ent']
@@ -393,10 +512,26 @@ def main():
     # (1400 W, tools/power_probe.sh), and the first milliseconds after an idle gap run at a different DVFS point
     # than the sustained state (same-box: 0.68 ms per launch cold, 0.54 sustained).  The timed region below is
     # still exactly W warm-up + K timed steps.
+    # What a reference-style script pays that calls evaluate() ONCE per epoch: the first call of a fresh evaluator
+    # (device-side filter index by sort / unique, FilterPlans of every batch, the MFMA accumulation self-test, eager
+    # launches, the rank vectors' copy to the host) ...
+    sync()
+    t0 = time.perf_counter()
+    ev.evaluate(args.batch, verbose=False)      # (first call: eager, builds index + plans)
+    sync()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    ev.evaluate(args.batch, verbose=False)      # (second call: captures the hipGraph)
+    sync()
+    # ... and the per-step time of a few evaluations after an idle gap, clocks NOT settled (what r01 / early r02 reported)
+    time.sleep(0.5)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ev.evaluate(args.batch, verbose=False)
+    sync()
+    cold_ms = (time.perf_counter() - t0) / 5 * 1e3
     settle_steps = 0
     if args.settle_ms > 0:
-        ev.evaluate(args.batch, verbose=False)      # (first call: eager, builds plans)
-        ev.evaluate(args.batch, verbose=False)      # (second call: captures the hipGraph)
         sync()
         t0 = time.perf_counter()
         ev.evaluate(args.batch, verbose=False)
@@ -423,34 +558,81 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # entity shards: the OTHER exchange measured beside the headline one -- the all-gather of the partial score
-    # tiles (B, N/P) -> (B, N) that north_star names, vs the all-reduce of rank counts (bit-identical ranks)
+    def timed_steps(evx, bsz, n):
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            evx.evaluate(bsz, verbose=False)
+        sync()
+        el = time.perf_counter() - t1
+        if multi:
+            tt_ = torch.tensor([el], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            el = float(tt_.item())
+        return el
+
+    def collective_ms(evx, bsz, n=3):
+        """Device time of the data-path collectives per evaluate() (events around every RCCL call on the launch stream)."""
+        evx.collective_timing(True)
+        for _ in range(n):
+            evx.evaluate(bsz, verbose=False)
+        c = evx.collective_timing(False)
+        return {'collectives_per_evaluate': c['collectives'] // n, 'ms_per_evaluate': round(c['ms'] / n, 4)}
+
+    headline_coll = None
+    if multi and shard == 'entities' and not args.materialize and device.type == 'cuda':
+        headline_coll = collective_ms(ev, args.batch)
+
+    # entity shards: the OTHER exchange measured beside the headline one, at the SAME b_size -- the all-gather of the
+    # partial score tiles (B, N/P) -> (B, N) that north_star names, vs the all-reduce of rank counts (bit-identical ranks)
     other_x = None
     if multi and shard == 'entities' and not args.materialize:
         ox = 'scores' if args.exchange == 'counts' else 'counts'
-        ob = args.scores_batch if ox == 'scores' else args.batch
-        ev_o = tk.LinkPredictionEvaluator(model, kg_test, shard=shard, exchange=ox, graph=not args.no_graph)
+        ob = args.batch
+        ev_o = tk.LinkPredictionEvaluator(model, kg_test, shard=shard, exchange=ox, graph=not args.no_graph,
+                                          both_sides=not args.no_both,
+                                          graph_collectives=True if args.graph_collectives else None)
         main_ranks = [ev.rank_true_heads.clone(), ev.rank_true_tails.clone(), ev.filt_rank_true_heads.clone(),
                       ev.filt_rank_true_tails.clone()]
-        ev_o.evaluate(ob, verbose=False)
-        sync()
-        t1 = time.perf_counter()
-        n_o = max(1, args.steps // 4)
-        for _ in range(n_o):
+        for _ in range(3):      # eager call, capture, one replay
             ev_o.evaluate(ob, verbose=False)
-        sync()
-        el_o = time.perf_counter() - t1
-        if multi:
-            tt = torch.tensor([el_o], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el_o = float(tt.item())
+        n_o = max(2, args.steps // 2)
+        el_o = timed_steps(ev_o, ob, n_o)
         same_o = all(torch.equal(a, b) for a, b in zip(main_ranks, [ev_o.rank_true_heads, ev_o.rank_true_tails,
                                                                     ev_o.filt_rank_true_heads, ev_o.filt_rank_true_tails]))
         other_x = {'exchange': ox, 'b_size': ob, 'steps': n_o, 'ms_per_step': round(el_o / n_o * 1e3, 4),
                    'value': round(n_test * 2 * n_ent * n_o / el_o, 1), 'ranks_identical_to_headline_run': bool(same_o),
                    'collective': 'RCCL all-gather of the (B, N/P) score tiles' if ox == 'scores'
-                                 else 'RCCL all-reduce of the (3, 2B) rank counts'}
+                                 else 'RCCL all-reduce of the (3, 2B) rank counts (+ one all-gather of the query-entity rows per evaluate)',
+                   'collective_time': collective_ms(ev_o, ob) if device.type == 'cuda' else None}
         del ev_o
+
+    # ... and, beside a strong-scaling run, the WEAK mode: the entity table grown to N dataset-sized shards (Xavier
+    # weights), every rank scoring its own shard for all test facts, counts exchange -- per-GPU work fixed as N grows
+    weak_mode = None
+    if multi and shard == 'entities' and args.scaling == 'strong' and not args.no_weak and not args.materialize \
+            and args.tables == 'sharded':
+        from torchkge_amd import distributed as kd
+        m_w, _, kg_w, kg_test_w, info_w = build_workload(args.workload, device, kg_kind=args.kg, weights='xavier',
+                                                         n_ent_mult=world)
+        if kind in ('transe', 'transh', 'transd'):
+            m_w.l2_mode = args.l2_mode
+        kg_test_w.head_idx, kg_test_w.tail_idx, kg_test_w.relations = (kg_test_w.head_idx.to(device), kg_test_w.tail_idx.to(device),
+                                                                       kg_test_w.relations.to(device))
+        kd.shard_model_(m_w)
+        ev_w = tk.LinkPredictionEvaluator(m_w, kg_test_w, shard='entities', exchange='counts', graph=not args.no_graph,
+                                          graph_collectives=True if args.graph_collectives else None)
+        for _ in range(3):
+            ev_w.evaluate(args.batch, verbose=False)
+        n_w = max(2, args.steps // 2)
+        el_w = timed_steps(ev_w, args.batch, n_w)
+        weak_mode = {'scaling': 'weak', 'n_ent': info_w['n_ent'], 'entity_shards': world, 'exchange': 'counts',
+                     'weights': 'xavier', 'steps': n_w, 'ms_per_step': round(el_w / n_w * 1e3, 4),
+                     'value': round(n_test * 2 * info_w['n_ent'] * n_w / el_w, 1),
+                     'scored_triples_per_step': n_test * 2 * info_w['n_ent'],
+                     'collective_time': collective_ms(ev_w, args.batch) if device.type == 'cuda' else None}
+        del ev_w, m_w, kg_w, kg_test_w
+        torch.cuda.empty_cache()
 
     # the same evaluation with the rank counts on the fp32 MFMA kernel only (reported beside the headline)
     f32_only_ms = None
@@ -544,53 +726,68 @@ def main():
             model.lp_guard_end()
         K = d * (2 if kind == 'complex' else 1)
         mode = prob.desc.mode
-        peak = PEAK_FP32_TFLOPS
+        pairs = B * n_ent
         extra = {}
+        # ALGORITHMIC flops per (query, candidate) pair -- 2K for the contraction kernels (K3 / K2 as a
+        # GEMM), 3d for the broadcast-subtract kernels (sub, mul|abs, add) -- over the measured launch time, against the
+        # dense peak of the UNIT the kernel runs on.  What the kernel additionally executes (the f16 split's three
+        # products over K padded to 16) is reported as executed_*; it is not the roofline fraction.
         if split:
-            # executed matrix-core work: 3 f16 products (hi*hi, hi*lo, lo*hi) over K+1 columns
-            # padded to 16: 2 flop each; the algorithmic fp32 work of the same pairs is 2K
             k16 = (K + 1 + 15) // 16 * 16
-            flops_per_pair = 3 * 2 * k16
-            kname = 'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)'
-            peak = PEAK_F16_TFLOPS
-            extra = {'algorithmic_flops_per_pair': 2 * K,
-                     'fp32_equivalent_TFLOPs': round(2 * K * B * n_ent / kern_s / 1e12, 2),
-                     'note': 'ranks are bit-identical to the fp32 path (pairs inside the proven error band are '
-                             're-scored exactly by kge_lp_split_recheck); achieved counts the f16 MFMA flops '
-                             'actually executed, peak is the dense f16 MFMA peak'}
+            alg_flops, exec_flops = 2 * K, 3 * 2 * k16
+            kname, ksym = 'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)', 'lp_split_count_kernel'
+            peak, bound = PEAK_F16_TFLOPS, 'mfma'
+            extra = {'peak_is': 'dense f16 MFMA (the unit the kernel runs on)',
+                     'executed_flops_per_pair': exec_flops,
+                     'executed_TFLOPs': round(exec_flops * pairs / kern_s / 1e12, 2),
+                     'executed_frac': round(exec_flops * pairs / kern_s / 1e12 / peak, 4),
+                     'frac_of_fp32_mfma_peak': round(alg_flops * pairs / kern_s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                     'note': 'ranks are bit-identical to the fp32 path (pairs inside the proven error band are re-scored '
+                             'exactly by kge_lp_split_recheck); frac = 2K algorithmic flop per pair against the f16 MFMA '
+                             'peak; the kernel executes 3 f16 products per element (hi*hi, hi*lo, lo*hi), see executed_*; '
+                             'SURVEY 8(d) names the fp32 MFMA peak as this row\'s bound: frac_of_fp32_mfma_peak'}
         elif mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND, _hip.LP_L2_PROJH, _hip.LP_L2_PROJD):
-            flops_per_pair = 2 * K           # one fp32 MFMA FMA per (pair, k)
-            kname = 'lp_gemm_kernel (fp32 MFMA 32x32x2%s)' % (
-                ', per-pair projection gather' if mode >= _hip.LP_L2_PROJH else '')
+            alg_flops = 2 * K               # one fp32 MFMA FMA per (pair, k)
+            kname = 'lp_gemm_kernel (fp32 MFMA 32x32x2%s)' % (', per-pair projection gather' if mode >= _hip.LP_L2_PROJH else '')
+            ksym, peak, bound = 'lp_gemm_kernel', PEAK_FP32_TFLOPS, 'mfma'
         elif getattr(prob, 'sad', None) is not None and not args.materialize:
-            flops_per_pair = 3 * K           # the fp32 work of the same pairs: sub, abs, add per (pair, k)
+            alg_flops = 3 * K               # the fp32 work of the same pairs: sub, abs, add per (pair, k)
             kname = 'lp_l1_sad_count_kernel (+ thresholds + exact recheck): v_sad_u16 on 16-bit fixed-point operands'
+            ksym, peak, bound = 'lp_l1_sad_count_kernel', PEAK_FP32_TFLOPS, 'valu'
             extra = {'note': 'ranks are bit-identical to the fp32 VALU path (pairs inside the proven error band are re-scored '
                              'exactly by kge_lp_sad_recheck); achieved = 3K fp32-equivalent flop per pair over the time of '
                              'the whole count (thresholds + SAD kernel + recheck), peak = fp32 VALU; the SAD kernel itself '
                              'issues K/2 half-rate integer ops per pair'}
         else:
-            flops_per_pair = 3 * K           # sub, mul, add on the VALU
-            kname = 'lp_direct_kernel (fp32 VALU)'
-        achieved = flops_per_pair * B * n_ent / kern_s / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile):
-            try:
-                # measured off-line with rocprofv3 --pmc (see profiles/), bytes per launch
-                traffic = (json.load(open(tfile)).get(args.workload + ('' if split else ':no-split')) or {}).get('bytes_per_launch')
-            except Exception:
-                traffic = None
-        roof = {'bound': 'mfma' if mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND, _hip.LP_L2_PROJH, _hip.LP_L2_PROJD) else 'valu',
-                'achieved': round(achieved, 2), 'peak': peak,
-                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
-                'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4),
-                'pairs_per_launch': B * n_ent, 'flops_per_pair': flops_per_pair}
+            alg_flops = 3 * K               # sub, mul|abs, add on the VALU
+            kname, ksym, peak, bound = 'lp_direct_kernel (fp32 VALU)', 'lp_direct_kernel', PEAK_FP32_TFLOPS, 'valu'
+        achieved = alg_flops * pairs / kern_s / 1e12
+        # HBM-side bytes of the dominant kernel per launch: two rocprofv3 --pmc passes OF THIS RUN (FETCH_SIZE and
+        # WRITE_SIZE cannot share a pass; corrections per MI355X_MICROARCH.md), else the checked-in figure, labelled
+        traffic, traffic_src = None, None
+        if not args.no_traffic and not multi:
+            traffic = _measure_traffic(args, ksym)
+            traffic_src = None if traffic is None else 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run ' \
+                                                       '(2 x FETCH_SIZE + WRITE_SIZE, KB -> B; MI355X_MICROARCH.md gfx950 note)'
+        if traffic is None:
+            tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tfile):
+                try:
+                    traffic = (json.load(open(tfile)).get(args.workload + ('' if split else ':no-split')) or {}).get('bytes_per_launch')
+                    traffic_src = None if traffic is None else 'static: profiles/traffic.json (rocprofv3 --pmc of an earlier run)'
+                except Exception:
+                    traffic = None
+        # algorithmic operand bytes of one launch: every operand row read once (fp32, or 4 B / element split cells)
+        cols = ((K + 1 + 15) // 16 * 16) if split else K        # (split cells: f16 hi + lo = 4 B per element, + the norm column)
+        alg_bytes = 4 * (B + n_ent) * cols
+        roof = {'bound': bound, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                'algorithmic_operand_bytes_per_launch': alg_bytes,
+                'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4), 'timing': 'HIP events on the launch stream, %d launches' % reps,
+                'pairs_per_launch': pairs, 'algorithmic_flops_per_pair': alg_flops}
         roof.update(extra)
         if power is not None:
             roof['package_power'] = power
-        # the algorithmic work of the same pairs (2K flop per pair) against the same peak
-        roof['useful_frac'] = round(2 * K * B * n_ent / kern_s / 1e12 / peak, 4)
 
     # ---- secondary numbers of the same hot path: scoring_function (K1) and corrupt_batch (K5) ----
     sec = None
@@ -627,12 +824,38 @@ def main():
         bytes_per_triple = {'complex': 24 * d + 28, 'transh': 16 * d + 28, 'transd': 20 * d + 28}.get(kind, 12 * d + 28)
         samp = tk.BernoulliNegativeSampler(kg)
         t_cb = ev_time(lambda: samp.corrupt_batch(h2, t2, r2), reps=10)
+        # K1 against HBM proper (the dataset-sized tables live in the 256 MiB Infinity Cache): the same kernel
+        # on a table that exceeds it -- 2,000,000 entities (1.6 GB per fp32 table at d = 200) and 1,048,576 triples with
+        # independent random ids, so one launch touches ~2 x B distinct rows (>= 1.6 GB) and nothing survives in the
+        # caches from launch to launch
+        hbm = None
+        try:
+            n_big, b_big = 2000000, 1 << 20
+            torch.manual_seed(11)
+            ctor = {'transe': lambda: tk.TransEModel(d, n_big, n_rel, 'L%d' % p), 'transh': lambda: tk.TransHModel(d, n_big, n_rel),
+                    'transd': lambda: tk.TransDModel(d, d, n_big, n_rel), 'distmult': lambda: tk.DistMultModel(d, n_big, n_rel),
+                    'complex': lambda: tk.ComplExModel(d, n_big, n_rel)}[kind]
+            big = ctor().to(device)
+            hb, tb, rb = orc.synthetic_triples(n_big, n_rel, b_big, seed=4, device=device)
+            with torch.no_grad():
+                t_big = ev_time(lambda: big.scoring_function(hb, tb, rb), reps=10)
+            hbm = {'n_ent': n_big, 'batch': b_big, 'entity_table_bytes': big.entity_table_bytes(), 'ms': round(t_big * 1e3, 4),
+                   'hbm_GBps': round(b_big * bytes_per_triple / t_big / 1e9, 1),
+                   'frac_of_8TBps': round(b_big * bytes_per_triple / t_big / 1e9 / PEAK_HBM_GBS, 4),
+                   'note': 'entity tables exceed the 256 MiB Infinity Cache and a launch touches > 1.6 GB of distinct rows: '
+                           'this is the HBM figure (relation rows, 1/3 of the algorithmic bytes for TransE, still come from L2)'}
+            del big, hb, tb, rb
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            hbm = {'error': str(exc)[:200]}
         sec = {'scoring_function': {'triples_per_s': round(Bt / t_sf, 1), 'batch': Bt, 'ms': round(t_sf * 1e3, 4),
                                     'timing': 'device time per launch (20 launches replayed as one hipGraph)',
                                     'ms_per_eager_call_host_bound': round(t_sf_call * 1e3, 4),
                                     'algorithmic_bytes_per_triple': bytes_per_triple,
-                                    'achieved_GBps': round(Bt * bytes_per_triple / t_sf / 1e9, 1),
-                                    'frac_of_8TBps': round(Bt * bytes_per_triple / t_sf / 1e9 / PEAK_HBM_GBS, 4)},
+                                    'cache_GBps': round(Bt * bytes_per_triple / t_sf / 1e9, 1),
+                                    'cache_note': 'dataset-sized tables (%.1f MB) sit in the L2 / 256 MiB Infinity Cache: this is '
+                                                  'cache bandwidth, not HBM' % (table_bytes_full / 1e6),
+                                    'hbm': hbm},
                'corrupt_batch': {'samples_per_s': round(Bt / t_cb, 1), 'batch': Bt, 'ms': round(t_cb * 1e3, 4),
                                  'note': 'includes the reference-compatible mask.sum().item() host sync'}}
 
@@ -690,6 +913,33 @@ def main():
                'filt_hits10_cpu_gpu': [mo['hit_at_k'][1], mg['hit_at_k'][1]],
                'filt_mrr_cpu_gpu': [mo['mrr'][1], mg['mrr'][1]]}
 
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and tables is None:
+        # cfg5-size: the reference's (b, N, d) temporaries are 9.4 GB each at b = 1 -> a few facts at b = 1 on the host
+        # cores, rate extrapolated linearly in n_test; needs ~60 GB of host memory
+        try:
+            import psutil
+            if psutil.virtual_memory().available > 120 * 2 ** 30:
+                nf = 2
+                cpu_tabs = [x.data.cpu() for x in model._tables()]
+                th, tt_, tr = kg_test.head_idx[:nf].cpu(), kg_test.tail_idx[:nf].cpu(), kg_test.relations[:nf].cpu()
+                dh, dtl = orc.filter_dicts_for_facts(kg.head_idx, kg.tail_idx, kg.relations, th, tt_, tr)
+                torch.set_num_threads(min(os.cpu_count(), 64))
+                with torch.no_grad():
+                    orc.lp_evaluate(kind, cpu_tabs, th[:1], tt_[:1], tr[:1], dh, dtl, 1, p)       # first touch
+                    c0 = time.perf_counter()
+                    rh, rt, frh, frt = orc.lp_evaluate(kind, cpu_tabs, th, tt_, tr, dh, dtl, 1, p)
+                    dt_ = time.perf_counter() - c0
+                cpu_r = torch.stack([rh, rt, frh, frt])
+                gpu_r = torch.stack([x[:nf] for x in ev_ranks])
+                cpu = {'value': round(nf * 2 * n_ent_full / dt_, 1), 'unit': 'triples_scored/s',
+                       'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'port',
+                       'sample': '%d test facts at b_size 1 (%.1f s; the (1, N, d) temporaries are 9.4 GB each), oracle.lp_evaluate '
+                                 '= the reference algorithm on torch CPU ops' % (nf, dt_),
+                       'ranks_differing': int((cpu_r != gpu_r).sum()), 'ranks_compared': int(cpu_r.numel())}
+                del cpu_tabs
+        except Exception as exc:
+            cpu = {'error': str(exc)[:200]}
+
     # ---- every rank of the whole test split vs the reference algorithm on ATen GPU ops ----
     parity = None
     if rank == 0 and world == 1 and not args.no_full_parity and tables is not None:
@@ -697,6 +947,11 @@ def main():
         if not parity['within_reference_tie_interval_2e-5'] or parity['abs_diff_filt_mrr'] >= 1e-5 \
                 or parity['abs_diff_filt_hits10'] >= 1e-5 + parity['filtered_ranks_across_the_hits10_boundary'] * 0.5 / n_test:
             raise SystemExit('bench: full-split parity against the reference algorithm failed: %s' % json.dumps(parity))
+
+    if rank == 0 and world == 1 and not args.no_full_parity and tables is None and args.parity_sample > 0:
+        parity = sample_parity(model, info, kg, kg_test, ev_ranks, device, n=args.parity_sample, b=2)
+        if not parity['within_reference_tie_interval_2e-5'] or parity['abs_diff_filt_mrr'] >= 1e-5:
+            raise SystemExit('bench: subsample parity against the reference algorithm failed: %s' % json.dumps(parity))
 
     # ---- training step through the same kernels (last: it changes the tables) ----
     if rank == 0 and sec is not None:
@@ -752,11 +1007,12 @@ def main():
         elif replicas:
             par = 'independent-replicas-%d' % world
         elif shard == 'entities':
-            par = 'entity-shards-%d, RCCL %s of %s' % (world, 'all-reduce' if args.exchange == 'counts' else 'all-gather',
-                                                       'rank counts' if args.exchange == 'counts' else 'score tiles')
+            par = 'entity-shards-%d (row-sharded tables), RCCL %s' % (
+                world, 'all-reduce of the (3, 2B) rank counts' if args.exchange == 'counts'
+                else 'all-gather of the partial (B, N/P) score tiles -> (B, N) on every rank')
         else:
             par = 'query-shards-%d' % world
-        used_split = bool(roof and 'fp32_equivalent_TFLOPs' in roof)
+        used_split = bool(roof and 'executed_frac' in roof)
         dtype = 'f32 (f16 hi/lo-split MFMA prefilter + exact f32 recheck; ranks bit-identical to f32)' \
             if used_split else ('f32 (u16 fixed-point SAD prefilter + exact f32 recheck; ranks bit-identical to f32)'
                                 if roof and 'lp_l1_sad' in roof.get('kernel', '') else 'f32')
@@ -765,6 +1021,10 @@ def main():
             'value': round(value, 1), 'unit': 'triples_scored/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'clock_settle': {'untimed_steps_before_warmup': settle_steps, 'target_ms': args.settle_ms},
+            'first_evaluate_ms': round(first_ms, 2), 'cold_ms_per_step': round(cold_ms, 4),
+            'first_evaluate_what': 'wall time of the first evaluate() of a fresh evaluator: device-side filter index, FilterPlans, '
+                                   'MFMA self-test, eager launches, ranks to the host; cold_ms_per_step: 5 graph replays after a '
+                                   '0.5 s idle gap, before the clock-settle phase',
             'higher_is_better': True, 'scaling': args.scaling if multi else 'weak',
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
@@ -787,7 +1047,7 @@ def main():
                 'layout': ('row-sharded: N/P rows per GPU, relation tables replicated' if (shard == 'entities' and args.tables == 'sharded')
                            else 'replicated'),
                 'bytes_full': table_bytes_full, 'bytes_this_rank': model.entity_table_bytes()},
-            'other_exchange': other_x,
+            'collective_time': headline_coll, 'other_exchange': other_x, 'weak_mode': weak_mode,
             'f32_mfma_only': None if f32_only_ms is None else {
                 'ms_per_step': round(f32_only_ms, 4), 'value': round(total_units / f32_only_ms * 1e3, 1),
                 'ranks_identical_to_headline_run': True},

@@ -20,7 +20,7 @@ def _bench(extra, forced, port):
         env.update({'KGE_FORCE_COLLECTIVES': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1',
                     'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
-           '--workload', 'complex_wn18rr', '--no-cpu-baseline', '--no-secondary', '--no-full-parity',
+           '--workload', 'complex_wn18rr', '--no-cpu-baseline', '--no-secondary', '--no-full-parity', '--no-traffic', '--no-weak',
            '--weights', 'xavier'] + extra     # (trained weights differ run to run: atomics in the backward)
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]

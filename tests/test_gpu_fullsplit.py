@@ -76,6 +76,37 @@ def test_full_test_split_vs_gpu_resident_reference(hip, workload, weights):
         assert torch.equal(a, b)
 
 
+def test_cfg5_wikidata5m_shape_subsample_vs_gpu_resident_reference(hip):
+    """BASELINE cfg5 (ComplEx d = 512, 4,594,485 entities, 822 relations; K = 1024: the regime where the f16-split band
+    is widest) against the REFERENCE ALGORITHM, as SURVEY 8(d) prescribes for this size: 64 test facts at b_size = 2
+    through oracle.lp_evaluate on ATen GPU ops (bilinear.py:501-556 with its (b, N, d) temporaries: 18.8 GB each at
+    b = 2), filter sets of the full graph restricted to the looked-up keys (oracle.filter_dicts_for_facts).  All 256
+    ranks inside the reference's tie interval, split == fp32, metrics equal.  Tables: uniform(-0.5, 0.5) -- scores of
+    unit scale like a fitted model's (Xavier at N = 4.6 M gives scores ~1e-8, where an absolute tolerance says nothing)."""
+    import bench
+    import torchkge_amd as tk
+    dev = torch.device('cuda', 0)
+    model, kg, kg_test, info = bench.build_cfg5_sample(dev, n_facts=400000, n_test=64)
+    ev = tk.LinkPredictionEvaluator(model, kg_test)
+    ev.evaluate(b_size=32768, verbose=False)
+    split = _ranks(ev)
+    par = bench.sample_parity(model, info, kg, kg_test, split, dev, n=64, b=2)
+    print('\ncfg5 subsample: %d of %d ranks differ from the GPU-resident reference (max |d| = %d), %d outside the tie '
+          'interval; filt MRR ref/hip = %.6f / %.6f; median filtered rank %.0f; %d filter-list entries in the sample'
+          % (par['ranks_differing'], par['ranks_compared'], par['max_abs_rank_diff'], par['outside_tie_interval'],
+             par['filt_mrr_ref_hip'][0], par['filt_mrr_ref_hip'][1], par['median_filt_rank_ref'],
+             par['filter_list_entries_of_the_sample']))
+    assert par['ranks_compared'] == 256
+    assert par['within_reference_tie_interval_2e-5'], par
+    assert par['abs_diff_filt_mrr'] < 1e-5 and abs(par['mrr_ref_hip'][0] - par['mrr_ref_hip'][1]) < 1e-5, par
+    assert par['abs_diff_filt_hits10'] < 1e-5 + par['filtered_ranks_across_the_hits10_boundary'] * 0.5 / 64, par
+    model.split_filter = False
+    ev2 = tk.LinkPredictionEvaluator(model, kg_test)
+    ev2.evaluate(b_size=32768, verbose=False)
+    for a, b in zip(split, _ranks(ev2)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('kind,p', [('transe', 2), ('transe', 1), ('complex', 2), ('transh', 2)])
 def test_grouped_filter_correction_with_hub_keys_bit_exact(hip, kind, p):
     """Hub keys (lists of 3000 / 1500 entities shared by hundreds of queries), duplicate keys with

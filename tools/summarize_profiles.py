@@ -27,6 +27,7 @@ def main(out):
                   os.path.basename(f), j['value'], j['unit'], j['ms_per_step'], j['filtered_hits_at_10'],
                   j['filtered_mrr'], r.get('kernel'), r.get('achieved', 0), r.get('unit'), 100 * r.get('frac', 0),
                   r.get('kernel_ms', 0)))
+        print('  * roofline: %s' % json.dumps({k: v for k, v in r.items() if k not in ('package_power', 'note')}))
         if r.get('package_power'):
             print('  * package_power (dominant kernel back to back): %s; clock_settle: %s' % (json.dumps(r['package_power']), json.dumps(j.get('clock_settle'))))
         if j.get('workload_detail'):

@@ -239,6 +239,7 @@ class LinkPredictionEvaluator(object):
         self._plan_stamp = None
         self._plan_refs = None
         self._plan_gen = 0
+        self._ctimes = None     # collective_timing(): (start, end) event pairs of the data-path collectives
         # row-sharded models: the distinct entities of the test facts and the facts re-indexed into that list
         # (static like the plans); their rows are exchanged ONCE per evaluate() (query_exchange='evaluate') instead
         # of the (2B, K) query rows of every batch ('batch')
@@ -341,14 +342,14 @@ class LinkPredictionEvaluator(object):
         if self.fused and not (sharded and self.exchange == 'scores'):
             s_true = eng.true_scores(prob, true_idx)
             if sharded:
-                kdist.all_reduce_sum(s_true, self.group)    # owner shard holds the value, others 0
+                self._timed(lambda: kdist.all_reduce_sum(s_true, self.group))()    # owner shard holds the value, others 0
             counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, index.targets)
             if sharded:
-                kdist.all_reduce_sum(counts, self.group)
+                self._timed(lambda: kdist.all_reduce_sum(counts, self.group))()
             return eng.finalize(counts)
         scores = eng.local_scores(prob)
         if sharded:
-            scores = kdist.all_gather_columns(scores, self.model.n_ent, self.group)
+            scores = self._timed(lambda: kdist.all_gather_columns(scores, self.model.n_ent, self.group))()
         return eng.ranks_from_scores(scores, true_idx, seg_lo, seg_hi, index.targets)
 
     def _rank_batch_both(self, h, t, r, index_t, index_h, out, off, lo, hi, sharded, last=False, guard=None):
@@ -409,10 +410,37 @@ class LinkPredictionEvaluator(object):
             kw['qctx'] = self._qb
         return kw
 
+    def _timed(self, fn):
+        """`fn` bracketed by two events on the current stream while collective timing is on (decided when the call
+        RUNS: the calls recorded into graph segments at capture time are timed at replay too)."""
+        def call(*a):
+            if self._ctimes is None:
+                return fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a)
+            e1.record()
+            self._ctimes.append((e0, e1))
+            return out
+        return call
+
+    def collective_timing(self, on=True):
+        """Device time of the data-path collectives (RCCL calls on the evaluation stream, bracketed by events):
+        ``collective_timing(True)`` starts collecting, ``collective_timing(False)`` returns
+        ``{'collectives': n, 'ms': total}`` for the evaluate() calls in between and stops."""
+        if on:
+            self._ctimes = []
+            return None
+        ev, self._ctimes = self._ctimes or [], None
+        if ev:
+            ev[-1][1].synchronize()
+        return {'collectives': len(ev), 'ms': round(sum(a.elapsed_time(b) for a, b in ev), 4)}
+
     def _collective_value(self, fn, shape, like):
         """A collective that RETURNS a tensor: run it now -- or, while evaluate() is being captured, allocate the
         result in the graph's pool, cut the capture, and record a call that fills that buffer at replay."""
         buf = like.new_empty(shape)
+        fn = self._timed(fn)
         if self._cut is None:
             fn(buf)
         else:
@@ -422,6 +450,7 @@ class LinkPredictionEvaluator(object):
     def _collective(self, fn):
         """Run a collective now -- or, while evaluate() is being captured, close the current
         graph segment, record the call, and open the next segment."""
+        fn = self._timed(fn)
         if self._cut is None:
             fn()
         else:
@@ -584,6 +613,10 @@ class LinkPredictionEvaluator(object):
             use_graph = (self.graph is not False and device.type == 'cuda' and n_local > 0 and
                          not self._generic_model and
                          (not multi or self.shard == 'queries' or segmented))
+            if segmented and os.environ.get('KGE_EAGER_COLLECTIVES') == '1':
+                # escape hatch for a multi-GPU box (no code change): no graph segments, no captured collectives --
+                # every kernel and every RCCL call of a sharded evaluate() is an ordinary eager launch
+                use_graph = one_graph = False
             key = None
             if use_graph:
                 # capture is keyed on everything that fixes shapes and ADDRESSES (tables, filter index); table
