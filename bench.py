@@ -398,13 +398,13 @@ def _measure_traffic(args, kernel_sym):
             env.pop(k, None)
         try:
             subprocess.run(cmd, cwd='/tmp', env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            got = []
-            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            got = {}        # per kernel NAME (the count kernel may run as two instantiations per launch: single-query
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):      # and grouped columns)
                 for r in csv.DictReader(open(f)):
                     if r.get('Counter_Name') == ctr and kernel_sym in r.get('Kernel_Name', ''):
-                        got.append(float(r['Counter_Value']))
+                        got.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
             if got:
-                vals[ctr] = sum(got) / len(got)
+                vals[ctr] = sum(sum(v) / len(v) for v in got.values())
         except Exception:
             pass
         finally:
@@ -679,8 +679,12 @@ def main():
             prob = None
             both = (shard is None and not args.materialize and ev.both_sides and not args.overlap
                     and hasattr(model, 'lp_problem_both'))
-            if both:    # as evaluate() builds it: both sides of the batch as one problem of 2B queries
-                prob = model.lp_problem_both(h, t, r)
+            cols = None
+            if both:    # as evaluate() builds it: both sides of the batch as one problem of 2B queries -- over the
+                # batch's COLUMNS (distinct query rows) where the evaluator's plan carries a ColumnPlan
+                pl = (getattr(ev, '_plans', None) or {}).get((0, int(h.shape[0])))
+                cols = getattr(pl, 'cols', None)
+                prob = model.lp_problem(h, t, r, 'both', cols=cols) if cols is not None else model.lp_problem_both(h, t, r)
             if prob is not None:
                 true = torch.cat([t, h])
                 if prob.pre is not None:
@@ -778,14 +782,21 @@ def main():
                 except Exception:
                     traffic = None
         # algorithmic operand bytes of one launch: every operand row read once (fp32, or 4 B / element split cells)
-        cols = ((K + 1 + 15) // 16 * 16) if split else K        # (split cells: f16 hi + lo = 4 B per element, + the norm column)
-        alg_bytes = 4 * (B + n_ent) * cols
+        kcols = ((K + 1 + 15) // 16 * 16) if split else K        # (split cells: f16 hi + lo = 4 B per element, + the norm column)
+        alg_bytes = 4 * (B + n_ent) * kcols
         roof = {'bound': bound, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_operand_bytes_per_launch': alg_bytes,
                 'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4), 'timing': 'HIP events on the launch stream, %d launches' % reps,
                 'pairs_per_launch': pairs, 'algorithmic_flops_per_pair': alg_flops}
         roof.update(extra)
+        if cols is not None:
+            roof['query_columns'] = {'queries': int(cols.n_queries), 'distinct_rows': int(cols.n_distinct_keys),
+                                     'columns': int(cols.n_columns), 'single': int(cols.n_single), 'grouped': int(cols.n_multi),
+                                     'sets_per_grouped_column': int(cols.sets),
+                                     'note': 'queries that share their key share the query row: the matrix-core sweep runs once '
+                                             'per column (two launches: single-query columns, grouped columns), the threshold '
+                                             'compare once per query; pairs_per_launch counts (query, candidate) pairs'}
         if power is not None:
             roof['package_power'] = power
 

@@ -113,15 +113,18 @@ enum {
  *                  with (p_i, z_i) = Wq[i*ldw + {0,1}] and X[r, c] = scal[r*scal_ld + c]
  *     L1/L2_DIRECT: diff_k = A0[i,k] - T0[c,k]; if Wq: diff_k = fmaf(a, Wq[i,k], diff_k)
  *                   with a = scal[c*scal_ld + (scal_ld > 1 ? r_idx[i] : 0)];
- *                   acc += |diff_k|  or  acc = fmaf(diff_k, diff_k, acc);  s = -acc
+ *                   L2: acc = fmaf(diff_k, diff_k, acc), k ascending;
+ *                   L1: acc += (|diff_k| + |diff_k+1|) + (|diff_k+2| + |diff_k+3|) per aligned group of four k
+ *                       (absent k >= K0 count as 0);  s = -acc
  *   chain(x, y, K): ONE accumulator, acc = fmaf(x[k], y[k], acc), k visiting
  *   the 8-blocks of [0,K) in ascending order and, inside each 8-block, the
  *   offsets 0,4,1,5,2,6,3,7 (absent k >= K skipped) -- exactly the sequence in
  *   which the tile kernel feeds v_mfma_f32_32x32x2_f32 (an fp32 fmaf chain) --
  *   so every kernel that scores a pair (tile kernels, pair kernel, filter
  *   kernel) produces bit-identical scores, and oracle/kge_oracle.c reproduces
- *   them bit for bit on the CPU.  The DIRECT modes accumulate in plain
- *   ascending k.
+ *   them bit for bit on the CPU.  L2_DIRECT accumulates in plain ascending k, L1_DIRECT
+ *   one add per aligned 4-group of k (the group summed as a tree: the same instruction
+ *   count, a quarter of the roundings at full magnitude).
  */
 typedef struct kge_lp_desc {
     int32_t mode;
@@ -342,6 +345,18 @@ int kge_filtered_rank_from_scores(const float *scores, int64_t ld, const int64_t
 int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, int k, int64_t *out_idx,
              float *out_val, kge_stream_t stream);
 
+/* Top-k over a candidate set processed TILE BY TILE (and shard by shard): `scores` (B, C) holds the scores of candidates
+ * [c_base, c_base + C) -- scratch, modified in place: the known targets of row i's filter segment that fall into the
+ * tile are masked first when `targets` != NULL (filter_scores with true_idx = None, inference.py:146, :241).  Writes the
+ * tile's k best of every row as (score, GLOBAL id) into columns [col_off, col_off + k) of the (B, ldo) outputs.
+ * `ids_in` != NULL: merge mode -- column c stands for candidate ids_in[i*ld_ids + c] (< 0: padding, never selected);
+ * c_base is ignored.  Replaces the (b, N) score matrix + full sort of EntityInference.evaluate (inference.py:216-250)
+ * by O(b * C) scratch; per-shard lists of a row-sharded model merge the same way. */
+int kge_topk_chunk(float *scores, int64_t ld, int64_t B, int64_t C, int64_t c_base, int k,
+                   const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                   const int64_t *ids_in, int64_t ld_ids, int64_t *out_idx, float *out_val, int64_t ldo,
+                   int64_t col_off, kge_stream_t stream);
+
 /* ---- negative sampling ----------------------------------------------------- */
 /* neg_heads/neg_tails (B*n_neg): position j (batch element j % B): mask[j] != 0
  * -> head := draws_h[#ones before j], tail kept; else tail := draws_t[#zeros
@@ -386,7 +401,19 @@ typedef struct kge_split_args {
     int32_t cap;
     int32_t *list_count;          /* device int32 */
     float *overflow;              /* device float, set to 1.0f on overflow (see above) */
+    /* COLUMNS instead of queries (optional; plain thresholds only).  Queries of a link-prediction batch that share
+     * their key -- (h, r) on the tail side, (t, r) on the head side -- share the query ROW and differ only in the true
+     * entity, i.e. in their thresholds: Qs then holds one row per column, n_single_p rows whose column carries ONE
+     * query (col_q[column] = query id, < 0: padding) followed by n_multi_p rows whose column carries up to
+     * kge_lp_split_group_sets() queries (members[column * sets + j], < 0: unused); both counts are multiples of the
+     * query panel (kge_lp_split_rows_padded).  The matrix-core sweep runs once per column, the compare once per
+     * query; thr, raw_count and the uncertain-pair list stay indexed by QUERY.  Both NULL: column == query. */
+    const int32_t *col_q;
+    int64_t n_single_p;
+    const int32_t *members;
+    int64_t n_multi_p;
 } kge_split_args;
+int kge_lp_split_group_sets(void);
 
 int kge_lp_split_units(int K, int with_aug);
 int64_t kge_lp_split_rows_padded(int64_t rows, int is_query);
@@ -424,6 +451,8 @@ int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const
                           const int64_t *r, int64_t B, const float *en, const float *emax, float *qmax_io,
                           int accum_model, float eps_scale, float *Q, float *qn, float *s_true, void *Qs,
                           float *thr, int32_t *list_count, const float *e2pref /* optional, see above */,
+                          const int32_t *qs_row /* optional: row of Qs that receives query i's split cells, < 0: none
+                                                   (columns, see kge_split_args.col_q); NULL: row i */,
                           kge_stream_t stream);
 /* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
 int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);

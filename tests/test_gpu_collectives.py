@@ -44,6 +44,36 @@ def test_forced_collectives_reproduce_single_gpu_metrics():
             assert got['other_exchange']['exchange'] == 'scores' and got['other_exchange']['ranks_identical_to_headline_run']
 
 
+def test_c_abi_collectives_world_of_one():
+    """include/kge_hip_coll.h through ctypes on a communicator of ONE rank (what a one-GPU box can run): the score
+    all-gather + re-layout reproduces the local tile (also with a padded last shard), the count / float all-reduces
+    are the identity; the gathered scores rank exactly like the local ones (kge_filtered_rank_from_scores)."""
+    import torch
+    from torchkge_amd import _hip, _hip_coll
+    _hip.load_library()
+    comm = _hip_coll.Comm(1, 0, _hip_coll.unique_id())
+    try:
+        g = torch.Generator(device='cuda').manual_seed(3)
+        B, N = 37, 1001
+        local = torch.randn(B, N, device='cuda', generator=g)
+        full = comm.allgather_scores(local, N)
+        assert torch.equal(full, local)
+        padded = torch.zeros(B, N + 7, device='cuda')
+        padded[:, :N] = local
+        assert torch.equal(comm.allgather_scores(padded, N), local)      # n_per > N: the caller's zero padding is dropped
+        counts = torch.randint(0, 1000, (3, B), device='cuda', dtype=torch.int32)
+        ref = counts.clone()
+        assert torch.equal(comm.allreduce_counts(counts), ref)
+        x = torch.randn(B, device='cuda', generator=g)
+        xr = x.clone()
+        assert torch.equal(comm.allreduce_sum(x), xr)
+        true = torch.randint(0, N, (B,), device='cuda', generator=g)
+        assert torch.equal(_hip.get_rank(full, true), _hip.get_rank(local, true))
+        torch.cuda.synchronize()
+    finally:
+        comm.close()
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
@@ -68,6 +98,13 @@ _, kg_test = kg.split_kg(sizes=(19000, 1000))
 ref = tk.LinkPredictionEvaluator(m, kg_test, graph=False)
 ref.evaluate(b_size=256, verbose=False)                            # the unsharded single-GPU ranks
 want = [ref.rank_true_heads, ref.rank_true_tails, ref.filt_rank_true_heads, ref.filt_rank_true_tails]
+want_inf = {}
+if kind in ('transe', 'transh', 'complex'):
+    dh_, dt_, _ = orc.build_filter_dicts(h, t, r)
+    for missing, dic in (('tails', dt_), ('heads', None)):
+        a = tk.EntityInference(m, h[-300:], r[-300:], top_k=7, missing=missing, dictionary=dic)
+        a.evaluate(b_size=128, verbose=False)
+        want_inf[missing] = (a.predictions, a.scores)
 full = m.entity_table_bytes()
 lo, hi = kd.shard_model_(m)
 assert m.entity_table_bytes() <= full // world + 4 * 2 * d * 2 * world
@@ -87,6 +124,16 @@ for exchange, graph, qx, co in (('counts', False, 'evaluate', None), ('counts', 
         if not torch.equal(a, b):
             ok = False
             print('MISMATCH', rank, kind, exchange, graph, qx, int((a != b).sum()), flush=True)
+# top-k inference on the row-sharded model (per-shard tiles -> partial lists -> all-gather -> merge) == unsharded
+if kind in ('transe', 'transh', 'complex'):
+    dh_, dt_, _ = orc.build_filter_dicts(h, t, r)
+    qe, qr = h[-300:], r[-300:]
+    for missing, dic in (('tails', dt_), ('heads', None)):
+        a = tk.EntityInference(m, qe, qr, top_k=7, missing=missing, dictionary=dic, tile=512)
+        a.evaluate(b_size=128, verbose=False)
+        if not (torch.equal(a.predictions, want_inf[missing][0]) and torch.equal(a.scores, want_inf[missing][1])):
+            ok = False
+            print('INFERENCE MISMATCH', rank, kind, missing, flush=True)
 dist.barrier()
 dist.destroy_process_group()
 open(out_path, 'w').write('ok' if ok else 'bad')

@@ -655,6 +655,43 @@ def test_entity_and_relation_inference(hip, kind, p):
     assert np.array_equal(f.cpu().numpy(), orc.filter_scores(s_ref, dt, h, r, None).numpy())
 
 
+@pytest.mark.parametrize('kind,p', CASES)
+def test_tiled_topk_inference_equals_materialised_topk(hip, kind, p):
+    """EntityInference processes the candidates tile by tile (kge_topk_chunk: O(b * C) scratch): for every
+    tile size -- also tiles smaller than k, ragged last tiles, one tile -- predictions and scores equal the top-k of the
+    materialised (b, N) score matrix (kge_lp_scores + kge_filter_scores + kge_topk: score descending, id ascending),
+    with and without the known-fact filter; exact ties (duplicated entity rows) come out id-ascending."""
+    import torchkge_amd as tk
+    n_ent, n_rel, d = 1203, 7, 32
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=4)
+    for tb in tables:
+        if tb.shape[0] == n_ent:
+            tb[700:710] = tb[100:110]              # exact ties between entity ids 100.. and 700..
+    m = build_model(kind, p, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 6000, 21, hubs=((300, 'tail'), (200, 'head')))
+    dh, dt, _ = orc.build_filter_dicts(h, t, r)
+    q_e, q_r = h[-150:].clone(), r[-150:].clone()
+    q_e[:10] = torch.arange(100, 110)
+    K = 12
+    for missing, dic in (('tails', dt), ('heads', dh), ('tails', None)):
+        ref = tk.EntityInference(m, q_e, q_r, top_k=K, missing=missing, dictionary=dic)
+        ref._evaluate_materialised(64, verbose=False)
+        for tile in (None, 256, 512, 1203, 4096):
+            inf = tk.EntityInference(m, q_e, q_r, top_k=K, missing=missing, dictionary=dic, tile=tile)
+            inf.evaluate(b_size=64, verbose=False)
+            assert torch.equal(inf.predictions, ref.predictions), (kind, missing, tile)
+            assert torch.equal(inf.scores, ref.scores)
+    # k larger than a tile and than the candidate set: padding (-inf, -1) never displaces a real candidate
+    small = build_model(kind, p, orc.init_tables(kind, 300, n_rel, d, seed=5), 300, n_rel)
+    qs = torch.arange(0, 40)
+    a = tk.EntityInference(small, qs, q_r[:40], top_k=300, tile=256)
+    a.evaluate(16, verbose=False)
+    b = tk.EntityInference(small, qs, q_r[:40], top_k=300)
+    b._evaluate_materialised(16, verbose=False)
+    assert torch.equal(a.predictions, b.predictions) and torch.equal(a.scores, b.scores)
+    assert (a.predictions.sort(dim=1).values == torch.arange(300)).all()
+
+
 def test_wikidata5m_scale_properties(hip):
     """BASELINE config 5 shape (ComplEx d=512, 4,594,485 entities, 18.8 GB of
     tables on one 288 GB GPU): the fused count over the full entity range equals
@@ -1173,6 +1210,88 @@ def test_query_pipeline_equals_separate_kernels(hip, B, N, d, side):
     assert st2 is pre['s_true']
     assert torch.equal(prob.count_ge(st2), exact)
     assert float(guard[2]) == 0.0
+
+
+@pytest.mark.parametrize('eps', [1.0, 1.0 / 16])
+def test_split_count_on_query_columns_equals_per_query_counts(hip, eps):
+    """Queries that share their key share the query row (filter_index.ColumnPlan): the count kernel sweeps one COLUMN per
+    distinct row -- single-query columns, then grouped columns with up to kge_lp_split_group_sets() threshold sets --
+    and must leave in raw_count exactly what the per-query sweep and the all-fp32 kernel leave there; also with the
+    error band shrunk (more listed pairs per grouped column), hub keys with hundreds of queries, keys on both sides."""
+    import torchkge_amd as tk
+    from torchkge_amd.filter_index import ColumnPlan
+    n_ent, n_rel, d = 2500, 6, 64
+    tables = orc.init_tables('transe', n_ent, n_rel, d, seed=8)
+    m = build_model('transe', 2, tables, n_ent, n_rel)
+    g = torch.Generator().manual_seed(12)
+    B = 1900
+    h = torch.randint(0, n_ent, (B,), generator=g)
+    t = torch.randint(0, n_ent, (B,), generator=g)
+    r = torch.randint(0, n_rel, (B,), generator=g)
+    h[:700] = torch.randint(0, 9, (700,), generator=g)          # tail-side keys (h, r): 54 keys share 700 queries
+    t[300:1200] = 17                                             # head-side hub: (17, r) for 900 queries
+    r[300:700] = 2
+    H, T, R = h.cuda(), t.cuda(), r.cuda()
+    cols = ColumnPlan(H, T, R, n_ent, n_rel, hip.split_group_sets(), hip.split_query_rows_padded)
+    # every query sits in exactly one column slot; only the first query of a column writes the row
+    placed = torch.cat([cols.col_q[cols.col_q >= 0], cols.members[cols.members >= 0]]).long()
+    assert torch.equal(placed.sort().values, torch.arange(2 * B, device='cuda'))
+    assert cols.n_multi > 0 and cols.n_single > 0 and cols.n_columns < 2 * B
+    assert int((cols.qs_row >= 0).sum()) == cols.n_columns
+    assert cols.n_single_p % 192 == 0 and cols.n_multi_p % 192 == 0
+    old = hip.SPLIT_EPS_SCALE
+    hip.SPLIT_EPS_SCALE = eps
+    try:
+        guard = m.lp_guard_begin(torch.device('cuda', 0))
+        true = torch.cat([T, H])
+        with m.lp_session():
+            raws = []
+            for c in (cols, None):
+                prob = m.lp_problem(H, T, R, 'both', cols=c)
+                assert prob.pre is not None and prob.split is not None
+                prob.pre['true_idx'] = true
+                s_true = prob.pair_scores(true)
+                raws.append(prob.count_ge(s_true))
+                n_listed = int(prob.last_split[0].item())
+            m.split_filter = False
+            pe = m.lp_problem(H, T, R, 'both')
+            raws.append(pe.count_ge(pe.pair_scores(true)))
+            m.split_filter = True
+        assert float(guard[2]) == 0.0           # no overflow
+        m.lp_guard_end()
+    finally:
+        hip.SPLIT_EPS_SCALE = old
+    assert torch.equal(raws[0], raws[1]) and torch.equal(raws[0], raws[2])
+    assert int(raws[0].min()) >= 1
+
+
+@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex'])
+def test_evaluator_dedupes_query_rows_and_keeps_the_ranks(hip, monkeypatch, kind):
+    """evaluate() on a graph with hub keys (TransE-L2: fused query pipeline writing one split row per column; DistMult /
+    ComplEx: rows gathered per column): identical rank vectors with the ColumnPlan path on (default) and off
+    (KGE_DEDUPE_QUERIES=0), eager and as hipGraph replays."""
+    import torchkge_amd as tk
+    import torchkge_amd.evaluation as evm
+    n_ent, n_rel, d = 3001, 9, 64
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=6)
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 30000, 3, hubs=((900, 'head'), (400, 'tail')))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(27000, 3000))
+    names = ['rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails']
+    monkeypatch.setattr(evm, 'DEDUPE_QUERIES', False)
+    ref = tk.LinkPredictionEvaluator(m, kg_test, graph=False)
+    ref.evaluate(b_size=1024, verbose=False)
+    assert all(getattr(pl, 'cols', None) is None for pl in ref._plans.values())
+    monkeypatch.setattr(evm, 'DEDUPE_QUERIES', True)
+    for graph in (False, True):
+        ev = tk.LinkPredictionEvaluator(m, kg_test, graph=graph)
+        for _ in range(3):
+            ev.evaluate(b_size=1024, verbose=False)
+            for nm in names:
+                assert torch.equal(getattr(ev, nm), getattr(ref, nm)), (graph, nm)
+        assert any(pl.cols is not None and pl.cols.n_multi > 0 for pl in ev._plans.values())
 
 
 def test_filter_lookup_both_equals_two_lookups(hip):

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     out = subprocess.check_output(['nm', '-D', '--defined-only', _hip.LIB_PATH], text=True)
     assert declared <= set(re.findall(r' T (kge_[a-z0-9_]+)', out))
-    assert lib.kge_abi_version() == 17 and lib.kge_build_arch() == b'gfx950'
+    assert lib.kge_abi_version() == 18 and lib.kge_build_arch() == b'gfx950'
     # the descriptor struct mirrors the header field for field
     fields = re.search(r'typedef struct kge_lp_desc \{(.*?)\} kge_lp_desc;', hdr, re.S).group(1)
     names = re.findall(r'\b(\w+)\s*(?:;|,)', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
@@ -87,6 +87,22 @@ def test_ctypes_signatures_match_the_header_prototypes():
         if decl:
             names += [re.sub(r'[\s\*]', '', x).split(' ')[-1] for x in re.sub(r'^(const\s+)?\w+\s+', '', decl).split(',')]
     assert names == [f[0] for f in _hip.SplitArgs._fields_]
+
+
+def test_collectives_library_loads_and_exports_its_header():
+    """libkge_hip_coll.so (include/kge_hip_coll.h, the RCCL exchange step behind the C-ABI): loads, exports every
+    declared entry point with the bound argument counts; libkge_hip.so itself does not depend on librccl."""
+    from torchkge_amd import _hip_coll
+    lib = _hip_coll.load_library()
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'kge_hip_coll.h')).read(), flags=re.S)
+    protos = dict(re.findall(r'\bint\s+(kge_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', hdr, flags=re.S))
+    assert set(protos) == set(_hip_coll._SIGNATURES)
+    for name, args in _hip_coll._SIGNATURES.items():
+        assert hasattr(lib, name) and len(protos[name].split(',')) == len(args), name
+    out = subprocess.run(['readelf', '-d', _hip.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert 'rccl' not in out
+    out = subprocess.run(['readelf', '-d', _hip_coll.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert 'librccl' in out
 
 
 def test_no_cpu_fallback():

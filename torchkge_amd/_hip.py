@@ -46,6 +46,7 @@ class SplitArgs(ctypes.Structure):
         ('emax0', _vp), ('emax1', _vp), ('xabsmax', _vp), ('yabsmax', _vp), ('accum_model', ctypes.c_int32),
         ('eps_scale', ctypes.c_float), ('thr_ready', ctypes.c_int32), ('q_cell_ss', _vp), ('e2pref', _vp),
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
+        ('col_q', _vp), ('n_single_p', _i64), ('members', _vp), ('n_multi_p', _i64),
     ]
 
 
@@ -85,11 +86,12 @@ _SIGNATURES = {
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
+    'kge_topk_chunk': [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp],
     'kge_lp_sad_rows': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp],
     'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
     'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
-                              _vp, _vp, _vp, _vp, _vp, _vp],
+                              _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -109,7 +111,7 @@ _SIGNATURES = {
 # every symbol include/kge_hip.h declares
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version', 'kge_lp_split_rows_padded',
                                                'kge_build_arch', 'kge_lp_filter_sub_ws_bytes', 'kge_lp_sad_cols_padded',
-                                               'kge_key_sort_ws_bytes'])
+                                               'kge_key_sort_ws_bytes', 'kge_lp_split_group_sets'])
 
 _lib = None
 
@@ -139,11 +141,13 @@ def load_library():
     lib.kge_key_sort_ws_bytes.restype = _i64
     lib.kge_lp_sad_cols_padded.argtypes = [_int]
     lib.kge_lp_sad_cols_padded.restype = _i64
+    lib.kge_lp_split_group_sets.argtypes = []
+    lib.kge_lp_split_group_sets.restype = _int
     lib.kge_abi_version.argtypes = []
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 17:
+    if lib.kge_abi_version() != 18:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -417,10 +421,11 @@ def split_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nm
     return Es, e2
 
 
-def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None):
+def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None):
     """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
     s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
-    the threshold kernel."""
+    the threshold kernel.  ``cols`` (filter_index.ColumnPlan): the split rows are written per COLUMN
+    (one row per distinct query row of the batch) instead of per query."""
     lib = load_library()
     require_cuda(E, R, h, t, r, en, emax, qmax_io)
     E, R = f32c(E), f32c(R)
@@ -429,16 +434,19 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None):
     Bq = 2 * B if side == SIDE_BOTH else B          # SIDE_BOTH: tail-side queries, then head-side queries
     Bp = int(lib.kge_lp_split_rows_padded(Bq, 1))
     units_p = int(lib.kge_lp_split_units(d, 1))
+    qrows = Bp if cols is None else cols.n_single_p + cols.n_multi_p
+    assert cols is None or cols.n_queries == Bq
     out = {'Q': torch.empty(Bq, d, dtype=torch.float32, device=dev), 'qn': torch.empty(Bq, dtype=torch.float32, device=dev),
            's_true': torch.empty(Bq, dtype=torch.float32, device=dev),
-           'Qs': torch.empty(max(Bp, 1) * units_p * 64, dtype=torch.uint8, device=dev),
+           'Qs': torch.empty(max(qrows, 1) * units_p * 64, dtype=torch.uint8, device=dev), 'cols': cols,
            'thr': torch.empty(4 * Bp, dtype=torch.float32, device=dev),
            'n_list': torch.empty(1, dtype=torch.int32, device=dev)}
     with _on(dev):
         _check(lib.kge_lp_query_pipeline(side, _p(E), _p(R), d, _p(h), _p(t), _p(r), B, _p(en), _p(emax), _p(qmax_io),
                                          split_accum_model(), SPLIT_EPS_SCALE, _p(out['Q']), _p(out['qn']),
                                          _p(out['s_true']), _p(out['Qs']), _p(out['thr']), _p(out['n_list']),
-                                         _p(e2pref), _stream()), 'kge_lp_query_pipeline')
+                                         _p(e2pref), _p(None if cols is None else cols.qs_row), _stream()),
+               'kge_lp_query_pipeline')
     return out
 
 
@@ -465,6 +473,16 @@ def absmax(x, max_io):
     with _on(x.device):
         _check(lib.kge_absmax(_p(x), x.numel(), _p(max_io), _stream()), 'kge_absmax')
     return max_io
+
+
+def split_query_rows_padded(n):
+    """Rows of a split QUERY operand for n queries / columns (a multiple of the count kernel's query panel)."""
+    return int(load_library().kge_lp_split_rows_padded(n, 1))
+
+
+def split_group_sets():
+    """Threshold sets per grouped column of kge_lp_split_count (kge_split_args.members)."""
+    return int(load_library().kge_lp_split_group_sets())
 
 
 def padded_cols(n):
@@ -556,6 +574,7 @@ class LpProblem(object):
         self.split = None
         self.sad = None         # TransE-L1: {'Ei', 'emax', 'rmax', 'overflow'} -> counts via the u16 SAD prefilter
         self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
+        self.cols = None        # filter_index.ColumnPlan of a both-sides batch: split count over distinct query rows
 
     def scores(self, out=None):
         lib = load_library()
@@ -564,6 +583,29 @@ class LpProblem(object):
         with _on(self.device):
             _check(lib.kge_lp_scores(ctypes.byref(self.desc), _p(out), out.stride(0), _stream()),
                    'kge_lp_scores')
+        return out
+
+    def scores_chunk(self, c0, c1, out):
+        """Scores of LOCAL candidates [c0, c1) only, into out[:, :c1 - c0] -- the same descriptor with its
+        candidate-side pointers advanced (kge_lp_desc is plain pointers + sizes)."""
+        lib = load_library()
+        d = LpDesc.from_buffer_copy(self.desc)
+        n = c1 - c0
+        d.N, d.c_base = n, self.desc.c_base + c0
+        d.T0 = self.desc.T0 + 4 * c0 * self.desc.ldt0
+        if self.desc.T1:
+            d.T1 = self.desc.T1 + 4 * c0 * self.desc.ldt1
+        if self.desc.en:
+            d.en = self.desc.en + 4 * c0
+        if self.desc.yc:
+            d.yc = self.desc.yc + 4 * c0
+        if self.desc.scal:
+            # DIRECT modes: per-candidate scalars (N, scal_ld) -> advance rows; projection modes: X (n_rel, scal_ld >= N)
+            # -> advance columns
+            proj = int(self.desc.mode) in (LP_L2_PROJH, LP_L2_PROJD)
+            d.scal = self.desc.scal + 4 * c0 * (1 if proj else self.desc.scal_ld)
+        with _on(self.device):
+            _check(lib.kge_lp_scores(ctypes.byref(d), _p(out), out.stride(0), _stream()), 'kge_lp_scores')
         return out
 
     def pair_scores(self, ci, qi=None):
@@ -601,15 +643,30 @@ class LpProblem(object):
         want_ss = self.split.get('e2pref') is not None     # prefix-norm magnitude bound of the error band
         if self.pre is not None:
             Qs, extra = self.pre['Qs'], {'thr_pre': self.pre['thr'], 'n_list_pre': self.pre['n_list'],
-                                         's_true_pre': self.pre['s_true']}
+                                         's_true_pre': self.pre['s_true'], 'cols': self.pre.get('cols')}
         elif int(self.desc.mode) == LP_DOT:
             qmax = torch.zeros(2, dtype=torch.float32, device=self.device)
             qn0 = row_sqnorm(A0, K=K, max_io=qmax[0:1])
             qn1 = row_sqnorm(A1, max_io=qmax[1:2]) if A1 is not None else None
             qn = qn0 if qn1 is None else qn0 + qn1
-            Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
-                            nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
-            extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
+            cols = self.cols
+            if cols is not None:
+                # COLUMNS: one split row per distinct query row of the batch (ColumnPlan) -- gathered from the query that
+                # provides it; the per-query cell sums of the error band are read back through the query -> column map
+                rep = cols.rep
+                Qs = split_rows(A0.index_select(0, rep), K=K, is_query=True, aug=qn.index_select(0, rep),
+                                X1=A1.index_select(0, rep) if A1 is not None else None, dot=True, nmax0=qmax[0:1],
+                                nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
+                if isinstance(Qs, tuple):
+                    Bp_q = int(lib.kge_lp_split_rows_padded(self.B, 1))
+                    ss_q = torch.zeros(Qs[1].shape[0], Bp_q, dtype=torch.float32, device=self.device)
+                    ss_q[:, :self.B] = Qs[1].index_select(1, cols.col_of_q)
+                    Qs = (Qs[0], ss_q)
+                extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax, 'cols': cols}
+            else:
+                Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
+                                nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
+                extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
         else:
             Qs = split_rows(A0, K=K, is_query=True, cell_ss=want_ss)
         if isinstance(Qs, tuple):
@@ -645,6 +702,10 @@ class LpProblem(object):
         prep['thr_used'] = True
         a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']
         a.list_count, a.overflow = _p(prep['n_list']), _p(sp['overflow'])
+        cols = prep.get('cols')
+        if cols is not None:    # the split query rows are per COLUMN (distinct query rows), not per query
+            a.col_q, a.n_single_p = _p(cols.col_q), cols.n_single_p
+            a.members, a.n_multi_p = _p(cols.members), cols.n_multi_p
         with _on(self.device):
             _check(lib.kge_lp_split_count(ctypes.byref(self.desc), ctypes.byref(a), _p(s_true), _p(raw), _stream()),
                    'kge_lp_split_count')
@@ -846,6 +907,20 @@ def topk(scores, k):
     with _on(scores.device):
         _check(lib.kge_topk(_p(scores), scores.stride(0), B, N, k, _p(idx), _p(val), _stream()), 'kge_topk')
     return val, idx
+
+
+def topk_chunk(scores, c_base, k, out_val, out_idx, col_off, seg_lo=None, seg_hi=None, targets=None, ids_in=None):
+    """kge_topk_chunk: the k best of every row of the (B, C) tile `scores` (candidates c_base ..; masked in place by the
+    rows' filter segments when `targets` is given) into columns [col_off, col_off + k) of out_val / out_idx (B, ldo);
+    ``ids_in`` (B, C) int64: merge mode, the columns' candidate ids."""
+    lib = load_library()
+    require_cuda(scores, out_val, out_idx)
+    assert scores.dtype == torch.float32 and scores.stride(1) == 1 and out_val.stride(0) == out_idx.stride(0)
+    B, C = scores.shape
+    with _on(scores.device):
+        _check(lib.kge_topk_chunk(_p(scores), scores.stride(0), B, C, c_base, k, _p(seg_lo), _p(seg_hi), _p(targets),
+                                  _p(ids_in), 0 if ids_in is None else ids_in.stride(0), _p(out_idx), _p(out_val),
+                                  out_val.stride(0), col_off, _stream()), 'kge_topk_chunk')
 
 
 def corrupt_scatter(heads, tails, mask_u8, draws_h, draws_t, n_neg):

@@ -18,6 +18,9 @@ SOURCES = ['score_triples.hip', 'lp_prep.hip', 'lp_gemm_mfma.hip', 'lp_split_mfm
            'lp_l1_sad.hip', 'rank_filter.hip', 'corrupt.hip', 'key_sort.hip']
 HEADERS = ['kge_common.h', os.path.join('..', '..', 'include', 'kge_hip.h')]
 LIB = os.path.join(HERE, 'libkge_hip.so')
+# the RCCL exchange step of the sharded path (include/kge_hip_coll.h): its own shared object, so that
+# libkge_hip.so does not depend on librccl
+COLL_SRC, COLL_LIB = 'collectives.hip', os.path.join(HERE, 'libkge_hip_coll.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-Wall', '-Wno-unused-function']
 # per-file extras.  lp_direct.hip: the SLP vectoriser turns the L1 inner loop (sub, then add |.|) into v_pk_add_f32
@@ -73,6 +76,10 @@ def build(force=False, verbose=False):
                     print(o)
     if force or jobs or _stale(LIB, objs):
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    cs = os.path.join(HERE, COLL_SRC)
+    if force or _stale(COLL_LIB, [cs, os.path.join(HERE, '..', '..', 'include', 'kge_hip_coll.h')] + hdrs):
+        # (-lrccl resolves to whichever librccl.so.1 the process has loaded first -- torch's own when the host is Python)
+        run([hipcc] + FLAGS + ['-shared', '-o', COLL_LIB, cs, '-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib'])
     return LIB
 
 

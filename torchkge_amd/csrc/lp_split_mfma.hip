@@ -70,7 +70,9 @@ constexpr int E_STAGE_BYTES = TC * 128;         // candidate operand, one stage 
 constexpr int Q_STAGE_BYTES = TQ * 128;
 constexpr int STAGE_BYTES = E_STAGE_BYTES + Q_STAGE_BYTES;
 constexpr int UNC_CAP = 2048;                   // uncertain pairs buffered per tile
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES + 16 + UNC_CAP * 4 + TQ * 20;   // + per-panel (thr4, X row) of the projection modes
+constexpr int GSETS = 4;                        // grouped columns: queries that share one query row (threshold sets per column)
+// + per-panel (thr4, X row) of the projection modes, or the (a_lo, a_hi) sets + counters of a grouped panel
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES + 16 + UNC_CAP * 4 + TQ * GSETS * 12 + 16;
 constexpr int SPLIT_SCALE_LOG2 = 12;
 
 struct SplitParams {
@@ -90,6 +92,10 @@ struct SplitParams {
     int32_t cap;
     int32_t *list_count;  // device scalar
     float *overflow;      // set to 1 when a buffer or the list overflowed
+    // Columns instead of queries (queries that share a key share the query ROW: its accumulators are computed once).
+    // col_q: column -> query id (< 0: padding column) for a launch whose columns carry ONE query each (NULL: column
+    // == query); members: [column][GSETS] query ids (< 0: unused set) for the grouped launch (template GS > 0).
+    const int32_t *col_q, *members;
     int q_panels, c_tiles;
     int64_t n_items;
     int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 4 no epilogue,
@@ -453,6 +459,8 @@ struct QueryPipeParams {
     _Float16 *Qs;
     int32_t *list_count;
     const float *e2pref;            // optional: prefix squared-norm maxima of the entity table (tighter error band)
+    const int32_t *qs_row;          // optional: row of Qs that receives query i's split cells (< 0: none -- a query whose
+                                    // row another query of the same key already provides); NULL: row i
 };
 
 template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
@@ -584,9 +592,12 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                     lo.h[e] = (_Float16)(xv - (float)hh);
                 }
                 const int kk = k0 + gq * 8, u = kk >> 4, hf = (kk >> 3) & 1;
-                uint4 *cell = reinterpret_cast<uint4 *>(p.Qs) + (row * p.units_p + u) * 4;
-                cell[hf] = hi.v;
-                cell[2 + hf] = lo.v;
+                const int64_t dst = p.qs_row ? (row < p.B ? (int64_t)p.qs_row[row] : -1) : row;
+                if (dst >= 0) {
+                    uint4 *cell = reinterpret_cast<uint4 *>(p.Qs) + (dst * p.units_p + u) * 4;
+                    cell[hf] = hi.v;
+                    cell[2 + hf] = lo.v;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
@@ -619,9 +630,13 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
 }
 
 // ---- the count kernel --------------------------------------------------------
-template <int NWAVES, bool DBG, int PM>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
+// GS > 0: GROUPED columns -- every column (one split query row) carries up to GS queries that share the row but
+// have their own true entity, hence their own thresholds: the MFMA sweep runs once per column, the epilogue once
+// per (column, set); thresholds and counters of the panel's sets live in LDS.
+template <int NWAVES, bool DBG, int PM, int GS = 0>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
+    static_assert(GS == 0 || (PM == 0 && GS == GSETS), "grouped columns: plain thresholds only");
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int MT = TC / 32 / (NWAVES / 2);                      // 32x32 candidate tiles per wave
@@ -632,6 +647,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + 16);
     float4 *pthr = reinterpret_cast<float4 *>(smem + 2 * STAGE_BYTES + 16 + UNC_CAP * 4);   // PM: per query of the panel
     int *prow = reinterpret_cast<int *>(pthr + TQ);
+    float2 *gthr = reinterpret_cast<float2 *>(pthr);                       // GS: [set][TQ] thresholds ...
+    int *gcnt = reinterpret_cast<int *>(gthr + (GS ? GS : 1) * TQ);         // ... [set][TQ] counters ...
+    int *gsets = gcnt + (GS ? GS : 1) * TQ;                                 // ... and the number of sets in use
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the LDS-DMA targets become SALU arithmetic)
     const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;   // waves: (NWAVES/2) x 2
 
@@ -660,7 +678,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         qp = grp * QG + (r - ct * gsz);
     };
     const int S = p.stages, G = nitems * S;
-    if (tid == 0) *unc_cnt = 0;
+    if (tid == 0) { *unc_cnt = 0; if (GS) *gsets = 0; }
+    if (GS) __syncthreads();
 
     // staging: 8 lanes cover one 128-byte row segment of a stage
     const int srow = tid >> 3, scs = tid & 7;
@@ -702,6 +721,18 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     int cnt[NT] = {0, 0, 0};
     float alo[NT] = {0.f, 0.f, 0.f}, ahi[NT] = {0.f, 0.f, 0.f};
     auto load_panel = [&](int64_t q0) __attribute__((always_inline)) {
+        if (GS) {   // thresholds of every (column, set) of the panel + zeroed counters; sets in use (block-wide max)
+            int used = 0;
+            for (int idx = tid; idx < TQ * GS; idx += NTHREADS) {
+                const int c = idx / GS, gs = idx - c * GS;
+                const int q = p.members[(q0 + c) * GS + gs];
+                gthr[gs * TQ + c] = q >= 0 ? p.thr[q] : make_float2(INFINITY, INFINITY);
+                gcnt[gs * TQ + c] = 0;
+                if (q >= 0) used = max(used, gs + 1);
+            }
+            if (used > 0) atomicMax(gsets, used);
+            return;
+        }
         if (PM) {   // thresholds + projection scalars + X row of the panel's queries live in LDS
             if (tid < TQ) {
                 pthr[tid] = p.thr4[q0 + tid];
@@ -711,17 +742,32 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const float2 t = p.thr[q0 + wc * 96 + nt * 32 + l31];
+            const int64_t col = q0 + wc * 96 + nt * 32 + l31;
+            const int64_t q = p.col_q ? (int64_t)p.col_q[col] : col;
+            const float2 t = q >= 0 ? p.thr[q] : make_float2(INFINITY, INFINITY);
             alo[nt] = t.x;
             ahi[nt] = t.y;
         }
     };
     auto flush_counts = [&](int64_t q0) __attribute__((always_inline)) {
+        if (GS) {   // (same idx -> thread mapping as load_panel: a thread flushes and re-zeroes its own entries)
+            for (int idx = tid; idx < TQ * GS; idx += NTHREADS) {
+                const int c = idx / GS, gs = idx - c * GS;
+                const int q = p.members[(q0 + c) * GS + gs];
+                const int v = gcnt[gs * TQ + c];
+                if (q >= 0 && v != 0) atomicAdd(&p.raw_count[q], v);
+            }
+            __syncthreads();
+            if (tid == 0) *gsets = 0;
+            __syncthreads();
+            return;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int v = cnt[nt] + __shfl_xor(cnt[nt], 32, 64);
-            const int64_t q = q0 + wc * 96 + nt * 32 + l31;
-            if (half == 0 && v != 0 && q < p.B) atomicAdd(&p.raw_count[q], v);
+            const int64_t col = q0 + wc * 96 + nt * 32 + l31;
+            const int64_t q = p.col_q ? (int64_t)p.col_q[col] : col;
+            if (half == 0 && v != 0 && q >= 0 && q < p.B) atomicAdd(&p.raw_count[q], v);
             cnt[nt] = 0;
         }
     };
@@ -843,7 +889,10 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         if (!(dbg & 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
         if (dbg & 512) __builtin_amdgcn_s_barrier();   // probe: barrier without waiting for the DMA pieces
         else if (!(dbg & 32)) __syncthreads();
-        if (more && !(dbg & 16)) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
+        // (grouped columns: on a tile's last stage the next stage's first fragments are fetched AFTER the multi-pass
+        // epilogue -- their 40 registers are what its temporaries need; the LDS buffer stays valid through the next stage)
+        const bool defer_frag = GS != 0 && s == S - 1;
+        if (more && !(dbg & 16) && !defer_frag) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
         __builtin_amdgcn_sched_barrier(0);
         if (two) { KGE_SMMA_PA(ah1, bl1) }
         __builtin_amdgcn_sched_barrier(0);
@@ -859,8 +908,54 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             // hoisted out of the tile loop and held in registers across the MFMA stream
             int cl_base = wr * (MT * 32) + 4 * half, ql_base = wc * 96 + l31;
             asm volatile("" : "+v"(cl_base), "+v"(ql_base));
+            if (GS) {
+                // Grouped columns: the accumulators of a column are compared with the thresholds of each of its
+                // queries in turn (block-uniform number of sets; the accumulators stay intact, w lives in temporaries).
+                const int nsets = *gsets;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int ql = ql_base + nt * 32;
+                    for (int gs = 0; gs < nsets; ++gs) {
+                        const float2 th = gthr[gs * TQ + ql];
+                        const f32x2 nlo2 = {-th.x, -th.x};
+                        const float hwf = th.y - th.x;
+                        const unsigned hwb = hwf >= 0.f ? __float_as_uint(hwf) : 0u;
+                        unsigned smask = 0u;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const f32x2 w01 = (f32x2){acc[mt][nt][g4 * 4 + 0], acc[mt][nt][g4 * 4 + 1]} + nlo2;
+                                const f32x2 w23 = (f32x2){acc[mt][nt][g4 * 4 + 2], acc[mt][nt][g4 * 4 + 3]} + nlo2;
+                                const unsigned b0 = __float_as_uint(w01.x), b1 = __float_as_uint(w01.y);
+                                const unsigned b2 = __float_as_uint(w23.x), b3 = __float_as_uint(w23.y);
+                                smask = __builtin_amdgcn_alignbit(smask, b0, 31);
+                                smask = __builtin_amdgcn_alignbit(smask, b1, 31);
+                                smask = __builtin_amdgcn_alignbit(smask, b2, 31);
+                                smask = __builtin_amdgcn_alignbit(smask, b3, 31);
+                                const unsigned mq = min(min(min(b0, b1), b2), b3);
+                                if (__ballot(mq <= hwb)) {
+#define KGE_GLIST(BITS, E)                                                                              \
+    if ((BITS) <= hwb) {                                                                                \
+        const int idx = atomicAdd(unc_cnt, 1);                                                          \
+        if (idx < UNC_CAP)                                                                              \
+            unc_list[idx] = ((unsigned)(cl_base + mt * 32 + (E) + 8 * g4) << 10) | ((unsigned)gs << 8) | (unsigned)ql; \
+    }
+                                    KGE_GLIST(b0, 0) KGE_GLIST(b1, 1) KGE_GLIST(b2, 2) KGE_GLIST(b3, 3)
+#undef KGE_GLIST
+                                }
+                                __builtin_amdgcn_sched_barrier(0);   // one quad at a time: its temporaries die here
+                            }
+                        }
+                        // the two lane halves hold the two row halves of the same column
+                        int v = 32 - __popc(smask);
+                        v += __shfl_xor(v, 32, 64);
+                        if (half == 0 && v != 0) atomicAdd(&gcnt[gs * TQ + ql], v);
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < (GS ? 0 : NT); ++nt) {
                 float lo_n = alo[nt], hi_n = ahi[nt], p_n = 0.f, z_n = 0.f;
                 const float *xrow = nullptr;
                 if (PM) {
@@ -959,8 +1054,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                         const unsigned e = unc_list[i];
                         const int pos = base + i;
                         if ((unsigned)pos < (unsigned)p.cap) {
-                            p.list[2 * pos] = (int32_t)(cur_q0 + (e & 255u));
-                            p.list[2 * pos + 1] = (int32_t)(c0 + (e >> 8));
+                            // (grouped: [cl:8][set:2][column:8]; columns with one query: [cl][column:8], via col_q if given)
+                            int32_t qid;
+                            if (GS) qid = p.members[(cur_q0 + (e & 255u)) * GS + ((e >> 8) & 3u)];
+                            else qid = p.col_q ? p.col_q[cur_q0 + (e & 255u)] : (int32_t)(cur_q0 + (e & 255u));
+                            p.list[2 * pos] = qid;
+                            p.list[2 * pos + 1] = (int32_t)(c0 + (e >> (GS ? 10 : 8)));
                         } else {
                             *p.overflow = 1.0f;
                         }
@@ -968,6 +1067,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                     if (lane == 0) *unc_cnt = 0;
                 }
             }
+            if (GS && more && !(dbg & 16)) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
             if (more) { // query panel change (block-uniform): flush counters, load the next thresholds
                 int qp_next, ct_next;
                 item_qp_ct(it + 1, qp_next, ct_next);
@@ -1011,10 +1111,10 @@ __global__ __launch_bounds__(64, 2) void split_recheck_kernel(const kge_lp_desc 
     }
 }
 
-template <int NWAVES, bool DBG, int PM>
+template <int NWAVES, bool DBG, int PM, int GS = 0>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
-    auto k = lp_split_count_kernel<NWAVES, DBG, PM>;
+    auto k = lp_split_count_kernel<NWAVES, DBG, PM, GS>;
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -1157,16 +1257,43 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     p.cap = cap;
     p.list_count = list_count;
     p.overflow = overflow;
-    p.q_panels = (int)((d->B + TQ - 1) / TQ);
+    p.col_q = nullptr; p.members = nullptr;
     p.c_tiles = (int)((d->N + TC - 1) / TC);
-    p.n_items = (int64_t)p.q_panels * p.c_tiles;
     p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
     const int slots = split_num_cus();
+    if (a->col_q || a->members) {
+        // Columns instead of queries: Qs holds n_single_p rows that carry one query each (col_q), then n_multi_p rows
+        // that carry up to GSETS queries of one key each (members); both counts multiples of the query panel.
+        if (proj || a->n_single_p < 0 || a->n_multi_p < 0 || a->n_single_p % TQ || a->n_multi_p % TQ ||
+            (a->n_single_p > 0 && !a->col_q) || (a->n_multi_p > 0 && !a->members))
+            return KGE_EINVAL;
+        if (a->n_single_p > 0) {
+            p.col_q = a->col_q;
+            p.q_panels = (int)(a->n_single_p / TQ);
+            p.n_items = (int64_t)p.q_panels * p.c_tiles;
+            rc = launch_split<8, false, 0>(p, (int)(p.n_items < slots ? p.n_items : slots), s);
+            if (rc) return rc;
+        }
+        if (a->n_multi_p > 0) {
+            p.col_q = nullptr;
+            p.members = a->members;
+            p.Qs = reinterpret_cast<const char *>(Qs) + a->n_single_p * (int64_t)p.row_bytes;
+            p.q_panels = (int)(a->n_multi_p / TQ);
+            p.n_items = (int64_t)p.q_panels * p.c_tiles;
+            rc = launch_split<8, false, 0, GSETS>(p, (int)(p.n_items < slots ? p.n_items : slots), s);
+        }
+        return rc;
+    }
+    p.q_panels = (int)((d->B + TQ - 1) / TQ);
+    p.n_items = (int64_t)p.q_panels * p.c_tiles;
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
     if (d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2>(p, grid, s);
     return p.dbg ? launch_split<8, true, 0>(p, grid, s) : launch_split<8, false, 0>(p, grid, s);
 }
+
+/* threshold sets per grouped column (kge_split_args.members) */
+extern "C" int kge_lp_split_group_sets(void) { return GSETS; }
 
 extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
                                     const int32_t *list_count, int32_t *raw_count, kge_stream_t stream)
@@ -1256,7 +1383,7 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
                                      const int64_t *t, const int64_t *r, int64_t B, const float *en,
                                      const float *emax, float *qmax_io, int accum_model, float eps_scale, float *Q,
                                      float *qn, float *s_true, void *Qs, float *thr, int32_t *list_count,
-                                     const float *e2pref, kge_stream_t stream)
+                                     const float *e2pref, const int32_t *qs_row, kge_stream_t stream)
 {
     const bool both = side == KGE_SIDE_BOTH;
     if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD && !both) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
@@ -1275,6 +1402,7 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     p.Qs = reinterpret_cast<_Float16 *>(Qs);
     p.list_count = list_count;
     p.e2pref = e2pref;
+    p.qs_row = qs_row;
     if (d % 4 != 0 || !kge_aligned16(E) || !kge_aligned16(R)) return KGE_EINVAL;   // float4 staging
     const int qpw = kge_env_int("KGE_QPIPE_QPW", 16);
     const int64_t groups = (p.Bp + qpw - 1) / qpw, blocks = (groups + 3) / 4;

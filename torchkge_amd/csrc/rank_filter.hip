@@ -576,6 +576,67 @@ __global__ __launch_bounds__(RB) void topk_kernel(const float *__restrict__ scor
     }
 }
 
+// Top-k of a row CHUNK: the columns are candidates [c_base, c_base + C) of a larger candidate set (one tile of the
+// entity table, or one entity shard), processed tile by tile so that only (B, C) scores ever exist.  Optionally the
+// known targets of the row's filter segment that fall into the chunk are masked first (filter_scores with
+// true_idx = None, utils/modeling.py:83-84 as used by inference.py:146, :241) -- in place, the tile is scratch.
+// Output slot `col_off` of a (B, ldo) buffer: the tile's k best as (score, GLOBAL id), order (score descending, id
+// ascending).  The same kernel MERGES partial lists: `ids_in` then names the candidates of the columns (entries
+// with id < 0 are padding and never selected); partial lists laid out chunk after chunk keep the id-ascending tie
+// order because every chunk's list is itself in that order and chunks are ascending id ranges.
+__global__ __launch_bounds__(RB) void topk_chunk_kernel(float *__restrict__ scores, int64_t ld, int64_t B, int64_t C,
+                                                        int64_t c_base, int k, const int64_t *__restrict__ seg_lo,
+                                                        const int64_t *__restrict__ seg_hi,
+                                                        const int32_t *__restrict__ targets,
+                                                        const int64_t *__restrict__ ids_in, int64_t ld_ids,
+                                                        int64_t *out_idx, float *out_val, int64_t ldo, int64_t col_off)
+{
+    __shared__ float sv[RB / 64];
+    __shared__ int64_t si[RB / 64];
+    for (int64_t i = blockIdx.x; i < B; i += gridDim.x) {
+        float *row = scores + i * ld;
+        if (targets) {
+            for (int64_t j = seg_lo[i] + threadIdx.x; j < seg_hi[i]; j += blockDim.x) {
+                const int64_t t = (int64_t)targets[j] - c_base;
+                if (t >= 0 && t < C) row[t] = -INFINITY;
+            }
+            __syncthreads();
+        }
+        const int64_t *ids = ids_in ? ids_in + i * ld_ids : nullptr;
+        float last_v = INFINITY;
+        int64_t last_i = -1;
+        for (int j = 0; j < k; ++j) {
+            float bv = -INFINITY;
+            int64_t bi = -1;
+            for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
+                const float v = row[c];
+                const bool after = (v < last_v) || (v == last_v && c > last_i);   // not picked yet
+                const bool better = (v > bv) || (v == bv && (bi < 0 || c < bi));
+                const bool real = ids ? ids[c] >= 0 : true;
+                if (after && better && v == v && real) { bv = v; bi = c; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int64_t oi = __shfl_xor(bi, o, 64);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+            __syncthreads();
+            bv = sv[0]; bi = si[0];
+            for (int w = 1; w < RB / 64; ++w)
+                if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] < bi))) { bv = sv[w]; bi = si[w]; }
+            if (threadIdx.x == 0) {
+                out_idx[i * ldo + col_off + j] = bi < 0 ? -1 : (ids ? ids[bi] : bi + c_base);
+                out_val[i * ldo + col_off + j] = bi >= 0 ? bv : -INFINITY;
+            }
+            if (bi < 0) { last_v = -INFINITY; last_i = C; } else { last_v = bv; last_i = bi; }
+        }
+        __syncthreads();
+    }
+}
+
 inline int grid1d(int64_t n, int per_block)
 {
     int64_t b = (n + per_block - 1) / per_block;
@@ -855,6 +916,22 @@ extern "C" int kge_lp_scores_batched(int mode, const float *q, int64_t ldq, cons
     return 0;
 }
 
+extern "C" int kge_topk_chunk(float *scores, int64_t ld, int64_t B, int64_t C, int64_t c_base, int k,
+                              const int64_t *seg_lo, const int64_t *seg_hi, const int32_t *targets,
+                              const int64_t *ids_in, int64_t ld_ids, int64_t *out_idx, float *out_val, int64_t ldo,
+                              int64_t col_off, kge_stream_t stream)
+{
+    if (B < 0 || C <= 0 || ld < C || k <= 0 || col_off < 0 || ldo < col_off + k) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!scores || !out_idx || !out_val) return KGE_EINVAL;
+    if (targets && (!seg_lo || !seg_hi)) return KGE_EINVAL;
+    if (ids_in && ld_ids < C) return KGE_EINVAL;
+    hipLaunchKernelGGL(topk_chunk_kernel, dim3(grid1d(B, 1)), dim3(RB), 0, kge_s(stream), scores, ld, B, C, c_base, k,
+                       seg_lo, seg_hi, targets, ids_in, ld_ids, out_idx, out_val, ldo, col_off);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, int k, int64_t *out_idx,
                         float *out_val, kge_stream_t stream)
 {
@@ -866,5 +943,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 17; }
+extern "C" int kge_abi_version(void) { return 18; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

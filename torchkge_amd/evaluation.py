@@ -34,7 +34,7 @@ from tqdm.autonotebook import tqdm
 from . import _hip
 from . import distributed as kdist
 from .exceptions import NotYetEvaluatedError
-from .filter_index import filter_index_for, KEY2_SPAN, FilterPlan
+from .filter_index import ColumnPlan, filter_index_for, KEY2_SPAN, FilterPlan
 from .utils.data import get_n_batches
 from .utils.modeling import filter_scores
 from .utils.operations import get_rank
@@ -43,6 +43,7 @@ from .utils.operations import get_rank
 # LinkPredictionEvaluator._internal_batch: facts per batch of the fused path / bound on a batch's uncertain-pair list
 COALESCE_BATCH = 32768
 COALESCE_LIST_BYTES = 2 << 30
+DEDUPE_QUERIES = os.environ.get('KGE_DEDUPE_QUERIES', '1') != '0'    # count kernel on distinct query rows (ColumnPlan)
 
 
 class HipRankEngine(object):
@@ -75,7 +76,7 @@ class HipRankEngine(object):
         return seg_lo, seg_hi, true_idx, self._targets_cat[1]
 
     @staticmethod
-    def problem(model, h, t, r, side, lo, hi, exchange=None, qctx=None):
+    def problem(model, h, t, r, side, lo, hi, exchange=None, qctx=None, cols=None):
         """ROW-SHARDED model: `qctx` = (replicas of the query entities' rows, h and t as indices into them),
         exchanged once per evaluate(); or `exchange`: completes the query rows of this batch (sum over the shards)."""
         if getattr(model, '_row_shard', None) is not None:
@@ -83,6 +84,8 @@ class HipRankEngine(object):
                 return model.lp_problem(qctx[1], qctx[2], r, side, ent_lo=lo, ent_hi=hi, qtabs=qctx[0])
             if exchange is not None:
                 return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, exchange=exchange)
+        if cols is not None:
+            return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, cols=cols)
         return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi)
 
     @staticmethod
@@ -93,10 +96,15 @@ class HipRankEngine(object):
 
     uses_plans = True       # per-batch FilterPlan (segments + grouping), built once per evaluator
 
-    def plan_both(self, index_t, index_h, h, t, r):
-        """FilterPlan of one both-sides batch: the filter lookup and the grouping of its 2B queries."""
+    def plan_both(self, index_t, index_h, h, t, r, model=None):
+        """FilterPlan of one both-sides batch: the filter lookup and the grouping of its 2B queries; for models whose
+        count kernel takes COLUMNS (distinct query rows, Model.lp_dedupe_queries) also the batch's ColumnPlan."""
         seg_lo, seg_hi, true_idx, targets = self.lookup_both(index_t, index_h, h, t, r)
-        return FilterPlan(seg_lo, seg_hi, true_idx, targets)
+        plan = FilterPlan(seg_lo, seg_hi, true_idx, targets)
+        plan.cols = None
+        if model is not None and getattr(model, 'lp_dedupe_queries', False) and h.shape[0] > 0 and DEDUPE_QUERIES:
+            plan.cols = ColumnPlan(h, t, r, model.n_ent, model.n_rel, _hip.split_group_sets(), _hip.split_query_rows_padded)
+        return plan
 
     flag_columns = True     # partial_counts(pad=k) appends k spare int32 columns (the guard flags ride the counts exchange)
 
@@ -320,7 +328,8 @@ class LinkPredictionEvaluator(object):
         plans = {}
         for i in range(get_n_batches(f_hi - f_lo, b_size)):
             sl = slice(i * b_size, (i + 1) * b_size)
-            plans[(i * b_size, heads[sl].shape[0])] = self.engine.plan_both(index_t, index_h, heads[sl], tails[sl], rels[sl])
+            plans[(i * b_size, heads[sl].shape[0])] = self.engine.plan_both(index_t, index_h, heads[sl], tails[sl], rels[sl],
+                                                                            model=self.model)
         self._plans, self._plan_stamp = plans, stamp
         self._plan_gen += 1
 
@@ -366,7 +375,10 @@ class LinkPredictionEvaluator(object):
             seg_lo, seg_hi, true_idx, targets = plan.seg_lo, plan.seg_hi, plan.true_idx, plan.targets
         else:
             seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
-        prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **self._xkw(sharded))
+        xkw = self._xkw(sharded)
+        if plan is not None and getattr(plan, 'cols', None) is not None and not sharded:
+            xkw['cols'] = plan.cols
+        prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
         s_true = None
         if sharded and self._qb is not None and hasattr(self.model, 'lp_true_scores_replica'):
             # row-sharded tables: the true entities' rows are in the query-entity replicas, so every rank scores

@@ -147,6 +147,69 @@ class FilterPlan(object):
         self.n_long = int(self.long_q.shape[0])
 
 
+class ColumnPlan(object):
+    """The distinct query ROWS of one both-sides link-prediction batch (2B queries, tail side first).  A query row is
+    a function of its key -- (h, r) on the tail side, (t, r) on the head side -- so queries that share a key share the
+    row and differ only in their true entity, i.e. in the thresholds of the rank count (on FB15k-237-like test splits
+    a quarter of the queries repeat an earlier key).  The count kernel then sweeps the matrix cores once per COLUMN:
+
+      * keys with one query            -> one column each, ``col_q[column] = query``;
+      * keys with m > 1 queries        -> ceil(m / sets) columns of up to ``sets`` queries, ``members[column, j]``;
+      * ``qs_row[query]``              -> the column (row of the split query table) the query's cells are written to,
+                                          -1 for all but the first query of a column.
+
+    Single-query columns come first, both parts padded to the kernel's query panel with -1.  A pure function of the
+    facts (not of the model or the index): built once per batch by the evaluator, on the device, no host loop."""
+
+    def __init__(self, h, t, r, n_ent, n_rel, sets, pad):
+        dev = h.device
+        B = h.shape[0]
+        n = 2 * B
+        self.n_queries = n
+        key = torch.cat([h * n_rel + r, (t * n_rel + r) + n_ent * n_rel])        # side bit: the two sides never share rows
+        uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+        order = torch.argsort(inv, stable=True)                       # queries grouped by key, original order inside
+        start = torch.cumsum(cnt, 0) - cnt
+        pos = torch.empty(n, dtype=torch.int64, device=dev)
+        pos[order] = torch.arange(n, device=dev) - start[inv[order]]  # position of a query inside its key group
+        chunks_of = (cnt + sets - 1) // sets                          # columns per key
+        chunk0 = torch.cumsum(chunks_of, 0) - chunks_of
+        chunk = chunk0[inv] + pos // sets                             # column (before the single / multi split)
+        slot = pos % sets
+        n_chunks = int(chunks_of.sum().item())                        # (host syncs at plan build only)
+        size = torch.zeros(n_chunks, dtype=torch.int64, device=dev).scatter_add_(0, chunk, torch.ones_like(chunk))
+        single = size == 1
+        n1 = int(single.sum().item())
+        n2 = n_chunks - n1
+        self.n_single, self.n_multi = n1, n2
+        self.n_single_p = pad(n1) if n1 > 0 else 0
+        self.n_multi_p = pad(n2) if n2 > 0 else 0
+        col1 = torch.cumsum(single.to(torch.int64), 0) - 1
+        # grouped columns in order of DEcreasing size: a panel's compare loop runs as many times as its fullest
+        # column has queries, so panels of equally full columns waste no passes
+        order2 = torch.argsort(torch.where(single, torch.zeros_like(size), size), descending=True, stable=True)
+        col2 = torch.empty(n_chunks, dtype=torch.int64, device=dev)
+        col2[order2] = torch.arange(n_chunks, device=dev)        # (multi-query chunks occupy ranks 0 .. n2-1)
+        is_single_q = single[chunk]
+        self.col_q = torch.full((max(self.n_single_p, 1),), -1, dtype=torch.int32, device=dev)
+        self.members = torch.full((max(self.n_multi_p, 1) * sets,), -1, dtype=torch.int32, device=dev)
+        q = torch.arange(n, device=dev)
+        self.col_q[col1[chunk[is_single_q]]] = q[is_single_q].to(torch.int32)
+        mq = ~is_single_q
+        self.members[col2[chunk[mq]] * sets + slot[mq]] = q[mq].to(torch.int32)
+        row = torch.where(is_single_q, col1[chunk], self.n_single_p + col2[chunk])
+        self.qs_row = torch.where(slot == 0, row, torch.full_like(row, -1)).to(torch.int32).contiguous()
+        # for operands built by gathers (the non-fused query paths): the query that provides a column's row (padding
+        # columns: query 0 -- their thresholds are +inf) and, per query, its column
+        self.col_of_q = row.contiguous()
+        self.rep = torch.zeros(max(self.n_single_p + self.n_multi_p, 1), dtype=torch.int64, device=dev)
+        first = slot == 0
+        self.rep[row[first]] = q[first]
+        self.sets = sets
+        self.n_columns = n_chunks
+        self.n_distinct_keys = int(uniq.shape[0])
+
+
 _CACHE = []          # [(dictionary, len, device, FilterIndex)] -- small LRU
 _CACHE_MAX = 8
 

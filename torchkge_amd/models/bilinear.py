@@ -65,13 +65,15 @@ class DistMultModel(BilinearModel):
             candidates = R.view(1, self.n_rel, self.emb_dim).expand(b_size, self.n_rel, self.emb_dim)
         return h, t, r, candidates
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None, cols=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
         Q0 = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)[0]
         T0 = self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi)
-        return self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, c_base=ent_lo), T0, c_base=ent_lo)
+        prob = self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, c_base=ent_lo), T0, c_base=ent_lo)
+        prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
+        return prob
 
 
 class ComplExModel(BilinearModel):
@@ -154,11 +156,13 @@ class ComplExModel(BilinearModel):
                     Rim.view(1, self.n_rel, self.emb_dim).expand(*shape))
         return h, t, r, cand
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None, cols=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
         Q0, Q1, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_q1=True)
         T0, T1 = self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), self._cand_rows(_hip.f32c(tabs[1]), ent_lo, ent_hi)
-        return self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, A1=Q1, T1=T1, c_base=ent_lo), T0, T1,
+        prob = self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, A1=Q1, T1=T1, c_base=ent_lo), T0, T1,
                                       c_base=ent_lo)
+        prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
+        return prob

@@ -567,6 +567,9 @@ class TranslationModel(Model):
 class BilinearModel(Model):
     """Bilinear models (interfaces.py:275-330)."""
 
+    # lp_problem(side='both', cols=ColumnPlan): the split count sweeps one column per distinct query row of the batch
+    lp_dedupe_queries = True
+
     def __init__(self, emb_dim, n_entities, n_relations):
         super().__init__(n_entities, n_relations)
         self.emb_dim = emb_dim

@@ -54,6 +54,9 @@ class TransEModel(TranslationModel):
         self._sad_bounds = self._abs_bounds
 
     _ENT_TABLES = ('ent_emb',)
+    # the evaluator may hand lp_problem(side='both') a ColumnPlan: the fused query pipeline then writes one split row
+    # per DISTINCT query row of the batch and the count kernel sweeps columns instead of queries
+    lp_dedupe_queries = True
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight]
@@ -91,19 +94,19 @@ class TransEModel(TranslationModel):
             candidates = R.view(1, self.n_rel, self.emb_dim).expand(b_size, self.n_rel, self.emb_dim)
         return h, t, r, candidates
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None, cols=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
         if (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
                 and self.split_filter and self._split_ok and ent_lo == 0 and ent_hi == self.n_ent
                 and self._row_shard is None and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
-            return self._fused_query_problem(h_idx, t_idx, r_idx, sd, tabs)
+            return self._fused_query_problem(h_idx, t_idx, r_idx, sd, tabs, cols if sd == _hip.SIDE_BOTH else None)
         Q0, _, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)
         return self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
 
-    def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs):
+    def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs, cols=None):
         """Inside evaluate(), unsharded: the whole query side of a batch (q, ||q||^2, true scores,
         split queries, thresholds) from ONE kernel; the evaluator's pair_scores(true_idx) /
         count_ge calls then find their inputs ready."""
@@ -112,7 +115,7 @@ class TransEModel(TranslationModel):
         key = '0_%d' % E.shape[0]
         en = self._cache.get('en_' + key, [E], lambda: _hip.row_sqnorm(E, max_io=g[1:2]))
         Es, e2 = self._cache.get('es_' + key, [E], lambda: _hip.split_table(E, aug=en))
-        pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2)
+        pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2, cols=cols)
         # (SIDE_BOTH: the evaluator fills in the concatenated true indices it gets from the filter lookup)
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
