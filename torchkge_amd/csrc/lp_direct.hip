@@ -29,6 +29,7 @@ struct DirectParams {
     const float *s_true;
     int *raw_count;
     int row_panels, col_tiles, tiles_per_block, col_chunks;
+    int out_vec4;       // out rows are 16-byte aligned (ldo % 4 == 0, aligned base): float4 stores
 };
 
 template <bool VEC4>
@@ -268,6 +269,292 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_kernel(const DirectPara
     }
 }
 
+// ---- packed-FMA variant of the L2 kernels (16-byte aligned operands) ---------------------------------------------
+// gfx950 issues v_fma_f32 at ~2/3 and v_pk_fma_f32 / v_pk_add_f32 (two lanes' worth of work per instruction) at
+// ~0.55 of the v_add_f32 rate (tools/probe/valu_rate_probe.hip: 42.6 / 35.9 / 34.8 vs 63.9 T lane-instr/s), so
+// sub + fma per (pair, k) costs 0.039 units while a packed sub + a packed fma over TWO pairs cost 0.028 per pair.
+// The two halves of a packed instruction are two ADJACENT CANDIDATES at the same k (the per-pair chains stay
+// "ascending k, one accumulator": bit-identical to lp_pair_score and to the scalar kernel above), the query value is
+// broadcast to both halves with op_sel.  That needs the candidate tile TRANSPOSED in LDS ([k][candidate], row stride
+// 132: 8 consecutive candidates of one k are two ds_read_b128) and a thread's 8 candidates contiguous (tx*8 + j).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// d = q.{lo|hi} - t  (both halves)      QH: 0 -> broadcast q.x, 1 -> broadcast q.y
+template <int QH>
+__device__ __forceinline__ f32x2 pk_sub_bcast(f32x2 q, f32x2 t)
+{
+    f32x2 d;
+    if (QH == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(q), "v"(t));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(q), "v"(t));
+    return d;
+}
+// d = a * w.{lo|hi} + d
+template <int WH>
+__device__ __forceinline__ f32x2 pk_fma_bcast(f32x2 a, f32x2 w, f32x2 d)
+{
+    if (WH == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d) : "v"(a), "v"(w));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(a), "v"(w));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sq_acc(f32x2 d, f32x2 acc)
+{
+    asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc) : "v"(d));
+    return acc;
+}
+
+constexpr int LDT_PK = BN + 4;      // row stride (floats) of the transposed candidate tile
+
+template <bool AXPY, bool COUNT, int TM>
+__global__ __launch_bounds__(NTHREADS, 2) void lp_direct_pk_kernel(const DirectParams p)
+{
+    constexpr int BM = 16 * TM;
+    constexpr int QCH = BM * 4 / NTHREADS;
+    constexpr int Q_FLOATS = BM * LDS_LD, T_FLOATS = BK * LDT_PK;
+    constexpr int BUF_FLOATS = Q_FLOATS * (AXPY ? 2 : 1) + T_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const kge_lp_desc &d = p.d;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+
+    const int nblk_grid = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk_grid >> 3, xr = nblk_grid & 7, xcd = bid & 7, loc = bid >> 3;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    const int rp = lid % p.row_panels, cc = lid / p.row_panels;
+    const int64_t row0 = (int64_t)rp * BM;
+    const int tile_begin = cc * p.tiles_per_block;
+    const int tile_end = min(tile_begin + p.tiles_per_block, p.col_tiles);
+    const int ntiles = tile_end - tile_begin;
+    if (ntiles <= 0) return;
+
+    const int K = d.K0;                 // K % 4 == 0 (the dispatcher checks)
+    const int S = (K + BK - 1) / BK;
+    const int G = ntiles * S;
+
+    float4 stQ[QCH][2], stW[AXPY ? QCH : 1][2], stT[2][2];
+    const int srow = tid >> 2, skc = tid & 3;
+
+    // unconditional loads from clamped addresses; out-of-range rows / k are zeroed when staged into LDS
+    auto ld4 = [&](const float *base, int64_t ld, int64_t r, int64_t rmax, int k) {
+        return *reinterpret_cast<const float4 *>(base + min(r, rmax) * ld + (k < K ? k : 0));
+    };
+    // (component-wise selects: a select between two float4 VALUES made hipcc index a scratch copy of them)
+    auto sel4 = [](bool c, const float4 v) { return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f); };
+    auto prefetch = [&](int g) {
+        const int ti = g / S, s = g - ti * S;
+        const int kq = s * BK + skc * 8;                    // query rows: 8 consecutive k per thread
+        const int kt = s * BK + skc * 4;                    // candidate rows: k = 4 skc + {0..3} and 16 + 4 skc + {0..3}
+        const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
+#pragma unroll
+        for (int j = 0; j < QCH; ++j) {
+            const int64_t r = row0 + srow + 64 * j;
+            stQ[j][0] = ld4(d.A0, d.lda0, r, d.B - 1, kq);
+            stQ[j][1] = ld4(d.A0, d.lda0, r, d.B - 1, kq + 4);
+            if (AXPY) {
+                stW[j][0] = ld4(d.Wq, d.ldw, r, d.B - 1, kq);
+                stW[j][1] = ld4(d.Wq, d.ldw, r, d.B - 1, kq + 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            stT[j][0] = ld4(d.T0, d.ldt0, col0 + srow + 64 * j, d.N - 1, kt);
+            stT[j][1] = ld4(d.T0, d.ldt0, col0 + srow + 64 * j, d.N - 1, kt + 16);
+        }
+    };
+    auto stage_store = [&](int buf, int g) {
+        float *Qs = smem + buf * BUF_FLOATS;
+        float *Ts = Qs + Q_FLOATS;
+        float *Ws = Ts + T_FLOATS;
+        const int ti = g / S, s = g - ti * S;
+        const int kq = s * BK + skc * 8, kt = s * BK + skc * 4;
+        const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
+#pragma unroll
+        for (int j = 0; j < QCH; ++j) {
+            const bool ok = row0 + srow + 64 * j < d.B;
+            float *qd = Qs + (srow + 64 * j) * LDS_LD + skc * 8;
+            *reinterpret_cast<float4 *>(qd) = sel4(ok && kq < K, stQ[j][0]);
+            *reinterpret_cast<float4 *>(qd + 4) = sel4(ok && kq + 4 < K, stQ[j][1]);
+            if (AXPY) {
+                float *wd = Ws + (srow + 64 * j) * LDS_LD + skc * 8;
+                *reinterpret_cast<float4 *>(wd) = sel4(ok && kq < K, stW[j][0]);
+                *reinterpret_cast<float4 *>(wd + 4) = sel4(ok && kq + 4 < K, stW[j][1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {      // transposed: Ts[k][candidate]
+            const int cl = srow + 64 * j;
+            const bool ok = col0 + cl < d.N;
+            const float4 a = sel4(ok && kt < K, stT[j][0]), b = sel4(ok && kt + 16 < K, stT[j][1]);
+            float *td = Ts + (skc * 4) * LDT_PK + cl;
+            td[0] = a.x; td[LDT_PK] = a.y; td[2 * LDT_PK] = a.z; td[3 * LDT_PK] = a.w;
+            td += 16 * LDT_PK;
+            td[0] = b.x; td[LDT_PK] = b.y; td[2 * LDT_PK] = b.z; td[3 * LDT_PK] = b.w;
+        }
+    };
+
+    f32x2 acc[TM][TN / 2];
+    f32x2 av[AXPY ? TM : 1][AXPY ? TN / 2 : 1];
+    int cnt[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        cnt[i] = 0;
+#pragma unroll
+        for (int j = 0; j < TN / 2; ++j) acc[i][j] = (f32x2){0.f, 0.f};
+    }
+
+    int *rc = reinterpret_cast<int *>(smem + 2 * BUF_FLOATS);
+    float *st_s = smem + 2 * BUF_FLOATS + BM;
+    if (tid < BM) {
+        const int64_t row = row0 + tid;
+        rc[tid] = 0;
+        st_s[tid] = (COUNT && row < d.B) ? p.s_true[row] : 0.f;
+    }
+
+    auto load_av = [&](int ti) {
+        if (AXPY) {
+            const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int64_t row = row0 + ty + 16 * i;
+                const int64_t rsel = (d.scal_ld > 1) ? d.r_idx[min(row, d.B - 1)] : 0;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { // clamped, unconditional (values of padded rows/cols are unused)
+                    const int64_t col = min(col0 + tx * TN + j, d.N - 1);
+                    const float a = d.scal[col * d.scal_ld + rsel];
+                    if (j & 1) av[AXPY ? i : 0][AXPY ? j / 2 : 0].y = a;
+                    else av[AXPY ? i : 0][AXPY ? j / 2 : 0].x = a;
+                }
+            }
+        }
+    };
+
+    prefetch(0);
+    stage_store(0, 0);
+    load_av(0);
+    __syncthreads();
+
+    for (int g = 0; g < G; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < G) prefetch(g + 1);
+        const int ti = g / S, s = g - ti * S;
+        const int nk4 = min(BK / 4, (K - s * BK + 3) >> 2);
+
+        const float *Qb = smem + buf * BUF_FLOATS + ty * LDS_LD;
+        const float *Tb = smem + buf * BUF_FLOATS + Q_FLOATS + tx * TN;
+        const float *Wb = smem + buf * BUF_FLOATS + Q_FLOATS + T_FLOATS + ty * LDS_LD;
+#pragma unroll 2
+        for (int k4 = 0; k4 < nk4; ++k4) {
+            float4 q[TM], w[AXPY ? TM : 1];
+            f32x2 t[4][TN / 2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                q[i] = *reinterpret_cast<const float4 *>(Qb + 16 * i * LDS_LD + k4 * 4);
+                if (AXPY) w[AXPY ? i : 0] = *reinterpret_cast<const float4 *>(Wb + 16 * i * LDS_LD + k4 * 4);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float4 a = *reinterpret_cast<const float4 *>(Tb + (k4 * 4 + kk) * LDT_PK);
+                const float4 b = *reinterpret_cast<const float4 *>(Tb + (k4 * 4 + kk) * LDT_PK + 4);
+                t[kk][0] = (f32x2){a.x, a.y}; t[kk][1] = (f32x2){a.z, a.w};
+                t[kk][2] = (f32x2){b.x, b.y}; t[kk][3] = (f32x2){b.z, b.w};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x2 q01 = {q[i].x, q[i].y}, q23 = {q[i].z, q[i].w};
+                f32x2 w01 = q01, w23 = q23;
+                if (AXPY) { w01 = (f32x2){w[AXPY ? i : 0].x, w[AXPY ? i : 0].y}; w23 = (f32x2){w[AXPY ? i : 0].z, w[AXPY ? i : 0].w}; }
+#pragma unroll
+                for (int jj = 0; jj < TN / 2; ++jj) {
+                    f32x2 v = acc[i][jj];
+                    f32x2 d0 = pk_sub_bcast<0>(q01, t[0][jj]), d1 = pk_sub_bcast<1>(q01, t[1][jj]);
+                    f32x2 d2 = pk_sub_bcast<0>(q23, t[2][jj]), d3 = pk_sub_bcast<1>(q23, t[3][jj]);
+                    if (AXPY) {
+                        const f32x2 a2 = av[AXPY ? i : 0][AXPY ? jj : 0];
+                        d0 = pk_fma_bcast<0>(a2, w01, d0); d1 = pk_fma_bcast<1>(a2, w01, d1);
+                        d2 = pk_fma_bcast<0>(a2, w23, d2); d3 = pk_fma_bcast<1>(a2, w23, d3);
+                    }
+                    v = pk_sq_acc(d0, v); v = pk_sq_acc(d1, v); v = pk_sq_acc(d2, v); v = pk_sq_acc(d3, v);
+                    acc[i][jj] = v;
+                }
+            }
+        }
+
+        if (s == S - 1) {
+            const int64_t col0 = (int64_t)(tile_begin + ti) * BN + tx * TN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int lrow = ty + 16 * i;
+                const int64_t row = row0 + lrow;
+                const float stv = COUNT ? st_s[lrow] : 0.f;
+                float sc[TN];
+#pragma unroll
+                for (int jj = 0; jj < TN / 2; ++jj) {
+                    sc[2 * jj] = -acc[i][jj].x; sc[2 * jj + 1] = -acc[i][jj].y;
+                    acc[i][jj] = (f32x2){0.f, 0.f};
+                }
+                if (COUNT) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) cnt[i] += (sc[j] >= stv) ? (col0 + j < d.N ? 1 : 0) : 0;
+                } else if (row < d.B) {
+                    float *o = p.out + row * p.ldo + col0;
+                    if (col0 + TN <= d.N && p.out_vec4) {
+                        *reinterpret_cast<float4 *>(o) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+                        *reinterpret_cast<float4 *>(o + 4) = make_float4(sc[4], sc[5], sc[6], sc[7]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) if (col0 + j < d.N) o[j] = sc[j];
+                    }
+                }
+            }
+            if (ti + 1 < ntiles) load_av(ti + 1);
+        }
+
+        if (g + 1 < G) stage_store(buf ^ 1, g + 1);
+        __syncthreads();
+    }
+
+    if (COUNT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            if (cnt[i]) atomicAdd(&rc[ty + 16 * i], cnt[i]);
+        __syncthreads();
+        if (tid < BM) {
+            const int64_t row = row0 + tid;
+            const int v = rc[tid];
+            if (row < d.B && v) atomicAdd(&p.raw_count[row], v);
+        }
+    }
+}
+
+template <bool AXPY, bool COUNT>
+int launch_pk(DirectParams &p, hipStream_t s)
+{
+    constexpr int TM = AXPY ? 4 : 8;
+    constexpr int BM = 16 * TM;
+    constexpr int BUF_FLOATS = BM * LDS_LD * (AXPY ? 2 : 1) + BK * LDT_PK;
+    constexpr int SMEM_BYTES = 2 * BUF_FLOATS * 4 + 2 * BM * 4;
+    const kge_lp_desc &d = p.d;
+    p.row_panels = (int)((d.B + BM - 1) / BM);
+    p.col_tiles = (int)((d.N + BN - 1) / BN);
+    const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 16384);
+    int chunks = (target_blocks + p.row_panels - 1) / p.row_panels;
+    if (chunks > p.col_tiles) chunks = p.col_tiles;
+    if (chunks < 1) chunks = 1;
+    p.tiles_per_block = (p.col_tiles + chunks - 1) / chunks;
+    p.col_chunks = (p.col_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
+    const int grid = p.row_panels * p.col_chunks;
+    auto k = lp_direct_pk_kernel<AXPY, COUNT, TM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), SMEM_BYTES, s, p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 template <bool VEC4, bool L1, bool AXPY, bool COUNT>
 int launch(DirectParams &p, hipStream_t s)
 {
@@ -278,7 +565,7 @@ int launch(DirectParams &p, hipStream_t s)
     const kge_lp_desc &d = p.d;
     p.row_panels = (int)((d.B + BM - 1) / BM);
     p.col_tiles = (int)((d.N + BN - 1) / BN);
-    const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 2048);
+    const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 16384);
     int chunks = (target_blocks + p.row_panels - 1) / p.row_panels;
     if (chunks > p.col_tiles) chunks = p.col_tiles;
     if (chunks < 1) chunks = 1;
@@ -319,12 +606,17 @@ int kge_lp_direct_run(const kge_lp_desc *d, float *out, int64_t ldo, const float
     p.ldo = ldo;
     p.s_true = s_true;
     p.raw_count = raw_count;
+    p.out_vec4 = (out != nullptr && (ldo % 4 == 0) && kge_aligned16(out)) ? 1 : 0;
     const bool axpy = d->Wq != nullptr;
     bool vec4 = (d->K0 % 4 == 0) && (d->lda0 % 4 == 0) && (d->ldt0 % 4 == 0) &&
                 kge_aligned16(d->A0) && kge_aligned16(d->T0);
     if (axpy) vec4 = vec4 && (d->ldw % 4 == 0) && kge_aligned16(d->Wq);
     const bool l1 = d->mode == KGE_LP_L1_DIRECT;
     const bool count = raw_count != nullptr;
+    if (vec4 && !l1 && !kge_env_int("KGE_DIRECT_SCALAR", 0)) {      // L2 on aligned operands: the packed-FMA kernel
+        if (axpy) return count ? launch_pk<true, true>(p, s) : launch_pk<true, false>(p, s);
+        return count ? launch_pk<false, true>(p, s) : launch_pk<false, false>(p, s);
+    }
     if (vec4) return l1 ? dispatch2<true, true>(p, axpy, count, s) : dispatch2<true, false>(p, axpy, count, s);
     return l1 ? dispatch2<false, true>(p, axpy, count, s) : dispatch2<false, false>(p, axpy, count, s);
 }
