@@ -97,6 +97,7 @@ struct SplitParams {
     // == query); members: [column][GSETS] query ids (< 0: unused set) for the grouped launch (template GS > 0).
     const int32_t *col_q, *members;
     int q_panels, c_tiles;
+    int qg;               // query panels interleaved under one sweep of the candidate tiles (work order)
     int64_t n_items;
     int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 4 no epilogue,
                           // 16 no LDS fragment reads, 32 no barriers, 128 every block streams tile (0,0)
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     // the ~32 CUs that share an L2 work on 4 query panels x 8 candidate tiles: every split row
     // that enters the L2 is used by 8 (queries) or 4 (candidates) CUs before it is evicted, and a
     // block stays on one query panel for a whole sweep (its rank counters live in registers).
-    constexpr int QG = 4;
+    const int QG = p.qg;
     const int nb = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
     const int nbx = (nb - xcd + 7) >> 3;                                   // blocks on this XCD
@@ -1260,6 +1261,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     p.col_q = nullptr; p.members = nullptr;
     p.c_tiles = (int)((d->N + TC - 1) / TC);
     p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
+    p.qg = kge_env_int("KGE_SPLIT_QG", 4);
     const int slots = split_num_cus();
     if (a->col_q || a->members) {
         // Columns instead of queries: Qs holds n_single_p rows that carry one query each (col_q), then n_multi_p rows
