@@ -1265,7 +1265,7 @@ def test_split_count_on_query_columns_equals_per_query_counts(hip, eps):
     assert int(raws[0].min()) >= 1
 
 
-@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex'])
+@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex', 'transh', 'transd'])
 def test_evaluator_dedupes_query_rows_and_keeps_the_ranks(hip, monkeypatch, kind):
     """evaluate() on a graph with hub keys (TransE-L2: fused query pipeline writing one split row per column; DistMult /
     ComplEx: rows gathered per column): identical rank vectors with the ColumnPlan path on (default) and off

@@ -667,6 +667,15 @@ class LpProblem(object):
                 Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
                                 nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
                 extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
+        elif self.cols is not None:     # L2 / projection modes on COLUMNS (gathered rows, as the DOT branch above)
+            cols = self.cols
+            Qs = split_rows(A0.index_select(0, cols.rep), K=K, is_query=True, cell_ss=want_ss)
+            if isinstance(Qs, tuple):
+                Bp_q = int(lib.kge_lp_split_rows_padded(self.B, 1))
+                ss_q = torch.zeros(Qs[1].shape[0], Bp_q, dtype=torch.float32, device=self.device)
+                ss_q[:, :self.B] = Qs[1].index_select(1, cols.col_of_q)
+                Qs = (Qs[0], ss_q)
+            extra = {'cols': cols}
         else:
             Qs = split_rows(A0, K=K, is_query=True, cell_ss=want_ss)
         if isinstance(Qs, tuple):

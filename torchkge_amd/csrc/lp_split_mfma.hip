@@ -72,7 +72,7 @@ constexpr int STAGE_BYTES = E_STAGE_BYTES + Q_STAGE_BYTES;
 constexpr int UNC_CAP = 2048;                   // uncertain pairs buffered per tile
 constexpr int GSETS = 4;                        // grouped columns: queries that share one query row (threshold sets per column)
 // + per-panel (thr4, X row) of the projection modes, or the (a_lo, a_hi) sets + counters of a grouped panel
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES + 16 + UNC_CAP * 4 + TQ * GSETS * 12 + 16;
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES + 16 + UNC_CAP * 4 + TQ * 20 + TQ * GSETS * 12 + 16;
 constexpr int SPLIT_SCALE_LOG2 = 12;
 
 struct SplitParams {
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
 template <int NWAVES, bool DBG, int PM, int GS = 0>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
-    static_assert(GS == 0 || (PM == 0 && GS == GSETS), "grouped columns: plain thresholds only");
+    static_assert(GS == 0 || GS == GSETS, "grouped columns carry GSETS threshold sets");
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int MT = TC / 32 / (NWAVES / 2);                      // 32x32 candidate tiles per wave
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + 16);
     float4 *pthr = reinterpret_cast<float4 *>(smem + 2 * STAGE_BYTES + 16 + UNC_CAP * 4);   // PM: per query of the panel
     int *prow = reinterpret_cast<int *>(pthr + TQ);
-    float2 *gthr = reinterpret_cast<float2 *>(pthr);                       // GS: [set][TQ] thresholds ...
+    float2 *gthr = reinterpret_cast<float2 *>(prow + TQ);                  // GS: [set][TQ] thresholds ...
     int *gcnt = reinterpret_cast<int *>(gthr + (GS ? GS : 1) * TQ);         // ... [set][TQ] counters ...
     int *gsets = gcnt + (GS ? GS : 1) * TQ;                                 // ... and the number of sets in use
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the LDS-DMA targets become SALU arithmetic)
@@ -727,17 +727,27 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             for (int idx = tid; idx < TQ * GS; idx += NTHREADS) {
                 const int c = idx / GS, gs = idx - c * GS;
                 const int q = p.members[(q0 + c) * GS + gs];
-                gthr[gs * TQ + c] = q >= 0 ? p.thr[q] : make_float2(INFINITY, INFINITY);
+                float2 t = make_float2(INFINITY, INFINITY);
+                if (q >= 0) {
+                    if (PM) { const float4 t4 = p.thr4[q]; t = make_float2(t4.x, t4.y); }
+                    else t = p.thr[q];
+                }
+                gthr[gs * TQ + c] = t;
                 gcnt[gs * TQ + c] = 0;
                 if (q >= 0) used = max(used, gs + 1);
+                if (PM && gs == 0) {    // the queries of a column share the key, hence relation and projection scalars
+                    pthr[c] = q >= 0 ? p.thr4[q] : make_float4(INFINITY, INFINITY, 0.f, 0.f);
+                    prow[c] = (int)p.r_idx[max(q, 0)];
+                }
             }
             if (used > 0) atomicMax(gsets, used);
             return;
         }
         if (PM) {   // thresholds + projection scalars + X row of the panel's queries live in LDS
             if (tid < TQ) {
-                pthr[tid] = p.thr4[q0 + tid];
-                prow[tid] = (int)p.r_idx[min(q0 + tid, p.B - 1)];
+                const int64_t q = p.col_q ? (int64_t)p.col_q[q0 + tid] : q0 + tid;
+                pthr[tid] = q >= 0 ? p.thr4[q] : make_float4(INFINITY, INFINITY, 0.f, 0.f);
+                prow[tid] = (int)p.r_idx[min(max(q, (int64_t)0), p.B - 1)];
             }
             return;
         }
@@ -916,6 +926,35 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int ql = ql_base + nt * 32;
+                    if (PM) {   // acc <- acc - 2^23 * corr once per element: the corrected value serves every set
+                        const float4 t4 = pthr[ql];
+                        const float p_n = t4.z, z_n = t4.w;
+                        const float *xrow = p.X + (int64_t)prow[ql] * p.ldx + c0 + wr * (MT * 32) + 4 * half;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            float4 x4[4], y4[4];
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                x4[g4] = *reinterpret_cast<const float4 *>(xrow + mt * 32 + 8 * g4);
+                                if (PM == 2)
+                                    y4[g4] = *reinterpret_cast<const float4 *>(p.yc + c0 + wr * (MT * 32) + 4 * half + mt * 32 + 8 * g4);
+                            }
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float xe = e == 0 ? x4[g4].x : (e == 1 ? x4[g4].y : (e == 2 ? x4[g4].z : x4[g4].w));
+                                    float corr;
+                                    if (PM == 1) {
+                                        corr = xe * fmaf(xe, z_n, p_n);
+                                    } else {
+                                        const float ye = e == 0 ? y4[g4].x : (e == 1 ? y4[g4].y : (e == 2 ? y4[g4].z : y4[g4].w));
+                                        corr = ye * fmaf(ye, z_n, fmaf(2.0f, xe, p_n));
+                                    }
+                                    acc[mt][nt][g4 * 4 + e] = fmaf(corr, -8388608.0f, acc[mt][nt][g4 * 4 + e]);
+                                }
+                        }
+                    }
                     for (int gs = 0; gs < nsets; ++gs) {
                         const float2 th = gthr[gs * TQ + ql];
                         const f32x2 nlo2 = {-th.x, -th.x};
@@ -1266,14 +1305,17 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     if (a->col_q || a->members) {
         // Columns instead of queries: Qs holds n_single_p rows that carry one query each (col_q), then n_multi_p rows
         // that carry up to GSETS queries of one key each (members); both counts multiples of the query panel.
-        if (proj || a->n_single_p < 0 || a->n_multi_p < 0 || a->n_single_p % TQ || a->n_multi_p % TQ ||
+        if (a->n_single_p < 0 || a->n_multi_p < 0 || a->n_single_p % TQ || a->n_multi_p % TQ ||
             (a->n_single_p > 0 && !a->col_q) || (a->n_multi_p > 0 && !a->members))
             return KGE_EINVAL;
+        const int pm = d->mode == KGE_LP_L2_PROJH ? 1 : (d->mode == KGE_LP_L2_PROJD ? 2 : 0);
         if (a->n_single_p > 0) {
             p.col_q = a->col_q;
             p.q_panels = (int)(a->n_single_p / TQ);
             p.n_items = (int64_t)p.q_panels * p.c_tiles;
-            rc = launch_split<8, false, 0>(p, (int)(p.n_items < slots ? p.n_items : slots), s);
+            const int grid = (int)(p.n_items < slots ? p.n_items : slots);
+            rc = pm == 1 ? launch_split<8, false, 1>(p, grid, s)
+                         : (pm == 2 ? launch_split<8, false, 2>(p, grid, s) : launch_split<8, false, 0>(p, grid, s));
             if (rc) return rc;
         }
         if (a->n_multi_p > 0) {
@@ -1282,7 +1324,9 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
             p.Qs = reinterpret_cast<const char *>(Qs) + a->n_single_p * (int64_t)p.row_bytes;
             p.q_panels = (int)(a->n_multi_p / TQ);
             p.n_items = (int64_t)p.q_panels * p.c_tiles;
-            rc = launch_split<8, false, 0, GSETS>(p, (int)(p.n_items < slots ? p.n_items : slots), s);
+            const int grid = (int)(p.n_items < slots ? p.n_items : slots);
+            rc = pm == 1 ? launch_split<8, false, 1, GSETS>(p, grid, s)
+                         : (pm == 2 ? launch_split<8, false, 2, GSETS>(p, grid, s) : launch_split<8, false, 0, GSETS>(p, grid, s));
         }
         return rc;
     }

@@ -103,7 +103,8 @@ class HipRankEngine(object):
         plan = FilterPlan(seg_lo, seg_hi, true_idx, targets)
         plan.cols = None
         if model is not None and getattr(model, 'lp_dedupe_queries', False) and h.shape[0] > 0 and DEDUPE_QUERIES:
-            plan.cols = ColumnPlan(h, t, r, model.n_ent, model.n_rel, _hip.split_group_sets(), _hip.split_query_rows_padded)
+            plan.cols = ColumnPlan(h, t, r, model.n_ent, model.n_rel, _hip.split_group_sets(), _hip.split_query_rows_padded,
+                                   relation_major=(model.lp_dedupe_queries == 'relation-major'))
         return plan
 
     flag_columns = True     # partial_counts(pad=k) appends k spare int32 columns (the guard flags ride the counts exchange)

@@ -161,12 +161,15 @@ class ColumnPlan(object):
     Single-query columns come first, both parts padded to the kernel's query panel with -1.  A pure function of the
     facts (not of the model or the index): built once per batch by the evaluator, on the device, no host loop."""
 
-    def __init__(self, h, t, r, n_ent, n_rel, sets, pad):
+    def __init__(self, h, t, r, n_ent, n_rel, sets, pad, relation_major=False):
         dev = h.device
         B = h.shape[0]
         n = 2 * B
         self.n_queries = n
-        key = torch.cat([h * n_rel + r, (t * n_rel + r) + n_ent * n_rel])        # side bit: the two sides never share rows
+        if relation_major:      # columns come out in key order: relation-major for kernels that gather per-relation rows
+            key = torch.cat([r * n_ent + h, (r * n_ent + t) + n_ent * n_rel])
+        else:
+            key = torch.cat([h * n_rel + r, (t * n_rel + r) + n_ent * n_rel])    # side bit: the two sides never share rows
         uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
         order = torch.argsort(inv, stable=True)                       # queries grouped by key, original order inside
         start = torch.cumsum(cnt, 0) - cnt

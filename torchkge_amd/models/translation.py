@@ -103,8 +103,10 @@ class TransEModel(TranslationModel):
                 and self._row_shard is None and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
             return self._fused_query_problem(h_idx, t_idx, r_idx, sd, tabs, cols if sd == _hip.SIDE_BOTH else None)
         Q0, _, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)
-        return self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi),
+        prob = self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
+        prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
+        return prob
 
     def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs, cols=None):
         """Inside evaluate(), unsharded: the whole query side of a batch (q, ||q||^2, true scores,
@@ -147,6 +149,7 @@ class TransHModel(TranslationModel):
     _ENT_TABLES = ('ent_emb',)
     # the count kernel's epilogue gathers X[r_i, c]: queries processed in relation order share those rows
     lp_sort_queries_by_relation = True
+    lp_dedupe_queries = 'relation-major'   # ColumnPlan with the columns in relation order (same reason)
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight, self.norm_vect.weight]
@@ -236,14 +239,16 @@ class TransHModel(TranslationModel):
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi), r_idx=cand.r_idx,
                                            c_base=ent_lo)
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None, cols=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
         Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_w=True)
-        return self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
+        prob = self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi),
                                            r_idx=_both_r(r_idx, sd), c_base=ent_lo)
+        prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
+        return prob
 
 
 class TransDModel(TranslationModel):
@@ -256,6 +261,7 @@ class TransDModel(TranslationModel):
     _ENT_TABLES = ('ent_emb', 'ent_proj_vect')
     _ENT_POS = (0, 2)
     lp_sort_queries_by_relation = True     # (as TransH: the epilogue gathers G[r_i, c])
+    lp_dedupe_queries = 'relation-major'
 
     def __init__(self, ent_emb_dim, rel_emb_dim, n_entities, n_relations):
         super().__init__(n_entities, n_relations, 'L2')
@@ -356,8 +362,10 @@ class TransDModel(TranslationModel):
         Wq = _hip.gather_rows(self.rel_proj_vect.weight.data, cand.r_idx)
         return self._problem(q, Wq, ent_lo, ent_hi, r_idx=cand.r_idx)
 
-    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None):
+    def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None, cols=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         sd = _hip.side_code(side)
         Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_w=True)
-        return self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_both_r(r_idx, sd))
+        prob = self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_both_r(r_idx, sd))
+        prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
+        return prob
