@@ -350,7 +350,7 @@ extern "C" int kge_lp_sad_count(const kge_lp_desc *d, const kge_sad_args *a, con
     p.list = a->list; p.cap = a->cap; p.list_count = a->list_count; p.overflow = a->overflow;
     p.row_panels = (int)((d->B + BM - 1) / BM);
     p.col_tiles = (int)((d->N + BN - 1) / BN);
-    const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 2048);
+    const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 16384);
     int chunks = (target_blocks + p.row_panels - 1) / p.row_panels;
     if (chunks > p.col_tiles) chunks = p.col_tiles;
     if (chunks < 1) chunks = 1;

@@ -79,14 +79,13 @@ class HipRankEngine(object):
     def problem(model, h, t, r, side, lo, hi, exchange=None, qctx=None, cols=None):
         """ROW-SHARDED model: `qctx` = (replicas of the query entities' rows, h and t as indices into them),
         exchanged once per evaluate(); or `exchange`: completes the query rows of this batch (sum over the shards)."""
+        kw = {'cols': cols} if cols is not None else {}
         if getattr(model, '_row_shard', None) is not None:
             if qctx is not None:
-                return model.lp_problem(qctx[1], qctx[2], r, side, ent_lo=lo, ent_hi=hi, qtabs=qctx[0])
+                return model.lp_problem(qctx[1], qctx[2], r, side, ent_lo=lo, ent_hi=hi, qtabs=qctx[0], **kw)
             if exchange is not None:
-                return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, exchange=exchange)
-        if cols is not None:
-            return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, cols=cols)
-        return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi)
+                return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, exchange=exchange, **kw)
+        return model.lp_problem(h, t, r, side, ent_lo=lo, ent_hi=hi, **kw)
 
     @staticmethod
     def true_scores(prob, true_idx):
@@ -377,8 +376,8 @@ class LinkPredictionEvaluator(object):
         else:
             seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
         xkw = self._xkw(sharded)
-        if plan is not None and getattr(plan, 'cols', None) is not None and not sharded:
-            xkw['cols'] = plan.cols
+        if plan is not None and getattr(plan, 'cols', None) is not None:
+            xkw['cols'] = plan.cols     # (entity shards too: the columns are a property of the queries, not of the candidates)
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
         s_true = None
         if sharded and self._qb is not None and hasattr(self.model, 'lp_true_scores_replica'):
