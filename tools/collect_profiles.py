@@ -28,10 +28,13 @@ def main(tag):
     if os.path.exists(os.path.join(src, 'trace_l1', 'bench_kernel_stats.csv')):
         shutil.copy(os.path.join(src, 'trace_l1', 'bench_kernel_stats.csv'),
                     os.path.join(dst, 'kernel_stats_evaluate_only_transe_l1_fb15k237.csv'))
+    for extra in ('topk_inference.jsonl',):
+        if os.path.exists(os.path.join(src, extra)):
+            shutil.copy(os.path.join(src, extra), dst)
     if os.path.exists(os.path.join(src, 'power_probe.txt')):
         shutil.copy(os.path.join(src, 'power_probe.txt'), os.path.join(dst, 'power_probe_round_end.txt'))
     rows = []
-    for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
+    for d in sorted(glob.glob(os.path.join(src, 'pmc*'))):
         if not os.path.isdir(d):
             continue
         for f in glob.glob(os.path.join(d, '*counter_collection.csv')) + glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
@@ -48,10 +51,10 @@ def main(tag):
             w.writerow(r)
 
     def mean(counter, kern):
-        for c, k, n, m in rows:
-            if c == counter and kern in k:
-                return m
-        return None
+        """per-launch mean, SUMMED over the instantiations of a kernel (the count kernel runs as two per evaluate:
+        single-query and grouped columns)"""
+        got = [m for c, k, n, m in rows if c == counter and kern in k]
+        return sum(got) if got else None
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     t = json.load(open(tfile))
     for key, kern in (('transe_fb15k237', 'lp_split_count'), ('transe_fb15k237:no-split', 'lp_gemm_kernel')):

@@ -54,7 +54,7 @@ def main(out):
     print('\n## PMC counters, mean per launch of the dominant kernels\n')
     print('| counter | kernel | launches | mean per launch |')
     print('|---|---|---|---|')
-    for d in sorted(glob.glob(os.path.join(out, 'pmc_*'))):
+    for d in sorted(glob.glob(os.path.join(out, 'pmc*'))):
         if not os.path.isdir(d):
             continue
         for f in glob.glob(os.path.join(d, '*counter_collection.csv')) + glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
