@@ -297,6 +297,9 @@ int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *fou
 int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
                            int64_t *out, int64_t ld, int64_t off, const int64_t *pos /* optional: fact j of the
                            evaluation goes to column pos[j] (facts processed in another order, e.g. sorted by relation) */,
+                           const float *guard /* optional, with flags: device floats [max ||q||^2, max ||e||^2, overflow] */,
+                           float *flags /* optional: flags[0] = guard[0] + guard[1], flags[1] = guard[2] (the evaluation's
+                           two guard decisions written behind the ranks by the same launch) */,
                            kge_stream_t stream);
 
 /* generic: every query has its own candidate matrix cand[i] (N,K) at

@@ -98,7 +98,7 @@ _SIGNATURES = {
     'kge_lp_filter_sub_planned': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                                   _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
-    'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp],
+    'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
     'kge_get_rank': [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     'kge_filter_lookup': [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -147,7 +147,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 18:
+    if lib.kge_abi_version() != 19:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -807,7 +807,7 @@ def rank_finalize(raw, sub, found):
     return rank, filt
 
 
-def rank_finalize_both(raw, sub, found, out, off, pos=None):
+def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=None):
     """kge_rank_finalize_both: the ranks of a 2B-query batch into the (4, n) int64 result matrix
     `out` (rows: head raw, tail raw, head filtered, tail filtered) at columns off .. off + B - 1."""
     lib = load_library()
@@ -816,7 +816,8 @@ def rank_finalize_both(raw, sub, found, out, off, pos=None):
     if out.dtype != torch.int64 or out.dim() != 2 or out.shape[0] != 4 or out.stride(1) != 1:
         raise RuntimeError('rank_finalize_both: out must be a (4, n) int64 matrix with unit column stride')
     with _on(raw.device):
-        _check(lib.kge_rank_finalize_both(_p(raw), _p(sub), _p(found), B, _p(out), out.stride(0), off, _p(pos), _stream()),
+        _check(lib.kge_rank_finalize_both(_p(raw), _p(sub), _p(found), B, _p(out), out.stride(0), off, _p(pos),
+                                          _p(guard if flags is not None else None), _p(flags), _stream()),
                'kge_rank_finalize_both')
     return out
 

@@ -498,8 +498,15 @@ __global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int3
 // [head raw, tail raw, head filtered, tail filtered] at column off + fact
 __global__ void rank_finalize_both_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
                                           const int32_t *__restrict__ found, int64_t B, int64_t *out, int64_t ld,
-                                          int64_t off, const int64_t *__restrict__ pos)
+                                          int64_t off, const int64_t *__restrict__ pos,
+                                          const float *__restrict__ guard, float *flags)
 {
+    // the evaluation's two guard decisions ride the last finalize (instead of an add + a copy node of their own):
+    // flags[0] = max ||q||^2 + max ||e||^2 (norm-expansion guard), flags[1] = overflow of the uncertain-pair list
+    if (flags && blockIdx.x == 0 && threadIdx.x == 0) {
+        flags[0] = guard[0] + guard[1];
+        flags[1] = guard[2];
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
         const bool tail = i < B;
         const int64_t j = off + (tail ? i : i - B);
@@ -891,13 +898,14 @@ extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const i
 }
 
 extern "C" int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
-                                      int64_t *out, int64_t ld, int64_t off, const int64_t *pos, kge_stream_t stream)
+                                      int64_t *out, int64_t ld, int64_t off, const int64_t *pos, const float *guard,
+                                      float *flags, kge_stream_t stream)
 {
     if (B < 0 || off < 0 || ld < off + B) return KGE_EINVAL;
     if (B == 0) return 0;
-    if (!raw || !sub || !found || !out) return KGE_EINVAL;
+    if (!raw || !sub || !found || !out || (flags && !guard)) return KGE_EINVAL;
     hipLaunchKernelGGL(rank_finalize_both_kernel, dim3(grid1d(2 * B, 256)), dim3(256), 0, kge_s(stream), raw, sub,
-                       found, B, out, ld, off, pos);
+                       found, B, out, ld, off, pos, guard, flags);
     KGE_CHECK_LAUNCH();
     return 0;
 }
@@ -943,5 +951,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 18; }
+extern "C" int kge_abi_version(void) { return 19; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -120,10 +120,13 @@ class HipRankEngine(object):
     def finalize(counts):
         return _hip.rank_finalize(counts[0], counts[1], counts[2])
 
+    writes_flags = True     # finalize_both(guard=, flags=): the guard decisions are written by the same launch
+
     @staticmethod
-    def finalize_both(counts, out, off, pos=None):
-        """Ranks of a 2B-query batch into the (4, n) result matrix at columns off..off+B-1 (or pos[off..])."""
-        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off, pos)
+    def finalize_both(counts, out, off, pos=None, guard=None, flags=None):
+        """Ranks of a 2B-query batch into the (4, n) result matrix at columns off..off+B-1 (or pos[off..]);
+        ``flags`` (2 floats behind the ranks): [max ||q||^2 + max ||e||^2, list overflow] from the guard vector."""
+        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off, pos, guard, flags)
 
     @staticmethod
     def local_scores(prob):
@@ -248,6 +251,7 @@ class LinkPredictionEvaluator(object):
         self._plan_refs = None
         self._plan_gen = 0
         self._ctimes = None     # collective_timing(): (start, end) event pairs of the data-path collectives
+        self._fl, self._fl_done = None, False
         # row-sharded models: the distinct entities of the test facts and the facts re-indexed into that list
         # (static like the plans); their rows are exchanged ONCE per evaluate() (query_exchange='evaluate') instead
         # of the (2B, K) query rows of every batch ('batch')
@@ -405,10 +409,14 @@ class LinkPredictionEvaluator(object):
             self._collective(lambda c_=counts: kdist.all_reduce_sum(c_, self.group))
         if ride:
             self._shard_flags = counts[0, n2:n2 + 2]
+        fkw = {}
+        if (last and guard is not None and not sharded and self._fl is not None and getattr(eng, 'writes_flags', False)):
+            fkw = {'guard': guard, 'flags': self._fl}       # the last finalize also writes the two guard flags
+            self._fl_done = True
         if self._perm is not None:
-            eng.finalize_both(counts[:, :n2] if ride else counts, out, off, self._perm)
+            eng.finalize_both(counts[:, :n2] if ride else counts, out, off, self._perm, **fkw)
         else:
-            eng.finalize_both(counts[:, :n2] if ride else counts, out, off)
+            eng.finalize_both(counts[:, :n2] if ride else counts, out, off, **fkw)
 
     def _xkw(self, sharded):
         """Engine keyword for the query exchange of row-sharded entity tables: every rank builds the
@@ -586,6 +594,7 @@ class LinkPredictionEvaluator(object):
                         guard.zero_()
                     n_batches = get_n_batches(n_local, b_size)
                     self._shard_flags = None
+                    self._fl, self._fl_done = fl, False
                     qt = None
                     if use_qmap:    # row-sharded tables: replicas of the rows of the query entities, once per evaluate()
                         gather = None
@@ -613,9 +622,12 @@ class LinkPredictionEvaluator(object):
                         # entity shards: the flags came back summed over the ranks with the last batch's counts
                         fl[0:1].copy_(torch.where(self._shard_flags[0:1] > 0, float('inf'), 0.0))
                         fl[1:2].copy_(self._shard_flags[1:2].to(torch.float32))
-                    elif guard is not None:   # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks
+                    elif guard is not None and not self._fl_done:
+                        # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks (the both-sides path
+                        # has the last batch's finalize write them)
                         torch.add(guard[0:1], guard[1:2], out=fl[0:1])
                         fl[1:2].copy_(guard[2:3])
+                    self._fl = None
 
             # one hipGraph when run() contains no collective (single GPU, query shards); graph segments with
             # the collectives between them for entity shards exchanging counts; eager otherwise
