@@ -105,6 +105,50 @@ def test_collectives_library_loads_and_exports_its_header():
     assert 'librccl' in out
 
 
+def test_column_plan_places_every_query_once_and_groups_by_key():
+    """filter_index.ColumnPlan (pure torch ops: runs on CPU tensors): every query of a both-sides batch sits in exactly one
+    column slot; the queries of a column share their key (and so their query row); exactly the first query of a column
+    writes the split row; single-query columns come first, grouped ones in order of decreasing size; both parts are
+    padded to the panel; relation-major order sorts the columns by relation."""
+    from torchkge_amd.filter_index import ColumnPlan
+    g = torch.Generator().manual_seed(4)
+    n_ent, n_rel, B, sets = 50, 4, 700, 4
+    h = torch.randint(0, n_ent, (B,), generator=g)
+    t = torch.randint(0, n_ent, (B,), generator=g)
+    r = torch.randint(0, n_rel, (B,), generator=g)
+    t[:300] = 7                                     # a head-side hub key per relation
+    pad = lambda n: (n + 191) // 192 * 192
+    for rel_major in (False, True):
+        cp = ColumnPlan(h, t, r, n_ent, n_rel, sets, pad, relation_major=rel_major)
+        key = torch.cat([h * n_rel + r, (t * n_rel + r) + n_ent * n_rel])
+        assert cp.n_queries == 2 * B and cp.n_distinct_keys == int(torch.unique(key).numel())
+        assert cp.n_single_p % 192 == 0 and cp.n_multi_p % 192 == 0
+        assert cp.col_q.shape[0] == max(cp.n_single_p, 1) and cp.members.shape[0] == max(cp.n_multi_p, 1) * sets
+        placed = torch.cat([cp.col_q[cp.col_q >= 0], cp.members[cp.members >= 0]]).long()
+        assert torch.equal(placed.sort().values, torch.arange(2 * B))
+        assert int((cp.col_q >= 0).sum()) == cp.n_single and cp.n_single + cp.n_multi == cp.n_columns
+        mem = cp.members.view(-1, sets)[:cp.n_multi]
+        sizes = (mem >= 0).sum(1)
+        assert int(sizes.min()) >= 2 and (sizes[:-1] >= sizes[1:]).all()          # grouped: >= 2 queries, sizes descending
+        assert (mem[:, 0] >= 0).all() and ((mem >= 0).long().diff(dim=1) <= 0).all()   # slots filled from the left
+        for row in mem[:50]:                            # the queries of a column share their key
+            q = row[row >= 0].long()
+            assert (key[q] == key[q[0]]).all()
+        # the split row of every column is written by exactly one query: its first
+        rows = cp.qs_row[cp.qs_row >= 0].long()
+        assert rows.numel() == cp.n_columns and rows.unique().numel() == cp.n_columns
+        assert torch.equal(cp.qs_row[cp.col_q[:cp.n_single].long()].long(), torch.arange(cp.n_single))
+        assert torch.equal(cp.qs_row[mem[:, 0].long()].long(), cp.n_single_p + torch.arange(cp.n_multi))
+        assert (cp.qs_row[mem[:, 1:][mem[:, 1:] >= 0].long()] == -1).all()
+        # query -> column and column -> representative are consistent
+        assert torch.equal(cp.rep[cp.col_of_q], torch.where(cp.qs_row >= 0, torch.arange(2 * B), cp.rep[cp.col_of_q]))
+        assert (key[cp.rep[cp.col_of_q]] == key).all()
+        if rel_major:                                   # single-query columns in relation order (per side)
+            rq = torch.cat([r, r])[cp.col_q[:cp.n_single].long()]
+            side = (cp.col_q[:cp.n_single] >= B)
+            assert (rq[~side][:-1] <= rq[~side][1:]).all() and (rq[side][:-1] <= rq[side][1:]).all()
+
+
 def test_no_cpu_fallback():
     m = tk.TransEModel(8, 10, 3)
     i = torch.tensor([0, 1])

@@ -1,28 +1,47 @@
-"""Wall time of the first, second and third LinkPredictionEvaluator.evaluate() on a fresh evaluator (cfg2 shape):
-filter index + plans + eager warm-up, hipGraph capture, replay."""
+#!/usr/bin/env python
+"""What a reference-style script pays per evaluate(): the first call of the process, the first call of a FRESH
+evaluator on the same graph (a script that builds its evaluator per epoch), and the steady state.
+    python tools/first_call.py [workload]"""
+import json
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
-import torchkge_amd as tk  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torchkge_amd as tk   # noqa: E402
+import bench                # noqa: E402
 
-dev = torch.device('cuda:0')
-model, tables, kg, kg_test, info = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else 'transe_fb15k237', dev,
-                                                        weights='xavier', kg_kind='zipf')
-torch.cuda.synchronize()
-for b in (256, 32768):
-    t0 = time.perf_counter()
-    ev = tk.LinkPredictionEvaluator(model, kg_test)
+
+def timed(fn):
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    ts = []
-    for _ in range(4):
-        ta = time.perf_counter()
-        ev.evaluate(b, verbose=False)
-        torch.cuda.synchronize()
-        ts.append((time.perf_counter() - ta) * 1e3)
-    print('b_size=%d: constructor %.1f ms, evaluate calls %s ms' % (b, (t1 - t0) * 1e3, ', '.join('%.2f' % x for x in ts)))
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) * 1e3, 3)
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else 'transe_fb15k237'
+    dev = torch.device('cuda', 0)
+    model, tables, kg, kg_test, info = bench.build_workload(wl, dev, weights='xavier')
+    out = {'workload': wl}
+    ev = tk.LinkPredictionEvaluator(model, kg_test)
+    out['first_evaluate_of_the_process_ms'] = timed(lambda: ev.evaluate(256, verbose=False))
+    out['second_call_captures_the_graph_ms'] = timed(lambda: ev.evaluate(256, verbose=False))
+    out['third_call_replay_ms'] = timed(lambda: ev.evaluate(256, verbose=False))
+    fresh = []
+    for _ in range(3):
+        ev2 = tk.LinkPredictionEvaluator(model, kg_test)
+        fresh.append(timed(lambda: ev2.evaluate(256, verbose=False)))
+    out['first_evaluate_of_a_fresh_evaluator_ms'] = fresh
+    ev3 = tk.LinkPredictionEvaluator(model, kg_test, graph=False)
+    ev3.evaluate(256, verbose=False)
+    out['eager_steady_ms'] = timed(lambda: [ev3.evaluate(256, verbose=False) for _ in range(10)]) / 10
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
