@@ -397,7 +397,7 @@ def _measure_traffic(args, kernel_sym):
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'KGE_FORCE_COLLECTIVES'):
             env.pop(k, None)
         try:
-            subprocess.run(cmd, cwd='/tmp', env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             got = {}        # per kernel NAME (the count kernel may run as two instantiations per launch: single-query
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):      # and grouped columns)
                 for r in csv.DictReader(open(f)):

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the LDS-DMA targets become SALU arithmetic)
     const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;   // waves: (NWAVES/2) x 2
 
-    // Work order.  The (query panel, candidate tile) items are listed with QG = 4 query panels
+    // Work order.  The (query panel, candidate tile) items are listed with QG (= p.qg: 4 or 16) query panels
     // interleaved under a sweep of the candidate tiles:  (g*4+0, ct) (g*4+1, ct) .. (g*4+3, ct)
     // (g*4+0, ct+1) ...;  XCD x (the blocks with bid % 8 == x, one per CU) owns an eighth of the
     // list and its blocks take the positions  start + loc, start + loc + nbx, ...  So at any moment
@@ -1300,7 +1300,12 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     p.col_q = nullptr; p.members = nullptr;
     p.c_tiles = (int)((d->N + TC - 1) / TC);
     p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
-    p.qg = kge_env_int("KGE_SPLIT_QG", 4);
+    // Query panels interleaved under one sweep of the candidate tiles (work order, see the kernel).  Measured r03
+    // (profiles/r03/split_work_order_sweep.txt): at K = 200 (172 KiB per panel) 16 panels per XCD cut the L2-miss
+    // traffic from 646 to 295 MB per evaluate and are ~0.5 % FASTER in the sustained, power-capped state (4: 0.819,
+    // 8: 0.812, 16: 0.807 ms per evaluate; 32 thrashes the 4 MiB L2 slice); at K = 400 (320 KiB per panel) 4 / 8 / 16
+    // are within noise with 4 ahead -> 16 while 16 panels stay below ~3 MiB, else 4.
+    p.qg = kge_env_int("KGE_SPLIT_QG", (int64_t)TQ * p.row_bytes * 16 <= (3 << 20) ? 16 : 4);
     const int slots = split_num_cus();
     if (a->col_q || a->members) {
         // Columns instead of queries: Qs holds n_single_p rows that carry one query each (col_q), then n_multi_p rows
