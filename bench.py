@@ -773,7 +773,7 @@ def main():
             traffic = _measure_traffic(args, ksym)
             traffic_src = None if traffic is None else 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run ' \
                                                        '(2 x FETCH_SIZE + WRITE_SIZE, KB -> B; MI355X_MICROARCH.md gfx950 note)'
-        if traffic is None:
+        if traffic is None and not args.no_traffic:      # (measurement failed: the checked-in figure, labelled as such)
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
                 try:
