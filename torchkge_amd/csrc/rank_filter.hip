@@ -427,19 +427,19 @@ __device__ __forceinline__ void fsub_cmp(const kge_lp_desc &d, const int32_t *__
     if (cg == ti) { found = 1; return; }
     sub += ((fs[j] >= tv) ? 1 : 0) - neg_inf_counts;
 }
-__global__ __launch_bounds__(256) void fsub_count_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
-                                                         const int64_t *__restrict__ true_idx,
-                                                         const int64_t *__restrict__ seg_lo,
-                                                         const int64_t *__restrict__ seg_hi,
-                                                         const int32_t *__restrict__ targets,
-                                                         const float *__restrict__ fs, int skip_long,
-                                                         int32_t *sub_out, int32_t *found_out)
+// the two compare kernels of the filter correction: short lists (a wavefront per query) and hub lists (a block per
+// query); bodies as device functions so that ONE launch can run both side by side (fsub_count_both_kernel)
+__device__ __forceinline__ void fsub_count_short(const kge_lp_desc &d, const float *__restrict__ s_true,
+                                                 const int64_t *__restrict__ true_idx, const int64_t *__restrict__ seg_lo,
+                                                 const int64_t *__restrict__ seg_hi, const int32_t *__restrict__ targets,
+                                                 const float *__restrict__ fs, int skip_long, int32_t *sub_out,
+                                                 int32_t *found_out, int bid, int nblk)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave = (int64_t)bid * 4 + (threadIdx.x >> 6), nwaves = (int64_t)nblk * 4;
     for (int64_t i = wave; i < d.B; i += nwaves) {
         const int64_t lo = seg_lo[i], hi = seg_hi[i];
-        if (skip_long && hi - lo > FS_SHORT) continue;      // fsub_count_long_kernel writes this query
+        if (skip_long && hi - lo > FS_SHORT) continue;      // the hub-list body writes this query
         int sub = 0, found = 0;
         if (hi > lo) {
             const float tv = s_true[i];
@@ -456,17 +456,14 @@ __global__ __launch_bounds__(256) void fsub_count_kernel(const kge_lp_desc d, co
         if (lane == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
     }
 }
-__global__ __launch_bounds__(256) void fsub_count_long_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
-                                                              const int64_t *__restrict__ true_idx,
-                                                              const int64_t *__restrict__ seg_lo,
-                                                              const int64_t *__restrict__ seg_hi,
-                                                              const int32_t *__restrict__ targets,
-                                                              const float *__restrict__ fs,
-                                                              const int64_t *__restrict__ long_q, int64_t n_long,
-                                                              int32_t *sub_out, int32_t *found_out)
+__device__ __forceinline__ void fsub_count_long(const kge_lp_desc &d, const float *__restrict__ s_true,
+                                                const int64_t *__restrict__ true_idx, const int64_t *__restrict__ seg_lo,
+                                                const int64_t *__restrict__ seg_hi, const int32_t *__restrict__ targets,
+                                                const float *__restrict__ fs, const int64_t *__restrict__ long_q,
+                                                int64_t n_long, int32_t *sub_out, int32_t *found_out, int bid, int nblk,
+                                                int *sh)
 {
-    __shared__ int sh[4];
-    for (int64_t q = blockIdx.x; q < n_long; q += gridDim.x) {
+    for (int64_t q = bid; q < n_long; q += nblk) {
         const int64_t i = long_q[q];
         const int64_t lo = seg_lo[i], hi = seg_hi[i];
         const float tv = s_true[i];
@@ -482,6 +479,36 @@ __global__ __launch_bounds__(256) void fsub_count_long_kernel(const kge_lp_desc 
         found = block_sum_i(found, sh);
         if (threadIdx.x == 0) { sub_out[i] = sub; found_out[i] = found ? 1 : 0; }
     }
+}
+__global__ __launch_bounds__(256) void fsub_count_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                         const int64_t *__restrict__ true_idx,
+                                                         const int64_t *__restrict__ seg_lo,
+                                                         const int64_t *__restrict__ seg_hi,
+                                                         const int32_t *__restrict__ targets,
+                                                         const float *__restrict__ fs, int skip_long,
+                                                         int32_t *sub_out, int32_t *found_out)
+{
+    fsub_count_short(d, s_true, true_idx, seg_lo, seg_hi, targets, fs, skip_long, sub_out, found_out, blockIdx.x, gridDim.x);
+}
+// ONE launch for both: the first gridDim.x - short_blocks blocks run the hub-list body, the rest the short-list body (they write disjoint
+// queries) -- the two kernels were 17 + 17 us back to back, each far from filling the GPU
+__global__ __launch_bounds__(256) void fsub_count_both_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                              const int64_t *__restrict__ true_idx,
+                                                              const int64_t *__restrict__ seg_lo,
+                                                              const int64_t *__restrict__ seg_hi,
+                                                              const int32_t *__restrict__ targets,
+                                                              const float *__restrict__ fs,
+                                                              const int64_t *__restrict__ long_q, int64_t n_long,
+                                                              int short_blocks, int32_t *sub_out, int32_t *found_out)
+{
+    __shared__ int sh[4];
+    const int long_blocks = (int)gridDim.x - short_blocks;     // the hub-list blocks come FIRST: they are the long ones
+    if ((int)blockIdx.x < long_blocks)
+        fsub_count_long(d, s_true, true_idx, seg_lo, seg_hi, targets, fs, long_q, n_long, sub_out, found_out,
+                        (int)blockIdx.x, long_blocks, sh);
+    else
+        fsub_count_short(d, s_true, true_idx, seg_lo, seg_hi, targets, fs, 1, sub_out, found_out,
+                         (int)blockIdx.x - long_blocks, short_blocks);
 }
 
 __global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
@@ -830,11 +857,14 @@ static int fsub_score_and_count(const kge_lp_desc *d, const float *s_true, const
             hipLaunchKernelGGL((fsub_score_kernel<false, false>), dim3(grid), dim3(64), 0, st, *d, seg_lo, targets, woff, fs);
         }
     }
-    hipLaunchKernelGGL(fsub_count_kernel, dim3(grid1d(d->B, 4)), dim3(256), 0, st, *d, s_true, true_idx, seg_lo, seg_hi,
-                       targets, fs, long_q ? 1 : 0, sub, found);
-    if (long_q && n_long > 0)
-        hipLaunchKernelGGL(fsub_count_long_kernel, dim3((int)(n_long < 256 * 16 ? n_long : 256 * 16)), dim3(256), 0, st, *d,
-                           s_true, true_idx, seg_lo, seg_hi, targets, fs, long_q, n_long, sub, found);
+    if (long_q && n_long > 0) {
+        const int sb = grid1d(d->B, 4), lb = (int)(n_long < 256 * 16 ? n_long : 256 * 16);
+        hipLaunchKernelGGL(fsub_count_both_kernel, dim3(sb + lb), dim3(256), 0, st, *d, s_true, true_idx, seg_lo, seg_hi,
+                           targets, fs, long_q, n_long, sb, sub, found);
+    } else {
+        hipLaunchKernelGGL(fsub_count_kernel, dim3(grid1d(d->B, 4)), dim3(256), 0, st, *d, s_true, true_idx, seg_lo, seg_hi,
+                           targets, fs, long_q ? 1 : 0, sub, found);
+    }
     KGE_CHECK_LAUNCH();
     return 0;
 }
