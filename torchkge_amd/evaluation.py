@@ -283,7 +283,7 @@ class LinkPredictionEvaluator(object):
             # both sides + ~4 (2B, K) fp32 query-side buffers) stays within a quarter of what is free right now.
             # (Sharded evaluators keep the rank-independent formula: every rank must cut the same batches.)
             try:
-                free = torch.cuda.mem_get_info(next(self.model.parameters()).device)[0]
+                free = torch.cuda.mem_get_info(getattr(self, '_dev', None) or next(self.model.parameters()).device)[0]
                 k_q = 2 * int(getattr(self.model, 'emb_dim', 0) or 0) + 64
                 fit = min(fit, max(1, int((free // 4) // (16 * per_query + 2 * 4 * 4 * k_q))))
             except Exception:
@@ -534,7 +534,9 @@ class LinkPredictionEvaluator(object):
     def evaluate(self, b_size, verbose=True):
         """Rank the true head and tail of every fact of ``kg`` among all
         entities, raw and filtered (evaluation.py:263-308)."""
-        device = next(self.model.parameters()).device
+        params = list(self.model.parameters())       # (walked once per evaluate(): device, capture key)
+        device = params[0].device
+        self._dev = device
         self.engine.check_device(device)
         kg = self.kg
         from .models.interfaces import Model as _BaseModel
@@ -648,7 +650,7 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, one_graph, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                       tuple(p_.data_ptr() for p_ in self.model.parameters()), self._plan_gen, use_qmap,
+                       tuple(p_.data_ptr() for p_ in params), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))
                 if self.graph is None and self._graph_key != key and self._graph_seen != key:

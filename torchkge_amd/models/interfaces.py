@@ -300,18 +300,22 @@ class Model(Module):
         norm kernels fold max ||q||^2 / max ||e||^2 into it and the split prefilter
         raises its overflow flag there -- no extra launch, graph-capturable, no host
         sync; the evaluator reads it once with the ranks."""
-        self._expand_ok = None
+        # (plain-Python state: object.__setattr__ skips nn.Module.__setattr__'s Parameter / Module / buffer checks, which
+        # cost ~2.5 us per assignment -- five of them per evaluate() were 1.5 % of a cfg2 step)
+        _set = object.__setattr__
+        _set(self, '_expand_ok', None)
         if not self._uses_guard():
             return None
         if self._lp_guard is None or self._lp_guard.device != device:
-            self._lp_guard = torch.zeros(8, dtype=torch.float32, device=device)
-        self._guard_on = True
+            _set(self, '_lp_guard', torch.zeros(8, dtype=torch.float32, device=device))
+        _set(self, '_guard_on', True)
         return self._lp_guard
 
     def lp_guard_end(self):
-        self._guard_on = False
-        self._expand_ok = None
-        self._split_ok = True
+        _set = object.__setattr__
+        _set(self, '_guard_on', False)
+        _set(self, '_expand_ok', None)
+        _set(self, '_split_ok', True)
 
     def _attach_dot_split(self, prob, T0, T1=None, c_base=0):
         """Rank counts of a KGE_LP_DOT problem through the certified f16-split
