@@ -415,6 +415,9 @@ typedef struct kge_split_args {
     int64_t n_single_p;
     const int32_t *members;
     int64_t n_multi_p;
+    /* with columns, q_cell_ss holds one column per COLUMN: query i reads column q_cell_ss_index[i], row stride q_cell_ss_ld */
+    const int64_t *q_cell_ss_index;
+    int64_t q_cell_ss_ld;
 } kge_split_args;
 int kge_lp_split_group_sets(void);
 
@@ -429,7 +432,10 @@ int64_t kge_lp_split_rows_padded(int64_t rows, int is_query);
  * (NULL: the fixed 2^12 of the norm-guarded L2 mode). */
 int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
                       int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
-                      const float *norm2max1, void *out, float *cell_ss, kge_stream_t stream);
+                      const float *norm2max1, void *out, float *cell_ss,
+                      const int64_t *row_index /* optional: output row r is built from source row row_index[r] of X0 / X1 /
+                                                  aug (query columns: the row of the column's first query) */,
+                      kge_stream_t stream);
 /* cell_ss (optional, [units_p][rows_padded] floats): per k16 cell the sum of squares of its data values.
  * kge_lp_split_prefix_max folds the cell sums of a CANDIDATE operand into e2pref[u] = max over rows of the squared
  * norm of the first (u+1)*16 columns (units_p floats, zeroed by the caller).  With the queries' cell sums in

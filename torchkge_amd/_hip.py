@@ -47,6 +47,7 @@ class SplitArgs(ctypes.Structure):
         ('eps_scale', ctypes.c_float), ('thr_ready', ctypes.c_int32), ('q_cell_ss', _vp), ('e2pref', _vp),
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
         ('col_q', _vp), ('n_single_p', _i64), ('members', _vp), ('n_multi_p', _i64),
+        ('q_cell_ss_index', _vp), ('q_cell_ss_ld', _i64),
     ]
 
 
@@ -81,7 +82,7 @@ _SIGNATURES = {
     'kge_lp_count_ge': [ctypes.POINTER(LpDesc), _vp, _vp, _vp],
     'kge_lp_split_units': [_int, _int],
     'kge_lp_split_rows': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _int, _vp, ctypes.c_float, _vp, _vp, _vp,
-                          _vp, _vp],
+                          _vp, _vp, _vp],
     'kge_lp_split_prefix_max': [_vp, _i64, _int, _int, _vp, _vp],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
@@ -147,7 +148,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 19:
+    if lib.kge_abi_version() != 20:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -376,7 +377,7 @@ SPLIT_LIST_PER_QUERY = 64      # capacity of the uncertain-pair list per query o
 
 
 def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None,
-               cell_ss=False):
+               cell_ss=False, row_index=None):
     """f16 hi/lo split operand of kge_lp_split_count (uint8 tensor holding
     [rows_p][units_p][64 bytes]) of [X | X1].  L2 mode (dot=False): candidates
     carry -||e||^2/2 in the extra column (aug = ||e||^2), queries carry 1, fixed
@@ -386,6 +387,8 @@ def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False,
     require_cuda(X, X1, aug, nmax0, nmax1)
     X = f32c(X)
     rows, ld = X.shape[0], X.stride(0)
+    if row_index is not None:       # output row r <- source row row_index[r] (gather inside the kernel)
+        rows = int(row_index.shape[0])
     K = X.shape[1] if K is None else K
     ld1 = 0
     if X1 is not None:
@@ -404,7 +407,8 @@ def split_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False,
     css = torch.empty(units_p, max(rows_p, 1), dtype=torch.float32, device=X.device) if cell_ss else None
     with _on(X.device):
         _check(lib.kge_lp_split_rows(_p(X), ld, K, _p(X1), ld1, K1, rows, 1 if is_query else 0, aug_mode, _p(aug),
-                                     aug_mul, _p(nmax0), _p(nmax1), _p(out), _p(css), _stream()), 'kge_lp_split_rows')
+                                     aug_mul, _p(nmax0), _p(nmax1), _p(out), _p(css), _p(row_index), _stream()),
+               'kge_lp_split_rows')
     return (out, css) if cell_ss else out
 
 
@@ -653,15 +657,8 @@ class LpProblem(object):
             if cols is not None:
                 # COLUMNS: one split row per distinct query row of the batch (ColumnPlan) -- gathered from the query that
                 # provides it; the per-query cell sums of the error band are read back through the query -> column map
-                rep = cols.rep
-                Qs = split_rows(A0.index_select(0, rep), K=K, is_query=True, aug=qn.index_select(0, rep),
-                                X1=A1.index_select(0, rep) if A1 is not None else None, dot=True, nmax0=qmax[0:1],
-                                nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
-                if isinstance(Qs, tuple):
-                    Bp_q = int(lib.kge_lp_split_rows_padded(self.B, 1))
-                    ss_q = torch.zeros(Qs[1].shape[0], Bp_q, dtype=torch.float32, device=self.device)
-                    ss_q[:, :self.B] = Qs[1].index_select(1, cols.col_of_q)
-                    Qs = (Qs[0], ss_q)
+                Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
+                                nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss, row_index=cols.rep)
                 extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax, 'cols': cols}
             else:
                 Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
@@ -669,12 +666,7 @@ class LpProblem(object):
                 extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
         elif self.cols is not None:     # L2 / projection modes on COLUMNS (gathered rows, as the DOT branch above)
             cols = self.cols
-            Qs = split_rows(A0.index_select(0, cols.rep), K=K, is_query=True, cell_ss=want_ss)
-            if isinstance(Qs, tuple):
-                Bp_q = int(lib.kge_lp_split_rows_padded(self.B, 1))
-                ss_q = torch.zeros(Qs[1].shape[0], Bp_q, dtype=torch.float32, device=self.device)
-                ss_q[:, :self.B] = Qs[1].index_select(1, cols.col_of_q)
-                Qs = (Qs[0], ss_q)
+            Qs = split_rows(A0, K=K, is_query=True, cell_ss=want_ss, row_index=cols.rep)
             extra = {'cols': cols}
         else:
             Qs = split_rows(A0, K=K, is_query=True, cell_ss=want_ss)
@@ -707,6 +699,9 @@ class LpProblem(object):
         a.eps_scale = SPLIT_EPS_SCALE
         # thresholds written by the fused query pipeline are valid for its own true scores, once
         a.q_cell_ss, a.e2pref = _p(prep.get('q_cell_ss')), _p(sp.get('e2pref') if prep.get('q_cell_ss') is not None else None)
+        if prep.get('q_cell_ss') is not None and prep.get('cols') is not None and self.pre is None:
+            # the cell sums are per COLUMN (rows gathered inside kge_lp_split_rows): query i reads its column's
+            a.q_cell_ss_index, a.q_cell_ss_ld = _p(prep['cols'].col_of_q), prep['q_cell_ss'].shape[1]
         a.thr_ready = 1 if (prep.get('s_true_pre') is s_true and not prep.get('thr_used')) else 0
         prep['thr_used'] = True
         a.thr, a.list, a.cap = _p(prep['thr']), _p(prep['list']), prep['cap']

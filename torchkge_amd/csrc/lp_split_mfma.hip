@@ -127,6 +127,7 @@ struct SplitRowsParams {
     int units_p;
     uint4 *out;
     float *cell_ss;           // optional [units_p][rows_p]: sum of squares of the cell's 16 data values (unscaled)
+    const int64_t *row_index; // optional: output row r is built from source row row_index[r] of X0 / X1 / aug (gather)
 };
 
 // A block converts tiles of 16 rows x 16 k16 cells: 16 consecutive threads read one row's 1-KiB run (float4 loads where the
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t row = (tile / tiles_u) * 16 + tr_;
         const int u = (int)(tile % tiles_u) * 16 + tu_;
+        const int64_t srow = (p.row_index && row < p.rows) ? p.row_index[row] : row;    // (gathered source row)
         float ss = 0.f;
         if (u < p.units_p) {
             const int k0 = u * 16;
@@ -158,19 +160,19 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p
             for (int e = 0; e < 16; ++e) xs[e] = 0.f;
             if (row < p.rows) {
                 if (k0 + 16 <= p.K0 && vec0) {
-                    const float4 *src = reinterpret_cast<const float4 *>(p.X0 + row * p.ld0 + k0);
+                    const float4 *src = reinterpret_cast<const float4 *>(p.X0 + srow * p.ld0 + k0);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) { const float4 t = src[v]; xs[4 * v] = t.x; xs[4 * v + 1] = t.y; xs[4 * v + 2] = t.z; xs[4 * v + 3] = t.w; }
                 } else if (k0 >= p.K0 && k0 + 16 <= K && vec1) {
-                    const float4 *src = reinterpret_cast<const float4 *>(p.X1 + row * p.ld1 + (k0 - p.K0));
+                    const float4 *src = reinterpret_cast<const float4 *>(p.X1 + srow * p.ld1 + (k0 - p.K0));
 #pragma unroll
                     for (int v = 0; v < 4; ++v) { const float4 t = src[v]; xs[4 * v] = t.x; xs[4 * v + 1] = t.y; xs[4 * v + 2] = t.z; xs[4 * v + 3] = t.w; }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int k = k0 + e;
-                        if (k < p.K0) xs[e] = p.X0[row * p.ld0 + k];
-                        else if (k < K) xs[e] = p.X1[row * p.ld1 + (k - p.K0)];
+                        if (k < p.K0) xs[e] = p.X0[srow * p.ld0 + k];
+                        else if (k < K) xs[e] = p.X1[srow * p.ld1 + (k - p.K0)];
                     }
                 }
             }
@@ -181,9 +183,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p
                 float x = xs[e];
                 if (row < p.rows) {
                     if (k < K) ss = fmaf(x, x, ss);
-                    else if (k == K && p.aug_mode == 1) x = p.aug[row] * p.aug_mul;
+                    else if (k == K && p.aug_mode == 1) x = p.aug[srow] * p.aug_mul;
                     else if (k == K && p.aug_mode == 2) x = p.aug_mul;
-                    else if (k == K && p.aug_mode == 3) x = 0.25f * (sqrtf(p.aug[row]) + sqrtf(nmax) * 0.00390625f);
+                    else if (k == K && p.aug_mode == 3) x = 0.25f * (sqrtf(p.aug[srow]) + sqrtf(nmax) * 0.00390625f);
                 }
                 x *= scale;
                 if (row < p.rows && k == K && p.aug_mode == 3) x = fmaxf(x, 1.0f);
@@ -317,7 +319,9 @@ struct SplitThrParams {
     float4 *thr4;
     float c_acc;                    // accumulation-error coefficient per product (2: any adder; 1.25: measured model)
     int K0;                         // columns of the first K-segment (K - K0 of the second)
-    const float *q_cell_ss;         // optional [units_p][Bp] cell sums of the queries (kge_lp_split_rows) ...
+    const float *q_cell_ss;         // optional [units_p][ss_ld] cell sums of the queries (kge_lp_split_rows) ...
+    const int64_t *ss_index;        // ... read at column ss_index[i] instead of i (query columns); ss_ld = their row stride
+    int64_t ss_ld;
     const float *e2pref;            // ... and prefix squared-norm maxima of the candidates (kge_lp_split_prefix_max)
     int units_p;
 };
@@ -397,7 +401,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
         if (have_pref) {
             float prefix = 0.f;
             amag = 0.f;
-            for (int u = 0; u < p.units; ++u) split_amag_step(prefix, amag, p.q_cell_ss[(int64_t)u * p.Bp + i], p.e2pref[u]);
+            for (int u = 0; u < p.units; ++u) split_amag_step(prefix, amag, p.q_cell_ss[(int64_t)u * p.ss_ld + (p.ss_index ? p.ss_index[i] : i)], p.e2pref[u]);
         }
         if (p.mode == KGE_LP_L2_EXPAND) {
             p.thr[i] = split_thr_l2(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale, amag);
@@ -1194,7 +1198,7 @@ extern "C" int64_t kge_lp_split_rows_padded(int64_t rows, int is_query) { return
 extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1,
                                  int64_t rows, int is_query, int aug_mode, const float *aug, float aug_mul,
                                  const float *norm2max0, const float *norm2max1, void *out, float *cell_ss,
-                                 kge_stream_t stream)
+                                 const int64_t *row_index, kge_stream_t stream)
 {
     if (rows < 0 || K0 <= 0 || K1 < 0 || ld0 < K0 || (K1 > 0 && ld1 < K1) || aug_mode < 0 || aug_mode > 4)
         return KGE_EINVAL;
@@ -1210,6 +1214,7 @@ extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const flo
     p.units_p = kge_lp_split_units(K0 + K1, aug_mode != 0);
     p.out = reinterpret_cast<uint4 *>(out);
     p.cell_ss = cell_ss;
+    p.row_index = row_index;
     const int64_t total = (p.rows_p / 16) * ((p.units_p + 15) / 16);     // tiles of 16 rows x 16 cells
     if (total == 0) return 0;
     const int grid = (int)(total < 65536 ? total : 65536);
@@ -1270,6 +1275,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.xabsmax = a->xabsmax; t.yabsmax = a->yabsmax;
     t.c_acc = a->accum_model == 1 ? 1.25f : 2.0f;
     t.q_cell_ss = a->q_cell_ss; t.e2pref = a->e2pref; t.units_p = units_p; t.K0 = d->K0;
+    t.ss_index = a->q_cell_ss_index; t.ss_ld = a->q_cell_ss_index ? a->q_cell_ss_ld : Bp;
+    if (a->q_cell_ss_index && a->q_cell_ss_ld <= 0) return KGE_EINVAL;
     t.list_count = a->list_count;
     t.overflow = a->overflow;
     if (!a->thr_ready) {    // (the fused query pipeline has already written thr and zeroed list_count)
