@@ -498,8 +498,11 @@ def main():
         from torchkge_amd import distributed as kd
         kd.shard_model_(model)
         torch.cuda.empty_cache()
+    # (N > 1: graph=None = 'auto' -- first call eager, second captures, and a capture that fails on real multi-GPU
+    # hardware falls back to eager launches instead of aborting the line; every rank still issues the same collectives)
+    graph_arg = (not args.no_graph) if not multi else (None if not args.no_graph else False)
     ev = tk.LinkPredictionEvaluator(model, kg_test, fused=not args.materialize, shard=shard,
-                                    exchange=args.exchange, graph=not args.no_graph, overlap=args.overlap,
+                                    exchange=args.exchange, graph=graph_arg, overlap=args.overlap,
                                     both_sides=not args.no_both, graph_collectives=True if args.graph_collectives else None)
 
     def sync():
@@ -589,7 +592,7 @@ def main():
     if multi and shard == 'entities' and not args.materialize:
         ox = 'scores' if args.exchange == 'counts' else 'counts'
         ob = args.batch
-        ev_o = tk.LinkPredictionEvaluator(model, kg_test, shard=shard, exchange=ox, graph=not args.no_graph,
+        ev_o = tk.LinkPredictionEvaluator(model, kg_test, shard=shard, exchange=ox, graph=graph_arg,
                                           both_sides=not args.no_both,
                                           graph_collectives=True if args.graph_collectives else None)
         main_ranks = [ev.rank_true_heads.clone(), ev.rank_true_tails.clone(), ev.filt_rank_true_heads.clone(),
@@ -620,7 +623,7 @@ def main():
         kg_test_w.head_idx, kg_test_w.tail_idx, kg_test_w.relations = (kg_test_w.head_idx.to(device), kg_test_w.tail_idx.to(device),
                                                                        kg_test_w.relations.to(device))
         kd.shard_model_(m_w)
-        ev_w = tk.LinkPredictionEvaluator(m_w, kg_test_w, shard='entities', exchange='counts', graph=not args.no_graph,
+        ev_w = tk.LinkPredictionEvaluator(m_w, kg_test_w, shard='entities', exchange='counts', graph=graph_arg,
                                           graph_collectives=True if args.graph_collectives else None)
         for _ in range(3):
             ev_w.evaluate(args.batch, verbose=False)

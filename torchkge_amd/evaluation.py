@@ -160,7 +160,9 @@ class _GraphSegments(object):
 
     def begin(self):
         self._g = torch.cuda.CUDAGraph()
-        self._ctx = torch.cuda.graph(self._g, pool=self.pool)
+        # thread-local capture mode: with a RCCL process group alive its watchdog thread keeps querying events, which
+        # invalidates a capture in the default (global) mode (tools/probe/rccl_graph_probe.py)
+        self._ctx = torch.cuda.graph(self._g, pool=self.pool, capture_error_mode='thread_local')
         self._ctx.__enter__()
 
     def end(self, exc=(None, None, None)):
