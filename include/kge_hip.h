@@ -487,10 +487,19 @@ typedef struct kge_sad_args {
     int32_t cap;
     int32_t *list_count;          /* device int32 */
     float *overflow;              /* device float, set to 1.0f on overflow (see above) */
+    /* COLUMNS instead of queries (optional, as kge_split_args.col_q / members): Qi holds one row per distinct query row of
+     * the batch -- n_single_p rows whose column carries one query (col_q[column], < 0: padding), then n_multi_p rows
+     * whose column carries up to kge_lp_split_group_sets() queries (members[column * sets + j]); thr, raw_count and the
+     * pair list stay indexed by QUERY.  Both NULL: row == query. */
+    const int32_t *col_q;
+    int64_t n_single_p;
+    const int32_t *members;
+    int64_t n_multi_p;
 } kge_sad_args;
 int64_t kge_lp_sad_cols_padded(int K);
 int kge_lp_sad_rows(const float *X, int64_t ld, int64_t rows, int K, const float *emax, const float *rmax,
-                    void *out, kge_stream_t stream);
+                    void *out, const int64_t *row_index /* optional: output row r <- source row row_index[r] */,
+                    kge_stream_t stream);
 int kge_lp_sad_count(const kge_lp_desc *d, const kge_sad_args *a, const float *s_true, int32_t *raw_count,
                      kge_stream_t stream);
 /* exact re-scoring of a (query, local candidate) pair list for plain KGE_LP_L1_DIRECT / _L2_DIRECT problems:

@@ -56,6 +56,7 @@ class SadArgs(ctypes.Structure):
     _fields_ = [
         ('Qi', _vp), ('Ei', _vp), ('emax', _vp), ('rmax', _vp), ('eps_scale', ctypes.c_float),
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
+        ('col_q', _vp), ('n_single_p', _i64), ('members', _vp), ('n_multi_p', _i64),
     ]
 
 
@@ -88,7 +89,7 @@ _SIGNATURES = {
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
     'kge_topk_chunk': [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp],
-    'kge_lp_sad_rows': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp],
+    'kge_lp_sad_rows': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
     'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
@@ -148,7 +149,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 20:
+    if lib.kge_abi_version() != 21:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -454,18 +455,21 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
     return out
 
 
-def sad_rows(X, emax, rmax, K=None):
+def sad_rows(X, emax, rmax, K=None, row_index=None):
     """16-bit fixed-point operand of the L1 prefilter (kge_lp_sad_rows): (rows, K padded to 8) uint16, scaled by
     32700 / (*emax + *rmax) (device scalars: max |x| of the entity and of the relation table)."""
     lib = load_library()
     require_cuda(X, emax, rmax)
     X = f32c(X)
     rows, ld = X.shape[0], X.stride(0)
+    if row_index is not None:       # output row r <- source row row_index[r] (query columns)
+        rows = int(row_index.shape[0])
     K = X.shape[1] if K is None else K
     Kp = int(lib.kge_lp_sad_cols_padded(K))
     out = torch.empty(max(rows, 1), Kp, dtype=torch.int16, device=X.device)
     with _on(X.device):
-        _check(lib.kge_lp_sad_rows(_p(X), ld, rows, K, _p(emax), _p(rmax), _p(out), _stream()), 'kge_lp_sad_rows')
+        _check(lib.kge_lp_sad_rows(_p(X), ld, rows, K, _p(emax), _p(rmax), _p(out), _p(row_index), _stream()),
+               'kge_lp_sad_rows')
     return out
 
 
@@ -729,7 +733,9 @@ class LpProblem(object):
         (kge_lp_sad_count / kge_lp_sad_recheck); self.sad is set by the model."""
         lib = load_library()
         sd = self.sad
-        Qi = sad_rows(self.keep[0], sd['emax'], sd['rmax'], K=int(self.desc.K0))
+        cols = self.cols
+        Qi = sad_rows(self.keep[0], sd['emax'], sd['rmax'], K=int(self.desc.K0),
+                      row_index=None if cols is None else cols.rep)
         cap = int(min(max(SPLIT_LIST_PER_QUERY, self.N // 50) * self.B, 2 ** 31 - 1))
         a = SadArgs()
         thr = torch.empty(2 * self.B, dtype=torch.int32, device=self.device)
@@ -738,6 +744,9 @@ class LpProblem(object):
         a.Qi, a.Ei, a.emax, a.rmax = _p(Qi), _p(sd['Ei']), _p(sd['emax']), _p(sd['rmax'])
         a.eps_scale = SPLIT_EPS_SCALE
         a.thr, a.list, a.cap, a.list_count, a.overflow = _p(thr), _p(lst), cap, _p(n_list), _p(sd['overflow'])
+        if cols is not None:    # the fixed-point query rows are per COLUMN (distinct query rows of the batch)
+            a.col_q, a.n_single_p = _p(cols.col_q), cols.n_single_p
+            a.members, a.n_multi_p = _p(cols.members), cols.n_multi_p
         with _on(self.device):
             _check(lib.kge_lp_sad_count(ctypes.byref(self.desc), ctypes.byref(a), _p(s_true), _p(raw), _stream()),
                    'kge_lp_sad_count')

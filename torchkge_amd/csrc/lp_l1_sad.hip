@@ -35,7 +35,8 @@ constexpr int SROW = 80;               // LDS row stride in bytes (64 data + 16 
 constexpr int NT = 256, TM = 8, TN = 8, BM = 16 * TM, BN = 16 * TN;
 constexpr int STAGE_BYTES = (BM + BN) * SROW;
 constexpr int UNC_CAP = 2048;
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES + BM * 4 /* rc */ + BM * 8 /* thresholds */ + 16 + UNC_CAP * 4;
+constexpr int GSETS = 4;               // queries per grouped column (= kge_lp_split_group_sets())
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES + GSETS * (BM * 4 /* rc */ + BM * 8 /* thresholds */) + 16 + UNC_CAP * 4;
 
 __device__ __forceinline__ float sad_scale(float emax, float rmax)
 {
@@ -49,6 +50,7 @@ struct SadRowsParams {
     int K, Kp;
     const float *emax, *rmax;          // device scalars: max |x| of the entity table / of the relation table
     uint16_t *out;                     // (rows, Kp)
+    const int64_t *row_index;          // optional: output row r <- source row row_index[r] (query columns)
 };
 
 __global__ void sad_rows_kernel(const SadRowsParams p)
@@ -62,7 +64,7 @@ __global__ void sad_rows_kernel(const SadRowsParams p)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
-            float x = k < p.K ? p.X[row * p.ld + k] : 0.f;
+            float x = k < p.K ? p.X[(p.row_index ? p.row_index[row] : row) * p.ld + k] : 0.f;
             // (k >= K: both operands hold 32768 there -> |difference| = 0)
             float r = rintf(x * s);
             r = fminf(fmaxf(r, -32767.0f), 32767.0f);      // never active for |x| <= xmax (s leaves 0.2 % of slack)
@@ -123,15 +125,22 @@ struct SadParams {
     int32_t *list_count;
     float *overflow;
     int row_panels, col_tiles, tiles_per_block;
+    // COLUMNS instead of queries (kge_sad_args.col_q / members, as for the f16-split count): the operand rows are the
+    // distinct query rows of the batch; qmap[row * GS + set] = the query that compares row's distances with ITS
+    // thresholds (< 0: none); NULL: row == query
+    const int32_t *qmap;
 };
 
+// GS = 1: one query per row (optionally through qmap); GS = GSETS: grouped columns -- the distances of a row are compared
+// with the thresholds of each of its queries (the SAD sweep runs once per distinct query row)
+template <int GS>
 __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *rc = reinterpret_cast<int *>(smem + 2 * STAGE_BYTES);
-    int2 *thr_s = reinterpret_cast<int2 *>(smem + 2 * STAGE_BYTES + BM * 4);
-    int *unc_cnt = reinterpret_cast<int *>(smem + 2 * STAGE_BYTES + BM * 12);
-    unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + BM * 12 + 16);
+    int *rc = reinterpret_cast<int *>(smem + 2 * STAGE_BYTES);                                   // [GS][BM]
+    int2 *thr_s = reinterpret_cast<int2 *>(smem + 2 * STAGE_BYTES + GSETS * BM * 4);              // [GS][BM]
+    int *unc_cnt = reinterpret_cast<int *>(smem + 2 * STAGE_BYTES + GSETS * BM * 12);
+    unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + GSETS * BM * 12 + 16);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
 
     // same XCD-aware (row panel, column chunk) assignment as lp_direct_kernel
@@ -148,7 +157,6 @@ __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams 
     const int Kp = p.Kp, S = (Kp + SK - 1) / SK, G = ntiles * S;
     const int srow = tid >> 2, skc = tid & 3;       // staging: 4 threads x 16 B cover one 64-byte row segment
     uint4 stQ[2], stT[2];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     auto prefetch = [&](int g) {
         const int ti = g / S, s = g - ti * S;
         const int k = s * SK + skc * 8;
@@ -168,23 +176,30 @@ __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool qok = k_ok && row0 + srow + 64 * j < p.B, tok = k_ok && col0 + srow + 64 * j < p.N;
-            *reinterpret_cast<uint4 *>(Qs + (srow + 64 * j) * SROW + skc * 16) = qok ? stQ[j] : zero4;
-            *reinterpret_cast<uint4 *>(Ts + (srow + 64 * j) * SROW + skc * 16) = tok ? stT[j] : zero4;
+            // (component-wise selects: a select between two uint4 VALUES made hipcc index a scratch copy of them)
+            *reinterpret_cast<uint4 *>(Qs + (srow + 64 * j) * SROW + skc * 16) =
+                make_uint4(qok ? stQ[j].x : 0u, qok ? stQ[j].y : 0u, qok ? stQ[j].z : 0u, qok ? stQ[j].w : 0u);
+            *reinterpret_cast<uint4 *>(Ts + (srow + 64 * j) * SROW + skc * 16) =
+                make_uint4(tok ? stT[j].x : 0u, tok ? stT[j].y : 0u, tok ? stT[j].z : 0u, tok ? stT[j].w : 0u);
         }
     };
 
     unsigned acc[TM][TN];
-    int cnt[TM];
+    int cnt[TM];        // GS == 1: per-row counters in registers over the whole sweep; grouped columns: one LDS atomic per
+                        // (row, set) and tile instead (32 more live registers would spill next to the 64 accumulators)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         cnt[i] = 0;
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = 0u;
     }
-    if (tid < BM) {
-        const int64_t row = row0 + tid;
-        rc[tid] = 0;
-        thr_s[tid] = row < p.B ? p.thr[row] : make_int2(-1, 0);
+    for (int idx = tid; idx < BM * GS; idx += NT) {
+        const int lrow = idx / GS, gs = idx - lrow * GS;
+        const int64_t row = row0 + lrow;
+        int64_t q = -1;
+        if (row < p.B) q = p.qmap ? (int64_t)p.qmap[row * GS + gs] : row;
+        rc[gs * BM + lrow] = 0;
+        thr_s[gs * BM + lrow] = q >= 0 ? p.thr[q] : make_int2(-1, 0);      // (D < 0 never holds: such a set counts nothing)
     }
     if (tid == 0) *unc_cnt = 0;
 
@@ -230,21 +245,28 @@ __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int lrow = ty + 16 * i;
-                const int2 th = thr_s[lrow];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int lcol = tx + 16 * j;
-                    const int D = (int)acc[i][j];           // <= 65534 * Kp < 2^31 (host check)
-                    const bool in = col0 + lcol < p.N;
-                    if (in && D < th.y) {
-                        ++cnt[i];
-                        if (D > th.x) {                     // inside the band: list it
-                            const int idx = atomicAdd(unc_cnt, 1);
-                            if (idx < UNC_CAP) unc_list[idx] = ((unsigned)lcol << 8) | (unsigned)lrow;
+                for (int gs = 0; gs < GS; ++gs) {
+                    const int2 th = thr_s[gs * BM + lrow];
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int lcol = tx + 16 * j;
+                        const int D = (int)acc[i][j];           // <= 65534 * Kp < 2^31 (host check)
+                        const bool in = col0 + lcol < p.N;
+                        if (in && D < th.y) {
+                            ++c;
+                            if (D > th.x) {                     // inside the band: list it ([lcol:7][set:2][lrow:7])
+                                const int idx = atomicAdd(unc_cnt, 1);
+                                if (idx < UNC_CAP) unc_list[idx] = ((unsigned)lcol << 9) | ((unsigned)gs << 7) | (unsigned)lrow;
+                            }
                         }
                     }
-                    acc[i][j] = 0u;
+                    if (GS == 1) cnt[i] += c;
+                    else if (c) atomicAdd(&rc[gs * BM + lrow], c);
                 }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = 0u;
             }
         }
         if (g + 1 < G) stage_store(buf ^ 1, g + 1);
@@ -261,8 +283,9 @@ __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams 
                         const unsigned e = unc_list[i];
                         const int pos = base + i;
                         if ((unsigned)pos < (unsigned)p.cap) {
-                            p.list[2 * pos] = (int32_t)(row0 + (e & 255u));
-                            p.list[2 * pos + 1] = (int32_t)(col0 + (e >> 8));
+                            const int64_t rw = row0 + (e & 127u);
+                            p.list[2 * pos] = p.qmap ? p.qmap[rw * GS + ((e >> 7) & 3u)] : (int32_t)rw;
+                            p.list[2 * pos + 1] = (int32_t)(col0 + (e >> 9));
                         } else {
                             *p.overflow = 1.0f;
                         }
@@ -274,14 +297,20 @@ __global__ __launch_bounds__(NT, 2) void lp_l1_sad_count_kernel(const SadParams 
         }
     }
 
+    if (GS == 1) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-        if (cnt[i]) atomicAdd(&rc[ty + 16 * i], cnt[i]);
+        for (int i = 0; i < TM; ++i)
+            if (cnt[i]) atomicAdd(&rc[ty + 16 * i], cnt[i]);
+    }
     __syncthreads();
-    if (tid < BM) {
-        const int64_t row = row0 + tid;
-        const int v = rc[tid];
-        if (row < p.B && v) atomicAdd(&p.raw_count[row], v);
+    for (int idx = tid; idx < BM * GS; idx += NT) {
+        const int lrow = idx / GS, gs = idx - lrow * GS;
+        const int64_t row = row0 + lrow;
+        const int v = rc[gs * BM + lrow];
+        if (row < p.B && v) {
+            const int64_t q = p.qmap ? (int64_t)p.qmap[row * GS + gs] : row;
+            if (q >= 0) atomicAdd(&p.raw_count[q], v);
+        }
     }
 }
 
@@ -311,12 +340,12 @@ __global__ __launch_bounds__(64, 2) void direct_recheck_kernel(const kge_lp_desc
 extern "C" int64_t kge_lp_sad_cols_padded(int K) { return ((int64_t)K + 7) / 8 * 8; }
 
 extern "C" int kge_lp_sad_rows(const float *X, int64_t ld, int64_t rows, int K, const float *emax, const float *rmax,
-                               void *out, kge_stream_t stream)
+                               void *out, const int64_t *row_index, kge_stream_t stream)
 {
     if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
     if (rows == 0) return 0;
     if (!X || !emax || !rmax || !out) return KGE_EINVAL;
-    SadRowsParams p{X, ld, rows, K, (int)kge_lp_sad_cols_padded(K), emax, rmax, reinterpret_cast<uint16_t *>(out)};
+    SadRowsParams p{X, ld, rows, K, (int)kge_lp_sad_cols_padded(K), emax, rmax, reinterpret_cast<uint16_t *>(out), row_index};
     const int64_t total = rows * (p.Kp / 8);
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipLaunchKernelGGL(sad_rows_kernel, dim3(grid), dim3(256), 0, kge_s(stream), p);
@@ -348,22 +377,42 @@ extern "C" int kge_lp_sad_count(const kge_lp_desc *d, const kge_sad_args *a, con
     p.thr = reinterpret_cast<const int2 *>(a->thr);
     p.raw_count = raw_count;
     p.list = a->list; p.cap = a->cap; p.list_count = a->list_count; p.overflow = a->overflow;
-    p.row_panels = (int)((d->B + BM - 1) / BM);
     p.col_tiles = (int)((d->N + BN - 1) / BN);
-    const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 16384);
-    int chunks = (target_blocks + p.row_panels - 1) / p.row_panels;
-    if (chunks > p.col_tiles) chunks = p.col_tiles;
-    if (chunks < 1) chunks = 1;
-    p.tiles_per_block = (p.col_tiles + chunks - 1) / chunks;
-    const int col_chunks = (p.col_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lp_l1_sad_count_kernel),
+    p.qmap = nullptr;
+    auto launch = [&](auto kern, int64_t rows) -> int {
+        p.B = rows;
+        p.row_panels = (int)((rows + BM - 1) / BM);
+        const int target_blocks = kge_env_int("KGE_LP_TARGET_BLOCKS", 16384);
+        int chunks = (target_blocks + p.row_panels - 1) / p.row_panels;
+        if (chunks > p.col_tiles) chunks = p.col_tiles;
+        if (chunks < 1) chunks = 1;
+        p.tiles_per_block = (p.col_tiles + chunks - 1) / chunks;
+        const int col_chunks = (p.col_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        hipLaunchKernelGGL(kern, dim3(p.row_panels * col_chunks), dim3(NT), SMEM_BYTES, st, p);
+        return 0;
+    };
+    if (a->col_q || a->members) {
+        // columns: Qi holds n_single_p rows with one query each (col_q), then n_multi_p rows with up to GSETS queries
+        if (a->n_single_p < 0 || a->n_multi_p < 0 || (a->n_single_p > 0 && !a->col_q) || (a->n_multi_p > 0 && !a->members))
+            return KGE_EINVAL;
+        if (a->n_single_p > 0) {
+            p.qmap = a->col_q;
+            rc = launch(lp_l1_sad_count_kernel<1>, a->n_single_p);
+            if (rc) return rc;
+        }
+        if (a->n_multi_p > 0) {
+            p.qmap = a->members;
+            p.Q = reinterpret_cast<const uint16_t *>(a->Qi) + a->n_single_p * p.ldq;
+            rc = launch(lp_l1_sad_count_kernel<GSETS>, a->n_multi_p);
+            if (rc) return rc;
+        }
+    } else {
+        rc = launch(lp_l1_sad_count_kernel<1>, d->B);
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL(lp_l1_sad_count_kernel, dim3(p.row_panels * col_chunks), dim3(NT), SMEM_BYTES, st, p);
     KGE_CHECK_LAUNCH();
     return 0;
 }
