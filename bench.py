@@ -764,7 +764,8 @@ def main():
             extra = {'note': 'ranks are bit-identical to the fp32 VALU path (pairs inside the proven error band are re-scored '
                              'exactly by kge_lp_sad_recheck); achieved = 3K fp32-equivalent flop per pair over the time of '
                              'the whole count (thresholds + SAD kernel + recheck), peak = fp32 VALU; the SAD kernel itself '
-                             'issues K/2 half-rate integer ops per pair'}
+                             'issues K/2 half-rate integer ops per pair and, since r03, sweeps the distinct query rows only -- '
+                             'frac > 1 means: faster than ANY fp32 VALU kernel could do the same algorithmic work'}
         else:
             alg_flops = 3 * K               # sub, mul|abs, add on the VALU
             kname, ksym, peak, bound = 'lp_direct_kernel (fp32 VALU)', 'lp_direct_kernel', PEAK_FP32_TFLOPS, 'valu'
