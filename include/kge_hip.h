@@ -252,6 +252,12 @@ int kge_lp_pair_scores(const kge_lp_desc *d, const int64_t *qi, const int64_t *c
  * caller zeroes raw_count).  No score is written to memory. */
 int kge_lp_count_ge(const kge_lp_desc *d, const float *s_true, int32_t *raw_count,
                     kge_stream_t stream);
+/* The same counts for a plain KGE_LP_L2_DIRECT problem (no rank-1 term, 16-byte aligned operands, K0 % 4 == 0) swept over
+ * query COLUMNS (see kge_split_args.col_q): column r is scored with query row rep[r]; columns [0, n_single_p) carry one
+ * query each (col_q), the next n_multi_p up to kge_lp_split_group_sets() (members); raw_count stays indexed by query. */
+int kge_lp_count_ge_cols(const kge_lp_desc *d, const float *s_true, int32_t *raw_count, const int64_t *rep,
+                         const int32_t *col_q, int64_t n_single_p, const int32_t *members, int64_t n_multi_p,
+                         kge_stream_t stream);
 
 /* per query i with filter segment targets[seg_lo[i]:seg_hi[i]) (GLOBAL ids):
  *   sub[i]   = sum over c in segment, c != true_idx[i], c in shard of

@@ -1265,7 +1265,7 @@ def test_split_count_on_query_columns_equals_per_query_counts(hip, eps):
     assert int(raws[0].min()) >= 1
 
 
-@pytest.mark.parametrize('kind', ['transe', 'transe_l1', 'distmult', 'complex', 'transh', 'transd'])
+@pytest.mark.parametrize('kind', ['transe', 'transe_l1', 'transe_direct', 'distmult', 'complex', 'transh', 'transd'])
 def test_evaluator_dedupes_query_rows_and_keeps_the_ranks(hip, monkeypatch, kind):
     """evaluate() on a graph with hub keys (TransE-L2: fused query pipeline writing one split row per column; DistMult /
     ComplEx: rows gathered per column): identical rank vectors with the ColumnPlan path on (default) and off
@@ -1274,9 +1274,12 @@ def test_evaluator_dedupes_query_rows_and_keeps_the_ranks(hip, monkeypatch, kind
     import torchkge_amd.evaluation as evm
     n_ent, n_rel, d = 3001, 9, 64
     p_norm = 1 if kind == 'transe_l1' else 2           # (TransE-L1: the SAD prefilter sweeps the columns)
-    kind = 'transe' if kind == 'transe_l1' else kind
+    direct = kind == 'transe_direct'                   # (l2_mode='direct': the packed-FMA broadcast-subtract count does)
+    kind = 'transe' if kind in ('transe_l1', 'transe_direct') else kind
     tables = orc.init_tables(kind, n_ent, n_rel, d, seed=6)
     m = build_model(kind, p_norm, tables, n_ent, n_rel)
+    if direct:
+        m.l2_mode = 'direct'
     h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 30000, 3, hubs=((900, 'head'), (400, 'tail')))
     kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
                            rel2ix={i: i for i in range(n_rel)})

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     out = subprocess.check_output(['nm', '-D', '--defined-only', _hip.LIB_PATH], text=True)
     assert declared <= set(re.findall(r' T (kge_[a-z0-9_]+)', out))
-    assert lib.kge_abi_version() == 21 and lib.kge_build_arch() == b'gfx950'
+    assert lib.kge_abi_version() == 22 and lib.kge_build_arch() == b'gfx950'
     # the descriptor struct mirrors the header field for field
     fields = re.search(r'typedef struct kge_lp_desc \{(.*?)\} kge_lp_desc;', hdr, re.S).group(1)
     names = re.findall(r'\b(\w+)\s*(?:;|,)', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))

@@ -88,6 +88,7 @@ _SIGNATURES = {
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
+    'kge_lp_count_ge_cols': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     'kge_topk_chunk': [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp],
     'kge_lp_sad_rows': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
@@ -149,7 +150,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 21:
+    if lib.kge_abi_version() != 22:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -636,6 +637,16 @@ class LpProblem(object):
             return self._count_ge_split(s_true, raw)
         if self.sad is not None and self.B > 0 and self.N > 0:
             return self._count_ge_sad(s_true, raw)
+        cols = self.cols
+        if (cols is not None and int(self.desc.mode) == LP_L2_DIRECT and not self.desc.Wq and self.N > 0
+                and int(self.desc.K0) % 4 == 0 and self.desc.lda0 % 4 == 0 and self.desc.ldt0 % 4 == 0
+                and self.desc.A0 % 16 == 0 and self.desc.T0 % 16 == 0):
+            # plain L2 broadcast-subtract counts over the batch's distinct query rows (packed-FMA kernel)
+            with _on(self.device):
+                _check(lib.kge_lp_count_ge_cols(ctypes.byref(self.desc), _p(s_true), _p(raw), _p(cols.rep), _p(cols.col_q),
+                                                cols.n_single_p, _p(cols.members), cols.n_multi_p, _stream()),
+                       'kge_lp_count_ge_cols')
+            return raw
         with _on(self.device):
             _check(lib.kge_lp_count_ge(ctypes.byref(self.desc), _p(s_true), _p(raw), _stream()),
                    'kge_lp_count_ge')

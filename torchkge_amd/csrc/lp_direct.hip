@@ -30,6 +30,10 @@ struct DirectParams {
     int *raw_count;
     int row_panels, col_tiles, tiles_per_block, col_chunks;
     int out_vec4;       // out rows are 16-byte aligned (ldo % 4 == 0, aligned base): float4 stores
+    // COUNT over query COLUMNS (packed L2 kernel, no rank-1 term): row r of the problem is the query row rep[r];
+    // qmap[r * GS + set] = the query that compares row r's scores with ITS true score (< 0: none); NULL: row == query
+    const int64_t *rep;
+    const int32_t *qmap;
 };
 
 template <bool VEC4>
@@ -304,9 +308,10 @@ __device__ __forceinline__ f32x2 pk_sq_acc(f32x2 d, f32x2 acc)
 
 constexpr int LDT_PK = BN + 4;      // row stride (floats) of the transposed candidate tile
 
-template <bool AXPY, bool COUNT, int TM>
+template <bool AXPY, bool COUNT, int TM, int GS = 1>
 __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_pk_kernel(const DirectParams p)
 {
+    static_assert(GS == 1 || (COUNT && !AXPY), "grouped columns: plain L2 counts only");
     constexpr int BM = 16 * TM;
     constexpr int QCH = BM * 4 / NTHREADS;
     constexpr int Q_FLOATS = BM * LDS_LD, T_FLOATS = BK * LDT_PK;
@@ -346,9 +351,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_pk_kernel(const DirectP
         const int64_t col0 = (int64_t)(tile_begin + ti) * BN;
 #pragma unroll
         for (int j = 0; j < QCH; ++j) {
-            const int64_t r = row0 + srow + 64 * j;
-            stQ[j][0] = ld4(d.A0, d.lda0, r, d.B - 1, kq);
-            stQ[j][1] = ld4(d.A0, d.lda0, r, d.B - 1, kq + 4);
+            int64_t r = row0 + srow + 64 * j;
+            if (p.rep) r = p.rep[min(r, d.B - 1)];          // (column -> the query row that provides it)
+            stQ[j][0] = ld4(d.A0, d.lda0, r, p.rep ? INT64_MAX : d.B - 1, kq);
+            stQ[j][1] = ld4(d.A0, d.lda0, r, p.rep ? INT64_MAX : d.B - 1, kq + 4);
             if (AXPY) {
                 stW[j][0] = ld4(d.Wq, d.ldw, r, d.B - 1, kq);
                 stW[j][1] = ld4(d.Wq, d.ldw, r, d.B - 1, kq + 4);
@@ -401,12 +407,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_pk_kernel(const DirectP
         for (int j = 0; j < TN / 2; ++j) acc[i][j] = (f32x2){0.f, 0.f};
     }
 
-    int *rc = reinterpret_cast<int *>(smem + 2 * BUF_FLOATS);
-    float *st_s = smem + 2 * BUF_FLOATS + BM;
-    if (tid < BM) {
-        const int64_t row = row0 + tid;
-        rc[tid] = 0;
-        st_s[tid] = (COUNT && row < d.B) ? p.s_true[row] : 0.f;
+    int *rc = reinterpret_cast<int *>(smem + 2 * BUF_FLOATS);        // [GS][BM]
+    float *st_s = smem + 2 * BUF_FLOATS + GS * BM;                    // [GS][BM]
+    for (int idx = tid; idx < BM * GS; idx += NTHREADS) {
+        const int lrow = idx / GS, gs = idx - lrow * GS;
+        const int64_t row = row0 + lrow;
+        int64_t q = -1;
+        if (COUNT && row < d.B) q = p.qmap ? (int64_t)p.qmap[row * GS + gs] : row;
+        rc[gs * BM + lrow] = 0;
+        st_s[gs * BM + lrow] = q >= 0 ? p.s_true[q] : INFINITY;      // (+inf: "sc >= st" never holds -> counts nothing)
     }
 
     auto load_av = [&](int ti) {
@@ -484,7 +493,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_pk_kernel(const DirectP
             for (int i = 0; i < TM; ++i) {
                 const int lrow = ty + 16 * i;
                 const int64_t row = row0 + lrow;
-                const float stv = COUNT ? st_s[lrow] : 0.f;
                 float sc[TN];
 #pragma unroll
                 for (int jj = 0; jj < TN / 2; ++jj) {
@@ -493,7 +501,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_pk_kernel(const DirectP
                 }
                 if (COUNT) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) cnt[i] += (sc[j] >= stv) ? (col0 + j < d.N ? 1 : 0) : 0;
+                    for (int gs = 0; gs < GS; ++gs) {       // a column's scores against the true score of each of its queries
+                        const float stv = st_s[gs * BM + lrow];
+                        int c = 0;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) c += (sc[j] >= stv) ? (col0 + j < d.N ? 1 : 0) : 0;
+                        if (GS == 1) cnt[i] += c;
+                        else if (c) atomicAdd(&rc[gs * BM + lrow], c);
+                    }
                 } else if (row < d.B) {
                     float *o = p.out + row * p.ldo + col0;
                     if (col0 + TN <= d.N && p.out_vec4) {
@@ -513,25 +528,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void lp_direct_pk_kernel(const DirectP
     }
 
     if (COUNT) {
+        if (GS == 1) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            if (cnt[i]) atomicAdd(&rc[ty + 16 * i], cnt[i]);
+            for (int i = 0; i < TM; ++i)
+                if (cnt[i]) atomicAdd(&rc[ty + 16 * i], cnt[i]);
+        }
         __syncthreads();
-        if (tid < BM) {
-            const int64_t row = row0 + tid;
-            const int v = rc[tid];
-            if (row < d.B && v) atomicAdd(&p.raw_count[row], v);
+        for (int idx = tid; idx < BM * GS; idx += NTHREADS) {
+            const int lrow = idx / GS, gs = idx - lrow * GS;
+            const int64_t row = row0 + lrow;
+            const int v = rc[gs * BM + lrow];
+            if (row < d.B && v) {
+                const int64_t q = p.qmap ? (int64_t)p.qmap[row * GS + gs] : row;
+                if (q >= 0) atomicAdd(&p.raw_count[q], v);
+            }
         }
     }
 }
 
-template <bool AXPY, bool COUNT>
+template <bool AXPY, bool COUNT, int GS = 1>
 int launch_pk(DirectParams &p, hipStream_t s)
 {
     constexpr int TM = AXPY ? 4 : 8;
     constexpr int BM = 16 * TM;
     constexpr int BUF_FLOATS = BM * LDS_LD * (AXPY ? 2 : 1) + BK * LDT_PK;
-    constexpr int SMEM_BYTES = 2 * BUF_FLOATS * 4 + 2 * BM * 4;
+    constexpr int SMEM_BYTES = 2 * BUF_FLOATS * 4 + 2 * GS * BM * 4;
     const kge_lp_desc &d = p.d;
     p.row_panels = (int)((d.B + BM - 1) / BM);
     p.col_tiles = (int)((d.N + BN - 1) / BN);
@@ -542,7 +563,7 @@ int launch_pk(DirectParams &p, hipStream_t s)
     p.tiles_per_block = (p.col_tiles + chunks - 1) / chunks;
     p.col_chunks = (p.col_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
     const int grid = p.row_panels * p.col_chunks;
-    auto k = lp_direct_pk_kernel<AXPY, COUNT, TM>;
+    auto k = lp_direct_pk_kernel<AXPY, COUNT, TM, GS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -595,12 +616,40 @@ int dispatch2(DirectParams &p, bool axpy, bool count, hipStream_t s)
 
 } // namespace
 
+// Rank counts of a plain KGE_LP_L2_DIRECT problem over query COLUMNS (the packed-FMA kernel): rows [0, n_single_p) carry
+// one query each (col_q), rows [n_single_p, n_single_p + n_multi_p) up to 4 (members); row r is the query row rep[r].
+int kge_lp_direct_count_cols(const kge_lp_desc *d, const float *s_true, int32_t *raw_count, const int64_t *rep,
+                             const int32_t *col_q, int64_t n_single_p, const int32_t *members, int64_t n_multi_p,
+                             hipStream_t s)
+{
+    if (d->mode != KGE_LP_L2_DIRECT || d->Wq || !rep || !s_true || !raw_count) return KGE_EINVAL;
+    if (!((d->K0 % 4 == 0) && (d->lda0 % 4 == 0) && (d->ldt0 % 4 == 0) && kge_aligned16(d->A0) && kge_aligned16(d->T0)))
+        return KGE_EINVAL;
+    if (n_single_p < 0 || n_multi_p < 0 || (n_single_p > 0 && !col_q) || (n_multi_p > 0 && !members)) return KGE_EINVAL;
+    if (d->N == 0) return 0;
+    DirectParams p;
+    p.d = *d;
+    p.out = nullptr; p.ldo = 0; p.s_true = s_true; p.raw_count = raw_count; p.out_vec4 = 0;
+    int rc = 0;
+    if (n_single_p > 0) {
+        p.d.B = n_single_p; p.rep = rep; p.qmap = col_q;
+        rc = launch_pk<false, true, 1>(p, s);
+        if (rc) return rc;
+    }
+    if (n_multi_p > 0) {
+        p.d.B = n_multi_p; p.rep = rep + n_single_p; p.qmap = members;
+        rc = launch_pk<false, true, 4>(p, s);
+    }
+    return rc;
+}
+
 int kge_lp_direct_run(const kge_lp_desc *d, float *out, int64_t ldo, const float *s_true,
                       int32_t *raw_count, hipStream_t s)
 {
     if (d->B == 0 || d->N == 0) return 0;
     if ((out != nullptr) == (raw_count != nullptr)) return KGE_EINVAL;
     DirectParams p;
+    p.rep = nullptr; p.qmap = nullptr;
     p.d = *d;
     p.out = out;
     p.ldo = ldo;

@@ -9,6 +9,9 @@
 
 int kge_lp_gemm_run(const kge_lp_desc *d, float *out, int64_t ldo, const float *s_true,
                     int32_t *raw_count, hipStream_t s);
+int kge_lp_direct_count_cols(const kge_lp_desc *d, const float *s_true, int32_t *raw_count, const int64_t *rep,
+                             const int32_t *col_q, int64_t n_single_p, const int32_t *members, int64_t n_multi_p,
+                             hipStream_t s);
 int kge_lp_direct_run(const kge_lp_desc *d, float *out, int64_t ldo, const float *s_true,
                       int32_t *raw_count, hipStream_t s);
 
@@ -770,6 +773,16 @@ extern "C" int kge_lp_count_ge(const kge_lp_desc *d, const float *s_true, int32_
     return kge_lp_direct_run(d, nullptr, 0, s_true, raw_count, kge_s(stream));
 }
 
+extern "C" int kge_lp_count_ge_cols(const kge_lp_desc *d, const float *s_true, int32_t *raw_count, const int64_t *rep,
+                                    const int32_t *col_q, int64_t n_single_p, const int32_t *members, int64_t n_multi_p,
+                                    kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0 || d->N == 0) return 0;
+    return kge_lp_direct_count_cols(d, s_true, raw_count, rep, col_q, n_single_p, members, n_multi_p, kge_s(stream));
+}
+
 extern "C" int kge_lp_pair_scores(const kge_lp_desc *d, const int64_t *qi, const int64_t *ci, int64_t P,
                                   float *out, kge_stream_t stream)
 {
@@ -981,5 +994,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 21; }
+extern "C" int kge_abi_version(void) { return 22; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

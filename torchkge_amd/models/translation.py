@@ -105,8 +105,10 @@ class TransEModel(TranslationModel):
         Q0, _, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)
         prob = self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
-        # (L2: f16-split count over columns; L1: the SAD count over columns)
-        prob.cols = cols if (sd == _hip.SIDE_BOTH and (prob.split is not None or prob.sad is not None)) else None
+        # (L2: f16-split count over columns; L1: the SAD count; broadcast-subtract L2: the packed-FMA count)
+        plain_l2_direct = int(prob.desc.mode) == _hip.LP_L2_DIRECT and not prob.desc.Wq    # (kge_lp_count_ge_cols)
+        prob.cols = cols if (sd == _hip.SIDE_BOTH and (prob.split is not None or prob.sad is not None or plain_l2_direct)) \
+            else None
         return prob
 
     def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs, cols=None):
