@@ -12,14 +12,16 @@ the model tables, the test triples and the filter index already resident in HBM.
 Metric = link-prediction triples scored / second (whole job, all ranks).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
-  --scaling weak --shard entities  (default) the entity table grows to N dataset-sized
-                   shards; every rank scores ITS entity shard for all test triples and the
-                   ranks exchange over RCCL: the owner's true scores (all-reduce of B floats)
-                   and the partial rank counts (all-reduce of 3*B int32), or with
-                   --exchange scores the partial score tiles themselves (all-gather).
+  --scaling strong --shard entities  (default) the ONE dataset-sized job BASELINE.json names with the entity
+                   tables row-sharded: every rank scores ITS N/P candidates for all test triples and the ranks meet
+                   in the exchange north_star names -- the partial score tiles, as an all-to-all in which every rank
+                   receives (and ranks) only the rows of its 2B/P queries (--exchange scores, the headline) -- or in
+                   one all-reduce of the (3, 2B) partial rank counts (--exchange counts; timed beside the headline).
+  --scaling weak --shard entities  the entity table grows to N dataset-sized shards (also reported beside a
+                   strong run: weak_mode).
   --scaling weak --shard queries   independent replicas: every rank evaluates its own
                    dataset-sized test split against its replica of the tables (no collective).
-  --scaling strong --shard entities | queries   one dataset-sized job split across ranks.
+  --scaling strong --shard queries   the test facts split across ranks, tables replicated.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
 objects: "roofline" (dominant kernel timed live with HIP events on the launch
@@ -79,9 +81,10 @@ def parse():
     ap.add_argument('--shard', default='entities', choices=['entities', 'queries'],
                     help='N>1: what is partitioned across ranks (weak+queries = independent replicas)')
     ap.add_argument('--exchange', default=None, choices=['counts', 'scores'],
-                    help="entity shards: what the ranks exchange.  Default for N>1: 'scores' = the RCCL all-gather of the "
-                         "partial (B, N/P) score tiles north_star names; the other exchange is timed beside it at the same "
-                         "b_size (other_exchange).  'counts' = one all-reduce of 3 x 2B int32 per batch, bit-identical ranks")
+                    help="entity shards: what the ranks exchange.  Default for N>1: 'scores' = the partial (2B, N/P) score "
+                         "tiles north_star names, exchanged as an RCCL all-to-all of row blocks (every rank receives and "
+                         "ranks only its 2B/P queries); the other exchange is timed beside it at the same b_size "
+                         "(other_exchange).  'counts' = one all-reduce of 3 x 2B int32 per batch, bit-identical ranks")
     ap.add_argument('--no-weak', action='store_true', help='N>1 strong run: skip the secondary weak-scaling measurement')
     ap.add_argument('--tables', default='sharded', choices=['sharded', 'replicated'],
                     help='entity shards: each rank HOLDS only its rows of the entity tables (default) or a full replica')
@@ -574,17 +577,41 @@ def main():
             el = float(tt_.item())
         return el
 
-    def collective_ms(evx, bsz, n=3):
-        """Device time of the data-path collectives per evaluate() (events around every RCCL call on the launch stream)."""
+    def modelled_xgmi(exchange, n_ent_all):
+        """Fabric time of one evaluate()'s rank exchange FROM BYTES: MI355X has 7 xGMI links per GPU, one per peer on an
+        8-GPU node, 153.6 GB/s each bidirectional = 76.8 GB/s per direction (the task's '7 x ~153 GB/s'); a direct
+        all-to-all / all-gather drives every link at once, so time = bytes one link carries in one direction / 76.8e9."""
+        n2 = 2 * n_test
+        per = -(-n_ent_all // world)
+        if exchange == 'scores':        # all-to-all of row tiles: one (2B/P, N/P) block to every peer
+            link = -(-n2 // world) * per * 4
+            what = 'all-to-all of (2B/P, N/P) fp32 score blocks + one int64 all-reduce of the (4, n) ranks'
+            sent = link * (world - 1) + 2 * 4 * n_test * 8 * (world - 1) // max(world, 1)
+        else:                           # counts: (3, 2B) int32 ring all-reduce, 2 (P-1)/P of the buffer per link
+            link = 2 * (world - 1) * 3 * n2 * 4 // max(world, 1)
+            what = 'all-reduce of the (3, 2B) int32 partial counts'
+            sent = link
+        if world == 1:
+            link = sent = 0
+        return {'what': what, 'bytes_sent_per_rank': int(sent), 'bytes_per_link_and_direction': int(link),
+                'link_GBps_per_direction': 76.8, 'ms': round(link / 76.8e9 * 1e3, 4),
+                'note': 'bandwidth term only: every collective also pays ~10-30 us of launch / protocol latency'}
+
+    def collective_ms(evx, bsz, n=3, exchange=None, n_ent_all=None):
+        """Device time of the data-path collectives per evaluate() (events around every RCCL call on the launch stream),
+        with the fabric time modelled from the bytes beside it."""
         evx.collective_timing(True)
         for _ in range(n):
             evx.evaluate(bsz, verbose=False)
         c = evx.collective_timing(False)
-        return {'collectives_per_evaluate': c['collectives'] // n, 'ms_per_evaluate': round(c['ms'] / n, 4)}
+        out = {'collectives_per_evaluate': c['collectives'] // n, 'ms_per_evaluate': round(c['ms'] / n, 4)}
+        if exchange is not None:
+            out['modelled_xgmi'] = modelled_xgmi(exchange, n_ent_all if n_ent_all is not None else n_ent)
+        return out
 
     headline_coll = None
     if multi and shard == 'entities' and not args.materialize and device.type == 'cuda':
-        headline_coll = collective_ms(ev, args.batch)
+        headline_coll = collective_ms(ev, args.batch, exchange=args.exchange)
 
     # entity shards: the OTHER exchange measured beside the headline one, at the SAME b_size -- the all-gather of the
     # partial score tiles (B, N/P) -> (B, N) that north_star names, vs the all-reduce of rank counts (bit-identical ranks)
@@ -605,9 +632,10 @@ def main():
                                                                     ev_o.filt_rank_true_heads, ev_o.filt_rank_true_tails]))
         other_x = {'exchange': ox, 'b_size': ob, 'steps': n_o, 'ms_per_step': round(el_o / n_o * 1e3, 4),
                    'value': round(n_test * 2 * n_ent * n_o / el_o, 1), 'ranks_identical_to_headline_run': bool(same_o),
-                   'collective': 'RCCL all-gather of the (B, N/P) score tiles' if ox == 'scores'
+                   'collective': 'RCCL all-to-all of the partial score tiles: every rank receives the (2B/P, N) score rows '
+                                 'of the queries it ranks as P rank-major (2B/P, N/P) tiles' if ox == 'scores'
                                  else 'RCCL all-reduce of the (3, 2B) rank counts (+ one all-gather of the query-entity rows per evaluate)',
-                   'collective_time': collective_ms(ev_o, ob) if device.type == 'cuda' else None}
+                   'collective_time': collective_ms(ev_o, ob, exchange=ox) if device.type == 'cuda' else None}
         del ev_o
 
     # ... and, beside a strong-scaling run, the WEAK mode: the entity table grown to N dataset-sized shards (Xavier
@@ -633,7 +661,8 @@ def main():
                      'weights': 'xavier', 'steps': n_w, 'ms_per_step': round(el_w / n_w * 1e3, 4),
                      'value': round(n_test * 2 * info_w['n_ent'] * n_w / el_w, 1),
                      'scored_triples_per_step': n_test * 2 * info_w['n_ent'],
-                     'collective_time': collective_ms(ev_w, args.batch) if device.type == 'cuda' else None}
+                     'collective_time': collective_ms(ev_w, args.batch, exchange='counts', n_ent_all=info_w['n_ent'])
+                     if device.type == 'cuda' else None}
         del ev_w, m_w, kg_w, kg_test_w
         torch.cuda.empty_cache()
 
@@ -1024,7 +1053,7 @@ def main():
         elif shard == 'entities':
             par = 'entity-shards-%d (row-sharded tables), RCCL %s' % (
                 world, 'all-reduce of the (3, 2B) rank counts' if args.exchange == 'counts'
-                else 'all-gather of the partial (B, N/P) score tiles -> (B, N) on every rank')
+                else 'all-to-all of the partial (2B, N/P) score tiles: each rank receives and ranks the rows of its 2B/P queries')
         else:
             par = 'query-shards-%d' % world
         used_split = bool(roof and 'executed_frac' in roof)
@@ -1046,7 +1075,7 @@ def main():
                                    'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
                                        kind, d, p, shape + (' x%d entity shards' % world if ent_weak else ''), n_ent_full, n_rel, n_test, args.batch),
                        'parallelism': par, 'fused_rank': not args.materialize, 'hip_graph': (not args.no_graph) and (not multi or shard == 'queries' or
-                                                               (shard == 'entities' and args.exchange == 'counts'
+                                                               (shard == 'entities'
                                                                 and not args.materialize and not args.no_both)),
                        'collectives_in_graph': bool(getattr(ev, 'graph_collectives', False)) and multi and shard == 'entities',
                        'scored_triples_per_step': total_units},

@@ -348,6 +348,17 @@ int kge_filtered_rank_from_scores(const float *scores, int64_t ld, const int64_t
                                   const int32_t *targets, int64_t B, int64_t N, int64_t *rank,
                                   int64_t *filt_rank, kge_stream_t stream);
 
+/* The same for score rows that arrive as `world` RANK-MAJOR tiles -- the receive buffer of kge_alltoall_scores
+ * (kge_hip_coll.h): tile p = (m, per) fp32 holds the scores of GLOBAL candidates [p*per, min(N, (p+1)*per)), row i of
+ * every tile belongs to query q_first + i of a 2B-query batch (tail-side queries first).  true_idx / seg_lo / seg_hi
+ * point at the first of the `rows` (<= m) queries; the true score is read from the tiles like the reference reads it
+ * from the score matrix (evaluation.py:291-300).  No (B, N) re-layout: every tile row is streamed where it lies.
+ * Ranks go straight into the (4, ld) result matrix of kge_rank_finalize_both (same off / pos meaning). */
+int kge_filtered_rank_from_tiles(const float *tiles, int64_t m, int64_t per, int world, int64_t N,
+                                 const int64_t *true_idx, const int64_t *seg_lo, const int64_t *seg_hi,
+                                 const int32_t *targets, int64_t rows, int64_t q_first, int64_t B,
+                                 int64_t *out, int64_t ld, int64_t off, const int64_t *pos, kge_stream_t stream);
+
 /* top-k per row in the order (score descending, index ascending); replaces the
  * full `scores.sort(descending=True)` + slice of EntityInference /
  * RelationInference (inference.py:148-150, :243-245).  out_idx/out_val: (B,k). */

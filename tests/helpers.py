@@ -131,6 +131,23 @@ class OracleRankEngine(object):
     def local_scores(self, prob):
         return prob.full[:, prob.lo:prob.hi].contiguous()
 
+    def score_rows(self, prob, q0, q1, out):
+        loc = self.local_scores(prob)
+        out[:q1 - q0, :loc.shape[1]] = loc[q0:q1]
+        return out
+
+    def rank_tiles(self, tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None):
+        """Rank-major tiles (P, m, per) of the score all-to-all -> ranks of `rows` queries, written like finalize_both."""
+        assert pos is None
+        P, m, per = tiles.shape
+        full = tiles.permute(1, 0, 2).reshape(m, P * per)[:rows, :n_total]
+        rk, frk = self.ranks_from_scores(full, true_idx[:rows], seg_lo[:rows], seg_hi[:rows], targets)
+        for i in range(rows):
+            q = q_first + i
+            tail = q < B
+            f = off + (q if tail else q - B)
+            out[1 if tail else 0, f], out[3 if tail else 2, f] = rk[i], frk[i]
+
     def ranks_from_scores(self, scores, true_idx, seg_lo, seg_hi, targets):
         B = scores.shape[0]
         rk = torch.empty(B, dtype=torch.long)

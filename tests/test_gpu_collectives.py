@@ -69,6 +69,12 @@ def test_c_abi_collectives_world_of_one():
         assert torch.equal(comm.allreduce_sum(x), xr)
         true = torch.randint(0, N, (B,), device='cuda', generator=g)
         assert torch.equal(_hip.get_rank(full, true), _hip.get_rank(local, true))
+        # the score all-to-all on one rank = the own block's device copy; the int64 rank all-reduce = identity
+        tiles = comm.alltoall_scores(local)
+        assert tiles.shape == (1, B, N) and torch.equal(tiles[0], local)
+        rk = torch.randint(0, 10 ** 12, (4, B), device='cuda', dtype=torch.int64)
+        rk0 = rk.clone()
+        assert torch.equal(comm.allreduce_ranks(rk), rk0)
         torch.cuda.synchronize()
     finally:
         comm.close()
@@ -114,7 +120,14 @@ ok = True
 for exchange, graph, qx, co in (('counts', False, 'evaluate', None), ('counts', True, 'evaluate', None),
                                 ('counts', False, 'batch', None), ('counts', True, 'batch', None),
                                 ('scores', False, 'evaluate', None), ('counts', True, 'evaluate', 0),
-                                ('counts', False, 'batch', 0)):
+                                ('counts', False, 'batch', 0),
+                                # the score ALL-TO-ALL (r04): as hipGraph segments, multi-batch, and cut into several row
+                                # tiles per batch ('tiles': 64 rows x P ranks per all-to-all, the last tile short)
+                                ('scores', True, 'evaluate', None), ('scores', False, 'batch', 0),
+                                ('scores', True, 'evaluate', 'tiles')):
+    import torchkge_amd.evaluation as ev_mod
+    ev_mod.SCORE_TILE_BYTES = (4 * kd.shard_size(n_ent, world) * world * 64) if co == 'tiles' else (256 << 20)
+    co = None if co == 'tiles' else co
     ev = tk.LinkPredictionEvaluator(m, kg_test, shard='entities', exchange=exchange, graph=graph, query_exchange=qx,
                                     coalesce=co)
     for _ in range(2):
@@ -159,3 +172,53 @@ def test_row_sharded_entity_tables_two_ranks_on_one_gpu(kind, world, tmp_path):
                               env=env, cwd=ROOT) for r in range(world)]
     codes = [p.wait(timeout=600) for p in procs]
     assert codes == [0] * world
+
+
+@pytest.mark.parametrize('world,N,B', [(1, 777, 9), (2, 1001, 33), (3, 1000, 64), (8, 14541, 50), (8, 4097, 7)])
+def test_rank_from_rank_major_tiles_equals_rank_from_the_score_matrix(world, N, B):
+    """kge_filtered_rank_from_tiles on P VIRTUAL shards of one device: the (2B, N) score matrix cut into the rank-major
+    tiles the score all-to-all delivers ((P, m, per), short last shard, garbage in the padding columns / rows) ranks
+    exactly like kge_filtered_rank_from_scores on the matrix itself -- raw and filtered, exact ties, -inf scores,
+    filter lists with the true entity present / absent / empty, ranks written through off / pos."""
+    import torch
+    from torchkge_amd import _hip
+    _hip.load_library()
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(world * 1000 + N)
+    n2 = 2 * B
+    scores = torch.randn(n2, N, device=dev, generator=g)
+    scores = (scores * 4).round() / 4                      # plenty of exact ties
+    scores[torch.rand(n2, N, device=dev, generator=g) < 0.01] = float('-inf')
+    true = torch.randint(0, N, (n2,), device=dev, generator=g)
+    # filter segments: lengths 0 .. 40, the true entity planted in two thirds of the non-empty ones
+    lens = torch.randint(0, 41, (n2,), device=dev, generator=g)
+    seg_hi = torch.cumsum(lens, 0)
+    seg_lo = seg_hi - lens
+    targets = torch.randint(0, N, (int(seg_hi[-1]) + 1,), device=dev, generator=g).int()
+    for i in range(n2):
+        if int(lens[i]) > 0 and i % 3 != 0:
+            targets[int(seg_lo[i]) + (i % int(lens[i]))] = int(true[i])
+    rk, frk = _hip.filtered_rank_from_scores(scores, true, seg_lo, seg_hi, targets)
+    want = torch.zeros(4, B + 5, dtype=torch.int64, device=dev)
+    want[1, 3:3 + B], want[3, 3:3 + B], want[0, 3:3 + B], want[2, 3:3 + B] = rk[:B], frk[:B], rk[B:], frk[B:]
+    per = -(-N // world)
+    m = -(-n2 // world)
+    got = torch.zeros(4, B + 5, dtype=torch.int64, device=dev)
+    padded = torch.full((world * m, world * per), float('nan'), device=dev)
+    padded[:n2, :N] = scores
+    for j in range(world):          # "rank j": the tiles it would receive for its m rows
+        tiles = padded[j * m:(j + 1) * m].view(m, world, per).permute(1, 0, 2).contiguous()
+        my0 = j * m
+        rows = max(0, min(m, n2 - my0))
+        if rows > 0:
+            _hip.filtered_rank_from_tiles(tiles, N, true[my0:], seg_lo[my0:], seg_hi[my0:], targets, rows, my0, B, got, 3)
+    assert torch.equal(got, want)
+    # through pos (facts processed in another order)
+    pos = torch.randperm(B + 5, device=dev, generator=g)
+    got2 = torch.zeros(4, B + 5, dtype=torch.int64, device=dev)
+    tiles = padded[:m].view(m, world, per).permute(1, 0, 2).contiguous()
+    rows = min(m, n2)
+    _hip.filtered_rank_from_tiles(tiles, N, true, seg_lo, seg_hi, targets, rows, 0, B, got2, 3, pos)
+    for q in range(rows):
+        f = int(pos[3 + (q if q < B else q - B)])
+        assert int(got2[1 if q < B else 0, f]) == int(rk[q]) and int(got2[3 if q < B else 2, f]) == int(frk[q])

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     out = subprocess.check_output(['nm', '-D', '--defined-only', _hip.LIB_PATH], text=True)
     assert declared <= set(re.findall(r' T (kge_[a-z0-9_]+)', out))
-    assert lib.kge_abi_version() == 22 and lib.kge_build_arch() == b'gfx950'
+    assert lib.kge_abi_version() == _hip.ABI_VERSION and lib.kge_build_arch() == b'gfx950'
     # the descriptor struct mirrors the header field for field
     fields = re.search(r'typedef struct kge_lp_desc \{(.*?)\} kge_lp_desc;', hdr, re.S).group(1)
     names = re.findall(r'\b(\w+)\s*(?:;|,)', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
@@ -322,6 +322,17 @@ for shard, exchange, fused in [('entities', 'counts', True), ('entities', 'score
         ok = ok and same
         if not same:
             print('MISMATCH', rank, shard, exchange, fused, nm, flush=True)
+# the score all-to-all cut into several row tiles per batch (tile = 2 ranks x 4 rows; the last one short)
+import torchkge_amd.evaluation as ev_mod
+from torchkge_amd import distributed as kd0
+ev_mod.SCORE_TILE_BYTES = 4 * kd0.shard_size(n_ent, world) * world * 4
+ev = tk.LinkPredictionEvaluator(m, kg_test, shard='entities', exchange='scores', engine=OracleRankEngine(kind, tables))
+ev.evaluate(b_size=13, verbose=False)
+for nm in ('rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails'):
+    if not np.array_equal(getattr(ev, nm).numpy(), z[nm]):
+        ok = False
+        print('MISMATCH tiled all-to-all', rank, nm, flush=True)
+ev_mod.SCORE_TILE_BYTES = 256 << 20
 # ROW-SHARDED entity tables (SURVEY 8e): each rank keeps only its rows of every entity-indexed table,
 # query rows are built by the owner rank and summed over the ranks; the ranks must still be the reference's
 from torchkge_amd import distributed as kd
@@ -455,7 +466,7 @@ def test_internal_batch_of_the_fused_evaluator():
         assert e._internal_batch(40000, 10 ** 6) == 40000 and e._internal_batch(7, 0) == 7
         assert _E(coalesce=0)._internal_batch(256, 20466) == 256
         assert _E(fused=False)._internal_batch(256, 20466) == 256
-        assert _E(shard='entities', exchange='scores')._internal_batch(256, 20466) == 256
+        assert _E(shard='entities', exchange='scores')._internal_batch(256, 20466) == 20466   # row tiles bound the memory
         assert _E(engine=object())._internal_batch(256, 20466) == 256
         _M.n_ent = 4594485          # Wikidata5M: the list of a batch would pass 2 GiB long before 32768 facts
         assert 256 < e._internal_batch(256, 5133) < 5133

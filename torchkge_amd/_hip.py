@@ -108,6 +108,8 @@ _SIGNATURES = {
     'kge_filter_lookup_both': [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     'kge_filter_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
     'kge_filtered_rank_from_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    'kge_filtered_rank_from_tiles': [_vp, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
+                                     _vp, _vp],
     'kge_corrupt_scatter': [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     'kge_topk': [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp],
 }
@@ -117,6 +119,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_key_sort_ws_bytes', 'kge_lp_split_group_sets'])
 
 _lib = None
+ABI_VERSION = 23        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -150,7 +153,7 @@ def load_library():
     lib.kge_abi_version.restype = _int
     lib.kge_build_arch.argtypes = []
     lib.kge_build_arch.restype = ctypes.c_char_p
-    if lib.kge_abi_version() != 22:
+    if lib.kge_abi_version() != ABI_VERSION:
         raise RuntimeError('torchkge_amd: libkge_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -617,6 +620,27 @@ class LpProblem(object):
             _check(lib.kge_lp_scores(ctypes.byref(d), _p(out), out.stride(0), _stream()), 'kge_lp_scores')
         return out
 
+    def scores_rows(self, q0, q1, out):
+        """Scores of QUERIES [q0, q1) against every local candidate, into out[:q1 - q0] (leading dimension out.stride(0)
+        >= N) -- the same descriptor with its query-side pointers advanced (the score tiles of the sharded path's
+        all-to-all exchange are produced a row block at a time)."""
+        lib = load_library()
+        d = LpDesc.from_buffer_copy(self.desc)
+        d.B = q1 - q0
+        d.A0 = self.desc.A0 + 4 * q0 * self.desc.lda0
+        if self.desc.A1:
+            d.A1 = self.desc.A1 + 4 * q0 * self.desc.lda1
+        if self.desc.qn:
+            d.qn = self.desc.qn + 4 * q0
+        if self.desc.Wq:
+            d.Wq = self.desc.Wq + 4 * q0 * self.desc.ldw
+        if self.desc.r_idx:
+            d.r_idx = self.desc.r_idx + 8 * q0
+        if q1 > q0 and self.N > 0:
+            with _on(self.device):
+                _check(lib.kge_lp_scores(ctypes.byref(d), _p(out), out.stride(0), _stream()), 'kge_lp_scores')
+        return out
+
     def pair_scores(self, ci, qi=None):
         if self.pre is not None and qi is None and ci is self.pre['true_idx']:
             return self.pre['s_true']       # already computed by the fused query pipeline (same chain)
@@ -919,6 +943,22 @@ def filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
                                                  _p(rank), _p(filt), _stream()),
                'kge_filtered_rank_from_scores')
     return rank, filt
+
+
+def filtered_rank_from_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None):
+    """kge_filtered_rank_from_tiles: ranks of `rows` queries whose score rows lie in the rank-major tiles
+    (P, m, per) of the score all-to-all; written into the (4, n) result matrix like rank_finalize_both."""
+    lib = load_library()
+    require_cuda(tiles, true_idx, out)
+    assert tiles.dtype == torch.float32 and tiles.is_contiguous() and tiles.dim() == 3
+    if out.dtype != torch.int64 or out.dim() != 2 or out.shape[0] != 4 or out.stride(1) != 1:
+        raise RuntimeError('filtered_rank_from_tiles: out must be a (4, n) int64 matrix with unit column stride')
+    P, m, per = tiles.shape
+    with _on(tiles.device):
+        _check(lib.kge_filtered_rank_from_tiles(_p(tiles), m, per, P, n_total, _p(true_idx), _p(seg_lo), _p(seg_hi),
+                                                _p(targets), rows, q_first, B, _p(out), out.stride(0), off, _p(pos),
+                                                _stream()), 'kge_filtered_rank_from_tiles')
+    return out
 
 
 def topk(scores, k):

@@ -79,7 +79,16 @@ def build(force=False, verbose=False):
     cs = os.path.join(HERE, COLL_SRC)
     if force or _stale(COLL_LIB, [cs, os.path.join(HERE, '..', '..', 'include', 'kge_hip_coll.h')] + hdrs):
         # (-lrccl resolves to whichever librccl.so.1 the process has loaded first -- torch's own when the host is Python)
-        run([hipcc] + FLAGS + ['-shared', '-o', COLL_LIB, cs, '-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib'])
+        # Optional: a box without the RCCL headers / library still gets the single-GPU core (libkge_hip.so); the sharded
+        # path through the C-ABI (torchkge_amd/_hip_coll.py) then fails loudly when it is first used.
+        try:
+            run([hipcc] + FLAGS + ['-shared', '-o', COLL_LIB, cs, '-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib'])
+        except RuntimeError as exc:
+            import warnings
+            if os.path.exists(COLL_LIB):
+                os.remove(COLL_LIB)
+            warnings.warn('torchkge_amd: libkge_hip_coll.so not built (RCCL headers / library missing?): %s'
+                          % str(exc).splitlines()[-1])
     return LIB
 
 

@@ -37,6 +37,10 @@ extern "C" int kge_comm_unique_id(void *id128)
 extern "C" int kge_comm_init(kge_comm_t *comm, int world, int rank, const void *id128)
 {
     if (!comm || !id128 || world < 1 || rank < 0 || rank >= world) return KGE_EINVAL;
+    // compiled against /opt/rocm's rccl.h, but the loader may have resolved librccl.so.1 to another copy (under Python:
+    // torch's bundled one): refuse a runtime whose major version differs from the header's (ncclUniqueId / comm ABI)
+    int v = 0;
+    if (ncclGetVersion(&v) != ncclSuccess || v / 10000 != NCCL_VERSION_CODE / 10000) return 1000 + (int)ncclInvalidUsage;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclComm_t c;
@@ -65,6 +69,38 @@ extern "C" int kge_allgather_scores(kge_comm_t comm, int world, const float *loc
     hipLaunchKernelGGL(unshard_kernel, dim3(grid), dim3(256), 0, s, gathered, full, ld_full, B, n_per, N, world);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int kge_alltoall_scores(kge_comm_t comm, int world, int rank, const float *local, float *recv, int64_t m,
+                                   int64_t n_per, void *stream)
+{
+    if (!comm || world < 1 || rank < 0 || rank >= world || m < 0 || n_per < 0) return KGE_EINVAL;
+    if (m == 0 || n_per == 0) return 0;
+    if (!local || !recv) return KGE_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t blk = (size_t)(m * n_per);
+    // the own block never touches the fabric: one device-to-device copy on the same stream
+    hipError_t e = hipMemcpyAsync(recv + (size_t)rank * blk, local + (size_t)rank * blk, blk * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    if (world == 1) return 0;
+    int rc = kge_nccl(ncclGroupStart());
+    if (rc) return rc;
+    for (int j = 0; j < world && rc == 0; ++j) {
+        if (j == rank) continue;
+        rc = kge_nccl(ncclSend(local + (size_t)j * blk, blk, ncclFloat, j, (ncclComm_t)comm, s));
+        if (rc == 0) rc = kge_nccl(ncclRecv(recv + (size_t)j * blk, blk, ncclFloat, j, (ncclComm_t)comm, s));
+    }
+    const int rc2 = kge_nccl(ncclGroupEnd());
+    return rc ? rc : rc2;
+}
+
+extern "C" int kge_allreduce_ranks(kge_comm_t comm, int64_t *ranks, int64_t n, void *stream)
+{
+    if (!comm || n < 0 || (n > 0 && !ranks)) return KGE_EINVAL;
+    if (n == 0) return 0;
+    return kge_nccl(ncclAllReduce(ranks, ranks, (size_t)n, ncclInt64, ncclSum, (ncclComm_t)comm,
+                                  reinterpret_cast<hipStream_t>(stream)));
 }
 
 extern "C" int kge_allreduce_counts(kge_comm_t comm, int32_t *counts, int64_t n, void *stream)

@@ -91,6 +91,54 @@ __global__ __launch_bounds__(RB) void filtered_rank_kernel(const float *__restri
     }
 }
 
+// Ranks of `rows` queries whose score rows arrive as P RANK-MAJOR tiles (the receive buffer of the score all-to-all of
+// the entity-sharded path, kge_hip_coll.h): tile p = (m, per) holds the scores of global candidates [p*per, (p+1)*per),
+// row i of every tile belongs to query q_first + i.  Same arithmetic as filtered_rank_kernel on the (B, N) matrix the
+// tiles would concatenate to -- no re-layout, every tile row read as one contiguous segment.  Results go straight to
+// the (4, ld) result matrix of kge_rank_finalize_both (query q < B: tail side of fact q, else head side of fact q - B).
+__global__ __launch_bounds__(RB) void filtered_rank_tiles_kernel(const float *__restrict__ tiles, int64_t m, int64_t per,
+                                                                 int P, int64_t N, const int64_t *__restrict__ true_idx,
+                                                                 const int64_t *__restrict__ seg_lo,
+                                                                 const int64_t *__restrict__ seg_hi,
+                                                                 const int32_t *__restrict__ targets, int64_t rows,
+                                                                 int64_t q_first, int64_t B, int64_t *out, int64_t ld,
+                                                                 int64_t off, const int64_t *__restrict__ pos)
+{
+    __shared__ int sh[RB / 64];
+    for (int64_t i = blockIdx.x; i < rows; i += gridDim.x) {
+        const int64_t ti = true_idx[i];
+        const int64_t tp = ti / per;
+        const float tv = tiles[(tp * m + i) * per + (ti - tp * per)];
+        int c = 0;
+        for (int p = 0; p < P; ++p) {
+            const int64_t w = N - (int64_t)p * per;      // candidates this tile really holds (the last one may be short)
+            if (w <= 0) break;
+            c += count_row(tiles + ((int64_t)p * m + i) * per, w < per ? w : per, tv, false);
+        }
+        const int raw = block_sum_i(c, sh);
+        int sub = 0, found = 0;
+        const int neg_inf_counts = (-INFINITY >= tv) ? 1 : 0;
+        for (int64_t j = seg_lo[i] + threadIdx.x; j < seg_hi[i]; j += blockDim.x) {
+            const int64_t cc = targets[j];
+            if (cc == ti) { found = 1; continue; }
+            if (cc >= 0 && cc < N) {
+                const int64_t cp = cc / per;
+                sub += ((tiles[(cp * m + i) * per + (cc - cp * per)] >= tv) ? 1 : 0) - neg_inf_counts;
+            }
+        }
+        sub = block_sum_i(sub, sh);
+        found = block_sum_i(found, sh);
+        if (threadIdx.x == 0) {
+            const int64_t q = q_first + i;
+            const bool tail = q < B;
+            const int64_t j = off + (tail ? q : q - B);
+            const int64_t f = pos ? pos[j] : j;
+            out[(tail ? 1 : 0) * ld + f] = raw;
+            out[(tail ? 3 : 2) * ld + f] = found ? raw - sub : raw;
+        }
+    }
+}
+
 __global__ __launch_bounds__(RB) void filter_scores_kernel(float *scores, int64_t ld,
                                                            const int64_t *__restrict__ true_idx,
                                                            const int64_t *__restrict__ seg_lo,
@@ -753,6 +801,22 @@ extern "C" int kge_filtered_rank_from_scores(const float *scores, int64_t ld, co
     return 0;
 }
 
+extern "C" int kge_filtered_rank_from_tiles(const float *tiles, int64_t m, int64_t per, int world, int64_t N,
+                                            const int64_t *true_idx, const int64_t *seg_lo, const int64_t *seg_hi,
+                                            const int32_t *targets, int64_t rows, int64_t q_first, int64_t B,
+                                            int64_t *out, int64_t ld, int64_t off, const int64_t *pos,
+                                            kge_stream_t stream)
+{
+    if (rows < 0 || rows > m || per <= 0 || world < 1 || N <= 0 || N > (int64_t)world * per) return KGE_EINVAL;
+    if (B < 0 || off < 0 || ld < off + B || q_first < 0 || q_first + rows > 2 * B) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!tiles || !true_idx || !seg_lo || !seg_hi || !out) return KGE_EINVAL;
+    hipLaunchKernelGGL(filtered_rank_tiles_kernel, dim3(grid1d(rows, 1)), dim3(RB), 0, kge_s(stream), tiles, m, per,
+                       world, N, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, ld, off, pos);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_lp_scores(const kge_lp_desc *d, float *out, int64_t ldo, kge_stream_t stream)
 {
     int rc = kge_lp_desc_check(d);
@@ -994,5 +1058,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 22; }
+extern "C" int kge_abi_version(void) { return 23; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -9,8 +9,11 @@ partitioning below is the one BASELINE.json's north star names:
     every entity-indexed table (relation tables stay replicated); the (2B, K) query rows of a batch
     are then built by the rank that owns each query's entity and summed over the ranks
     (zeros elsewhere: exact), one all-reduce per query matrix;
-  * exchange='scores': every rank all-gathers the partial score tiles
-    S_p (B, N/P) into S (B, N) and ranks on the full matrix;
+  * exchange='scores': the partial score tiles S_p (B, N/P) are exchanged.  Since r04 as an ALL-TO-ALL of row
+    blocks: every rank receives only the score rows of the B/P queries IT ranks, as P rank-major tiles, and ranks
+    them in place (`all_to_all_rows` + kge_filtered_rank_from_tiles) -- 1/P of the bytes of the all-gather and 1/P
+    of its ranking work per rank; `all_gather_columns` (every rank gets the full (B, N) matrix and ranks all of
+    it) remains for engines without tile ranking and for the drop-in composition;
   * exchange='counts': ranks are sums over candidates, so each rank counts
     `>=` on its shard and ONE all-reduce of 3*B int32 (raw, filter correction,
     found flag) gives bit-identical ranks -- B*12 bytes instead of B*N*4;
@@ -98,6 +101,35 @@ def all_gather_columns(local, n_total, group=None):
     dist.all_gather_into_tensor(gathered.view(world * B, per), send, group=group)
     full = gathered.permute(1, 0, 2).reshape(B, world * per)
     return full[:, :n_total].contiguous()
+
+
+_A2A_FALLBACK = set()     # (backend, device type) pairs whose all_to_all_single is not implemented (gloo on HIP tensors)
+
+
+def all_to_all_rows(local, recv, group=None):
+    """Score tile (P * m, per) of this rank -- rows [j*m, (j+1)*m) are the queries rank j ranks -- ->
+    recv (P, m, per): tile p = the scores rank p computed for THIS rank's m queries (rank-major, no re-layout).
+    ONE all-to-all: (P-1)/P of one local tile per rank on the fabric."""
+    world, rank = world_and_rank(group)
+    P, m, per = recv.shape
+    if not multi(world):
+        recv.copy_(local.view(P, m, per))
+        return recv
+    assert P == world and local.shape[0] == world * m and local.is_contiguous() and recv.is_contiguous()
+    key = (backend_name(group), local.device.type)
+    if key not in _A2A_FALLBACK:
+        try:
+            dist.all_to_all_single(recv.view(world * m, per), local, group=group)
+            return recv
+        except (RuntimeError, NotImplementedError) as exc:
+            if key[0] == 'nccl':
+                raise
+            _A2A_FALLBACK.add(key)      # unsupported-op errors are raised before anything is sent, on every rank alike
+    # debugging backends only (two gloo ranks sharing one GPU): gather every rank's tile, keep this rank's row block
+    gathered = local.new_empty(world, world * m, per)
+    dist.all_gather_into_tensor(gathered.view(world * world * m, per), local, group=group)
+    recv.copy_(gathered[:, rank * m:(rank + 1) * m])
+    return recv
 
 
 def all_gather_blocks(block, out, group=None):

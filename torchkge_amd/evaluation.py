@@ -43,6 +43,9 @@ from .utils.operations import get_rank
 # LinkPredictionEvaluator._internal_batch: facts per batch of the fused path / bound on a batch's uncertain-pair list
 COALESCE_BATCH = 32768
 COALESCE_LIST_BYTES = 2 << 30
+# exchange='scores': bytes of the local (rows, N/P) fp32 score tile of one all-to-all (the receive buffer has the same
+# size).  A batch is cut into as many row tiles as it takes, so b_size never decides whether the score exchange fits.
+SCORE_TILE_BYTES = int(os.environ.get('KGE_SCORE_TILE_BYTES', 256 << 20))
 DEDUPE_QUERIES = os.environ.get('KGE_DEDUPE_QUERIES', '1') != '0'    # count kernel on distinct query rows (ColumnPlan)
 
 
@@ -131,6 +134,17 @@ class HipRankEngine(object):
     @staticmethod
     def local_scores(prob):
         return prob.scores()
+
+    @staticmethod
+    def score_rows(prob, q0, q1, out):
+        """Local scores of queries [q0, q1) into out[:q1 - q0] (one row block of the score all-to-all)."""
+        return prob.scores_rows(q0, q1, out)
+
+    @staticmethod
+    def rank_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None):
+        """Ranks of `rows` queries from the rank-major tiles (P, m, per) the all-to-all delivered, into `out`."""
+        return _hip.filtered_rank_from_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B,
+                                             out, off, pos)
 
     @staticmethod
     def ranks_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
@@ -275,19 +289,27 @@ class LinkPredictionEvaluator(object):
         of the GPU, so the facts are processed max(b_size, COALESCE_BATCH) at a time -- less when the list of a batch
         would pass COALESCE_LIST_BYTES (16 B per query and list slot, both sides).  Same formula on every rank."""
         target = COALESCE_BATCH if self.coalesce is None else int(self.coalesce)
-        if (target <= b_size or not self.fused or self._generic_model or not isinstance(self.engine, HipRankEngine)
-                or (self.shard == 'entities' and self.exchange == 'scores')):
+        if target <= b_size or not self.fused or self._generic_model or not isinstance(self.engine, HipRankEngine):
             return b_size
         per_query = max(_hip.SPLIT_LIST_PER_QUERY, self.model.n_ent // 50)
         fit = max(1, int(COALESCE_LIST_BYTES // (16 * per_query)))
         if self.shard is None and torch.cuda.is_available():
             # next to a training job the device may be nearly full: the scratch of one internal batch (list slots of
-            # both sides + ~4 (2B, K) fp32 query-side buffers) stays within a quarter of what is free right now.
+            # both sides + ~4 (2B, K) fp32 query-side buffers) stays within a quarter of what is free.  Decided ONCE per
+            # evaluator (b_size keys the plans and the hipGraph: a value that followed the allocator's jitter would
+            # rebuild both on every call), as a power of two, counting the blocks torch's allocator holds cached as
+            # free; re-decided only when the memory now free would shrink the batch by 2x or more.
             # (Sharded evaluators keep the rank-independent formula: every rank must cut the same batches.)
             try:
-                free = torch.cuda.mem_get_info(getattr(self, '_dev', None) or next(self.model.parameters()).device)[0]
+                dev = getattr(self, '_dev', None) or next(self.model.parameters()).device
+                free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
                 k_q = 2 * int(getattr(self.model, 'emb_dim', 0) or 0) + 64
-                fit = min(fit, max(1, int((free // 4) // (16 * per_query + 2 * 4 * 4 * k_q))))
+                now = max(1, int((free // 4) // (16 * per_query + 2 * 4 * 4 * k_q)))
+                now = 1 << (now.bit_length() - 1)
+                kept = getattr(self, '_mem_fit', None)
+                if kept is None or now * 2 <= kept:
+                    self._mem_fit = kept = now
+                fit = min(fit, kept)
             except Exception:
                 pass
         return max(b_size, min(target, fit, max(n_local, 1)))
@@ -382,9 +404,12 @@ class LinkPredictionEvaluator(object):
         else:
             seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
         xkw = self._xkw(sharded)
-        if plan is not None and getattr(plan, 'cols', None) is not None:
+        by_scores = sharded and self.exchange == 'scores'
+        if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores:
             xkw['cols'] = plan.cols     # (entity shards too: the columns are a property of the queries, not of the candidates)
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
+        if by_scores:
+            return self._exchange_score_tiles(prob, h.shape[0], true_idx, seg_lo, seg_hi, targets, out, off)
         s_true = None
         if sharded and self._qb is not None and hasattr(self.model, 'lp_true_scores_replica'):
             # row-sharded tables: the true entities' rows are in the query-entity replicas, so every rank scores
@@ -419,6 +444,35 @@ class LinkPredictionEvaluator(object):
             eng.finalize_both(counts[:, :n2] if ride else counts, out, off, self._perm, **fkw)
         else:
             eng.finalize_both(counts[:, :n2] if ride else counts, out, off, **fkw)
+
+    def _exchange_score_tiles(self, prob, B, true_idx, seg_lo, seg_hi, targets, out, off):
+        """exchange='scores' of one both-sides batch (2B queries): the collective north_star names, as a path that
+        scales.  The queries are cut into row tiles of P * m rows; every rank scores a tile against ITS candidates
+        (fp32 scores, (P * m, N/P) -- bounded by SCORE_TILE_BYTES whatever b_size is), ONE all-to-all hands rank j the
+        m rows it ranks as P rank-major tiles, and kge_filtered_rank_from_tiles ranks them where they lie (true score
+        read from the tiles like the reference reads it from the score matrix, evaluation.py:291-300).  Per rank and
+        evaluation: (P-1)/P^2 * 2B*N*4 bytes on the fabric (the all-gather moved P times that and ranked all 2B rows on
+        every rank).  Each rank writes only its queries' columns of the zero-initialised result matrix; one int64
+        all-reduce at the end of evaluate() completes it."""
+        eng = self.engine
+        world, rank = kdist.world_and_rank(self.group)
+        n_ent = self.model.n_ent
+        per = kdist.shard_size(n_ent, world)
+        n2 = 2 * B
+        m_max = max(1, min(-(-n2 // world), SCORE_TILE_BYTES // (4 * per * world)))
+        dev = true_idx.device
+        for q0 in range(0, n2, world * m_max):
+            q1 = min(n2, q0 + world * m_max)
+            m = -(-(q1 - q0) // world)
+            loc = torch.empty(world * m, per, dtype=torch.float32, device=dev)     # rows >= q1 - q0 / columns >= the
+            eng.score_rows(prob, q0, q1, loc)                                      # shard's width: never read
+            recv = torch.empty(world, m, per, dtype=torch.float32, device=dev)
+            self._collective(lambda a_=loc, b_=recv: kdist.all_to_all_rows(a_, b_, self.group))
+            my0 = q0 + rank * m
+            rows = min(m, q1 - my0)
+            if rows > 0:
+                eng.rank_tiles(recv, n_ent, true_idx[my0:], seg_lo[my0:], seg_hi[my0:], targets, rows, my0, B, out, off,
+                               self._perm)
 
     def _xkw(self, sharded):
         """Engine keyword for the query exchange of row-sharded entity tables: every rank builds the
@@ -570,8 +624,12 @@ class LinkPredictionEvaluator(object):
             overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
                        isinstance(self.engine, HipRankEngine) and device.type == 'cuda')
 
+            # (exchange='scores' on entity shards: the all-to-all of score row tiles needs an engine that ranks tiles;
+            # others keep the per-side all-gather of full score rows)
+            by_scores = sharded and self.exchange == 'scores'
             both = (self.both_sides and self.fused and not self._generic_model and not overlap and
-                    not (sharded and self.exchange == 'scores') and hasattr(self.engine, 'lookup_both'))
+                    (not by_scores or hasattr(self.engine, 'rank_tiles')) and hasattr(self.engine, 'lookup_both'))
+            by_scores = by_scores and both
             if both and getattr(self.engine, 'uses_plans', False) and n_local > 0:
                 self._ensure_plans(kg, f_lo, f_hi, b_size, index_t, index_h, device)
             else:
@@ -597,6 +655,8 @@ class LinkPredictionEvaluator(object):
                     if guard is not None and self.model._expand_ok is None:
                         guard.zero_()
                     n_batches = get_n_batches(n_local, b_size)
+                    if by_scores:       # every rank writes only the columns of the queries it ranks
+                        out.zero_()
                     self._shard_flags = None
                     self._fl, self._fl_done = fl, False
                     qt = None
@@ -622,6 +682,8 @@ class LinkPredictionEvaluator(object):
                             continue
                         out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                         out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
+                    if by_scores:       # ... and one SUM completes the (4, n) rank matrix on every rank
+                        self._collective(lambda o_=out: kdist.all_reduce_sum(o_, self.group))
                     if guard is not None and self._shard_flags is not None:
                         # entity shards: the flags came back summed over the ranks with the last batch's counts
                         fl[0:1].copy_(torch.where(self._shard_flags[0:1] > 0, float('inf'), 0.0))
