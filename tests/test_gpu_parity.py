@@ -640,14 +640,6 @@ def test_entity_and_relation_inference(hip, kind, p):
         assert torch.equal(inf.predictions[gap_ok], eix[gap_ok])
     with pytest.raises(tk.exceptions.WrongArgumentsError):
         tk.EntityInference(m, h, r, missing='both')
-    if kind != 'transh':
-        rinf = tk.RelationInference(m, h, t, top_k=3, dictionary=dr)
-        rinf.evaluate(b_size=16, verbose=False)
-        so = orc.filter_scores(orc.rp_scores(kind, tables, h, t, p), dr, h, t, None)
-        v, ix = so.sort(descending=True)
-        assert (rinf.scores - v[:, :3]).abs().max().item() < TOL or torch.isinf(v[:, :3]).any()
-        fin = torch.isfinite(v[:, :3]).all(dim=1) & ((v[:, :2] - v[:, 1:3]).min(dim=1).values > 4 * TOL)
-        assert torch.equal(rinf.predictions[fin], ix[:, :3][fin])
     # filter_scores with true_idx=None masks every known target
     from torchkge_amd.utils import filter_scores
     s_ref = torch.from_numpy(z['s_tail'])

@@ -967,57 +967,3 @@ class RelationPredictionEvaluator(object):
                 i, round(self.hit_at_k(k=i)[0], n_digits), i, round(self.hit_at_k(k=i)[1], n_digits)))
         print('Mean Rank : {} \t Filt. Mean Rank : {}'.format(int(self.mean_rank()[0]), int(self.mean_rank()[1])))
         print('MRR : {} \t\t Filt. MRR : {}'.format(round(self.mrr()[0], n_digits), round(self.mrr()[1], n_digits)))
-
-
-class TripletClassificationEvaluator(object):
-    """Triplet classification (Socher et al. 2013) with the reference's interface
-    (evaluation.py:428-585): per-relation score thresholds from negatively sampled
-    validation facts, accuracy on the test facts and their negatives.  Scores come
-    from the fused ``scoring_function`` kernel; the per-relation threshold loop of
-    the reference (:533-538) is one scatter-max."""
-
-    def __init__(self, model, kg_val, kg_test):
-        from .sampling import PositionalNegativeSampler
-        self.model = model
-        self.kg_val = kg_val
-        self.kg_test = kg_test
-        self.is_cuda = next(self.model.parameters()).is_cuda
-        self.evaluated = False
-        self.thresholds = None
-        self.sampler = PositionalNegativeSampler(self.kg_val, kg_test=self.kg_test)
-
-    def get_scores(self, heads, tails, relations, batch_size):
-        """scoring_function over (heads, tails, relations) in batches (evaluation.py:479-511)."""
-        device = next(self.model.parameters()).device
-        scores = []
-        with torch.no_grad():
-            for i in range(get_n_batches(heads.shape[0], batch_size)):
-                sl = slice(i * batch_size, (i + 1) * batch_size)
-                scores.append(self.model.scoring_function(heads[sl].to(device), tails[sl].to(device),
-                                                          relations[sl].to(device)))
-        return torch.cat(scores, dim=0) if scores else torch.zeros(0, device=device)
-
-    def evaluate(self, b_size):
-        """Thresholds: for each relation the largest score of its negative validation
-        samples; a relation without validation facts gets the overall largest negative
-        score (evaluation.py:513-541)."""
-        r_idx = self.kg_val.relations
-        neg_heads, neg_tails = self.sampler.corrupt_kg(b_size, self.is_cuda, which='main')
-        neg_scores = self.get_scores(neg_heads, neg_tails, r_idx, b_size)
-        thr = torch.full((self.kg_val.n_rel,), float('-inf'), device=neg_scores.device)
-        thr.scatter_reduce_(0, r_idx.to(neg_scores.device), neg_scores, reduce='amax', include_self=True)
-        thr = torch.where(torch.isinf(thr) & (thr < 0), neg_scores.max(), thr)
-        self.thresholds = thr.detach()
-        self.evaluated = True
-
-    def accuracy(self, b_size):
-        """Share of the test facts scored above and of their negatives scored below the
-        threshold of their relation (evaluation.py:543-585)."""
-        if not self.evaluated:
-            self.evaluate(b_size)
-        r_idx = self.kg_test.relations
-        neg_heads, neg_tails = self.sampler.corrupt_kg(b_size, self.is_cuda, which='test')
-        scores = self.get_scores(self.kg_test.head_idx, self.kg_test.tail_idx, r_idx, b_size)
-        neg_scores = self.get_scores(neg_heads, neg_tails, r_idx, b_size)
-        thr = self.thresholds.to(scores.device)[r_idx.to(scores.device)]
-        return ((scores > thr).sum().item() + (neg_scores < thr).sum().item()) / (2 * self.kg_test.n_facts)

@@ -1,8 +1,7 @@
 # -*- coding: utf-8 -*-
-"""Top-k inference of missing entities / relations with the reference's
-interface (torchkge/inference.py:77-250): ``EntityInference(model,
-known_entities, known_relations, top_k=1, missing='tails', dictionary=None)``
-and ``RelationInference(model, entities1, entities2, top_k=1, dictionary=None)``,
+"""Top-k inference of missing entities with the reference's
+interface (torchkge/inference.py:156-250): ``EntityInference(model,
+known_entities, known_relations, top_k=1, missing='tails', dictionary=None)``,
 ``.evaluate(b_size, verbose)`` filling ``.predictions`` (n, top_k) long and
 ``.scores`` (n, top_k) float on the CPU.
 
@@ -47,41 +46,6 @@ def _device_of(model):
     if dev.type != 'cuda':
         raise RuntimeError('torchkge_amd inference runs on MI355X (HIP) only: move the model to `cuda`.')
     return dev
-
-
-class RelationInference(object):
-    """Infer the top_k most plausible relations between entity pairs
-    (inference.py:77-153)."""
-
-    def __init__(self, model, entities1, entities2, top_k=1, dictionary=None):
-        self.model = model
-        self.entities1 = entities1
-        self.entities2 = entities2
-        self.topk = top_k
-        self.dictionary = dictionary
-        self.predictions = torch.empty(size=(len(entities1), top_k)).long()
-        self.scores = torch.empty(size=(len(entities2), top_k))
-
-    def evaluate(self, b_size, verbose=True):
-        dev = _device_of(self.model)
-        e1, e2 = self.entities1.to(dev), self.entities2.to(dev)
-        none = torch.zeros(0, dtype=torch.long, device=dev)
-        preds, vals = [], []
-        n_batches = get_n_batches(len(e1), b_size)
-        with torch.no_grad():
-            for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose), desc='Inference'):
-                sl = slice(i * b_size, (i + 1) * b_size)
-                ents1, ents2 = e1[sl], e2[sl]
-                h_emb, t_emb, _, candidates = self.model.inference_prepare_candidates(ents1, ents2, none,
-                                                                                      entities=False)
-                scores = self.model.inference_scoring_function(h_emb, t_emb, candidates)
-                if self.dictionary is not None:
-                    scores = filter_scores(scores, self.dictionary, ents1, ents2, None)
-                v, ix = _hip.topk(scores, min(self.topk, scores.shape[1]))
-                preds.append(ix)
-                vals.append(v)
-        self.predictions = torch.cat(preds).cpu() if preds else self.predictions
-        self.scores = torch.cat(vals).cpu() if vals else self.scores
 
 
 class EntityInference(object):
