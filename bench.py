@@ -63,6 +63,7 @@ WORKLOADS = {
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
 PEAK_F16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA (~2.5 PF, no sparsity)
 PEAK_HBM_GBS = 8000.0
+PEAK_SAD_TINST = 39.3        # v_sad_u16 (half-rate VALU op): 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-instructions / s
 
 
 def parse():
@@ -372,13 +373,15 @@ def _sample_power(run, device, seconds=1.6):
     return out
 
 
-def _measure_traffic(args, kernel_sym):
+def _measure_traffic(args, kernel_sym, extra_out=None):
     """HBM-side bytes per launch of the dominant kernel, measured in THIS run: bench.py re-runs itself (timed loop only,
     eager launches, Xavier weights: the count kernel's traffic does not depend on the weights) under
     ``rocprofv3 --pmc <counter> --kernel-trace`` once per counter -- FETCH_SIZE (3 TCC slots) and WRITE_SIZE (2) do
     not fit one pass -- and averages the counter over the launches of `kernel_sym`.  FETCH_SIZE / WRITE_SIZE are in
     KB; gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> 2 x FETCH_SIZE.
-    Infinity-Cache hits are counted by these memory-side counters, i.e. this is L2-miss traffic, not DRAM traffic."""
+    Infinity-Cache hits are counted by these memory-side counters, i.e. this is L2-miss traffic, not DRAM traffic.
+    A third pass (extra_out: dict) collects the matrix-pipe counters of the same kernel: SQ_INSTS_MFMA (executed MFMA
+    instructions per evaluate, summed over the kernel's instantiations), SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE."""
     import csv
     import glob
     import shutil
@@ -388,9 +391,12 @@ def _measure_traffic(args, kernel_sym):
     if not os.path.exists(rp):
         return None
     vals = {}
-    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+    passes = [('FETCH_SIZE',), ('WRITE_SIZE',)]
+    if extra_out is not None:
+        passes.append(('SQ_INSTS_MFMA', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))
+    for ctrs in passes:
         d = tempfile.mkdtemp(prefix='kge_pmc_', dir='/tmp')
-        cmd = [rp, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 't', '--', sys.executable,
+        cmd = [rp, '--pmc'] + list(ctrs) + ['--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 't', '--', sys.executable,
                os.path.abspath(__file__), '--only-timed', '--no-graph', '--no-traffic', '--weights',
                'xavier' if args.weights == 'trained' else args.weights, '--steps', '3', '--warmup', '0',
                '--settle-ms', '0', '--workload', args.workload, '--batch', str(args.batch), '--kg', args.kg, '--l2-mode', args.l2_mode]
@@ -401,19 +407,30 @@ def _measure_traffic(args, kernel_sym):
             env.pop(k, None)
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            got = {}        # per kernel NAME (the count kernel may run as two instantiations per launch: single-query
-            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):      # and grouped columns)
+            got = {}        # per (counter, kernel NAME): the count kernel may run as two instantiations per launch
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):      # (single / grouped columns)
                 for r in csv.DictReader(open(f)):
-                    if r.get('Counter_Name') == ctr and kernel_sym in r.get('Kernel_Name', ''):
-                        got.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
-            if got:
-                vals[ctr] = sum(sum(v) / len(v) for v in got.values())
+                    if r.get('Counter_Name') in ctrs and kernel_sym in r.get('Kernel_Name', ''):
+                        got.setdefault((r['Counter_Name'], r['Kernel_Name']), []).append(float(r['Counter_Value']))
+            for ctr in ctrs:
+                per_kernel = [sum(v) / len(v) for (c, _), v in got.items() if c == ctr]
+                if per_kernel:
+                    vals[ctr] = sum(per_kernel)
         except Exception:
             pass
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    if extra_out is not None and 'SQ_INSTS_MFMA' in vals:
+        extra_out['SQ_INSTS_MFMA'] = vals['SQ_INSTS_MFMA']
+        if vals.get('GRBM_GUI_ACTIVE') and 'SQ_VALU_MFMA_BUSY_CYCLES' in vals:
+            extra_out['SQ_VALU_MFMA_BUSY_CYCLES'] = vals['SQ_VALU_MFMA_BUSY_CYCLES']
+            extra_out['GRBM_GUI_ACTIVE'] = vals['GRBM_GUI_ACTIVE']
+            # busy cycles are summed over the chip's 1024 SIMDs, GUI_ACTIVE over its 8 XCDs (how r03's review derived it)
+            extra_out['mfma_busy_frac'] = round(vals['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (vals['GRBM_GUI_ACTIVE'] / 8.0), 4)
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
         return None
+    if extra_out is not None:
+        extra_out['write_bytes'] = int(vals['WRITE_SIZE'] * 1024)
     return int((2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
 
 
@@ -773,10 +790,18 @@ def main():
             alg_flops, exec_flops = 2 * K, 3 * 2 * k16
             kname, ksym = 'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)', 'lp_split_count_kernel'
             peak, bound = PEAK_F16_TFLOPS, 'mfma'
+            # what the matrix cores EXECUTE: the sweep runs over the batch's COLUMNS (distinct query rows, padded to the
+            # 192-column panel) x the candidates padded to the 256-row tile, three f16 products per k16 unit -- not over
+            # (query, candidate) pairs (r03 multiplied by pairs and over-stated executed_frac: 0.51 where PMC says 0.39)
+            mfma_cols = (cols.n_single_p + cols.n_multi_p) if cols is not None else (B + 191) // 192 * 192
+            mfma_pairs = mfma_cols * ((n_ent + 255) // 256 * 256)
             extra = {'peak_is': 'dense f16 MFMA (the unit the kernel runs on)',
-                     'executed_flops_per_pair': exec_flops,
-                     'executed_TFLOPs': round(exec_flops * pairs / kern_s / 1e12, 2),
-                     'executed_frac': round(exec_flops * pairs / kern_s / 1e12 / peak, 4),
+                     'executed_flops_per_column_pair': exec_flops,
+                     'mfma_column_pairs_per_launch': int(mfma_pairs),
+                     'executed_TFLOPs': round(exec_flops * mfma_pairs / kern_s / 1e12, 2),
+                     'executed_frac': round(exec_flops * mfma_pairs / kern_s / 1e12 / peak, 4),
+                     'executed_from': '3 x 2 x 16 flop per k16 unit x (padded query columns x padded candidates); '
+                                      'pmc.SQ_INSTS_MFMA x 32768 flop is the same figure from the counters',
                      'frac_of_fp32_mfma_peak': round(alg_flops * pairs / kern_s / 1e12 / PEAK_FP32_TFLOPS, 4),
                      'note': 'ranks are bit-identical to the fp32 path (pairs inside the proven error band are re-scored '
                              'exactly by kge_lp_split_recheck); frac = 2K algorithmic flop per pair against the f16 MFMA '
@@ -790,11 +815,19 @@ def main():
             alg_flops = 3 * K               # the fp32 work of the same pairs: sub, abs, add per (pair, k)
             kname = 'lp_l1_sad_count_kernel (+ thresholds + exact recheck): v_sad_u16 on 16-bit fixed-point operands'
             ksym, peak, bound = 'lp_l1_sad_count_kernel', PEAK_FP32_TFLOPS, 'valu'
+            sad_cols = (cols.n_single_p + cols.n_multi_p) if cols is not None else B
+            sad_insts = sad_cols * n_ent * (K // 2 + K % 2)        # one v_sad_u16 per two elements of a (column, candidate) pair
+            sad_extra = {'sad_issue': {'v_sad_u16_per_launch': int(sad_insts), 'T_inst_per_s': round(sad_insts / kern_s / 1e12, 2),
+                                       'issue_peak_T_inst_per_s': PEAK_SAD_TINST,
+                                       'frac_of_issue_peak': round(sad_insts / kern_s / 1e12 / PEAK_SAD_TINST, 4),
+                                       'note': 'the unit this kernel runs on: v_sad_u16 issues at half rate (256 CUs x 4 SIMDs x 16 '
+                                               'lanes x 2.4 GHz = 39.3 T lane-instructions/s); swept over the distinct query rows'}}
             extra = {'note': 'ranks are bit-identical to the fp32 VALU path (pairs inside the proven error band are re-scored '
                              'exactly by kge_lp_sad_recheck); achieved = 3K fp32-equivalent flop per pair over the time of '
                              'the whole count (thresholds + SAD kernel + recheck), peak = fp32 VALU; the SAD kernel itself '
                              'issues K/2 half-rate integer ops per pair and, since r03, sweeps the distinct query rows only -- '
-                             'frac > 1 means: faster than ANY fp32 VALU kernel could do the same algorithmic work'}
+                             'frac_fp32_equivalent > 1 means: faster than ANY fp32 VALU kernel could do the same algorithmic work'}
+            extra.update(sad_extra)
         else:
             alg_flops = 3 * K               # sub, mul|abs, add on the VALU
             kname, ksym, peak, bound = 'lp_direct_kernel (fp32 VALU)', 'lp_direct_kernel', PEAK_FP32_TFLOPS, 'valu'
@@ -802,8 +835,9 @@ def main():
         # HBM-side bytes of the dominant kernel per launch: two rocprofv3 --pmc passes OF THIS RUN (FETCH_SIZE and
         # WRITE_SIZE cannot share a pass; corrections per MI355X_MICROARCH.md), else the checked-in figure, labelled
         traffic, traffic_src = None, None
+        pmc = {}
         if not args.no_traffic and not multi:
-            traffic = _measure_traffic(args, ksym)
+            traffic = _measure_traffic(args, ksym, pmc if bound == 'mfma' else None)
             traffic_src = None if traffic is None else 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run ' \
                                                        '(2 x FETCH_SIZE + WRITE_SIZE, KB -> B; MI355X_MICROARCH.md gfx950 note)'
         if traffic is None and not args.no_traffic:      # (measurement failed: the checked-in figure, labelled as such)
@@ -823,6 +857,20 @@ def main():
                 'kernel': kname, 'kernel_ms': round(kern_s * 1e3, 4), 'timing': 'HIP events on the launch stream, %d launches' % reps,
                 'pairs_per_launch': pairs, 'algorithmic_flops_per_pair': alg_flops}
         roof.update(extra)
+        if 'sad_issue' in roof:     # TransE-L1: the roofline fraction is taken on the unit the kernel runs on
+            roof['frac_fp32_equivalent'] = roof['frac']
+            roof['frac'] = roof['sad_issue']['frac_of_issue_peak']
+            roof['peak_is'] = 'v_sad_u16 issue rate (39.3 T lane-instructions/s); frac_fp32_equivalent = 3K flop per pair against the fp32 VALU peak'
+        if pmc:
+            pm = {'source': 'rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass spawned by this run '
+                            '(eager launches, Xavier weights), summed over the kernel\'s instantiations per evaluate'}
+            pm.update(pmc)
+            if 'SQ_INSTS_MFMA' in pmc and split:
+                pm['executed_TFLOPs_from_SQ_INSTS_MFMA'] = round(pmc['SQ_INSTS_MFMA'] * 32768 / kern_s / 1e12, 2)
+                pm['executed_frac_from_SQ_INSTS_MFMA'] = round(pmc['SQ_INSTS_MFMA'] * 32768 / kern_s / 1e12 / peak, 4)
+            roof['pmc'] = pm
+            if 'mfma_busy_frac' in pmc:
+                roof['mfma_busy_frac'] = pmc['mfma_busy_frac']
         if cols is not None:
             roof['query_columns'] = {'queries': int(cols.n_queries), 'distinct_rows': int(cols.n_distinct_keys),
                                      'columns': int(cols.n_columns), 'single': int(cols.n_single), 'grouped': int(cols.n_multi),

@@ -353,11 +353,14 @@ int kge_filtered_rank_from_scores(const float *scores, int64_t ld, const int64_t
  * every tile belongs to query q_first + i of a 2B-query batch (tail-side queries first).  true_idx / seg_lo / seg_hi
  * point at the first of the `rows` (<= m) queries; the true score is read from the tiles like the reference reads it
  * from the score matrix (evaluation.py:291-300).  No (B, N) re-layout: every tile row is streamed where it lies.
- * Ranks go straight into the (4, ld) result matrix of kge_rank_finalize_both (same off / pos meaning). */
+ * Ranks go straight into the (4, ld) result matrix of kge_rank_finalize_both (same off / pos meaning).
+ * own != NULL: tile own_rank is read from `own` (m, per) -- the block of the caller's local score tile that holds its
+ * own queries -- instead of from `tiles`, so the exchange never has to copy it (kge_alltoall_scores with recv_own = 0). */
 int kge_filtered_rank_from_tiles(const float *tiles, int64_t m, int64_t per, int world, int64_t N,
                                  const int64_t *true_idx, const int64_t *seg_lo, const int64_t *seg_hi,
                                  const int32_t *targets, int64_t rows, int64_t q_first, int64_t B,
-                                 int64_t *out, int64_t ld, int64_t off, const int64_t *pos, kge_stream_t stream);
+                                 int64_t *out, int64_t ld, int64_t off, const int64_t *pos,
+                                 const float *own, int own_rank, kge_stream_t stream);
 
 /* top-k per row in the order (score descending, index ascending); replaces the
  * full `scores.sort(descending=True)` + slice of EntityInference /

@@ -53,9 +53,11 @@ int kge_allgather_scores(kge_comm_t comm, int world, const float *local, float *
  * Bytes on the fabric per rank: (world-1)/world of ONE local tile -- 1/world of kge_allgather_scores' -- and the ranking
  * work is split world ways instead of repeated on every rank.  The tile rank entry of kge_hip.h [kge_filtered_rank_from_tiles] ranks straight
  * from `recv` (no re-layout); each rank writes only its queries' columns of the zero-initialised (4, n) result matrix
- * and ONE kge_allreduce_ranks at the end of the evaluation completes it everywhere.  The own block is a device copy. */
+ * and ONE kge_allreduce_ranks at the end of the evaluation completes it everywhere.  The own block is a device copy --
+ * or stays where it is (recv_own = 0) and is ranked from `local` (kge_filtered_rank_from_tiles: own / own_rank). */
 int kge_alltoall_scores(kge_comm_t comm, int world, int rank, const float *local, float *recv, int64_t m,
-                        int64_t n_per, void *stream);
+                        int64_t n_per, int recv_own /* 1: also copy the own block into recv[rank]; 0: leave it in `local` */,
+                        void *stream);
 /* in-place SUM of n int64 (the (4, n_facts) rank matrix: every column written by exactly one rank, 0 elsewhere) */
 int kge_allreduce_ranks(kge_comm_t comm, int64_t *ranks, int64_t n, void *stream);
 

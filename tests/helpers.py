@@ -136,9 +136,13 @@ class OracleRankEngine(object):
         out[:q1 - q0, :loc.shape[1]] = loc[q0:q1]
         return out
 
-    def rank_tiles(self, tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None):
+    def rank_tiles(self, tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None, own=None,
+                   own_rank=0):
         """Rank-major tiles (P, m, per) of the score all-to-all -> ranks of `rows` queries, written like finalize_both."""
         assert pos is None
+        if own is not None:
+            tiles = tiles.clone()
+            tiles[own_rank] = own
         P, m, per = tiles.shape
         full = tiles.permute(1, 0, 2).reshape(m, P * per)[:rows, :n_total]
         rk, frk = self.ranks_from_scores(full, true_idx[:rows], seg_lo[:rows], seg_hi[:rows], targets)

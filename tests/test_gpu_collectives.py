@@ -72,6 +72,9 @@ def test_c_abi_collectives_world_of_one():
         # the score all-to-all on one rank = the own block's device copy; the int64 rank all-reduce = identity
         tiles = comm.alltoall_scores(local)
         assert tiles.shape == (1, B, N) and torch.equal(tiles[0], local)
+        untouched = torch.full((1, B, N), 7.0, device='cuda')
+        comm.alltoall_scores(local, untouched, recv_own=False)      # own block left in `local`: nothing is written
+        assert bool((untouched == 7.0).all())
         rk = torch.randint(0, 10 ** 12, (4, B), device='cuda', dtype=torch.int64)
         rk0 = rk.clone()
         assert torch.equal(comm.allreduce_ranks(rk), rk0)
@@ -211,7 +214,13 @@ def test_rank_from_rank_major_tiles_equals_rank_from_the_score_matrix(world, N, 
         my0 = j * m
         rows = max(0, min(m, n2 - my0))
         if rows > 0:
-            _hip.filtered_rank_from_tiles(tiles, N, true[my0:], seg_lo[my0:], seg_hi[my0:], targets, rows, my0, B, got, 3)
+            if j % 2 == 0:
+                _hip.filtered_rank_from_tiles(tiles, N, true[my0:], seg_lo[my0:], seg_hi[my0:], targets, rows, my0, B, got, 3)
+            else:       # the own block read in place (the exchange did not copy it: garbage in its slot of the tiles)
+                own = tiles[j].clone()
+                tiles[j] = float('nan')
+                _hip.filtered_rank_from_tiles(tiles, N, true[my0:], seg_lo[my0:], seg_hi[my0:], targets, rows, my0, B, got, 3,
+                                              None, own, j)
     assert torch.equal(got, want)
     # through pos (facts processed in another order)
     pos = torch.randperm(B + 5, device=dev, generator=g)

@@ -109,7 +109,7 @@ _SIGNATURES = {
     'kge_filter_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
     'kge_filtered_rank_from_scores': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     'kge_filtered_rank_from_tiles': [_vp, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
-                                     _vp, _vp],
+                                     _vp, _vp, _int, _vp],
     'kge_corrupt_scatter': [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     'kge_topk': [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp],
 }
@@ -945,19 +945,24 @@ def filtered_rank_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
     return rank, filt
 
 
-def filtered_rank_from_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None):
+def filtered_rank_from_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None,
+                             own=None, own_rank=0):
     """kge_filtered_rank_from_tiles: ranks of `rows` queries whose score rows lie in the rank-major tiles
-    (P, m, per) of the score all-to-all; written into the (4, n) result matrix like rank_finalize_both."""
+    (P, m, per) of the score all-to-all; written into the (4, n) result matrix like rank_finalize_both.
+    ``own`` (m, per): tile `own_rank` is read from there instead (the block the caller scored itself)."""
     lib = load_library()
     require_cuda(tiles, true_idx, out)
     assert tiles.dtype == torch.float32 and tiles.is_contiguous() and tiles.dim() == 3
     if out.dtype != torch.int64 or out.dim() != 2 or out.shape[0] != 4 or out.stride(1) != 1:
         raise RuntimeError('filtered_rank_from_tiles: out must be a (4, n) int64 matrix with unit column stride')
     P, m, per = tiles.shape
+    if own is not None:
+        require_cuda(own)
+        assert own.dtype == torch.float32 and own.is_contiguous() and tuple(own.shape) == (m, per)
     with _on(tiles.device):
         _check(lib.kge_filtered_rank_from_tiles(_p(tiles), m, per, P, n_total, _p(true_idx), _p(seg_lo), _p(seg_hi),
                                                 _p(targets), rows, q_first, B, _p(out), out.stride(0), off, _p(pos),
-                                                _stream()), 'kge_filtered_rank_from_tiles')
+                                                _p(own), own_rank, _stream()), 'kge_filtered_rank_from_tiles')
     return out
 
 

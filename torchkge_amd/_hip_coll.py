@@ -18,7 +18,7 @@ _SIGNATURES = {
     'kge_comm_init': [_vp, _int, _int, _vp],
     'kge_comm_destroy': [_vp],
     'kge_allgather_scores': [_vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
-    'kge_alltoall_scores': [_vp, _int, _int, _vp, _vp, _i64, _i64, _vp],
+    'kge_alltoall_scores': [_vp, _int, _int, _vp, _vp, _i64, _i64, _int, _vp],
     'kge_allreduce_ranks': [_vp, _vp, _i64, _vp],
     'kge_allreduce_counts': [_vp, _vp, _i64, _vp],
     'kge_allreduce_sum_f32': [_vp, _vp, _i64, _vp],
@@ -71,24 +71,27 @@ class Comm(object):
         _hip.require_cuda(local)
         local = _hip.f32c(local)
         B, per = local.shape
-        if per != -(-int(n_total) // self.world):
-            raise RuntimeError('allgather_scores: the local tile must have ceil(n_total / world) = %d columns '
-                               '(pad the last shard), got %d' % (-(-int(n_total) // self.world), per))
+        need = -(-int(n_total) // self.world)
+        if per < need:      # a short last shard: zero-pad it here (ncclAllGather takes ONE count for every rank; a caller
+            padded = local.new_zeros(B, need)      # that pads further must pad to the same width on every rank)
+            padded[:, :per] = local
+            local, per = padded, need
         gathered = local.new_empty(self.world, B, per)
         full = local.new_empty(B, n_total)
         _check(load_library().kge_allgather_scores(self._h, self.world, _hip._p(local), _hip._p(gathered), _hip._p(full),
                                                    n_total, B, per, n_total, _hip._stream()), 'kge_allgather_scores')
         return full
 
-    def alltoall_scores(self, local, recv=None):
-        """(world * m, n_per) local score tile -> (world, m, n_per) rank-major tiles of THIS rank's m queries."""
+    def alltoall_scores(self, local, recv=None, recv_own=True):
+        """(world * m, n_per) local score tile -> (world, m, n_per) rank-major tiles of THIS rank's m queries
+        (recv_own=False: block `rank` of the result is left unwritten -- rank it from local[rank * m:] instead)."""
         _hip.require_cuda(local)
         assert local.dtype == torch.float32 and local.is_contiguous() and local.shape[0] % self.world == 0
         m, per = local.shape[0] // self.world, local.shape[1]
         if recv is None:
             recv = local.new_empty(self.world, m, per)
         _check(load_library().kge_alltoall_scores(self._h, self.world, self.rank, _hip._p(local), _hip._p(recv), m, per,
-                                                  _hip._stream()), 'kge_alltoall_scores')
+                                                  1 if recv_own else 0, _hip._stream()), 'kge_alltoall_scores')
         return recv
 
     def allreduce_ranks(self, ranks):

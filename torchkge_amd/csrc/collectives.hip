@@ -72,17 +72,20 @@ extern "C" int kge_allgather_scores(kge_comm_t comm, int world, const float *loc
 }
 
 extern "C" int kge_alltoall_scores(kge_comm_t comm, int world, int rank, const float *local, float *recv, int64_t m,
-                                   int64_t n_per, void *stream)
+                                   int64_t n_per, int recv_own, void *stream)
 {
     if (!comm || world < 1 || rank < 0 || rank >= world || m < 0 || n_per < 0) return KGE_EINVAL;
     if (m == 0 || n_per == 0) return 0;
-    if (!local || !recv) return KGE_EINVAL;
+    if (!local || (!recv && (world > 1 || recv_own))) return KGE_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t blk = (size_t)(m * n_per);
-    // the own block never touches the fabric: one device-to-device copy on the same stream
-    hipError_t e = hipMemcpyAsync(recv + (size_t)rank * blk, local + (size_t)rank * blk, blk * sizeof(float),
-                                  hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return (int)e;
+    // the own block never touches the fabric: one device-to-device copy on the same stream -- or none at all when the
+    // caller ranks it where it lies (recv_own = 0; kge_filtered_rank_from_tiles' `own`)
+    if (recv_own) {
+        hipError_t e = hipMemcpyAsync(recv + (size_t)rank * blk, local + (size_t)rank * blk, blk * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (world == 1) return 0;
     int rc = kge_nccl(ncclGroupStart());
     if (rc) return rc;

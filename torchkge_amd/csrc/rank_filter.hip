@@ -102,18 +102,22 @@ __global__ __launch_bounds__(RB) void filtered_rank_tiles_kernel(const float *__
                                                                  const int64_t *__restrict__ seg_hi,
                                                                  const int32_t *__restrict__ targets, int64_t rows,
                                                                  int64_t q_first, int64_t B, int64_t *out, int64_t ld,
-                                                                 int64_t off, const int64_t *__restrict__ pos)
+                                                                 int64_t off, const int64_t *__restrict__ pos,
+                                                                 const float *__restrict__ own, int own_rank)
 {
     __shared__ int sh[RB / 64];
+    // tile p: the receive buffer's block p -- or, for the caller's own rank, the block it scored itself, read where the
+    // scorer wrote it (`own`): the own block never needs to be copied
+    auto tile = [&](int64_t p) -> const float * { return (own && p == own_rank) ? own : tiles + p * m * per; };
     for (int64_t i = blockIdx.x; i < rows; i += gridDim.x) {
         const int64_t ti = true_idx[i];
         const int64_t tp = ti / per;
-        const float tv = tiles[(tp * m + i) * per + (ti - tp * per)];
+        const float tv = tile(tp)[i * per + (ti - tp * per)];
         int c = 0;
         for (int p = 0; p < P; ++p) {
             const int64_t w = N - (int64_t)p * per;      // candidates this tile really holds (the last one may be short)
             if (w <= 0) break;
-            c += count_row(tiles + ((int64_t)p * m + i) * per, w < per ? w : per, tv, false);
+            c += count_row(tile(p) + i * per, w < per ? w : per, tv, false);
         }
         const int raw = block_sum_i(c, sh);
         int sub = 0, found = 0;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(RB) void filtered_rank_tiles_kernel(const float *__
             if (cc == ti) { found = 1; continue; }
             if (cc >= 0 && cc < N) {
                 const int64_t cp = cc / per;
-                sub += ((tiles[(cp * m + i) * per + (cc - cp * per)] >= tv) ? 1 : 0) - neg_inf_counts;
+                sub += ((tile(cp)[i * per + (cc - cp * per)] >= tv) ? 1 : 0) - neg_inf_counts;
             }
         }
         sub = block_sum_i(sub, sh);
@@ -805,14 +809,15 @@ extern "C" int kge_filtered_rank_from_tiles(const float *tiles, int64_t m, int64
                                             const int64_t *true_idx, const int64_t *seg_lo, const int64_t *seg_hi,
                                             const int32_t *targets, int64_t rows, int64_t q_first, int64_t B,
                                             int64_t *out, int64_t ld, int64_t off, const int64_t *pos,
-                                            kge_stream_t stream)
+                                            const float *own, int own_rank, kge_stream_t stream)
 {
     if (rows < 0 || rows > m || per <= 0 || world < 1 || N <= 0 || N > (int64_t)world * per) return KGE_EINVAL;
+    if (own && (own_rank < 0 || own_rank >= world)) return KGE_EINVAL;
     if (B < 0 || off < 0 || ld < off + B || q_first < 0 || q_first + rows > 2 * B) return KGE_EINVAL;
     if (rows == 0) return 0;
-    if (!tiles || !true_idx || !seg_lo || !seg_hi || !out) return KGE_EINVAL;
+    if ((!tiles && !(own && world == 1)) || !true_idx || !seg_lo || !seg_hi || !out) return KGE_EINVAL;
     hipLaunchKernelGGL(filtered_rank_tiles_kernel, dim3(grid1d(rows, 1)), dim3(RB), 0, kge_s(stream), tiles, m, per,
-                       world, N, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, ld, off, pos);
+                       world, N, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, ld, off, pos, own, own_rank);
     KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -109,27 +109,32 @@ _A2A_FALLBACK = set()     # (backend, device type) pairs whose all_to_all_single
 def all_to_all_rows(local, recv, group=None):
     """Score tile (P * m, per) of this rank -- rows [j*m, (j+1)*m) are the queries rank j ranks -- ->
     recv (P, m, per): tile p = the scores rank p computed for THIS rank's m queries (rank-major, no re-layout).
-    ONE all-to-all: (P-1)/P of one local tile per rank on the fabric."""
+    ONE all-to-all: (P-1)/P of one local tile per rank on the fabric.  Returns True when recv[rank] was filled as
+    well, False when the own block was left where the scorer wrote it (local[rank*m : (rank+1)*m]) -- RCCL: the own
+    block is not part of the exchange at all, the rank kernel reads it in place."""
     world, rank = world_and_rank(group)
     P, m, per = recv.shape
     if not multi(world):
-        recv.copy_(local.view(P, m, per))
-        return recv
+        return False
     assert P == world and local.shape[0] == world * m and local.is_contiguous() and recv.is_contiguous()
     key = (backend_name(group), local.device.type)
+    if key[0] == 'nccl':
+        if world > 1:       # grouped send / recv per peer; zero-sized entries (the own block) are skipped by the backend
+            none = local.new_empty(0)
+            dist.all_to_all([recv[j] if j != rank else none for j in range(world)],
+                            [local[j * m:(j + 1) * m] if j != rank else none for j in range(world)], group=group)
+        return False
     if key not in _A2A_FALLBACK:
         try:
             dist.all_to_all_single(recv.view(world * m, per), local, group=group)
-            return recv
-        except (RuntimeError, NotImplementedError) as exc:
-            if key[0] == 'nccl':
-                raise
+            return True
+        except (RuntimeError, NotImplementedError):
             _A2A_FALLBACK.add(key)      # unsupported-op errors are raised before anything is sent, on every rank alike
     # debugging backends only (two gloo ranks sharing one GPU): gather every rank's tile, keep this rank's row block
     gathered = local.new_empty(world, world * m, per)
     dist.all_gather_into_tensor(gathered.view(world * world * m, per), local, group=group)
     recv.copy_(gathered[:, rank * m:(rank + 1) * m])
-    return recv
+    return True
 
 
 def all_gather_blocks(block, out, group=None):

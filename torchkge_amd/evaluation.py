@@ -141,10 +141,12 @@ class HipRankEngine(object):
         return prob.scores_rows(q0, q1, out)
 
     @staticmethod
-    def rank_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None):
-        """Ranks of `rows` queries from the rank-major tiles (P, m, per) the all-to-all delivered, into `out`."""
+    def rank_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B, out, off, pos=None, own=None,
+                   own_rank=0):
+        """Ranks of `rows` queries from the rank-major tiles (P, m, per) the all-to-all delivered, into `out`
+        (own: the block of this rank's own local tile, read in place instead of tiles[own_rank])."""
         return _hip.filtered_rank_from_tiles(tiles, n_total, true_idx, seg_lo, seg_hi, targets, rows, q_first, B,
-                                             out, off, pos)
+                                             out, off, pos, own, own_rank)
 
     @staticmethod
     def ranks_from_scores(scores, true_idx, seg_lo, seg_hi, targets):
@@ -467,12 +469,16 @@ class LinkPredictionEvaluator(object):
             loc = torch.empty(world * m, per, dtype=torch.float32, device=dev)     # rows >= q1 - q0 / columns >= the
             eng.score_rows(prob, q0, q1, loc)                                      # shard's width: never read
             recv = torch.empty(world, m, per, dtype=torch.float32, device=dev)
+            # (RCCL: the own block is not exchanged -- the rank kernel reads it from `loc`; the choice is a property of
+            # the backend, so it is the same when this call is recorded into graph segments and replayed)
+            in_place = kdist.backend_name(self.group) == 'nccl' or not kdist.multi(world)
             self._collective(lambda a_=loc, b_=recv: kdist.all_to_all_rows(a_, b_, self.group))
             my0 = q0 + rank * m
             rows = min(m, q1 - my0)
             if rows > 0:
+                kw = {'own': loc[rank * m:(rank + 1) * m], 'own_rank': rank} if in_place else {}
                 eng.rank_tiles(recv, n_ent, true_idx[my0:], seg_lo[my0:], seg_hi[my0:], targets, rows, my0, B, out, off,
-                               self._perm)
+                               self._perm, **kw)
 
     def _xkw(self, sharded):
         """Engine keyword for the query exchange of row-sharded entity tables: every rank builds the
