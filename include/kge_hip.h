@@ -56,6 +56,7 @@ typedef void *kge_stream_t; /* hipStream_t */
 
 #define KGE_EINVAL (-1)   /* bad argument (null pointer, bad size / kind) */
 #define KGE_EALIGN (-2)   /* pointer or leading dimension not aligned as required */
+#define KGE_EUNSUPPORTED (-3) /* valid arguments outside what the kernel handles (the caller takes its general path) */
 
 /* model kinds (kge_score_triples, kge_lp_prep) */
 enum {
@@ -361,6 +362,43 @@ int kge_filtered_rank_from_tiles(const float *tiles, int64_t m, int64_t per, int
                                  const int32_t *targets, int64_t rows, int64_t q_first, int64_t B,
                                  int64_t *out, int64_t ld, int64_t off, const int64_t *pos,
                                  const float *own, int own_rank, kge_stream_t stream);
+
+/* ---- device-side construction of the evaluator's static integer structures (index_build.hip) ----
+ * rocPRIM radix sorts / scans on the caller's stream + flag and scatter kernels: no ATen sort / unique.  Every builder
+ * writes its element counts to a device array; the host reads them once (the only sync) to size the views. */
+/* maxima of three id arrays (out: 3 uint64 device scalars, caller-zeroed) */
+int kge_i64_max3(const int64_t *a, const int64_t *b, const int64_t *c, int64_t n, int64_t *out, kge_stream_t stream);
+/* The filter index: index[(key1_j, key2_j)] contains values_j (duplicates collapse), as a sorted-key CSR -- what the
+ * reference keeps as dict_of_heads / dict_of_tails (data_structures.py:386-397).  key1 < n_key1, key2 < n_key2 <= key2_span,
+ * values < n_values.  keys (capacity n, int64: key1 * key2_span + key2, ascending), offsets (n + 1), targets (n, int32,
+ * ascending inside a key), counts[0] = number of keys, counts[1] = number of targets.  KGE_EUNSUPPORTED when
+ * bits(n_key1 * n_key2) + bits(n_values) > 64 (one 64-bit radix sort carries key and value). */
+int64_t kge_filter_index_ws_bytes(int64_t n);
+int kge_filter_index_build(const int64_t *key1, const int64_t *key2, const int64_t *values, int64_t n,
+                           int64_t n_key1, int64_t n_key2, int64_t n_values, int64_t key2_span,
+                           int64_t *keys, int64_t *offsets, int32_t *targets, int64_t *counts, void *ws,
+                           int64_t ws_bytes, kge_stream_t stream);
+/* The plan of kge_lp_filter_sub_planned from a batch's filter segments: woff (n + 1), long_q (capacity n: the queries whose
+ * segment is longer than long_len, ascending), counts[0] = n_pairs = woff[n], counts[1] = n_long. */
+int64_t kge_filter_plan_ws_bytes(int64_t n, int64_t n_targets);
+int kge_filter_plan_build(const int64_t *seg_lo, const int64_t *seg_hi, int64_t n, int64_t n_targets,
+                          int64_t long_len, int64_t *woff, int64_t *long_q, int64_t *counts, void *ws,
+                          int64_t ws_bytes, kge_stream_t stream);
+/* The query COLUMNS of a both-sides batch (kge_split_args.col_q / members): queries that share their key -- (h, r) on the
+ * tail side, (t, r) on the head side -- share the query row.  Keys in ascending order (relation_major: r-major), a key with m
+ * queries gives ceil(m / sets) columns of up to `sets` queries; columns with ONE query come first (in key order), the
+ * grouped ones follow in order of decreasing size.  _build: phase A, counts = [columns, single-query columns, distinct
+ * keys]; the host pads the two column counts to the query panel and calls _emit on the SAME workspace:
+ * col_q (max(n_single_p, 1) int32, -1 = padding), members (max(n_multi_p, 1) * sets int32, -1 = unused), qs_row (2B int32:
+ * the column a query's split row is written to, -1 for all but the first query of a column), col_of_q (2B int64),
+ * rep (max(n_single_p + n_multi_p, 1) int64: the query that provides a column's row). */
+int64_t kge_column_plan_ws_bytes(int64_t n_queries, int64_t n_ent, int64_t n_rel);
+int kge_column_plan_build(const int64_t *h, const int64_t *t, const int64_t *r, int64_t B, int64_t n_ent,
+                          int64_t n_rel, int sets, int relation_major, int64_t *counts, void *ws,
+                          int64_t ws_bytes, kge_stream_t stream);
+int kge_column_plan_emit(int64_t B, int64_t n_ent, int64_t n_rel, int sets, int64_t n_single_p,
+                         int64_t n_multi_p, int32_t *col_q, int32_t *members, int32_t *qs_row,
+                         int64_t *col_of_q, int64_t *rep, void *ws, int64_t ws_bytes, kge_stream_t stream);
 
 /* top-k per row in the order (score descending, index ascending); replaces the
  * full `scores.sort(descending=True)` + slice of EntityInference /

@@ -169,7 +169,8 @@ def test_grouped_filter_correction_with_hub_keys_bit_exact(hip, kind, p):
         assert torch.equal(acc[0], sub_g) and torch.equal(acc[1], found_g)
 
 
-def test_evaluator_on_skewed_graph_equals_materialised_path(hip):
+@pytest.mark.parametrize('coalesce_mode', ['literal', 'default'])
+def test_evaluator_on_skewed_graph_equals_materialised_path(hip, coalesce_mode):
     """LinkPredictionEvaluator on a Zipf graph with hubs: fused (grouped filter correction, both sides
     as one batch) == side by side == materialised score matrices, rank for rank."""
     import bench

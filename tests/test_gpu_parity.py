@@ -247,8 +247,9 @@ def _rank_bounds(scores, true_idx, tol):
     return (scores >= st + tol).sum(1), (scores >= st - tol).sum(1)
 
 
+@pytest.mark.parametrize('coalesce_mode', ['literal', 'default'])
 @pytest.mark.parametrize('kind,p', CASES)
-def test_evaluator_vs_reference(hip, kind, p):
+def test_evaluator_vs_reference(hip, kind, p, coalesce_mode):
     """LinkPredictionEvaluator: fused == materialised == composed drop-in path
     bit for bit; vs the reference's ranks: equal, except where the reference's
     own scores tie within 2*TOL (then inside the tie interval); metrics 1e-5."""
@@ -297,7 +298,8 @@ def test_evaluator_vs_reference(hip, kind, p):
     # a reference-style small b_size is coalesced into large internal batches (evaluation._internal_batch): same ranks
     ev8 = tk.LinkPredictionEvaluator(m, kg_test, coalesce=32768)
     ev8.evaluate(b_size=3, verbose=False)
-    assert ev8._internal_batch(3, nt) == nt and ev._internal_batch(3, nt) == 3    # (conftest switches the default off)
+    assert ev8._internal_batch(3, nt) == nt                                        # (the shipped default does the same:
+    assert ev._internal_batch(3, nt) == (3 if coalesce_mode == 'literal' else nt)  #  conftest switches it off in 'literal' mode)
     for nm in names:
         assert torch.equal(getattr(ev, nm), getattr(ev8, nm))
     # ... and so does the SHIPPED default configuration replayed as a hipGraph (coalesced internal batch: its plan keys,
@@ -1257,8 +1259,9 @@ def test_split_count_on_query_columns_equals_per_query_counts(hip, eps):
     assert int(raws[0].min()) >= 1
 
 
+@pytest.mark.parametrize('coalesce_mode', ['literal', 'default'])
 @pytest.mark.parametrize('kind', ['transe', 'transe_l1', 'transe_direct', 'distmult', 'complex', 'transh', 'transd'])
-def test_evaluator_dedupes_query_rows_and_keeps_the_ranks(hip, monkeypatch, kind):
+def test_evaluator_dedupes_query_rows_and_keeps_the_ranks(hip, monkeypatch, kind, coalesce_mode):
     """evaluate() on a graph with hub keys (TransE-L2: fused query pipeline writing one split row per column; DistMult /
     ComplEx: rows gathered per column): identical rank vectors with the ColumnPlan path on (default) and off
     (KGE_DEDUPE_QUERIES=0), eager and as hipGraph replays."""
@@ -1418,3 +1421,51 @@ def test_l1_evaluator_uses_the_prefilter_and_matches_exact_counts(hip):
             assert prob.sad is not None and guard is not None
     finally:
         m.lp_guard_end()
+
+
+@pytest.mark.parametrize('n_ent,n_rel,n,seed', [(60, 5, 5000, 3), (14541, 237, 60000, 4), (7, 1, 9, 5), (3000, 11, 1, 6),
+                                                 (200000, 50, 300000, 7)])
+def test_device_built_index_and_plans_equal_the_torch_builds(hip, n_ent, n_rel, n, seed):
+    """The library's own index / plan builders (index_build.hip: kge_filter_index_build, kge_filter_plan_build,
+    kge_column_plan_build / _emit -- rocPRIM sorts and scans + flag / scatter kernels) against the ATen compositions they
+    replace, run on CPU tensors: every output tensor equal, element for element.  Hub keys (lists longer than 512, keys
+    with more queries than a grouped column holds), duplicate facts, a relation-major column order."""
+    from torchkge_amd.filter_index import FilterIndex, FilterPlan, ColumnPlan, KEY2_SPAN
+    g = torch.Generator().manual_seed(seed)
+    h = torch.randint(0, n_ent, (n,), generator=g)
+    t = torch.randint(0, n_ent, (n,), generator=g)
+    r = torch.randint(0, n_rel, (n,), generator=g)
+    if n >= 5000:       # hub keys: one (h, r) with 900 tails, one (t, r) with 700 heads, and exact duplicates
+        h[:900], r[:900] = 1, 0
+        t[1000:1700], r[1000:1700] = 2, n_rel - 1
+        h[2000:2050], t[2000:2050], r[2000:2050] = h[0], t[0], r[0]
+    for k1, k2, v in ((h, r, t), (t, r, h)):
+        ref = FilterIndex.from_triples(k1.numpy(), k2.numpy(), v.numpy(), 'cpu')
+        for bounds in ((n_ent, n_rel, n_ent), (None, None, None)):
+            got = FilterIndex.from_triples_device(k1, k2, v, 'cuda', *bounds)
+            assert torch.equal(got.keys.cpu(), ref.keys) and torch.equal(got.offsets.cpu(), ref.offsets)
+            assert torch.equal(got.targets.cpu()[:int(ref.offsets[-1])], ref.targets[:int(ref.offsets[-1])])
+    # plans of a batch of test facts: the last facts of the graph (they hit the hub keys when n is large)
+    idx_t = FilterIndex.from_triples_device(h, r, t, 'cuda', n_ent, n_rel, n_ent)
+    idx_h = FilterIndex.from_triples_device(t, r, h, 'cuda', n_ent, n_rel, n_ent)
+    B = min(n, 3000)
+    sel = torch.cat([torch.arange(0, min(n, 1200)), torch.arange(max(0, n - (B - min(n, 1200))), n)])[:B]
+    hb, tb, rb = h[sel].cuda(), t[sel].cuda(), r[sel].cuda()
+    lo, hi, true = hip.filter_lookup_both(idx_t.keys, idx_t.offsets, idx_h.keys, idx_h.offsets, idx_t.targets.shape[0],
+                                          hb, tb, rb, KEY2_SPAN)
+    targets = torch.cat([idx_t.targets, idx_h.targets])
+    pd = FilterPlan(lo, hi, true, targets)
+    pc = FilterPlan(lo.cpu(), hi.cpu(), true.cpu(), targets.cpu())
+    assert pd.n_pairs == pc.n_pairs and pd.n_long == pc.n_long
+    assert torch.equal(pd.woff.cpu(), pc.woff) and torch.equal(pd.long_q.cpu(), pc.long_q)
+    sets = hip.split_group_sets()
+    for rel_major in (False, True):
+        cd = ColumnPlan(hb, tb, rb, n_ent, n_rel, sets, hip.split_query_rows_padded, relation_major=rel_major)
+        cc = ColumnPlan(hb.cpu(), tb.cpu(), rb.cpu(), n_ent, n_rel, sets, hip.split_query_rows_padded, relation_major=rel_major)
+        for nm in ('n_queries', 'n_single', 'n_multi', 'n_single_p', 'n_multi_p', 'sets', 'n_columns', 'n_distinct_keys'):
+            assert getattr(cd, nm) == getattr(cc, nm), nm
+        for nm in ('col_q', 'members', 'qs_row', 'col_of_q', 'rep'):
+            assert torch.equal(getattr(cd, nm).cpu(), getattr(cc, nm)), nm
+    # the relation order of a batch (TransH / TransD): the library's radix sort == a stable argsort
+    keys = (torch.arange(B) // 1000) * n_rel + rb.cpu()
+    assert torch.equal(hip.sort_perm(keys.cuda(), (B // 1000 + 1) * n_rel).cpu(), torch.argsort(keys, stable=True))

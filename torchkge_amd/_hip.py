@@ -111,12 +111,19 @@ _SIGNATURES = {
     'kge_filtered_rank_from_tiles': [_vp, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
                                      _vp, _vp, _int, _vp],
     'kge_corrupt_scatter': [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    'kge_i64_max3': [_vp, _vp, _vp, _i64, _vp, _vp],
+    'kge_filter_index_build': [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    'kge_filter_plan_build': [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    'kge_column_plan_build': [_vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp, _i64, _vp],
+    'kge_column_plan_emit': [_i64, _i64, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     'kge_topk': [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp],
 }
 # every symbol include/kge_hip.h declares
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_version', 'kge_lp_split_rows_padded',
                                                'kge_build_arch', 'kge_lp_filter_sub_ws_bytes', 'kge_lp_sad_cols_padded',
-                                               'kge_key_sort_ws_bytes', 'kge_lp_split_group_sets'])
+                                               'kge_key_sort_ws_bytes', 'kge_lp_split_group_sets',
+                                               'kge_filter_index_ws_bytes', 'kge_filter_plan_ws_bytes',
+                                               'kge_column_plan_ws_bytes'])
 
 _lib = None
 ABI_VERSION = 23        # kge_abi_version() of the library this binding was written against
@@ -145,6 +152,12 @@ def load_library():
     lib.kge_lp_filter_sub_ws_bytes.restype = _i64
     lib.kge_key_sort_ws_bytes.argtypes = [_i64, _int]
     lib.kge_key_sort_ws_bytes.restype = _i64
+    lib.kge_filter_index_ws_bytes.argtypes = [_i64]
+    lib.kge_filter_index_ws_bytes.restype = _i64
+    lib.kge_filter_plan_ws_bytes.argtypes = [_i64, _i64]
+    lib.kge_filter_plan_ws_bytes.restype = _i64
+    lib.kge_column_plan_ws_bytes.argtypes = [_i64, _i64, _i64]
+    lib.kge_column_plan_ws_bytes.restype = _i64
     lib.kge_lp_sad_cols_padded.argtypes = [_int]
     lib.kge_lp_sad_cols_padded.restype = _i64
     lib.kge_lp_split_group_sets.argtypes = []
@@ -245,6 +258,25 @@ BWD_SORTED_MIN_BATCH = 2048     # below this the plain atomic scatter is as fast
 
 _KEY_SORT_WS = {}
 BWD_PERM = os.environ.get('KGE_BWD_PERM', 'sort')      # 'sort' (kge_key_sort) | 'torch' (torch.sort) | 'count' (kge_key_hist / _scatter): how score_triples_bwd orders the ids of a large batch
+
+
+def sort_perm(keys, n_keys):
+    """Stable ascending order of small non-negative int64 keys (< n_keys <= 2**32): perm[j] = position of the j-th
+    key (kge_key_sort: one device radix sort of (key, position) pairs)."""
+    lib = load_library()
+    require_cuda(keys)
+    keys = i64c(keys)
+    n, dev = keys.shape[0], keys.device
+    bits = max(1, int(n_keys - 1).bit_length())
+    if bits > 32:
+        raise RuntimeError('sort_perm: keys need more than 32 bits')
+    nb = int(lib.kge_key_sort_ws_bytes(n, bits))
+    ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
+    perm = torch.empty(n, dtype=torch.int64, device=dev)
+    if n > 0:
+        with _on(dev):
+            _check(lib.kge_key_sort(_p(keys), n, None, 0, bits, _p(perm), _p(ws), nb, _stream()), 'kge_key_sort')
+    return perm
 
 
 def score_triples_bwd(kind, tables, d_ent, d_rel, h, t, r, grad_out, needs):
@@ -991,6 +1023,99 @@ def topk_chunk(scores, c_base, k, out_val, out_idx, col_off, seg_lo=None, seg_hi
         _check(lib.kge_topk_chunk(_p(scores), scores.stride(0), B, C, c_base, k, _p(seg_lo), _p(seg_hi), _p(targets),
                                   _p(ids_in), 0 if ids_in is None else ids_in.stride(0), _p(out_idx), _p(out_val),
                                   out_val.stride(0), col_off, _stream()), 'kge_topk_chunk')
+
+
+KGE_EUNSUPPORTED = -3
+
+
+def _host_counts(counts):
+    """The element counts a builder left in a small device array -> Python ints (one pinned copy, one stream sync)."""
+    host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+    host.copy_(counts, non_blocking=True)
+    torch.cuda.current_stream(counts.device).synchronize()
+    return [int(x) for x in host.tolist()]
+
+
+def i64_max3(a, b, c):
+    """(max a, max b, max c) of three int64 id vectors of equal length, one launch + one sync."""
+    lib = load_library()
+    require_cuda(a, b, c)
+    out = torch.zeros(3, dtype=torch.int64, device=a.device)
+    with _on(a.device):
+        _check(lib.kge_i64_max3(_p(a), _p(b), _p(c), a.shape[0], _p(out), _stream()), 'kge_i64_max3')
+    return _host_counts(out)
+
+
+def filter_index_build(key1, key2, values, n_key1, n_key2, n_values, key2_span):
+    """kge_filter_index_build: (keys, offsets, targets) of the sorted-key CSR, or None when the composite
+    (key, value) does not fit one 64-bit radix key (the caller then takes the two-sort path)."""
+    lib = load_library()
+    require_cuda(key1, key2, values)
+    key1, key2, values = i64c(key1), i64c(key2), i64c(values)
+    n, dev = key1.shape[0], key1.device
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    targets = torch.empty(n, dtype=torch.int32, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    nb = int(lib.kge_filter_index_ws_bytes(n))
+    ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        rc = lib.kge_filter_index_build(_p(key1), _p(key2), _p(values), n, n_key1, n_key2, n_values, key2_span, _p(keys),
+                                        _p(offsets), _p(targets), _p(counts), _p(ws), nb, _stream())
+    if rc == KGE_EUNSUPPORTED:
+        return None
+    _check(rc, 'kge_filter_index_build')
+    n_keys, n_t = _host_counts(counts)
+    # (compact copies: the capacity-n buffers would pin 20 bytes per fact for the lifetime of the index)
+    return keys[:n_keys].clone(), offsets[:n_keys + 1].clone(), targets[:n_t].clone()
+
+
+def filter_plan_build(seg_lo, seg_hi, n_targets, long_len):
+    """kge_filter_plan_build: (woff (n + 1), long_q (n_long), n_pairs)."""
+    lib = load_library()
+    require_cuda(seg_lo, seg_hi)
+    n, dev = seg_lo.shape[0], seg_lo.device
+    woff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    long_q = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    nb = int(lib.kge_filter_plan_ws_bytes(n, n_targets))
+    ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        _check(lib.kge_filter_plan_build(_p(seg_lo), _p(seg_hi), n, n_targets, long_len, _p(woff), _p(long_q), _p(counts),
+                                         _p(ws), nb, _stream()), 'kge_filter_plan_build')
+    n_pairs, n_long = _host_counts(counts)
+    return woff, long_q[:n_long], n_pairs
+
+
+def column_plan_build(h, t, r, n_ent, n_rel, sets, pad, relation_major):
+    """kge_column_plan_build + _emit: the tensors of filter_index.ColumnPlan, or None when the keys do not fit 64 bits."""
+    lib = load_library()
+    require_cuda(h, t, r)
+    h, t, r = i64c(h), i64c(t), i64c(r)
+    B, dev = h.shape[0], h.device
+    n = 2 * B
+    nb = int(lib.kge_column_plan_ws_bytes(n, n_ent, n_rel))
+    ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
+    counts = torch.empty(3, dtype=torch.int64, device=dev)
+    with _on(dev):
+        rc = lib.kge_column_plan_build(_p(h), _p(t), _p(r), B, n_ent, n_rel, sets, 1 if relation_major else 0, _p(counts),
+                                       _p(ws), nb, _stream())
+    if rc == KGE_EUNSUPPORTED:
+        return None
+    _check(rc, 'kge_column_plan_build')
+    n_chunks, n1, n_distinct = _host_counts(counts)
+    n2 = n_chunks - n1
+    n1p, n2p = (pad(n1) if n1 > 0 else 0), (pad(n2) if n2 > 0 else 0)
+    col_q = torch.empty(max(n1p, 1), dtype=torch.int32, device=dev)
+    members = torch.empty(max(n2p, 1) * sets, dtype=torch.int32, device=dev)
+    qs_row = torch.empty(n, dtype=torch.int32, device=dev)
+    col_of_q = torch.empty(n, dtype=torch.int64, device=dev)
+    rep = torch.empty(max(n1p + n2p, 1), dtype=torch.int64, device=dev)
+    with _on(dev):
+        _check(lib.kge_column_plan_emit(B, n_ent, n_rel, sets, n1p, n2p, _p(col_q), _p(members), _p(qs_row), _p(col_of_q),
+                                        _p(rep), _p(ws), nb, _stream()), 'kge_column_plan_emit')
+    return {'n_single': n1, 'n_multi': n2, 'n_single_p': n1p, 'n_multi_p': n2p, 'col_q': col_q, 'members': members,
+            'qs_row': qs_row, 'col_of_q': col_of_q, 'rep': rep, 'n_columns': n_chunks, 'n_distinct_keys': n_distinct}
 
 
 def corrupt_scatter(heads, tails, mask_u8, draws_h, draws_t, n_neg):

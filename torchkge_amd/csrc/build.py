@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['score_triples.hip', 'lp_prep.hip', 'lp_gemm_mfma.hip', 'lp_split_mfma.hip', 'lp_direct.hip',
-           'lp_l1_sad.hip', 'rank_filter.hip', 'corrupt.hip', 'key_sort.hip']
+           'lp_l1_sad.hip', 'rank_filter.hip', 'corrupt.hip', 'key_sort.hip', 'index_build.hip']
 HEADERS = ['kge_common.h', os.path.join('..', '..', 'include', 'kge_hip.h')]
 LIB = os.path.join(HERE, 'libkge_hip.so')
 # the RCCL exchange step of the sharded path (include/kge_hip_coll.h): its own shared object, so that

@@ -100,7 +100,9 @@ struct SplitParams {
     int qg;               // query panels interleaved under one sweep of the candidate tiles (work order)
     int64_t n_items;
     int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 4 no epilogue,
-                          // 16 no LDS fragment reads, 32 no barriers, 128 every block streams tile (0,0)
+                          // 16 no LDS fragment reads, 32 no barriers, 128 every block streams tile (0,0),
+                          // 1024 hi*hi product only (one-product first level), 2048 half of the LDS-DMA pieces
+                          // (a planar hi table would move half the bytes)
 };
 
 // ---- operand preparation ---------------------------------------------------
@@ -881,13 +883,14 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         // registers of an LDS-DMA still in flight: keep those registers occupied until here)
         asm volatile("" :: "v"(gE), "v"(gE1));
         __builtin_amdgcn_sched_barrier(0);
-        KGE_SMMA_PA(ah0, bl0)
+        const bool hi1 = DBG && (dbg & 1024), halfdma = DBG && (dbg & 2048);
+        if (!hi1) { KGE_SMMA_PA(ah0, bl0) }
         __builtin_amdgcn_sched_barrier(0);
-        if (pf) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
+        if (pf && !halfdma) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
         __builtin_amdgcn_sched_barrier(0);
-        KGE_SMMA_PA(al0, bh0)
+        if (!hi1) { KGE_SMMA_PA(al0, bh0) }
         __builtin_amdgcn_sched_barrier(0);
-        if (pf) { dma(gQ, nQ); dma(gQ + rstep, nQ + SROWS * 128); dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128); }
+        if (pf) { dma(gQ, nQ); if (!halfdma) { dma(gQ + rstep, nQ + SROWS * 128); dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128); } }
         if (more && pf) {
             if (++pf_s == S) {
                 pf_s = 0;
@@ -909,9 +912,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         const bool defer_frag = GS != 0 && s == S - 1;
         if (more && !(dbg & 16) && !defer_frag) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
         __builtin_amdgcn_sched_barrier(0);
-        if (two) { KGE_SMMA_PA(ah1, bl1) }
+        if (two && !hi1) { KGE_SMMA_PA(ah1, bl1) }
         __builtin_amdgcn_sched_barrier(0);
-        if (two) { KGE_SMMA_PA(al1, bh1) }
+        if (two && !hi1) { KGE_SMMA_PA(al1, bh1) }
         __builtin_amdgcn_sched_barrier(0);
 
         const bool tile_done = s == S - 1;

@@ -73,7 +73,11 @@ class _LazyDicts(object):
                 self._index[key] = FilterIndex.load(path, device)
                 return self._index[key]
             h, t, r = self.src
-            build = FilterIndex.from_triples_torch if torch.device(device).type == 'cuda' else FilterIndex.from_triples
+            if torch.device(device).type == 'cuda':
+                n_ent, n_rel = getattr(self, 'n_ent', None), getattr(self, 'n_rel', None)
+                build = lambda a, b, c, dv: FilterIndex.from_triples_torch(a, b, c, dv, n_ent, n_rel, n_ent)   # noqa: E731
+            else:
+                build = FilterIndex.from_triples
             if side == 'heads':
                 self._index[key] = build(t, r, h, device)
             else:
@@ -125,6 +129,7 @@ class KnowledgeGraph(Dataset):
             self._lazy = _filter_src
         elif self._explicit_dicts is None:
             self._lazy = _LazyDicts(self.head_idx.cpu(), self.tail_idx.cpu(), self.relations.cpu())
+            self._lazy.n_ent, self._lazy.n_rel = self.n_ent, self.n_rel      # id bounds for the device-side index build
         else:
             self._lazy = None
         try:

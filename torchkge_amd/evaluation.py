@@ -336,13 +336,20 @@ class LinkPredictionEvaluator(object):
         if want_sort and rels.shape[0] > 0:
             # stable sort by relation INSIDE every batch (batch membership is unchanged)
             batch_of = torch.div(torch.arange(rels.shape[0], device=device), b_size, rounding_mode='floor')
-            self._perm = torch.argsort(batch_of * (int(rels.max()) + 1) + rels, stable=True).contiguous()
+            n_rel = int(self.model.n_rel)
+            n_keys = (int(rels.shape[0] - 1) // b_size + 1) * n_rel
+            if rels.is_cuda and n_keys <= (1 << 32) and isinstance(self.engine, HipRankEngine):
+                self._perm = _hip.sort_perm(batch_of * n_rel + rels, n_keys)   # the library's radix sort (no ATen sort)
+            else:
+                self._perm = torch.argsort(batch_of * n_rel + rels, stable=True).contiguous()
             heads, tails, rels = heads[self._perm], tails[self._perm], rels[self._perm]
-        uniq, inv = torch.unique(torch.cat([heads, tails]), return_inverse=True)
         n = heads.shape[0]
-        self._qmap = {'uniq': uniq.contiguous(), 'hq': inv[:n].contiguous(), 'tq': inv[n:].contiguous()}
         world, rank = kdist.world_and_rank(self.group) if self.shard else (1, 0)
+        self._qmap = None
         if self.shard == 'entities' and kdist.multi(world):
+            # (row-sharded tables only: the distinct entities of the test facts and the facts re-indexed into that list)
+            uniq, inv = torch.unique(torch.cat([heads, tails]), return_inverse=True)
+            self._qmap = {'uniq': uniq.contiguous(), 'hq': inv[:n].contiguous(), 'tq': inv[n:].contiguous()}
             # uniq is sorted and the shards are contiguous id ranges: rank p owns ONE slice [a_p, b_p) of uniq
             per = kdist.shard_size(self.model.n_ent, world)
             cuts = torch.searchsorted(uniq, torch.arange(world + 1, device=device, dtype=uniq.dtype) * per).tolist()

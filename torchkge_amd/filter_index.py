@@ -70,11 +70,39 @@ class FilterIndex(object):
         return cls(ukeys, offsets, v.astype(np.int32), device)
 
     @classmethod
-    def from_triples_torch(cls, key1, key2, values, device):
-        """The same index built ON the target device with torch sort / unique_consecutive
-        (two stable sorts = lexicographic (key, value) order): at Wikidata5M scale (2e7 facts)
-        this replaces minutes of per-fact Python (data_structures.py:386-397) by a few
-        device-side sorts.  Bit-identical to from_triples."""
+    def from_triples_device(cls, key1, key2, values, device, n_key1=None, n_key2=None, n_values=None):
+        """The same index built ON the GPU by the library's own kernels (kge_filter_index_build: ONE 64-bit radix sort
+        of the composite (key, value), flags, a scan, a scatter -- no ATen sort / unique, whose first use in a process
+        costs ~0.5 s of kernel loading).  n_key1 / n_key2 / n_values: exclusive upper bounds of the ids (n_ent, n_rel,
+        n_ent for a KnowledgeGraph); found by one reduction launch when not given.  Bit-identical to from_triples."""
+        dev = torch.device(device)
+        key1 = torch.as_tensor(key1, dtype=torch.int64).to(dev)
+        key2 = torch.as_tensor(key2, dtype=torch.int64).to(dev)
+        v = torch.as_tensor(values, dtype=torch.int64).to(dev)
+        if key1.numel() == 0:
+            return cls(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int32), device)
+        if n_key1 is None or n_key2 is None or n_values is None:
+            m1, m2, m3 = _hip.i64_max3(key1, key2, v)
+            n_key1, n_key2, n_values = m1 + 1, m2 + 1, m3 + 1
+        if not (0 < n_key2 <= KEY2_SPAN and 0 < n_values < (1 << 31) and n_key1 > 0):
+            raise ValueError('filter index: ids out of range (negative, or a relation id >= 2**31)')
+        built = _hip.filter_index_build(key1, key2, v, int(n_key1), int(n_key2), int(n_values), KEY2_SPAN)
+        if built is None:       # (key, value) does not fit 64 bits: the two-sort ATen composition
+            return cls._from_triples_aten(key1, key2, v, device)
+        return cls(built[0], built[1], built[2], device)
+
+    @classmethod
+    def from_triples_torch(cls, key1, key2, values, device, n_key1=None, n_key2=None, n_values=None):
+        """The index built ON the target device: the library's own kernels on the GPU (from_triples_device), the ATen
+        sort / unique_consecutive composition elsewhere.  At Wikidata5M scale (2e7 facts) this replaces minutes of
+        per-fact Python (data_structures.py:386-397) by a few device-side passes.  Bit-identical to from_triples."""
+        if torch.device(device).type == 'cuda':
+            return cls.from_triples_device(key1, key2, values, device, n_key1, n_key2, n_values)
+        return cls._from_triples_aten(key1, key2, values, device)
+
+    @classmethod
+    def _from_triples_aten(cls, key1, key2, values, device):
+        """torch sort / unique_consecutive (two stable sorts = lexicographic (key, value) order)."""
         dev = torch.device(device)
         key1 = torch.as_tensor(key1, dtype=torch.int64).to(dev)
         key2 = torch.as_tensor(key2, dtype=torch.int64).to(dev)
@@ -131,6 +159,10 @@ class FilterPlan(object):
         self.seg_lo, self.seg_hi, self.true_idx, self.targets = seg_lo, seg_hi, true_idx, targets
         n = seg_lo.shape[0]
         dev = seg_lo.device
+        if seg_lo.is_cuda and n > 0:    # the library's own kernels (atomicMin claim, one packed scan): no ATen scatter_reduce
+            self.woff, self.long_q, self.n_pairs = _hip.filter_plan_build(seg_lo, seg_hi, int(targets.shape[0]), self.LONG)
+            self.n_long = int(self.long_q.shape[0])
+            return
         ln = seg_hi - seg_lo
         nonempty = ln > 0
         # first query of every distinct segment start (segments of one index are disjoint: the start names the key)
@@ -166,6 +198,13 @@ class ColumnPlan(object):
         B = h.shape[0]
         n = 2 * B
         self.n_queries = n
+        self.sets = sets
+        if h.is_cuda and B > 0:     # the library's own kernels (radix sort of (key, query), scans, one scatter)
+            built = _hip.column_plan_build(h, t, r, n_ent, n_rel, sets, pad, relation_major)
+            if built is not None:
+                for k_, v_ in built.items():
+                    setattr(self, k_, v_)
+                return
         if relation_major:      # columns come out in key order: relation-major for kernels that gather per-relation rows
             key = torch.cat([r * n_ent + h, (r * n_ent + t) + n_ent * n_rel])
         else:
