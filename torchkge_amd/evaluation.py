@@ -503,7 +503,9 @@ class LinkPredictionEvaluator(object):
         """`fn` bracketed by two events on the current stream while collective timing is on (decided when the call
         RUNS: the calls recorded into graph segments at capture time are timed at replay too)."""
         def call(*a):
-            if self._ctimes is None:
+            # (timing-enabled events must not be recorded into a stream capture: with the collectives captured inside
+            # the graph -- graph_collectives -- the capture call runs untimed, and replays contain no Python calls)
+            if self._ctimes is None or torch.cuda.is_current_stream_capturing():
                 return fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -516,7 +518,9 @@ class LinkPredictionEvaluator(object):
     def collective_timing(self, on=True):
         """Device time of the data-path collectives (RCCL calls on the evaluation stream, bracketed by events):
         ``collective_timing(True)`` starts collecting, ``collective_timing(False)`` returns
-        ``{'collectives': n, 'ms': total}`` for the evaluate() calls in between and stops."""
+        ``{'collectives': n, 'ms': total}`` for the evaluate() calls in between and stops.  Collectives that were
+        captured INSIDE the hipGraph of evaluate() (``graph_collectives``) are not Python calls at replay: they are
+        not timed (0 collectives reported); graph segments and eager evaluations are."""
         if on:
             self._ctimes = []
             return None
