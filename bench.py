@@ -93,6 +93,9 @@ def parse():
     ap.add_argument('--l2-mode', default='auto', choices=['auto', 'expand', 'direct'])
     ap.add_argument('--no-split', action='store_true',
                     help='rank counts on the fp32 MFMA kernel only (no f16-split prefilter)')
+    ap.add_argument('--split-level', default='auto', choices=['auto', '0', '1'],
+                    help="level of the f16-split prefilter: 'auto' (the evaluator's policy: one product per k16 unit when the "
+                         "previous evaluation re-scored few pairs per query, else three), or forced")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the scoring_function / sampler / train-step timings')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per evaluate()')
@@ -399,7 +402,8 @@ def _measure_traffic(args, kernel_sym, extra_out=None):
         cmd = [rp, '--pmc'] + list(ctrs) + ['--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 't', '--', sys.executable,
                os.path.abspath(__file__), '--only-timed', '--no-graph', '--no-traffic', '--weights',
                'xavier' if args.weights == 'trained' else args.weights, '--steps', '3', '--warmup', '0',
-               '--settle-ms', '0', '--workload', args.workload, '--batch', str(args.batch), '--kg', args.kg, '--l2-mode', args.l2_mode]
+               '--settle-ms', '0', '--workload', args.workload, '--batch', str(args.batch), '--kg', args.kg, '--l2-mode', args.l2_mode,
+               '--split-level', str(getattr(args, 'level_used', args.split_level))]
         cmd += (['--no-split'] if args.no_split else []) + (['--materialize'] if args.materialize else []) \
             + (['--no-both'] if args.no_both else [])
         env = dict(os.environ, TMPDIR='/tmp')
@@ -492,6 +496,7 @@ def main():
     if kind in ('transe', 'transh', 'transd'):
         model.l2_mode = args.l2_mode
     model.split_filter = not args.no_split
+    model.split_level = 'auto' if args.split_level == 'auto' else int(args.split_level)
     replicas = multi and args.scaling == 'weak' and args.shard != 'entities'
     if replicas:
         # every rank evaluates its own test split of the same size (facts of the same graph)
@@ -786,9 +791,13 @@ def main():
         # dense peak of the UNIT the kernel runs on.  What the kernel additionally executes (the f16 split's three
         # products over K padded to 16) is reported as executed_*; it is not the roofline fraction.
         if split:
-            k16 = (K + 1 + 15) // 16 * 16
-            alg_flops, exec_flops = 2 * K, 3 * 2 * k16
-            kname, ksym = 'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)', 'lp_split_count_kernel'
+            level = int(prob.split.get('level', 0))      # 1: the one-product level (planar hi operands, one MFMA per k16 unit)
+            k16 = ((K + 2 + 15) // 16 * 16) if level == 1 else ((K + 1 + 15) // 16 * 16)
+            alg_flops, exec_flops = 2 * K, (1 if level == 1 else 3) * 2 * k16
+            kname = ('lp_split_count_kernel, LV = 1 (f16 hi operands, ONE v_mfma_f32_32x32x16_f16 product per k16 unit, fp32 '
+                     'accumulate; band from the measured f16 residuals)') if level == 1 else \
+                'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)'
+            ksym = 'lp_split_count_kernel'
             peak, bound = PEAK_F16_TFLOPS, 'mfma'
             # what the matrix cores EXECUTE: the sweep runs over the batch's COLUMNS (distinct query rows, padded to the
             # 192-column panel) x the candidates padded to the 256-row tile, three f16 products per k16 unit -- not over
@@ -800,12 +809,14 @@ def main():
                      'mfma_column_pairs_per_launch': int(mfma_pairs),
                      'executed_TFLOPs': round(exec_flops * mfma_pairs / kern_s / 1e12, 2),
                      'executed_frac': round(exec_flops * mfma_pairs / kern_s / 1e12 / peak, 4),
-                     'executed_from': '3 x 2 x 16 flop per k16 unit x (padded query columns x padded candidates); '
-                                      'pmc.SQ_INSTS_MFMA x 32768 flop is the same figure from the counters',
+                     'split_level': level,
+                     'executed_from': '%d x 2 x 16 flop per k16 unit x (padded query columns x padded candidates); '
+                                      'pmc.SQ_INSTS_MFMA x 32768 flop is the same figure from the counters' % (1 if level == 1 else 3),
                      'frac_of_fp32_mfma_peak': round(alg_flops * pairs / kern_s / 1e12 / PEAK_FP32_TFLOPS, 4),
                      'note': 'ranks are bit-identical to the fp32 path (pairs inside the proven error band are re-scored '
                              'exactly by kge_lp_split_recheck); frac = 2K algorithmic flop per pair against the f16 MFMA '
-                             'peak; the kernel executes 3 f16 products per element (hi*hi, hi*lo, lo*hi), see executed_*; '
+                             'peak; the kernel executes 3 f16 products per element (hi*hi, hi*lo, lo*hi) -- or ONE (hi*hi) on '
+                             'the one-product level a fitted model is evaluated on, split_level = 1 --, see executed_*; '
                              'SURVEY 8(d) names the fp32 MFMA peak as this row\'s bound: frac_of_fp32_mfma_peak'}
         elif mode in (_hip.LP_DOT, _hip.LP_L2_EXPAND, _hip.LP_L2_PROJH, _hip.LP_L2_PROJD):
             alg_flops = 2 * K               # one fp32 MFMA FMA per (pair, k)
@@ -836,6 +847,7 @@ def main():
         # WRITE_SIZE cannot share a pass; corrections per MI355X_MICROARCH.md), else the checked-in figure, labelled
         traffic, traffic_src = None, None
         pmc = {}
+        args.level_used = int(prob.split.get('level', 0)) if split else args.split_level   # the counters' run uses the same level
         if not args.no_traffic and not multi:
             traffic = _measure_traffic(args, ksym, pmc if bound == 'mfma' else None)
             traffic_src = None if traffic is None else 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run ' \
@@ -851,6 +863,8 @@ def main():
         # algorithmic operand bytes of one launch: every operand row read once (fp32, or 4 B / element split cells)
         kcols = ((K + 1 + 15) // 16 * 16) if split else K        # (split cells: f16 hi + lo = 4 B per element, + the norm column)
         alg_bytes = 4 * (B + n_ent) * kcols
+        if split and int(prob.split.get('level', 0)) == 1:       # planar hi operands: 2 B per element, K + 2 columns padded to 64
+            alg_bytes = 2 * (B + n_ent) * ((K + 2 + 63) // 64 * 64)
         roof = {'bound': bound, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_operand_bytes_per_launch': alg_bytes,
@@ -1128,6 +1142,11 @@ def main():
                        'collectives_in_graph': bool(getattr(ev, 'graph_collectives', False)) and multi and shard == 'entities',
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
+            'split_prefilter': {'level_of_the_timed_evaluations': int(getattr(model, '_split_level', 0)),
+                                'rescored_pairs_per_query': getattr(ev, 'last_rescored_per_query', None),
+                                'policy': 'level 1 (one MFMA product per k16 unit, 8x wider band) when the previous evaluation '
+                                          're-scored <= %.0f pairs per query on three products; back to three products above %.0f'
+                                          % (tk.evaluation.LEVEL1_ENTER, tk.evaluation.LEVEL1_LEAVE)},
             'workload_detail': {'kg': args.kg, 'weights': weights, 'train': info.get('train'), 'train_s': info.get('train_s'),
                                 'filter_lists': flt_stats},
             'roofline': roof, 'cpu_baseline': cpu, 'parity_full_split': parity, 'secondary': sec,

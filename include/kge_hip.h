@@ -304,9 +304,11 @@ int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *fou
 int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
                            int64_t *out, int64_t ld, int64_t off, const int64_t *pos /* optional: fact j of the
                            evaluation goes to column pos[j] (facts processed in another order, e.g. sorted by relation) */,
-                           const float *guard /* optional, with flags: device floats [max ||q||^2, max ||e||^2, overflow] */,
-                           float *flags /* optional: flags[0] = guard[0] + guard[1], flags[1] = guard[2] (the evaluation's
-                           two guard decisions written behind the ranks by the same launch) */,
+                           const float *guard /* optional, with flags: >= 7 device floats [max ||q||^2, max ||e||^2, overflow,
+                           .., .., .., re-scored pairs] */,
+                           float *flags /* optional, 3 floats: flags[0] = guard[0] + guard[1], flags[1] = guard[2], flags[2] =
+                           guard[6] (the evaluation's guard decisions and the split prefilter's re-scored pair count, written
+                           behind the ranks by the same launch) */,
                            kge_stream_t stream);
 
 /* generic: every query has its own candidate matrix cand[i] (N,K) at
@@ -476,6 +478,17 @@ typedef struct kge_split_args {
     /* with columns, q_cell_ss holds one column per COLUMN: query i reads column q_cell_ss_index[i], row stride q_cell_ss_ld */
     const int64_t *q_cell_ss_index;
     int64_t q_cell_ss_ld;
+    /* ONE-PRODUCT first level (r04).  level = 1: Qs / Es are PLANAR hi operands (kge_lp_hi_rows: 32 bytes per k16 unit,
+     * f16 hi parts only, kge_lp_hi_units(K) units per row) and the sweep runs ONE MFMA product per unit -- a third of the
+     * matrix work, half the operand bytes.  The error band then carries the operands' measured f16 residuals:
+     * q_dn2[i] = ||q_i - hi(q_i)||^2 (read at q_dn2_index[i] when given: query columns) and de2max = device scalar
+     * >= max_c ||e_c - hi(e_c)||^2; it is ~8x wider than the three-product band (4.7e-4 of ||q|| max||e|| at K = 200), so
+     * this level pays when the true entities sit in the sparse upper tail of the scores (a fitted model).  L2_EXPAND and
+     * DOT modes; counts stay exact (kge_lp_split_recheck).  level = 0: the three-product sweep. */
+    int32_t level;
+    const float *q_dn2;
+    const int64_t *q_dn2_index;
+    const float *de2max;
 } kge_split_args;
 int kge_lp_split_group_sets(void);
 
@@ -501,6 +514,15 @@ int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const float *X1, int
  * (Cauchy-Schwarz on the prefix) instead of || q || || e || throughout: about half the accumulation term. */
 int kge_lp_split_prefix_max(const float *cell_ss, int64_t rows, int is_query, int units_p, float *e2pref,
                             kge_stream_t stream);
+/* PLANAR hi operand of the one-product level (kge_split_args.level = 1): [rows_padded][kge_lp_hi_units(K0 + K1)][32 bytes],
+ * the f16 hi parts of [X0 | X1] at the same scale as kge_lp_split_rows, plus TWO augmentation columns K, K + 1 (aug_mode
+ * as above; mode 1 puts hi and lo of aug * aug_mul there, mode 2 aug_mul twice, mode 3 the guard column at K).
+ * dn2 (optional, rows floats): ||x - hi(x)||^2 per row, unscaled;  dn2max (optional device scalar): its maximum folded in. */
+int kge_lp_hi_units(int K);
+int kge_lp_hi_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                   int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
+                   const float *norm2max1, void *out, float *dn2, float *dn2max, const int64_t *row_index,
+                   kge_stream_t stream);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
 /* 1 if v_mfma_f32_32x32x16_f16 on the current device accumulates as the tighter error model assumes (two
@@ -520,11 +542,16 @@ int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const
                           float *thr, int32_t *list_count, const float *e2pref /* optional, see above */,
                           const int32_t *qs_row /* optional: row of Qs that receives query i's split cells, < 0: none
                                                    (columns, see kge_split_args.col_q); NULL: row i */,
+                          int level /* 1: Qs is the PLANAR hi operand and thr the thresholds of the one-product level */,
+                          const float *de2max /* level 1: device scalar >= max_c ||e_c - hi(e_c)||^2 (kge_lp_hi_rows) */,
+                          float *q_dn2 /* level 1, optional out: ||q_i - hi(q_i)||^2 per query (kge_split_args.q_dn2) */,
                           kge_stream_t stream);
 /* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
 int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
-                         const int32_t *list_count, int32_t *raw_count, kge_stream_t stream);
+                         const int32_t *list_count, int32_t *raw_count,
+                         float *list_stat /* optional device float: the number of re-scored pairs is added to it */,
+                         kge_stream_t stream);
 
 /* ---- certified integer prefilter of the fused rank count, TransE-L1 (torchkge_amd/csrc/lp_l1_sad.hip) ----------
  * kge_lp_sad_count + kge_lp_sad_recheck leave in raw_count exactly what kge_lp_count_ge leaves there for a plain

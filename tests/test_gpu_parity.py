@@ -1469,3 +1469,167 @@ def test_device_built_index_and_plans_equal_the_torch_builds(hip, n_ent, n_rel, 
     # the relation order of a batch (TransH / TransD): the library's radix sort == a stable argsort
     keys = (torch.arange(B) // 1000) * n_rel + rb.cpu()
     assert torch.equal(hip.sort_perm(keys.cuda(), (B // 1000 + 1) * n_rel).cpu(), torch.argsort(keys, stable=True))
+
+
+@pytest.mark.parametrize('B,N,K,cols_on', [(64, 300, 32, False), (1000, 3000, 200, False), (193, 257, 17, False), (5, 2, 1, False),
+                                           (700, 1500, 203, False), (1000, 3000, 200, True), (400, 5000, 64, True)])
+def test_split_one_product_level_counts_equal_exact_counts(hip, B, N, K, cols_on):
+    """The ONE-PRODUCT level of the split prefilter (kge_split_args.level = 1: planar hi operands, one MFMA product per
+    k16 unit, thresholds from the operands' measured f16 residuals) + exact recheck leave exactly the counts of the
+    fp32 kernel -- TransE-L2 shaped problems, per query and over query columns (hub keys), also with the band shrunk."""
+    from torchkge_amd.filter_index import ColumnPlan
+    g = torch.Generator().manual_seed(B * 11 + K)
+    E = torch.nn.functional.normalize(torch.randn(N, K, generator=g), dim=1)
+    R = torch.randn(7, K, generator=g) * (0.6 / K ** 0.5)
+    if cols_on:     # a both-sides batch of B // 2 facts with repeated (h, r) / (t, r) keys
+        nb = B // 2
+        h = torch.randint(0, max(N // 20, 1), (nb,), generator=g); t = torch.randint(0, N, (nb,), generator=g)
+        r = torch.randint(0, 3, (nb,), generator=g)
+        h[:40], r[:40] = 1, 0                     # one key with 40 queries: ten grouped columns
+        q = torch.cat([E[h] + R[r], E[t] - R[r]])
+        true = torch.cat([t, h])
+        cols = ColumnPlan(h.cuda(), t.cuda(), r.cuda(), N, 7, hip.split_group_sets(), hip.split_query_rows_padded)
+        B = 2 * nb
+    else:
+        h = torch.randint(0, N, (B,), generator=g); r = torch.randint(0, 7, (B,), generator=g)
+        q = E[h] + R[r]
+        true = torch.randint(0, N, (B,), generator=g)
+        cols = None
+    dE, dq, dt = E.cuda(), q.cuda().contiguous(), true.cuda()
+    guard = torch.zeros(8, device='cuda')
+    en = hip.row_sqnorm(dE, max_io=guard[1:2]); qn = hip.row_sqnorm(dq, max_io=guard[0:1])
+    prob = hip.LpProblem(hip.LP_L2_EXPAND, dq, dE, qn=qn, en=en)
+    st = prob.pair_scores(dt)
+    exact = prob.count_ge(st)
+    Eh, de2 = hip.hi_table(dE, aug=en)
+    assert 0.0 <= float(de2) < 1e-6 * float(guard[1])         # ||e - hi(e)|| ~ 2^-12 ||e|| (0 when every value is an f16)
+    prob.split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'level': 1, 'de2max': de2,
+                  'list_stat': guard[6:7]}
+    prob.cols = cols
+    try:
+        # (the band's residual term bounds ACTUAL f16 rounding errors by Cauchy-Schwarz: tight at small K, so only a
+        # mild shrink at K >= 200 -- tests/test_split_band_model.py)
+        for eps in ((1.0, 0.5) if K >= 200 else (1.0,)):
+            hip.SPLIT_EPS_SCALE = eps
+            guard[6] = 0
+            got = prob.count_ge(st)
+            assert torch.equal(got, exact), (eps, int((got != exact).sum()))
+            n_unc = int(prob.last_split[0].item())
+            assert B <= n_unc                        # at least the true entity of every query is re-scored
+            assert float(guard[6]) == n_unc          # the re-scored pairs are reported (the evaluator's level policy)
+    finally:
+        hip.SPLIT_EPS_SCALE = 1.0
+    assert float(guard[2]) == 0.0
+
+
+@pytest.mark.parametrize('B,N,K,K1,scale', [(300, 1000, 64, 0, 1.0), (257, 700, 40, 40, 30.0), (100, 513, 17, 17, 1e-3),
+                                          (64, 300, 200, 200, 1.0)])
+def test_split_one_product_level_dot_mode(hip, B, N, K, K1, scale):
+    """The one-product level on KGE_LP_DOT problems (DistMult / ComplEx: two K-segments, operands with their own
+    power-of-two scales, negative true scores, an all-zero query)."""
+    g = torch.Generator().manual_seed(B * 7 + K + 1)
+    T0 = (torch.randn(N, K, generator=g) * scale).cuda()
+    T1 = (torch.randn(N, K1, generator=g) * scale).cuda() if K1 else None
+    A0 = (torch.randn(B, K, generator=g) * scale).cuda()
+    A1 = (torch.randn(B, K1, generator=g) * scale).cuda() if K1 else None
+    A0[0] = 0.0
+    if A1 is not None:
+        A1[0] = 0.0
+    t = torch.randint(0, N, (B,), generator=g).cuda()
+    prob = hip.LpProblem(hip.LP_DOT, A0, T0, A1=A1, T1=T1)
+    st = prob.pair_scores(t)
+    exact = prob.count_ge(st)
+    guard = torch.zeros(8, device='cuda')
+    hip.row_sqnorm(T0, max_io=guard[1:2])
+    nm1 = None
+    if T1 is not None:
+        hip.row_sqnorm(T1, max_io=guard[5:6])
+        nm1 = guard[5:6]
+    Eh, de2 = hip.hi_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=nm1)
+    prob.split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'enmax1': nm1, 'overflow': guard[2:3], 'level': 1,
+                  'de2max': de2, 'list_stat': guard[6:7]}
+    try:
+        for eps in ((1.0, 0.5) if K + K1 >= 200 else (1.0,)):
+            hip.SPLIT_EPS_SCALE = eps
+            got = prob.count_ge(st)
+            assert torch.equal(got, exact), (eps, int((got != exact).sum()))
+    finally:
+        hip.SPLIT_EPS_SCALE = 1.0
+
+
+@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex'])
+def test_evaluator_level_policy_and_identical_ranks(hip, kind):
+    """LinkPredictionEvaluator with the one-product level forced on (model.split_level = 1), forced off (0) and on
+    'auto' (first evaluation three products, the next ones follow the re-scored pair count): identical rank vectors,
+    eager and as hipGraph replays; an evaluation whose one-product list overflows is redone on three products."""
+    import torchkge_amd as tk
+    import torchkge_amd.evaluation as evm
+    n_ent, n_rel, d = 4000, 9, 64
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=5)
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 30000, 31, hubs=((1500, 'head'), (600, 'tail')))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(28000, 2000))
+
+    def ranks(ev):
+        return [ev.rank_true_heads.clone(), ev.rank_true_tails.clone(), ev.filt_rank_true_heads.clone(),
+                ev.filt_rank_true_tails.clone()]
+    m.split_level = 0
+    ev0 = tk.LinkPredictionEvaluator(m, kg_test, graph=False)
+    ev0.evaluate(512, verbose=False)
+    want = ranks(ev0)
+    assert ev0._level == 0 and ev0.last_rescored_per_query >= 1.0
+    m.split_level = 1
+    for graph in (False, True):
+        ev1 = tk.LinkPredictionEvaluator(m, kg_test, graph=graph)
+        ev1._level = 1
+        for _ in range(3):
+            ev1.evaluate(512, verbose=False)
+            for a, b in zip(want, ranks(ev1)):
+                assert torch.equal(a, b)
+        assert ev1.last_rescored_per_query > ev0.last_rescored_per_query     # the wider band re-scores more pairs
+    if kind == 'transe':
+        # the fused query pipeline on level 1: a second split_count on the same operands recomputes the thresholds from the
+        # per-query residuals the pipeline left (thr_ready = 0) -- same counts, equal to the exact kernel's
+        hb, tb, rb = kg_test.head_idx[:700].cuda(), kg_test.tail_idx[:700].cuda(), kg_test.relations[:700].cuda()
+        m.lp_guard_begin(torch.device('cuda'))
+        try:
+            with m.lp_session():
+                prob = m.lp_problem(hb, tb, rb, 'both')
+                assert prob.pre is not None and int(prob.split['level']) == 1
+                true = torch.cat([tb, hb])
+                prob.pre['true_idx'] = true
+                st = prob.pair_scores(true)
+                prep = prob.split_prepare()
+                raws = []
+                for _ in range(2):
+                    raw = torch.zeros(prob.B, dtype=torch.int32, device='cuda')
+                    prob.split_count(prep, st, raw)
+                    prob.split_recheck(prep, st, raw)
+                    raws.append(raw)
+                prob.split = None
+                exact = prob.count_ge(st)
+                assert torch.equal(raws[0], exact) and torch.equal(raws[1], exact)
+        finally:
+            m.lp_guard_end()
+    m.split_level = 'auto'
+    old = evm.LEVEL1_ENTER, evm.LEVEL1_LEAVE
+    try:
+        evm.LEVEL1_ENTER, evm.LEVEL1_LEAVE = 1e9, 1e9        # always enter, never leave
+        ev2 = tk.LinkPredictionEvaluator(m, kg_test)
+        seen = []
+        for _ in range(4):
+            ev2.evaluate(512, verbose=False)
+            seen.append(ev2._level)
+            for a, b in zip(want, ranks(ev2)):
+                assert torch.equal(a, b)
+        assert seen == [1, 1, 1, 1]                          # (the level the NEXT evaluation will use)
+        evm.LEVEL1_LEAVE = 0.0                               # ... and leave again at once
+        ev2.evaluate(512, verbose=False)
+        assert ev2._level == 0
+        for a, b in zip(want, ranks(ev2)):
+            assert torch.equal(a, b)
+    finally:
+        evm.LEVEL1_ENTER, evm.LEVEL1_LEAVE = old
+        m.split_level = 'auto'

@@ -144,3 +144,80 @@ def test_split_band_is_certified_under_the_measured_accumulation_model(kind, K):
         uncertain = ~(sure_yes | sure_no)
         assert uncertain[np.arange(B), t].all() or kind == 'cancel'      # the true entity itself sits in the band
         assert uncertain.mean() < (0.3 if kind in ('ties', 'near', 'cancel') else 0.05)
+
+
+# ---- the ONE-PRODUCT level (kge_split_args.level = 1, lp_split_mfma.hip: split_thr_l2_hi / LV = 1 count kernel) ----------
+def _hi_accumulate(qh, eh, units):
+    """(B, N) accumulators of Sum_k qh*eh, one MFMA (two passes of 8 products) per k16 unit."""
+    B, N = qh.shape[0], eh.shape[0]
+    acc = np.zeros(B * N)
+    for u in range(units):
+        for half in range(2):
+            sl = slice(u * 16 + half * 8, u * 16 + half * 8 + 8)
+            acc = _mfma_pass(acc, (qh[:, None, sl] * eh[None, :, sl]).reshape(B * N, 8))
+    return acc.reshape(B, N).astype(F)
+
+
+def _thresholds_hi(qn, st, em, K, units, dq2, de2m, eps_scale, c_acc=F(1.25)):
+    """split_thr_l2_hi (fp32 arithmetic as in the kernel): the band carries the measured residuals ||q - hi(q)||, max ||e - hi(e)||."""
+    qn, st, dq2 = qn.astype(F), st.astype(F), dq2.astype(F)
+    enrm, qnrm = np.sqrt(em) * F(1.000001), np.sqrt(qn) * F(1.000001)
+    u = -st
+    mag = qnrm * enrm + F(0.5) * em
+    acc_err = c_acc * F(16.0) * TWO24 * (F(units) * mag)
+    chain_err = F(1.01) * F(K) * TWO24 * mag
+    dqn, den = np.sqrt(dq2) * F(1.0001), np.sqrt(F(de2m)) * F(1.0001)
+    resid = (dqn * enrm + (qnrm + dqn) * den) * F(1.0005) + F(1.01) * TWO22 * F(0.5) * em
+    eps_dot = acc_err + chain_err + resid + F(2.5e-7) * (qnrm + enrm) + F(4e-9)
+    eps_v = (F(2.0) * eps_dot + F(4.0) * TWO22 * (qn + em + np.abs(u))) * F(eps_scale)
+    mid = F(0.5) * (qn - u)
+    hw = F(0.5) * eps_v + TWO22 * (np.abs(qn) + np.abs(u))
+    return ((mid - hw) * S * S).astype(F), ((mid + hw) * S * S).astype(F)
+
+
+@pytest.mark.parametrize('kind', ['plain', 'ties', 'near', 'range', 'cancel'])
+@pytest.mark.parametrize('K', [200, 40, 512])
+def test_one_product_band_is_certified_under_the_measured_accumulation_model(kind, K):
+    """Level 1: acc = Sum_k hi(q) hi(e) + (1)(hi(aug)) + (1)(lo(aug)), one MFMA per unit; thresholds from the measured
+    residuals.  acc >= a_hi => the exact score counts, acc < a_lo => it does not -- on the adversarial inputs of the
+    three-product test; the band is wide (8x) but still a small fraction of the candidates."""
+    lib = oracle_clib()
+    rng = np.random.default_rng(1000 * K + ['plain', 'ties', 'near', 'range', 'cancel'].index(kind))
+    B, N = 12, 300
+    Q, E, t = _case(kind, B, N, K, rng)
+    qn, en = np.empty(B, F), np.empty(N, F)
+    i64 = ctypes.c_int64
+    lib.orc_row_sqnorm_chain(fptr(Q), i64(K), i64(B), i64(K), fptr(qn))
+    lib.orc_row_sqnorm_chain(fptr(E), i64(K), i64(N), i64(K), fptr(en))
+    exact = np.empty((B, N), F)
+    lib.orc_lp_gemm_chain(fptr(Q), i64(K), fptr(E), i64(K), i64(K), None, i64(0), None, i64(0), i64(0),
+                          i64(B), i64(N), ctypes.c_int(1), fptr(qn), fptr(en), fptr(exact))
+    st = exact[np.arange(B), t]
+    units = (K + 2 + 15) // 16
+    Kp = units * 16
+    Qa, Ea = np.zeros((B, Kp), F), np.zeros((N, Kp), F)
+    Qa[:, :K], Ea[:, :K] = Q, E
+    qh = ((Qa * S).astype(F)).astype(np.float16).astype(np.float64)
+    eh = ((Ea * S).astype(F)).astype(np.float16).astype(np.float64)
+    # measured residuals (hi_rows_kernel / the query pipeline: exact fp32 differences, summed, unscaled)
+    dq2 = ((((Qa * S).astype(F).astype(np.float64) - qh) ** 2).sum(axis=1) / float(S) ** 2 * 1.0001).astype(F)
+    de2m = float(((((Ea * S).astype(F).astype(np.float64) - eh) ** 2).sum(axis=1) / float(S) ** 2 * 1.0001).max())
+    # the two augmentation columns: queries 1, 1; candidates hi and lo of -||e||^2 / 2
+    aug = (en * F(-0.5) * S).astype(F)
+    a_hi_ = aug.astype(np.float16)
+    a_lo_ = (aug - a_hi_.astype(F)).astype(F).astype(np.float16)
+    qh[:, K] = qh[:, K + 1] = float(S)
+    eh[:, K], eh[:, K + 1] = a_hi_.astype(np.float64), a_lo_.astype(np.float64)
+    acc = _hi_accumulate(qh, eh, units)
+    em = F(en.max())
+    counts_exact = exact >= st[:, None]
+    # (the residual term is a Cauchy-Schwarz bound on ACTUAL rounding errors -- tight for small K, where two residual
+    # vectors can be nearly parallel: no large shrink factor survives; at K >= 200 half the band still certifies)
+    for eps_scale in ((1.0, 0.5) if K >= 200 else (1.0,)):
+        lo, hi = _thresholds_hi(qn, st, em, K, units, dq2, de2m, eps_scale)
+        sure_yes, sure_no = acc >= hi[:, None], acc < lo[:, None]
+        assert not (sure_yes & ~counts_exact).any(), (kind, K, eps_scale)
+        assert not (sure_no & counts_exact).any(), (kind, K, eps_scale)
+        uncertain = ~(sure_yes | sure_no)
+        assert uncertain[np.arange(B), t].all() or kind == 'cancel'
+        assert uncertain.mean() < (0.5 if kind in ('ties', 'near', 'cancel') else 0.2)

@@ -48,6 +48,7 @@ class SplitArgs(ctypes.Structure):
         ('thr', _vp), ('list', _vp), ('cap', ctypes.c_int32), ('list_count', _vp), ('overflow', _vp),
         ('col_q', _vp), ('n_single_p', _i64), ('members', _vp), ('n_multi_p', _i64),
         ('q_cell_ss_index', _vp), ('q_cell_ss_ld', _i64),
+        ('level', ctypes.c_int32), ('q_dn2', _vp), ('q_dn2_index', _vp), ('de2max', _vp),
     ]
 
 
@@ -85,8 +86,11 @@ _SIGNATURES = {
     'kge_lp_split_rows': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _int, _vp, ctypes.c_float, _vp, _vp, _vp,
                           _vp, _vp, _vp],
     'kge_lp_split_prefix_max': [_vp, _i64, _int, _int, _vp, _vp],
+    'kge_lp_hi_units': [_int],
+    'kge_lp_hi_rows': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _int, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
+                       _vp, _vp],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
-    'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
+    'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
     'kge_lp_count_ge_cols': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     'kge_topk_chunk': [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp],
@@ -94,7 +98,7 @@ _SIGNATURES = {
     'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
     'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
-                              _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                              _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -126,7 +130,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 23        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 24        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -462,7 +466,49 @@ def split_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nm
     return Es, e2
 
 
-def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None):
+def hi_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None, want_dn2=False,
+            dn2max=None, row_index=None):
+    """PLANAR hi operand of the one-product level (kge_lp_hi_rows): uint8 tensor [rows_p][hi_units][32 bytes] of
+    [X | X1] (+ the per-row residuals ||x - hi(x)||^2 when want_dn2; their maximum folded into the device scalar
+    dn2max).  Augmentation / scale conventions as split_rows."""
+    lib = load_library()
+    require_cuda(X, X1, aug, nmax0, nmax1, dn2max)
+    X = f32c(X)
+    rows, ld = X.shape[0], X.stride(0)
+    if row_index is not None:
+        rows = int(row_index.shape[0])
+    K = X.shape[1] if K is None else K
+    ld1 = 0
+    if X1 is not None:
+        X1 = f32c(X1)
+        K1 = X1.shape[1] if K1 is None else K1
+        ld1 = X1.stride(0)
+    else:
+        K1 = 0
+    if dot:
+        aug_mode, aug_mul = (3, 1.0) if is_query else (4, 0.0)
+    else:
+        aug_mode, aug_mul = (2, 1.0) if is_query else (1, -0.5)
+    units_p = int(lib.kge_lp_hi_units(K + K1))
+    rows_p = int(lib.kge_lp_split_rows_padded(rows, 1 if is_query else 0))
+    out = torch.empty(max(rows_p, 1) * units_p * 32, dtype=torch.uint8, device=X.device)
+    dn2 = torch.empty(max(rows, 1), dtype=torch.float32, device=X.device) if want_dn2 else None
+    with _on(X.device):
+        _check(lib.kge_lp_hi_rows(_p(X), ld, K, _p(X1), ld1, K1, rows, 1 if is_query else 0, aug_mode, _p(aug), aug_mul,
+                                  _p(nmax0), _p(nmax1), _p(out), _p(dn2), _p(dn2max), _p(row_index), _stream()),
+               'kge_lp_hi_rows')
+    return (out, dn2) if want_dn2 else out
+
+
+def hi_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None):
+    """Candidate operand of the one-product level: (Eh, de2max) -- the planar hi table and the device scalar
+    max_c ||e_c - hi(e_c)||^2 of its error band."""
+    de2 = torch.zeros(1, dtype=torch.float32, device=X.device)
+    Eh = hi_rows(X, K=K, aug=aug, X1=X1, K1=K1, dot=dot, nmax0=nmax0, nmax1=nmax1, dn2max=de2)
+    return Eh, de2
+
+
+def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None, level=0, de2max=None):
     """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
     s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
     the threshold kernel.  ``cols`` (filter_index.ColumnPlan): the split rows are written per COLUMN
@@ -474,19 +520,23 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
     B, d, dev = h.shape[0], E.shape[1], E.device
     Bq = 2 * B if side == SIDE_BOTH else B          # SIDE_BOTH: tail-side queries, then head-side queries
     Bp = int(lib.kge_lp_split_rows_padded(Bq, 1))
-    units_p = int(lib.kge_lp_split_units(d, 1))
+    # (level 1: the PLANAR hi operand of the one-product sweep, 32 bytes per unit)
+    units_p, cell = (int(lib.kge_lp_hi_units(d)), 32) if level == 1 else (int(lib.kge_lp_split_units(d, 1)), 64)
     qrows = Bp if cols is None else cols.n_single_p + cols.n_multi_p
     assert cols is None or cols.n_queries == Bq
     out = {'Q': torch.empty(Bq, d, dtype=torch.float32, device=dev), 'qn': torch.empty(Bq, dtype=torch.float32, device=dev),
            's_true': torch.empty(Bq, dtype=torch.float32, device=dev),
-           'Qs': torch.empty(max(qrows, 1) * units_p * 64, dtype=torch.uint8, device=dev), 'cols': cols,
+           'Qs': torch.empty(max(qrows, 1) * units_p * cell, dtype=torch.uint8, device=dev), 'cols': cols, 'level': level,
            'thr': torch.empty(4 * Bp, dtype=torch.float32, device=dev),
            'n_list': torch.empty(1, dtype=torch.int32, device=dev)}
+    if level == 1:      # (the residuals ||q - hi(q)||^2: a later split_count that recomputes the thresholds needs them)
+        out['q_dn2'] = torch.empty(Bq, dtype=torch.float32, device=dev)
     with _on(dev):
         _check(lib.kge_lp_query_pipeline(side, _p(E), _p(R), d, _p(h), _p(t), _p(r), B, _p(en), _p(emax), _p(qmax_io),
                                          split_accum_model(), SPLIT_EPS_SCALE, _p(out['Q']), _p(out['qn']),
                                          _p(out['s_true']), _p(out['Qs']), _p(out['thr']), _p(out['n_list']),
-                                         _p(e2pref), _p(None if cols is None else cols.qs_row), _stream()),
+                                         _p(None if level == 1 else e2pref), _p(None if cols is None else cols.qs_row),
+                                         level, _p(de2max), _p(out.get('q_dn2')), _stream()),
                'kge_lp_query_pipeline')
     return out
 
@@ -715,17 +765,26 @@ class LpProblem(object):
         K = int(self.desc.K0)
         A0, A1 = self.keep[0], self.keep[2]
         extra = {}
-        want_ss = self.split.get('e2pref') is not None     # prefix-norm magnitude bound of the error band
+        level = int(self.split.get('level', 0))
+        want_ss = self.split.get('e2pref') is not None and level == 0    # prefix-norm magnitude bound of the error band
         if self.pre is not None:
+            assert int(self.pre.get('level', 0)) == level
             Qs, extra = self.pre['Qs'], {'thr_pre': self.pre['thr'], 'n_list_pre': self.pre['n_list'],
                                          's_true_pre': self.pre['s_true'], 'cols': self.pre.get('cols')}
+            if level == 1:      # per QUERY (the fused pipeline computes every query's residual itself)
+                extra['q_dn2'], extra['q_dn2_per_query'] = self.pre['q_dn2'], True
         elif int(self.desc.mode) == LP_DOT:
             qmax = torch.zeros(2, dtype=torch.float32, device=self.device)
             qn0 = row_sqnorm(A0, K=K, max_io=qmax[0:1])
             qn1 = row_sqnorm(A1, max_io=qmax[1:2]) if A1 is not None else None
             qn = qn0 if qn1 is None else qn0 + qn1
             cols = self.cols
-            if cols is not None:
+            if level == 1:      # one-product level: planar hi rows (per column when the batch has a ColumnPlan) + residuals
+                Qs, dn2 = hi_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
+                                  nmax1=qmax[1:2] if A1 is not None else None, want_dn2=True,
+                                  row_index=None if cols is None else cols.rep)
+                extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax, 'cols': cols, 'q_dn2': dn2}
+            elif cols is not None:
                 # COLUMNS: one split row per distinct query row of the batch (ColumnPlan) -- gathered from the query that
                 # provides it; the per-query cell sums of the error band are read back through the query -> column map
                 Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
@@ -735,6 +794,10 @@ class LpProblem(object):
                 Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
                                 nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
                 extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
+        elif level == 1:                # L2 on the one-product level (non-fused query path)
+            cols = self.cols
+            Qs, dn2 = hi_rows(A0, K=K, is_query=True, want_dn2=True, row_index=None if cols is None else cols.rep)
+            extra = {'cols': cols, 'q_dn2': dn2}
         elif self.cols is not None:     # L2 / projection modes on COLUMNS (gathered rows, as the DOT branch above)
             cols = self.cols
             Qs = split_rows(A0, K=K, is_query=True, cell_ss=want_ss, row_index=cols.rep)
@@ -781,6 +844,12 @@ class LpProblem(object):
         if cols is not None:    # the split query rows are per COLUMN (distinct query rows), not per query
             a.col_q, a.n_single_p = _p(cols.col_q), cols.n_single_p
             a.members, a.n_multi_p = _p(cols.members), cols.n_multi_p
+        a.level = int(sp.get('level', 0))
+        if a.level == 1:        # one-product level: the band needs the operands' measured f16 residuals
+            a.de2max = _p(sp['de2max'])
+            a.q_dn2 = _p(prep.get('q_dn2'))
+            if prep.get('q_dn2') is not None and cols is not None and not prep.get('q_dn2_per_query'):
+                a.q_dn2_index = _p(cols.col_of_q)
         with _on(self.device):
             _check(lib.kge_lp_split_count(ctypes.byref(self.desc), ctypes.byref(a), _p(s_true), _p(raw), _stream()),
                    'kge_lp_split_count')
@@ -791,7 +860,8 @@ class LpProblem(object):
         lib = load_library()
         with _on(self.device):
             _check(lib.kge_lp_split_recheck(ctypes.byref(self.desc), _p(s_true), _p(prep['list']), prep['cap'],
-                                            _p(prep['n_list']), _p(raw), _stream()), 'kge_lp_split_recheck')
+                                            _p(prep['n_list']), _p(raw), _p(self.split.get('list_stat')), _stream()),
+                   'kge_lp_split_recheck')
         return raw
 
     def _count_ge_sad(self, s_true, raw):

@@ -216,6 +216,118 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p
     }
 }
 
+// ---- one-product level: PLANAR hi operands -----------------------------------------------------------------------
+// [rows_p][units_p][32 bytes]: the f16 hi parts of the 16 values of a k16 unit (units_p a multiple of 4: one 128-byte
+// row segment = one stage of the LV = 1 count kernel).  Two extra columns K, K+1: L2 candidates carry hi and lo of
+// -||e||^2/2 there (queries 1, 1), so the norm term keeps its 2^-22 precision; DOT queries their guard column at K.
+// Also emitted: dn2[row] = ||x - hi(x)||^2 (unscaled; the exact fp32 differences, summed) and its maximum.
+struct HiRowsParams {
+    const float *X0, *X1;
+    int64_t ld0, ld1;
+    int K0, K1;
+    int64_t rows, rows_p;
+    int aug_mode;             // as SplitRowsParams
+    const float *aug;
+    float aug_mul;
+    const float *nmax0, *nmax1;
+    int units_p;
+    uint4 *out;
+    float *dn2;               // optional (rows)
+    float *dn2max;            // optional device scalar, max folded in
+    const int64_t *row_index;
+};
+
+__global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
+{
+    __shared__ unsigned bmax[4];
+    float scale = (float)(1 << SPLIT_SCALE_LOG2), nmax = 0.f;
+    if (p.nmax0) {
+        nmax = *p.nmax0 + (p.nmax1 ? *p.nmax1 : 0.f);
+        scale = split_scale(nmax);
+    }
+    const float inv2 = 1.0f / (scale * scale);
+    const int K = p.K0 + p.K1;
+    const int tr_ = threadIdx.x >> 4, tu_ = threadIdx.x & 15;
+    const bool vec0 = (p.ld0 % 4 == 0) && ((size_t)p.X0 & 15) == 0;
+    const bool vec1 = p.X1 && (p.ld1 % 4 == 0) && ((size_t)p.X1 & 15) == 0 && (p.K0 % 4 == 0);
+    float dmax = 0.f;
+    for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < p.rows_p; r0 += (int64_t)gridDim.x * 16) {
+        const int64_t row = r0 + tr_;
+        const bool real = row < p.rows;
+        const int64_t srow = (p.row_index && real) ? p.row_index[row] : row;
+        float dn = 0.f;
+        for (int u = tu_; u < p.units_p; u += 16) {
+            const int k0 = u * 16;
+            float xs[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xs[e] = 0.f;
+            if (real) {
+                if (k0 + 16 <= p.K0 && vec0) {
+                    const float4 *src = reinterpret_cast<const float4 *>(p.X0 + srow * p.ld0 + k0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { const float4 t = src[v]; xs[4 * v] = t.x; xs[4 * v + 1] = t.y; xs[4 * v + 2] = t.z; xs[4 * v + 3] = t.w; }
+                } else if (k0 >= p.K0 && k0 + 16 <= K && vec1) {
+                    const float4 *src = reinterpret_cast<const float4 *>(p.X1 + srow * p.ld1 + (k0 - p.K0));
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { const float4 t = src[v]; xs[4 * v] = t.x; xs[4 * v + 1] = t.y; xs[4 * v + 2] = t.z; xs[4 * v + 3] = t.w; }
+                } else if (k0 < K) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = k0 + e;
+                        if (k < p.K0) xs[e] = p.X0[srow * p.ld0 + k];
+                        else if (k < K) xs[e] = p.X1[srow * p.ld1 + (k - p.K0)];
+                    }
+                }
+            }
+            union { _Float16 h[16]; uint4 v[2]; } hi;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + e;
+                float x = xs[e] * scale;
+                _Float16 h = (_Float16)x;                   // round to nearest even
+                if (real && k < K) {
+                    const float d = x - (float)h;           // exact in fp32
+                    dn = fmaf(d, d, dn);
+                }
+                if (k == K || k == K + 1) {                 // the augmentation columns
+                    float a = 0.f;
+                    if (real) {
+                        if (p.aug_mode == 1) {              // L2 candidates: hi (column K) and lo (column K + 1) of -||e||^2/2
+                            const float full = p.aug[srow] * p.aug_mul * scale;
+                            const _Float16 fh = (_Float16)full;
+                            a = k == K ? (float)fh : (float)(_Float16)(full - (float)fh);
+                        } else if (p.aug_mode == 2) {       // L2 queries: 1 against both
+                            a = p.aug_mul * scale;
+                        } else if (p.aug_mode == 3 && k == K) {   // DOT queries: the guard column (see split_rows_kernel)
+                            a = fmaxf(0.25f * (sqrtf(p.aug[srow]) + sqrtf(nmax) * 0.00390625f) * scale, 1.0f);
+                        }
+                    } else if ((p.aug_mode == 1 || (p.aug_mode == 4 && k == K))) {
+                        a = -65504.f;                       // padding candidate: can never count
+                    }
+                    h = (_Float16)a;
+                }
+                hi.h[e] = h;
+            }
+            uint4 *o = p.out + (row * p.units_p + u) * 2;
+            o[0] = hi.v[0]; o[1] = hi.v[1];
+        }
+        dn += __shfl_xor(dn, 8, 64);    // the 16 lanes of a row sit in one aligned group of the wavefront
+        dn += __shfl_xor(dn, 4, 64);
+        dn += __shfl_xor(dn, 2, 64);
+        dn += __shfl_xor(dn, 1, 64);
+        dn *= inv2 * 1.0001f;           // (fp32 summation error: K * 2^-24 relative)
+        if (real && tu_ == 0 && p.dn2) p.dn2[row] = dn;
+        if (real) dmax = fmaxf(dmax, dn);
+    }
+    if (p.dn2max) {
+        unsigned m = __float_as_uint(dmax);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if ((threadIdx.x & 63) == 0) bmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.dn2max), max(max(bmax[0], bmax[1]), max(bmax[2], bmax[3])));
+    }
+}
+
 // e2pref[u] = max over rows of the squared norm of the row's first (u+1)*16 data columns: with the
 // same prefix norms of a query, || q[:k] || * sqrt(e2pref) bounds every partial sum the MFMA
 // accumulator holds while it works through unit u (Cauchy-Schwarz on the prefix) -- the error band
@@ -326,6 +438,10 @@ struct SplitThrParams {
     int64_t ss_ld;
     const float *e2pref;            // ... and prefix squared-norm maxima of the candidates (kge_lp_split_prefix_max)
     int units_p;
+    int level;                      // 1: thresholds of the one-product sweep (q_dn2, de2max; L2_EXPAND and DOT modes)
+    const float *q_dn2;             // ||q_i - hi(q_i)||^2, read at q_dn2_index[i] when given (query columns)
+    const int64_t *q_dn2_index;
+    const float *de2max;            // device scalar >= max_c ||e_c - hi(e_c)||^2
 };
 
 // (a_lo, a_hi) of the plain L2 expansion, unscaled half-width logic shared by split_thr_kernel and the fused
@@ -337,11 +453,12 @@ __device__ __forceinline__ float split_nonzero_lo(float lo) { return lo == 0.f ?
 // amag: the sum over the k16 units of the bound on the accumulator's magnitude in that unit (split_amag_step,
 // times 1.003 for the cross terms and f16 roundings), or < 0 when the prefix norms are not at hand: every unit is
 // then charged with the full ||q|| ||e||.
-__device__ __forceinline__ float split_acc_err(float amag, float aug_mag, float mag, int units, float c_acc)
+__device__ __forceinline__ float split_acc_err(float amag, float aug_mag, float mag, int units, float c_acc,
+                                               float adds_per_unit = 48.0f)
 {
     const float two24 = 5.9604645e-8f;
     const float sum_mag = amag >= 0.f ? amag * 1.003f + aug_mag : (float)units * mag;
-    return c_acc * 48.0f * two24 * sum_mag;          // 48 additions per unit, each within c_acc * 2^-24 of the magnitude
+    return c_acc * adds_per_unit * two24 * sum_mag;  // 48 (one-product level: 16) additions per unit, each within c_acc * 2^-24 of the magnitude
 }
 // Rounding error of the exact fp32 chain the counts are defined by: one fmaf rounding per element, each within
 // 2^-24 of the partial sum it produces (running error bound) -- 16 per unit against the same prefix magnitudes,
@@ -363,6 +480,36 @@ __device__ __forceinline__ float2 split_thr_l2(float q, float st, float em, int 
     const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
     const float eps_dot = split_acc_err(amag, 0.5f * em, mag, units, c_acc) + split_chain_err(amag, mag, K) + eps_rel * mag +
                           2.5e-7f * (qnrm + enrm) + 4e-9f;
+    const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
+    const float mid = 0.5f * (q - u);
+    const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
+    return make_float2(split_nonzero_lo((mid - hw) * out_scale), (mid + hw) * out_scale);
+}
+
+// ONE-PRODUCT level (LV = 1 of the count kernel): acc = sum_k qh*eh (+ the two-term augmentation column), i.e. the
+// split residual is no longer 3 * 2^-22 of the magnitude but the operands' own f16 rounding residuals,
+//     q.e - qh.eh = dq.e + qh.de,    |.| <= ||dq|| ||e|| + ||qh|| ||de||,   ||qh|| <= ||q|| + ||dq||,
+// with dq = q - hi(q) MEASURED per query (dq2 = ||dq||^2, exact differences summed in fp32) and de2m >= max_c ||de_c||^2:
+// ~4.7e-4 of ||q|| max||e|| at K = 200 (a third of the candidates' values round up, a third down ...), 8 x the band of the
+// three-product sweep -- which buys one MFMA per k16 unit instead of three and half the operand bytes.  The augmentation
+// column -||e||^2/2 rides as TWO columns (hi, lo: residual 2^-22); the accumulation term has 16 additions per unit.
+__device__ __forceinline__ float split_hi_resid(float qnrm, float enrm, float em_aug, float dq2, float de2m)
+{
+    const float two22 = 2.3841858e-7f;
+    const float dqn = sqrtf(dq2) * 1.0001f, den = sqrtf(de2m) * 1.0001f;
+    return (dqn * enrm + (qnrm + dqn) * den) * 1.0005f + 1.01f * two22 * em_aug;
+}
+
+__device__ __forceinline__ float2 split_thr_l2_hi(float q, float st, float em, int K, int units, float c_acc, float eps_scale,
+                                                  float dq2, float de2m)
+{
+    const float two22 = 2.3841858e-7f;
+    const float enrm = sqrtf(em) * 1.000001f, qnrm = sqrtf(q) * 1.000001f;
+    const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
+    const float u = -st;                             // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
+    const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
+    const float eps_dot = split_acc_err(-1.0f, 0.5f * em, mag, units, c_acc, 16.0f) + split_chain_err(-1.0f, mag, K) +
+                          split_hi_resid(qnrm, enrm, 0.5f * em, dq2, de2m) + 2.5e-7f * (qnrm + enrm) + 4e-9f;
     const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * eps_scale;
     const float mid = 0.5f * (q - u);
     const float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
@@ -405,7 +552,10 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             amag = 0.f;
             for (int u = 0; u < p.units; ++u) split_amag_step(prefix, amag, p.q_cell_ss[(int64_t)u * p.ss_ld + (p.ss_index ? p.ss_index[i] : i)], p.e2pref[u]);
         }
-        if (p.mode == KGE_LP_L2_EXPAND) {
+        const float dq2 = p.level == 1 ? p.q_dn2[p.q_dn2_index ? p.q_dn2_index[i] : i] : 0.f;
+        if (p.mode == KGE_LP_L2_EXPAND && p.level == 1) {
+            p.thr[i] = split_thr_l2_hi(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale, dq2, *p.de2max);
+        } else if (p.mode == KGE_LP_L2_EXPAND) {
             p.thr[i] = split_thr_l2(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale, amag);
         } else if (p.mode >= KGE_LP_L2_PROJH) {
             const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
@@ -434,9 +584,12 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float st = p.s_true[i];
             const float sqk = sqrtf((float)p.K);
             const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
-            const float eps_dot = (split_acc_err(amag, 0.f, qnrm * enrm, p.units, p.c_acc) +
-                                   split_chain_err(amag, qnrm * enrm, p.K) + straddle * qnrm * enrm +
-                                   eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
+            const float eps_dot = p.level == 1
+                ? (split_acc_err(-1.0f, 0.f, qnrm * enrm, p.units, p.c_acc, 16.0f) + split_chain_err(-1.0f, qnrm * enrm, p.K) +
+                   split_hi_resid(qnrm, enrm, 0.f, dq2, *p.de2max) + eps_abs) * p.eps_scale
+                : (split_acc_err(amag, 0.f, qnrm * enrm, p.units, p.c_acc) +
+                   split_chain_err(amag, qnrm * enrm, p.K) + straddle * qnrm * enrm +
+                   eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
             const float hw = eps_dot + two22 * fabsf(st);
             p.thr[i] = make_float2(split_nonzero_lo((st - hw) * out_scale), (st + hw) * out_scale);
         }
@@ -468,6 +621,11 @@ struct QueryPipeParams {
     const float *e2pref;            // optional: prefix squared-norm maxima of the entity table (tighter error band)
     const int32_t *qs_row;          // optional: row of Qs that receives query i's split cells (< 0: none -- a query whose
                                     // row another query of the same key already provides); NULL: row i
+    int level;                      // 1: one-product level -- Qs is a PLANAR hi operand (units_p = kge_lp_hi_units), two
+                                    // augmentation columns, thresholds from the measured residual ||q - hi(q)||
+    const float *de2max;            // level 1: device scalar >= max_c ||e_c - hi(e_c)||^2
+    float *q_dn2;                   // level 1, optional: ||q_i - hi(q_i)||^2 per query (for a later kge_lp_split_count
+                                    // that recomputes the thresholds: thr_ready = 0)
 };
 
 template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
@@ -498,6 +656,7 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
         const int tli = tl ? 1 : 0;
         float qn = 0.f, acc = 0.f;
         float amag = 0.f;                                        // split_thr's magnitude sum
+        float dn = 0.f;                                          // level 1: || (q - hi(q)) * 2^12 ||^2
         // Software-pipelined staging: the three row loads of the NEXT chunk are issued before this chunk's two
         // sequential chains run (they are the latency of this kernel: 48 dependent FMA pairs per chunk), so a
         // group of queries costs one load latency plus its chains instead of one load latency per chunk.
@@ -564,6 +723,14 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                     }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) qn = fmaf(xv[j], xv[j], qn);
+                    if (p.level == 1) {      // (independent of the two chains: fills their latency)
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const float xsj = xv[j] * (float)(1 << SPLIT_SCALE_LOG2);
+                            const float dj = xsj - (float)(_Float16)xsj;
+                            dn = fmaf(dj, dj, dn);
+                        }
+                    }
 #pragma unroll
                     for (int b8 = 0; b8 < 16; b8 += 8) {
 #pragma unroll
@@ -577,6 +744,11 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 const int ktail = k;
                 for (; k < kc; ++k) {
                     qn = fmaf(x[k], x[k], qn);
+                    if (p.level == 1) {
+                        const float xsj = x[k] * (float)(1 << SPLIT_SCALE_LOG2);
+                        const float dj = xsj - (float)(_Float16)xsj;
+                        dn = fmaf(dj, dj, dn);
+                    }
                     if (p.e2pref && (((k0 + k) & 15) == 15 || k0 + k == d - 1))
                         amag = amag + sqrtf(qn * p.e2pref[(k0 + k) >> 4]);
                 }
@@ -592,7 +764,7 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 for (int e = 0; e < 8; ++e) {
                     const int k = k0 + gq * 8 + e;
                     float xv = 0.f;
-                    if (row < p.B) xv = k < d ? qs[rr * LD + gq * 8 + e] : (k == d ? 1.0f : 0.f);
+                    if (row < p.B) xv = k < d ? qs[rr * LD + gq * 8 + e] : ((k == d || (p.level == 1 && k == d + 1)) ? 1.0f : 0.f);
                     xv *= (float)(1 << SPLIT_SCALE_LOG2);
                     const _Float16 hh = (_Float16)xv;
                     hi.h[e] = hh;
@@ -600,7 +772,10 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 }
                 const int kk = k0 + gq * 8, u = kk >> 4, hf = (kk >> 3) & 1;
                 const int64_t dst = p.qs_row ? (row < p.B ? (int64_t)p.qs_row[row] : -1) : row;
-                if (dst >= 0) {
+                if (dst >= 0 && p.level == 1) {      // planar hi operand: 32 bytes per unit
+                    uint4 *cell = reinterpret_cast<uint4 *>(p.Qs) + (dst * p.units_p + u) * 2;
+                    cell[hf] = hi.v;
+                } else if (dst >= 0) {
                     uint4 *cell = reinterpret_cast<uint4 *>(p.Qs) + (dst * p.units_p + u) * 4;
                     cell[hf] = hi.v;
                     cell[2 + hf] = lo.v;
@@ -619,7 +794,14 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 } else {
                     amag = -1.0f;
                 }
-                p.thr[i] = split_thr_l2(qn, st, em, d, p.units, p.c_acc, p.eps_scale, amag);
+                if (p.level == 1) {
+                    const float inv2 = 1.0f / ((float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2));
+                    const float dq2 = dn * inv2 * 1.0001f;
+                    if (p.q_dn2) p.q_dn2[i] = dq2;
+                    p.thr[i] = split_thr_l2_hi(qn, st, em, d, p.units, p.c_acc, p.eps_scale, dq2, *p.de2max);
+                } else {
+                    p.thr[i] = split_thr_l2(qn, st, em, d, p.units, p.c_acc, p.eps_scale, amag);
+                }
                 qbig = __uint_as_float(max(__float_as_uint(qbig), __float_as_uint(qn)));
             } else {
                 p.thr[i] = make_float2(INFINITY, INFINITY);
@@ -640,10 +822,15 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
 // GS > 0: GROUPED columns -- every column (one split query row) carries up to GS queries that share the row but
 // have their own true entity, hence their own thresholds: the MFMA sweep runs once per column, the epilogue once
 // per (column, set); thresholds and counters of the panel's sets live in LDS.
-template <int NWAVES, bool DBG, int PM, int GS = 0>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
+// LV = 1: the ONE-PRODUCT level.  Operands are PLANAR hi tables (kge_lp_hi_rows: 32 bytes per k16 unit), a 128-byte stage
+// row holds FOUR units, and a stage is four MFMA groups qh*eh instead of 2 x 3 -- a third of the matrix work and half
+// the operand bytes per (pair, unit); same tile, same LDS-DMA staging and swizzle, same epilogue against thresholds
+// that carry the operands' measured f16 residuals (split_thr_l2_hi).  p.units / p.stages then count hi units / 4-unit stages.
+template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
     static_assert(GS == 0 || GS == GSETS, "grouped columns carry GSETS threshold sets");
+    static_assert(LV == 0 || PM == 0, "the one-product level has plain thresholds only");
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int MT = TC / 32 / (NWAVES / 2);                      // 32x32 candidate tiles per wave
@@ -721,6 +908,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) a_off[u][pc] = lds0 + a_row + ((u * 4 + pc * 2 + half) ^ sw) * 16;
+    unsigned h_off[4];      // LV = 1: the hi fragment of unit j of a stage is chunk 2 j + half
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h_off[j] = lds0 + a_row + ((j * 2 + half) ^ sw) * 16;
     // the query fragments sit a wave-uniform distance behind the candidate fragments (scalar register)
     const unsigned b_delta = __builtin_amdgcn_readfirstlane(b_row - a_row);
 
@@ -831,6 +1021,16 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 #define KGE_SWAIT(AH, AL, BH, BL)                                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(AH[0]), "+v"(AH[1]), "+v"(AL[0]), "+v"(AL[1]),      \
                  "+v"(BH[0]), "+v"(BH[1]), "+v"(BH[2]), "+v"(BL[0]), "+v"(BL[1]), "+v"(BL[2]) :: "memory");
+#define KGE_HLOAD(AH, BH, BASE, J) /* LV = 1: the hi fragments of unit J of the stage at BASE */     \
+    {                                                                                               \
+        const unsigned ah_ = (BASE) + h_off[J];                                                     \
+        const unsigned bh_ = ah_ + b_delta;                                                         \
+        KGE_DSR(AH[0], ah_, 0); KGE_DSR(BH[0], bh_, 0); KGE_DSR(AH[1], ah_, 4096);                  \
+        KGE_DSR(BH[1], bh_, 4096); KGE_DSR(BH[2], bh_, 8192);                                       \
+        asm volatile("" :: "v"(ah_), "v"(bh_));                                                     \
+    }
+#define KGE_HWAIT(AH, BH)                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(AH[0]), "+v"(AH[1]), "+v"(BH[0]), "+v"(BH[1]), "+v"(BH[2]) :: "memory");
 #define KGE_SMMA_P(A, B, C) /* one of the three split products over the wave's MT x NT tiles, given C */ \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
@@ -852,7 +1052,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16;
 
     f16x8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
-    KGE_SLOAD(ah0, al0, bh0, bl0, 0u, 0)
+    if (LV == 1) { KGE_HLOAD(ah0, bh0, 0u, 0) } else { KGE_SLOAD(ah0, al0, bh0, bl0, 0u, 0) }
     int it = 0, s = 0;
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
@@ -871,51 +1071,95 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         char *nE = smem + (buf ^ 1) * STAGE_BYTES + wid * 1024, *nQ = nE + E_STAGE_BYTES;
         const char *gE = pfE + pf_s * 128, *gQ = pfQ + pf_s * 128;
 
-        // (this stage's first k16 fragments were fetched behind the previous stage's barrier, below)
-        KGE_SWAIT(ah0, al0, bh0, bl0)
-        if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
-        __builtin_amdgcn_sched_barrier(0);
-        const char *gE1 = gE + rstep;
-        if (pf) { dma(gE, nE); dma(gE1, nE + SROWS * 128); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah1, al1, bh1, bl1, sb, 1) }
-        // (hipcc would drain lgkmcnt before a fragment load whose destination reuses the address
-        // registers of an LDS-DMA still in flight: keep those registers occupied until here)
-        asm volatile("" :: "v"(gE), "v"(gE1));
-        __builtin_amdgcn_sched_barrier(0);
-        const bool hi1 = DBG && (dbg & 1024), halfdma = DBG && (dbg & 2048);
-        if (!hi1) { KGE_SMMA_PA(ah0, bl0) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (pf && !halfdma) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!hi1) { KGE_SMMA_PA(al0, bh0) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (pf) { dma(gQ, nQ); if (!halfdma) { dma(gQ + rstep, nQ + SROWS * 128); dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128); } }
-        if (more && pf) {
-            if (++pf_s == S) {
-                pf_s = 0;
-                if (++pf_it < nitems) pf_new_item();
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        KGE_SWAIT(ah1, al1, bh1, bl1)
-        if (two) { KGE_SMMA_PA(ah1, bh1) }
-        __builtin_amdgcn_sched_barrier(0);
-        // The stage's last two MFMA groups run BEHIND the barrier, next to the fetch of the next
-        // stage's first fragments: right after a barrier all 8 waves read LDS at once (80 KB), and
-        // without matrix work in flight the MFMA pipe would idle for that long.
-        if (!(dbg & 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
-        if (dbg & 512) __builtin_amdgcn_s_barrier();   // probe: barrier without waiting for the DMA pieces
-        else if (!(dbg & 32)) __syncthreads();
         // (grouped columns: on a tile's last stage the next stage's first fragments are fetched AFTER the multi-pass
-        // epilogue -- their 40 registers are what its temporaries need; the LDS buffer stays valid through the next stage)
+        // epilogue -- their registers are what its temporaries need; the LDS buffer stays valid through the next stage)
         const bool defer_frag = GS != 0 && s == S - 1;
-        if (more && !(dbg & 16) && !defer_frag) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (two && !hi1) { KGE_SMMA_PA(ah1, bl1) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (two && !hi1) { KGE_SMMA_PA(al1, bh1) }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LV == 1) {
+            // ONE product per k16 unit, four units per stage: [u0] dma E0 E1 | frag u1 [u1] dma E2 E3 | frag u2 [u2] dma Q |
+            // frag u3 -- barrier -- frag u0 of the next stage [u3].  Every fragment overwrite has an LDS wait (or an MFMA
+            // group) between it and the MFMAs that last read those registers.
+            const int nu = min(4, p.units - 4 * s);
+            KGE_HWAIT(ah0, bh0)
+            if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
+            __builtin_amdgcn_sched_barrier(0);
+            const char *gE1 = gE + rstep;
+            if (pf) { dma(gE, nE); dma(gE1, nE + SROWS * 128); }
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_HLOAD(ah1, bh1, sb, 1)
+            asm volatile("" :: "v"(gE), "v"(gE1));
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_HWAIT(ah1, bh1)
+            if (nu > 1) { KGE_SMMA_PA(ah1, bh1) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pf) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_HLOAD(ah0, bh0, sb, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_HWAIT(ah0, bh0)
+            if (nu > 2) { KGE_SMMA_PA(ah0, bh0) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pf) { dma(gQ, nQ); dma(gQ + rstep, nQ + SROWS * 128); dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128); }
+            if (more && pf) {
+                if (++pf_s == S) {
+                    pf_s = 0;
+                    if (++pf_it < nitems) pf_new_item();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_HLOAD(ah1, bh1, sb, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_HWAIT(ah1, bh1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next stage landed in LDS
+            __syncthreads();
+            if (more && !defer_frag) { KGE_HLOAD(ah0, bh0, sb_next, 0) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (nu > 3) { KGE_SMMA_PA(ah1, bh1) }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // (this stage's first k16 fragments were fetched behind the previous stage's barrier, below)
+            KGE_SWAIT(ah0, al0, bh0, bl0)
+            if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
+            __builtin_amdgcn_sched_barrier(0);
+            const char *gE1 = gE + rstep;
+            if (pf) { dma(gE, nE); dma(gE1, nE + SROWS * 128); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 16) || g == 0) { KGE_SLOAD(ah1, al1, bh1, bl1, sb, 1) }
+            // (hipcc would drain lgkmcnt before a fragment load whose destination reuses the address
+            // registers of an LDS-DMA still in flight: keep those registers occupied until here)
+            asm volatile("" :: "v"(gE), "v"(gE1));
+            __builtin_amdgcn_sched_barrier(0);
+            const bool hi1 = DBG && (dbg & 1024), halfdma = DBG && (dbg & 2048);
+            if (!hi1) { KGE_SMMA_PA(ah0, bl0) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pf && !halfdma) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!hi1) { KGE_SMMA_PA(al0, bh0) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pf) { dma(gQ, nQ); if (!halfdma) { dma(gQ + rstep, nQ + SROWS * 128); dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128); } }
+            if (more && pf) {
+                if (++pf_s == S) {
+                    pf_s = 0;
+                    if (++pf_it < nitems) pf_new_item();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            KGE_SWAIT(ah1, al1, bh1, bl1)
+            if (two) { KGE_SMMA_PA(ah1, bh1) }
+            __builtin_amdgcn_sched_barrier(0);
+            // The stage's last two MFMA groups run BEHIND the barrier, next to the fetch of the next
+            // stage's first fragments: right after a barrier all 8 waves read LDS at once (80 KB), and
+            // without matrix work in flight the MFMA pipe would idle for that long.
+            if (!(dbg & 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage landed in LDS
+            if (dbg & 512) __builtin_amdgcn_s_barrier();   // probe: barrier without waiting for the DMA pieces
+            else if (!(dbg & 32)) __syncthreads();
+            if (more && !(dbg & 16) && !defer_frag) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (two && !hi1) { KGE_SMMA_PA(ah1, bl1) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (two && !hi1) { KGE_SMMA_PA(al1, bh1) }
+            __builtin_amdgcn_sched_barrier(0);
+
+        }
 
         const bool tile_done = s == S - 1;
         if (tile_done && !(dbg & 4)) {
@@ -1114,7 +1358,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                     if (lane == 0) *unc_cnt = 0;
                 }
             }
-            if (GS && more && !(dbg & 16)) { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
+            if (GS && more && !(dbg & 16)) {
+                if (LV == 1) { KGE_HLOAD(ah0, bh0, sb_next, 0) } else { KGE_SLOAD(ah0, al0, bh0, bl0, sb_next, 0) }
+            }
             if (more) { // query panel change (block-uniform): flush counters, load the next thresholds
                 int qp_next, ct_next;
                 item_qp_ct(it + 1, qp_next, ct_next);
@@ -1130,6 +1376,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     }
 #undef KGE_SMMA_PA
 #undef KGE_SMMA_P
+#undef KGE_HLOAD
+#undef KGE_HWAIT
 #undef KGE_SLOAD
 #undef KGE_SWAIT
 #undef KGE_DSR
@@ -1141,12 +1389,14 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 template <bool VEC4>
 __global__ __launch_bounds__(64, 2) void split_recheck_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
                                                            const int32_t *__restrict__ list, int32_t cap,
-                                                           const int32_t *__restrict__ list_count, int32_t *raw_count)
+                                                           const int32_t *__restrict__ list_count, int32_t *raw_count,
+                                                           float *list_stat)
 {
     __shared__ __attribute__((aligned(16))) float qs[64 * KGE_PS_LD];
     __shared__ __attribute__((aligned(16))) float es[64 * KGE_PS_LD];
     const int lane = threadIdx.x;
     const int n = (int)min((unsigned)*list_count, (unsigned)cap);   // (a count past the capacity means overflow: the caller redoes the count)
+    if (list_stat && blockIdx.x == 0 && lane == 0) atomicAdd(list_stat, (float)n);   // pairs re-scored per evaluation (level policy)
     const int ngroups = (n + 63) >> 6;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int pi = grp * 64 + lane;
@@ -1158,10 +1408,10 @@ __global__ __launch_bounds__(64, 2) void split_recheck_kernel(const kge_lp_desc 
     }
 }
 
-template <int NWAVES, bool DBG, int PM, int GS = 0>
+template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
-    auto k = lp_split_count_kernel<NWAVES, DBG, PM, GS>;
+    auto k = lp_split_count_kernel<NWAVES, DBG, PM, GS, LV>;
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -1226,6 +1476,34 @@ extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const flo
     return 0;
 }
 
+/* units of a PLANAR hi operand (one-product level): k16 units of K + 2 columns, rounded up to 4 (one 128-byte stage) */
+extern "C" int kge_lp_hi_units(int K) { return (int)round_up((K + 2 + 15) / 16, 4); }
+
+extern "C" int kge_lp_hi_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                              int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
+                              const float *norm2max1, void *out, float *dn2, float *dn2max, const int64_t *row_index,
+                              kge_stream_t stream)
+{
+    if (rows < 0 || K0 <= 0 || K1 < 0 || ld0 < K0 || (K1 > 0 && ld1 < K1) || aug_mode < 1 || aug_mode > 4) return KGE_EINVAL;
+    if (rows == 0 && is_query) return 0;
+    if ((rows > 0 && !X0) || (rows > 0 && K1 > 0 && !X1) || !out || ((aug_mode == 1 || aug_mode == 3) && rows > 0 && !aug))
+        return KGE_EINVAL;
+    HiRowsParams p;
+    p.X0 = X0; p.X1 = X1; p.ld0 = ld0; p.ld1 = ld1; p.K0 = K0; p.K1 = K1;
+    p.rows = rows;
+    p.rows_p = kge_lp_split_rows_padded(rows, is_query);
+    p.aug_mode = aug_mode; p.aug = aug; p.aug_mul = aug_mul;
+    p.nmax0 = norm2max0; p.nmax1 = norm2max1;
+    p.units_p = kge_lp_hi_units(K0 + K1);
+    p.out = reinterpret_cast<uint4 *>(out);
+    p.dn2 = dn2; p.dn2max = dn2max; p.row_index = row_index;
+    const int64_t blocks = p.rows_p / 16;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(hi_rows_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_lp_split_prefix_max(const float *cell_ss, int64_t rows, int is_query, int units_p, float *e2pref,
                                        kge_stream_t stream)
 {
@@ -1258,10 +1536,13 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     if (d->mode == KGE_LP_DOT && (!a->qn0 || !a->qmax0 || (d->K1 > 0 && (!a->qn1 || !a->qmax1 || !a->emax1))))
         return KGE_EINVAL;
     if (d->B > INT32_MAX || d->N > INT32_MAX) return KGE_EINVAL;
+    if (a->level != 0 && a->level != 1) return KGE_EINVAL;
+    const bool lv1 = a->level == 1;     // one-product level: planar hi operands, plain thresholds
+    if (lv1 && (proj || (!a->thr_ready && (!a->q_dn2 || !a->de2max)))) return KGE_EINVAL;
     hipStream_t s = kge_s(stream);
     const int K = d->K0 + d->K1;
-    const int units_p = kge_lp_split_units(K, 1);
-    const int units = (K + 1 + 15) / 16;
+    const int units_p = lv1 ? kge_lp_hi_units(K) : kge_lp_split_units(K, 1);
+    const int units = lv1 ? (K + 2 + 15) / 16 : (K + 1 + 15) / 16;
     const int64_t Bp = kge_lp_split_rows_padded(d->B, 1);
     SplitThrParams t;
     t.mode = d->mode;
@@ -1280,6 +1561,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.q_cell_ss = a->q_cell_ss; t.e2pref = a->e2pref; t.units_p = units_p; t.K0 = d->K0;
     t.ss_index = a->q_cell_ss_index; t.ss_ld = a->q_cell_ss_index ? a->q_cell_ss_ld : Bp;
     if (a->q_cell_ss_index && a->q_cell_ss_ld <= 0) return KGE_EINVAL;
+    t.level = a->level; t.q_dn2 = a->q_dn2; t.q_dn2_index = a->q_dn2_index; t.de2max = a->de2max;
+    if (lv1) { t.q_cell_ss = nullptr; t.e2pref = nullptr; }
     t.list_count = a->list_count;
     t.overflow = a->overflow;
     if (!a->thr_ready) {    // (the fused query pipeline has already written thr and zeroed list_count)
@@ -1294,9 +1577,9 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     SplitParams p;
     p.Es = reinterpret_cast<const char *>(Es);
     p.Qs = reinterpret_cast<const char *>(Qs);
-    p.row_bytes = units_p * 64;
+    p.row_bytes = lv1 ? units_p * 32 : units_p * 64;
     p.units = units;
-    p.stages = units_p / 2;
+    p.stages = lv1 ? units_p / 4 : units_p / 2;
     p.B = d->B;
     p.N = d->N;
     p.thr = reinterpret_cast<const float2 *>(thr);
@@ -1329,8 +1612,9 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
             p.q_panels = (int)(a->n_single_p / TQ);
             p.n_items = (int64_t)p.q_panels * p.c_tiles;
             const int grid = (int)(p.n_items < slots ? p.n_items : slots);
-            rc = pm == 1 ? launch_split<8, false, 1>(p, grid, s)
-                         : (pm == 2 ? launch_split<8, false, 2>(p, grid, s) : launch_split<8, false, 0>(p, grid, s));
+            rc = lv1 ? launch_split<8, false, 0, 0, 1>(p, grid, s)
+                     : (pm == 1 ? launch_split<8, false, 1>(p, grid, s)
+                                : (pm == 2 ? launch_split<8, false, 2>(p, grid, s) : launch_split<8, false, 0>(p, grid, s)));
             if (rc) return rc;
         }
         if (a->n_multi_p > 0) {
@@ -1340,14 +1624,16 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
             p.q_panels = (int)(a->n_multi_p / TQ);
             p.n_items = (int64_t)p.q_panels * p.c_tiles;
             const int grid = (int)(p.n_items < slots ? p.n_items : slots);
-            rc = pm == 1 ? launch_split<8, false, 1, GSETS>(p, grid, s)
-                         : (pm == 2 ? launch_split<8, false, 2, GSETS>(p, grid, s) : launch_split<8, false, 0, GSETS>(p, grid, s));
+            rc = lv1 ? launch_split<8, false, 0, GSETS, 1>(p, grid, s)
+                     : (pm == 1 ? launch_split<8, false, 1, GSETS>(p, grid, s)
+                                : (pm == 2 ? launch_split<8, false, 2, GSETS>(p, grid, s) : launch_split<8, false, 0, GSETS>(p, grid, s)));
         }
         return rc;
     }
     p.q_panels = (int)((d->B + TQ - 1) / TQ);
     p.n_items = (int64_t)p.q_panels * p.c_tiles;
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
+    if (lv1) return launch_split<8, false, 0, 0, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2>(p, grid, s);
     return p.dbg ? launch_split<8, true, 0>(p, grid, s) : launch_split<8, false, 0>(p, grid, s);
@@ -1357,7 +1643,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
 extern "C" int kge_lp_split_group_sets(void) { return GSETS; }
 
 extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
-                                    const int32_t *list_count, int32_t *raw_count, kge_stream_t stream)
+                                    const int32_t *list_count, int32_t *raw_count, float *list_stat, kge_stream_t stream)
 {
     int rc = kge_lp_desc_check(d);
     if (rc) return rc;
@@ -1368,10 +1654,10 @@ extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, c
     const int grid = split_num_cus() * kge_env_int("KGE_SPLIT_RECHECK_WAVES", 160 * 1024 / (2 * 64 * KGE_PS_LD * 4));
     if (vec4)
         hipLaunchKernelGGL(split_recheck_kernel<true>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list, cap,
-                           list_count, raw_count);
+                           list_count, raw_count, list_stat);
     else
         hipLaunchKernelGGL(split_recheck_kernel<false>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list,
-                           cap, list_count, raw_count);
+                           cap, list_count, raw_count, list_stat);
     KGE_CHECK_LAUNCH();
     return 0;
 }
@@ -1444,8 +1730,11 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
                                      const int64_t *t, const int64_t *r, int64_t B, const float *en,
                                      const float *emax, float *qmax_io, int accum_model, float eps_scale, float *Q,
                                      float *qn, float *s_true, void *Qs, float *thr, int32_t *list_count,
-                                     const float *e2pref, const int32_t *qs_row, kge_stream_t stream)
+                                     const float *e2pref, const int32_t *qs_row, int level, const float *de2max,
+                                     float *q_dn2, kge_stream_t stream)
 {
+    if (level != 0 && level != 1) return KGE_EINVAL;
+    if (level == 1 && !de2max) return KGE_EINVAL;
     const bool both = side == KGE_SIDE_BOTH;
     if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD && !both) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
     if (B == 0) return 0;
@@ -1458,6 +1747,8 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     p.en = en; p.emax = emax; p.qmax_io = qmax_io;
     p.c_acc = accum_model == 1 ? 1.25f : 2.0f; p.eps_scale = eps_scale;
     p.units = (d + 1 + 15) / 16; p.units_p = kge_lp_split_units(d, 1);
+    p.level = level; p.de2max = de2max; p.q_dn2 = q_dn2;
+    if (level == 1) { p.units = (d + 2 + 15) / 16; p.units_p = kge_lp_hi_units(d); }
     p.Q = Q; p.qn = qn; p.s_true = s_true;
     p.thr = reinterpret_cast<float2 *>(thr);
     p.Qs = reinterpret_cast<_Float16 *>(Qs);

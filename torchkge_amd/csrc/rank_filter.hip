@@ -588,6 +588,7 @@ __global__ void rank_finalize_both_kernel(const int32_t *__restrict__ raw, const
     if (flags && blockIdx.x == 0 && threadIdx.x == 0) {
         flags[0] = guard[0] + guard[1];
         flags[1] = guard[2];
+        flags[2] = guard[6];        // pairs the split prefilter re-scored in this evaluation (kge_lp_split_recheck list_stat)
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
         const bool tail = i < B;
@@ -1063,5 +1064,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 23; }
+extern "C" int kge_abi_version(void) { return 24; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -47,6 +47,11 @@ COALESCE_LIST_BYTES = 2 << 30
 # size).  A batch is cut into as many row tiles as it takes, so b_size never decides whether the score exchange fits.
 SCORE_TILE_BYTES = int(os.environ.get('KGE_SCORE_TILE_BYTES', 256 << 20))
 DEDUPE_QUERIES = os.environ.get('KGE_DEDUPE_QUERIES', '1') != '0'    # count kernel on distinct query rows (ColumnPlan)
+# One-product level of the split prefilter (model.split_level = 'auto'): an evaluation whose three-product sweep re-scored
+# at most LEVEL1_ENTER pairs per query hands the NEXT one to the one-product sweep (a third of the matrix work, ~4x the
+# re-scored pairs); one whose one-product sweep re-scored more than LEVEL1_LEAVE per query hands it back.  Break-even on
+# cfg2: ~24 extra pairs per query (0.25 ms of count kernel against ~4 G exact pair scores / s).
+LEVEL1_ENTER, LEVEL1_LEAVE = 6.0, 30.0
 
 
 class HipRankEngine(object):
@@ -282,6 +287,8 @@ class LinkPredictionEvaluator(object):
         # relation rows of that table instead of 32 different ones.  _perm[j] = original position of the j-th processed
         # fact (the ranks are written straight to it); static like the plans.
         self._perm = None
+        self._level = 0         # level of the split prefilter the next evaluation runs (see LEVEL1_ENTER)
+        self.last_rescored_per_query = None
 
     def _internal_batch(self, b_size, n_local):
         """Batch the fused kernels see.  In the reference ``b_size`` only bounds the (b, N, d) temporaries
@@ -663,8 +670,9 @@ class LinkPredictionEvaluator(object):
                 return hh, tt, rr
 
             def alloc_out():
-                # (4, n) ranks + one trailing int64 that carries the two guard flags: ONE device-to-host copy
-                flat = torch.empty(4 * n_local + 1, dtype=torch.int64, device=device)
+                # (4, n) ranks + two trailing int64 that carry the guard flags (4 floats: norm guard, list overflow,
+                # re-scored pairs, spare): ONE device-to-host copy
+                flat = torch.empty(4 * n_local + 2, dtype=torch.int64, device=device)
                 return flat, flat[:4 * n_local].view(4, n_local), flat[4 * n_local:].view(torch.float32)
 
             def run(heads, tails, rels, out, fl):
@@ -710,10 +718,15 @@ class LinkPredictionEvaluator(object):
                         # has the last batch's finalize write them)
                         torch.add(guard[0:1], guard[1:2], out=fl[0:1])
                         fl[1:2].copy_(guard[2:3])
+                        fl[2:3].copy_(guard[6:7])
                     self._fl = None
 
             # one hipGraph when run() contains no collective (single GPU, query shards); graph segments with
             # the collectives between them for entity shards exchanging counts; eager otherwise
+            # level of the split prefilter for THIS evaluation (single GPU, fused): decided by the previous one
+            level_now = self._level if (guard is not None and not kdist.multi(world) and both) else 0
+            if hasattr(self.model, '_split_level'):
+                object.__setattr__(self.model, '_split_level', level_now)
             multi = kdist.multi(world)
             segmented = multi and sharded and both
             one_graph = segmented and self.graph_collectives and kdist.backend_name(self.group) == 'nccl'
@@ -731,6 +744,7 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, one_graph, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
+                       level_now, getattr(self.model, 'split_level', None),
                        tuple(p_.data_ptr() for p_ in params), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))
@@ -815,28 +829,49 @@ class LinkPredictionEvaluator(object):
                     flat, out, fl = st['out']
 
             res = None
-            if guard is not None:
+            for attempt in (0, 1):
+                if guard is None:
+                    break
                 # the expansion was safe iff ||q||^2 + ||e||^2 stayed small; otherwise its
                 # cancellation error could exceed the score tolerance -> redo on the VALU kernel
                 if kdist.multi(world) and self._shard_flags is None:
-                    flags = fl.clone()
+                    flags = fl[:2].clone()
                     kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
                     worst, overflow = flags.tolist()
-                else:   # one device-to-host transfer for the ranks and the two flags (8 bytes = one int64)
+                    rescored = 0.0
+                else:   # one device-to-host transfer for the ranks and the flags (16 bytes = two int64)
                     packed = _to_host(flat)
-                    worst, overflow = packed[-1:].view(torch.float32).tolist()
-                    res = packed[:-1].view(4, n_local)
-                redo = False
+                    worst, overflow, rescored, _ = packed[-2:].view(torch.float32).tolist()
+                    res = packed[:-2].view(4, n_local)
+                redo = check_again = False
                 if not worst <= self.model.L2_EXPAND_LIMIT:
                     self.model._expand_ok = False
                     redo = True
+                elif overflow > 0 and level_now == 1 and attempt == 0 and getattr(self.model, 'split_level', 0) == 'auto':
+                    # the one-product level's wider band overflowed the list: this evaluation again on the three-product
+                    # sweep (whose own flags are then checked like a first run's)
+                    self._level = level_now = 0
+                    object.__setattr__(self.model, '_split_level', 0)
+                    redo = check_again = True
                 elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
                     self.model._split_ok = False
                     redo = True
-                if redo:
-                    res = None
-                    flat, out, fl = alloc_out()
-                    run(*facts(), out, fl)
+                elif n_local > 0 and not kdist.multi(world):
+                    # level policy for the NEXT evaluation, from the pairs this one re-scored (flags[2])
+                    per_q = rescored / (2.0 * n_local)
+                    self.last_rescored_per_query = per_q
+                    if level_now == 0 and per_q <= LEVEL1_ENTER and getattr(self.model, 'split_level', 0) == 'auto' \
+                            and rescored > 0:
+                        self._level = 1
+                    elif level_now == 1 and per_q > LEVEL1_LEAVE:
+                        self._level = 0
+                if not redo:
+                    break
+                res = None
+                flat, out, fl = alloc_out()
+                run(*facts(), out, fl)
+                if not check_again:
+                    break
         finally:
             self._qb = None
             if guard is not None:      # never leave the model in guarded mode (exceptions included)

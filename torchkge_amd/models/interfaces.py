@@ -311,6 +311,16 @@ class Model(Module):
         _set(self, '_guard_on', True)
         return self._lp_guard
 
+    # One-product level of the split prefilter (kge_split_args.level): 'auto' = the evaluator decides from the number of
+    # pairs the last evaluation re-scored (LinkPredictionEvaluator._level); 0 / 1 force a level.
+    split_level = 'auto'
+    _split_level = 0        # what the running evaluation uses (set by the evaluator)
+
+    def _use_level1(self):
+        lv = self.split_level
+        want = self._split_level == 1 if lv == 'auto' else int(lv) == 1
+        return bool(want) and _hip.split_accum_model() == 1     # (the band assumes the measured MFMA accumulation)
+
     def lp_guard_end(self):
         _set = object.__setattr__
         _set(self, '_guard_on', False)
@@ -325,15 +335,23 @@ class Model(Module):
         g = self._lp_guard
         key = '%d_%d' % (c_base, T0.shape[0])
 
-        def build():
+        def norms():
             en0 = _hip.row_sqnorm(T0, max_io=g[1:2])
             if T1 is not None:
                 _hip.row_sqnorm(T1, max_io=g[5:6])
             del en0
-            return _hip.split_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=g[5:6] if T1 is not None else None)
-        Es, e2 = self._cache.get('esd_' + key, [T0] + ([T1] if T1 is not None else []), build)
-        prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'enmax1': g[5:6] if T1 is not None else None,
-                      'overflow': g[2:3]}
+            return True
+        srcs = [T0] + ([T1] if T1 is not None else [])
+        self._cache.get('esn_' + key, srcs, norms)       # the norm maxima fix the operands' scale: before either table
+        nm1 = g[5:6] if T1 is not None else None
+        if self._use_level1() and c_base == 0 and T0.shape[0] == self.n_ent:
+            # one-product level (see TransEModel._fused_query_problem): planar hi table + its residual maximum
+            Eh, de2 = self._cache.get('ehd_' + key, srcs, lambda: _hip.hi_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=nm1))
+            prob.split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'level': 1,
+                          'de2max': de2, 'list_stat': g[6:7]}
+            return prob
+        Es, e2 = self._cache.get('esd_' + key, srcs, lambda: _hip.split_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=nm1))
+        prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'list_stat': g[6:7]}
         return prob
 
     def lp_problem_both(self, h_idx, t_idx, r_idx):

@@ -119,12 +119,22 @@ class TransEModel(TranslationModel):
         g = self._lp_guard
         key = '0_%d' % E.shape[0]
         en = self._cache.get('en_' + key, [E], lambda: _hip.row_sqnorm(E, max_io=g[1:2]))
-        Es, e2 = self._cache.get('es_' + key, [E], lambda: _hip.split_table(E, aug=en))
-        pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2, cols=cols)
+        if self._use_level1():
+            # one-product level of the split prefilter (a fitted model: the true entities sit in the sparse upper tail,
+            # the 8x wider band still holds few pairs): planar hi table, thresholds from the measured f16 residuals
+            Eh, de2 = self._cache.get('eh_' + key, [E], lambda: _hip.hi_table(E, aug=en))
+            pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], cols=cols, level=1,
+                                         de2max=de2)
+            split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'overflow': g[2:3], 'level': 1, 'de2max': de2,
+                     'list_stat': g[6:7]}
+        else:
+            Es, e2 = self._cache.get('es_' + key, [E], lambda: _hip.split_table(E, aug=en))
+            pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2, cols=cols)
+            split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'overflow': g[2:3], 'list_stat': g[6:7]}
         # (SIDE_BOTH: the evaluator fills in the concatenated true indices it gets from the filter lookup)
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
-        prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'overflow': g[2:3]}
+        prob.split = split
         prob.pre = pre
         return prob
 
