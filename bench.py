@@ -240,22 +240,38 @@ def unit_scale_(model, seed=0):
     return model
 
 
-def build_cfg5_sample(device, n_facts=400000, n_test=64, seed=1005):
-    """cfg5's MODEL (ComplEx d = 512 on 4,594,485 entities / 822 relations, unit-scale tables) with a small Zipf graph
-    over those entities: what tests/test_gpu_fullsplit.py compares with the reference algorithm at b_size = 2."""
+def build_cfg5_sample(device, n_facts=5000000, n_test=64, seed=1005, hub_tests=32):
+    """cfg5's MODEL (ComplEx d = 512 on 4,594,485 entities / 822 relations, unit-scale tables) with a 5 M-fact Zipf graph
+    over those entities (planted hub keys with thousands of known heads / tails): what tests/test_gpu_fullsplit.py
+    compares with the reference algorithm at b_size = 2.  Half of the `n_test` test facts are taken FROM the hub keys, so
+    the filtered ranks of the sample walk filter lists of thousands of entities at N = 4.6 M (r03's 400 k-fact graph
+    left them almost empty)."""
     import torchkge_amd as tk
     from oracle import kge_oracle as orc
     n_ent, n_rel = orc.DATASET_SHAPES['wikidata5m'][:2]
     torch.manual_seed(0)
     model = unit_scale_(tk.ComplExModel(512, n_ent, n_rel).to(device))
-    heads, tails, rels = orc.synthetic_triples_zipf(n_ent, n_rel, n_facts, seed)
+    hubs = ((6000, 'head'), (3000, 'head'), (1500, 'tail'), (800, 'tail'))
+    heads, tails, rels = orc.synthetic_triples_zipf(n_ent, n_rel, n_facts, seed, hubs=hubs)
     ident_e, ident_r = {i: i for i in range(n_ent)}, {i: i for i in range(n_rel)}
     kg = tk.KnowledgeGraph(kg={'heads': heads, 'tails': tails, 'relations': rels}, ent2ix=ident_e, rel2ix=ident_r)
-    kg_test = tk.KnowledgeGraph(kg={'heads': heads[-n_test:].clone(), 'tails': tails[-n_test:].clone(),
-                                    'relations': rels[-n_test:].clone()}, ent2ix=ident_e, rel2ix=ident_r,
+    # test facts: the last n_test - hub_tests facts of the (shuffled) graph + hub_tests facts of the most frequent
+    # (h, r) / (t, r) keys, alternating sides
+    sel = list(range(n_facts - (n_test - hub_tests), n_facts))
+    if hub_tests > 0:
+        for side_key, cnt in ((heads * n_rel + rels, hub_tests - hub_tests // 2), (tails * n_rel + rels, hub_tests // 2)):
+            uk, inv, c = torch.unique(side_key, return_inverse=True, return_counts=True)
+            top = torch.argsort(c, descending=True)[:4]
+            per = -(-cnt // 4)
+            for k in top.tolist():
+                sel += torch.nonzero(inv == k).view(-1)[:per].tolist()
+        sel = sel[:n_test]
+    sel = torch.tensor(sel, dtype=torch.long)
+    kg_test = tk.KnowledgeGraph(kg={'heads': heads[sel].clone(), 'tails': tails[sel].clone(),
+                                    'relations': rels[sel].clone()}, ent2ix=ident_e, rel2ix=ident_r,
                                 _filter_src=kg._lazy)
     info = {'kind': 'complex', 'shape': 'wikidata5m', 'd': 512, 'p': 2, 'n_ent': n_ent, 'n_rel': n_rel,
-            'n_test': n_test, 'kg_kind': 'zipf', 'weights': 'unit'}
+            'n_test': int(sel.shape[0]), 'kg_kind': 'zipf', 'weights': 'unit', 'graph_facts': n_facts}
     return model, kg, kg_test, info
 
 

@@ -483,8 +483,8 @@ typedef struct kge_split_args {
      * matrix work, half the operand bytes.  The error band then carries the operands' measured f16 residuals:
      * q_dn2[i] = ||q_i - hi(q_i)||^2 (read at q_dn2_index[i] when given: query columns) and de2max = device scalar
      * >= max_c ||e_c - hi(e_c)||^2; it is ~8x wider than the three-product band (4.7e-4 of ||q|| max||e|| at K = 200), so
-     * this level pays when the true entities sit in the sparse upper tail of the scores (a fitted model).  L2_EXPAND and
-     * DOT modes; counts stay exact (kge_lp_split_recheck).  level = 0: the three-product sweep. */
+     * this level pays when the true entities sit in the sparse upper tail of the scores (a fitted model).  Every MFMA
+     * mode; counts stay exact (kge_lp_split_recheck).  level = 0: the three-product sweep. */
     int32_t level;
     const float *q_dn2;
     const int64_t *q_dn2_index;

@@ -86,7 +86,7 @@ def test_cfg5_wikidata5m_shape_subsample_vs_gpu_resident_reference(hip):
     import bench
     import torchkge_amd as tk
     dev = torch.device('cuda', 0)
-    model, kg, kg_test, info = bench.build_cfg5_sample(dev, n_facts=400000, n_test=64)
+    model, kg, kg_test, info = bench.build_cfg5_sample(dev, n_facts=5000000, n_test=64)      # 5 M facts, hub keys: long filter lists
     ev = tk.LinkPredictionEvaluator(model, kg_test)
     ev.evaluate(b_size=32768, verbose=False)
     split = _ranks(ev)
@@ -97,6 +97,7 @@ def test_cfg5_wikidata5m_shape_subsample_vs_gpu_resident_reference(hip):
              par['filt_mrr_ref_hip'][0], par['filt_mrr_ref_hip'][1], par['median_filt_rank_ref'],
              par['filter_list_entries_of_the_sample']))
     assert par['ranks_compared'] == 256
+    assert par['filter_list_entries_of_the_sample'] > 20000        # the filtered path is really exercised at N = 4.6 M
     assert par['within_reference_tie_interval_2e-5'], par
     assert par['abs_diff_filt_mrr'] < 1e-5 and abs(par['mrr_ref_hip'][0] - par['mrr_ref_hip'][1]) < 1e-5, par
     assert par['abs_diff_filt_hits10'] < 1e-5 + par['filtered_ranks_across_the_hits10_boundary'] * 0.5 / 64, par

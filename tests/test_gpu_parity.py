@@ -1085,6 +1085,13 @@ def test_split_prefilter_projection_modes_counts_equal_exact_counts(hip, mode_na
         hip.SPLIT_EPS_SCALE = 1.0
     assert float(guard[2]) == 0.0
     assert B <= int(prob.last_split[0].item()) <= 64 * B
+    # ... and on the ONE-PRODUCT level (planar hi table, thresholds from the measured residuals; same epilogue)
+    Eh, de2 = hip.hi_table(dT, aug=en)
+    prob.split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'xabsmax': guard[3:4],
+                  'yabsmax': guard[4:5] if mode_name == 'D' else None, 'level': 1, 'de2max': de2}
+    got = prob.count_ge(st)
+    assert torch.equal(got, exact), int((got != exact).sum())
+    assert float(guard[2]) == 0.0 and B <= int(prob.last_split[0].item())
 
 
 @pytest.mark.parametrize('n0,n1,rows', [(1000, 0, 237), (32768, 32768, 14541), (5, 3, 2), (70000, 1, 1 << 20), (1, 0, 1)])
@@ -1557,7 +1564,7 @@ def test_split_one_product_level_dot_mode(hip, B, N, K, K1, scale):
         hip.SPLIT_EPS_SCALE = 1.0
 
 
-@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex'])
+@pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex', 'transh', 'transd'])
 def test_evaluator_level_policy_and_identical_ranks(hip, kind):
     """LinkPredictionEvaluator with the one-product level forced on (model.split_level = 1), forced off (0) and on
     'auto' (first evaluation three products, the next ones follow the re-scored pair count): identical rank vectors,
@@ -1565,7 +1572,7 @@ def test_evaluator_level_policy_and_identical_ranks(hip, kind):
     import torchkge_amd as tk
     import torchkge_amd.evaluation as evm
     n_ent, n_rel, d = 4000, 9, 64
-    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=5)
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=5, d_rel=(48 if kind == 'transd' else None))
     m = build_model(kind, 2, tables, n_ent, n_rel)
     h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 30000, 31, hubs=((1500, 'head'), (600, 'tail')))
     kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},

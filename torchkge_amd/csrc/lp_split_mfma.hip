@@ -561,8 +561,11 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float out_scale = (float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2);
             const float u = -p.s_true[i];                    // count c iff v_c <= u, v = ||q||^2 + ||e||^2 - 2 q.e
             const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
-            const float eps_dot = split_acc_err(amag, 0.5f * em, mag, p.units, p.c_acc) + split_chain_err(amag, mag, p.K) +
-                                  eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
+            const float eps_dot = p.level == 1
+                ? split_acc_err(-1.0f, 0.5f * em, mag, p.units, p.c_acc, 16.0f) + split_chain_err(-1.0f, mag, p.K) +
+                  split_hi_resid(qnrm, enrm, 0.5f * em, dq2, *p.de2max) + 2.5e-7f * (qnrm + enrm) + 4e-9f
+                : split_acc_err(amag, 0.5f * em, mag, p.units, p.c_acc) + split_chain_err(amag, mag, p.K) +
+                  eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
             const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * p.eps_scale;
             const float mid = 0.5f * (q - u);
             float hw = 0.5f * eps_v + two22 * (fabsf(q) + fabsf(u));
@@ -830,7 +833,6 @@ template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0>   // PM: 0 plain
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
     static_assert(GS == 0 || GS == GSETS, "grouped columns carry GSETS threshold sets");
-    static_assert(LV == 0 || PM == 0, "the one-product level has plain thresholds only");
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int MT = TC / 32 / (NWAVES / 2);                      // 32x32 candidate tiles per wave
@@ -1538,7 +1540,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     if (d->B > INT32_MAX || d->N > INT32_MAX) return KGE_EINVAL;
     if (a->level != 0 && a->level != 1) return KGE_EINVAL;
     const bool lv1 = a->level == 1;     // one-product level: planar hi operands, plain thresholds
-    if (lv1 && (proj || (!a->thr_ready && (!a->q_dn2 || !a->de2max)))) return KGE_EINVAL;
+    if (lv1 && !a->thr_ready && (!a->q_dn2 || !a->de2max)) return KGE_EINVAL;
     hipStream_t s = kge_s(stream);
     const int K = d->K0 + d->K1;
     const int units_p = lv1 ? kge_lp_hi_units(K) : kge_lp_split_units(K, 1);
@@ -1612,7 +1614,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
             p.q_panels = (int)(a->n_single_p / TQ);
             p.n_items = (int64_t)p.q_panels * p.c_tiles;
             const int grid = (int)(p.n_items < slots ? p.n_items : slots);
-            rc = lv1 ? launch_split<8, false, 0, 0, 1>(p, grid, s)
+            rc = lv1 ? (pm == 1 ? launch_split<8, false, 1, 0, 1>(p, grid, s)
+                                : (pm == 2 ? launch_split<8, false, 2, 0, 1>(p, grid, s) : launch_split<8, false, 0, 0, 1>(p, grid, s)))
                      : (pm == 1 ? launch_split<8, false, 1>(p, grid, s)
                                 : (pm == 2 ? launch_split<8, false, 2>(p, grid, s) : launch_split<8, false, 0>(p, grid, s)));
             if (rc) return rc;
@@ -1624,7 +1627,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
             p.q_panels = (int)(a->n_multi_p / TQ);
             p.n_items = (int64_t)p.q_panels * p.c_tiles;
             const int grid = (int)(p.n_items < slots ? p.n_items : slots);
-            rc = lv1 ? launch_split<8, false, 0, GSETS, 1>(p, grid, s)
+            rc = lv1 ? (pm == 1 ? launch_split<8, false, 1, GSETS, 1>(p, grid, s)
+                                : (pm == 2 ? launch_split<8, false, 2, GSETS, 1>(p, grid, s) : launch_split<8, false, 0, GSETS, 1>(p, grid, s)))
                      : (pm == 1 ? launch_split<8, false, 1, GSETS>(p, grid, s)
                                 : (pm == 2 ? launch_split<8, false, 2, GSETS>(p, grid, s) : launch_split<8, false, 0, GSETS>(p, grid, s)));
         }
@@ -1633,6 +1637,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     p.q_panels = (int)((d->B + TQ - 1) / TQ);
     p.n_items = (int64_t)p.q_panels * p.c_tiles;
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
+    if (lv1 && d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1, 0, 1>(p, grid, s);
+    if (lv1 && d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2, 0, 1>(p, grid, s);
     if (lv1) return launch_split<8, false, 0, 0, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2>(p, grid, s);

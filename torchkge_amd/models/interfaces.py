@@ -493,12 +493,17 @@ class TranslationModel(Model):
         g = self._lp_guard
         key = '%d_%d' % (prob.desc.c_base, table.shape[0])
         Kq = table.shape[1] if K0 is None else K0
-        Es, e2 = self._cache.get('es_' + key, [table], lambda: _hip.split_table(table, K=Kq, aug=en))
         self._cache.get('xmax_' + key, [X], lambda: _hip.absmax(X, g[3:4]))
         if yc is not None:
             self._cache.get('ymax_' + key, [yc], lambda: _hip.absmax(yc, g[4:5]))
-        prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': g[3:4],
-                      'yabsmax': g[4:5] if yc is not None else None}
+        prob.split = {'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': g[3:4], 'yabsmax': g[4:5] if yc is not None else None,
+                      'list_stat': g[6:7]}
+        if self._use_level1():      # one-product level (see TransEModel._fused_query_problem)
+            Eh, de2 = self._cache.get('eh_' + key, [table], lambda: _hip.hi_table(table, K=Kq, aug=en))
+            prob.split.update({'Es': Eh, 'e2pref': None, 'level': 1, 'de2max': de2})
+        else:
+            Es, e2 = self._cache.get('es_' + key, [table], lambda: _hip.split_table(table, K=Kq, aug=en))
+            prob.split.update({'Es': Es, 'e2pref': e2})
         return prob
 
     def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
