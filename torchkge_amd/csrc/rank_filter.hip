@@ -727,6 +727,81 @@ __global__ __launch_bounds__(RB) void topk_chunk_kernel(float *__restrict__ scor
     }
 }
 
+// The same selection in ONE pass over the tile for k <= KMAX (r04): a wavefront per row, every lane keeps the KMAX best
+// of its columns (lane, lane + 64, ...) as a sorted register list -- a compare-exchange chain per visited element whose
+// list it enters --, then the 64 lists are merged by k rounds of a wave arg-max over the list heads (the winner's list
+// shifts up).  Order (score descending, id ascending), NaN never selected, -inf entries fill up in id order, padding
+// ids (< 0, merge mode) skipped: output identical to topk_chunk_kernel's, which re-read the whole tile k times.
+template <int KMAX>
+__global__ __launch_bounds__(RB) void topk_chunk_reg_kernel(float *__restrict__ scores, int64_t ld, int64_t B, int64_t C,
+                                                            int64_t c_base, int k, const int64_t *__restrict__ seg_lo,
+                                                            const int64_t *__restrict__ seg_hi,
+                                                            const int32_t *__restrict__ targets,
+                                                            const int64_t *__restrict__ ids_in, int64_t ld_ids,
+                                                            int64_t *out_idx, float *out_val, int64_t ldo, int64_t col_off)
+{
+    constexpr int EMPTY = 0x7fffffff;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t i0 = (int64_t)blockIdx.x * (RB / 64); i0 < B; i0 += (int64_t)gridDim.x * (RB / 64)) {
+        const int64_t i = i0 + wv;
+        const bool active = i < B;
+        float *row = scores + (active ? i : 0) * ld;
+        if (targets) {
+            if (active)
+                for (int64_t j = seg_lo[i] + lane; j < seg_hi[i]; j += 64) {
+                    const int64_t t = (int64_t)targets[j] - c_base;
+                    if (t >= 0 && t < C) row[t] = -INFINITY;
+                }
+            __syncthreads();
+        }
+        if (!active) continue;      // (no block-wide barrier below this point)
+        const int64_t *ids = ids_in ? ids_in + i * ld_ids : nullptr;
+        float lv[KMAX];
+        int li[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) { lv[j] = -INFINITY; li[j] = EMPTY; }
+        for (int64_t c = lane; c < C; c += 64) {
+            const float v = row[c];
+            const bool real = ids ? ids[c] >= 0 : true;
+            // enters the list iff it beats the list's last entry (strictly, or at equal score by the smaller column)
+            if (real && (v > lv[KMAX - 1] || (v == lv[KMAX - 1] && (int)c < li[KMAX - 1]))) {
+                float cv = v;
+                int ci = (int)c;
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) {
+                    const bool gt = cv > lv[j] || (cv == lv[j] && ci < li[j]);
+                    const float tv = gt ? lv[j] : cv;
+                    const int ti = gt ? li[j] : ci;
+                    lv[j] = gt ? cv : lv[j];
+                    li[j] = gt ? ci : li[j];
+                    cv = tv;
+                    ci = ti;
+                }
+            }
+        }
+        for (int j = 0; j < k; ++j) {
+            float bv = lv[0];
+            int bi = li[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (oi != EMPTY && (bi == EMPTY || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) {
+                out_idx[i * ldo + col_off + j] = bi == EMPTY ? -1 : (ids ? ids[bi] : (int64_t)bi + c_base);
+                out_val[i * ldo + col_off + j] = bi != EMPTY ? bv : -INFINITY;
+            }
+            if (bi != EMPTY && li[0] == bi) {     // this lane's head was taken: its list moves up
+#pragma unroll
+                for (int q = 0; q + 1 < KMAX; ++q) { lv[q] = lv[q + 1]; li[q] = li[q + 1]; }
+                lv[KMAX - 1] = -INFINITY;
+                li[KMAX - 1] = EMPTY;
+            }
+        }
+    }
+}
+
 inline int grid1d(int64_t n, int per_block)
 {
     int64_t b = (n + per_block - 1) / per_block;
@@ -1047,6 +1122,22 @@ extern "C" int kge_topk_chunk(float *scores, int64_t ld, int64_t B, int64_t C, i
     if (!scores || !out_idx || !out_val) return KGE_EINVAL;
     if (targets && (!seg_lo || !seg_hi)) return KGE_EINVAL;
     if (ids_in && ld_ids < C) return KGE_EINVAL;
+    // k <= 32 (and columns that fit an int): the single-pass register selection; larger k: k passes over the tile
+    static const int reg_topk = kge_env_int("KGE_TOPK_REG", 1);
+    if (reg_topk && k <= 32 && C < 0x7fffffff) {
+        const dim3 grid(grid1d(B, RB / 64)), block(RB);
+        if (k <= 8)
+            hipLaunchKernelGGL(topk_chunk_reg_kernel<8>, grid, block, 0, kge_s(stream), scores, ld, B, C, c_base, k, seg_lo, seg_hi,
+                               targets, ids_in, ld_ids, out_idx, out_val, ldo, col_off);
+        else if (k <= 16)
+            hipLaunchKernelGGL(topk_chunk_reg_kernel<16>, grid, block, 0, kge_s(stream), scores, ld, B, C, c_base, k, seg_lo, seg_hi,
+                               targets, ids_in, ld_ids, out_idx, out_val, ldo, col_off);
+        else
+            hipLaunchKernelGGL(topk_chunk_reg_kernel<32>, grid, block, 0, kge_s(stream), scores, ld, B, C, c_base, k, seg_lo, seg_hi,
+                               targets, ids_in, ld_ids, out_idx, out_val, ldo, col_off);
+        KGE_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(topk_chunk_kernel, dim3(grid1d(B, 1)), dim3(RB), 0, kge_s(stream), scores, ld, B, C, c_base, k,
                        seg_lo, seg_hi, targets, ids_in, ld_ids, out_idx, out_val, ldo, col_off);
     KGE_CHECK_LAUNCH();
