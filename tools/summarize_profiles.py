@@ -40,15 +40,19 @@ def main(out):
             print('  * f32_mfma_only: %s' % json.dumps(j['f32_mfma_only']))
         if j.get('secondary'):
             print('  * secondary: %s' % json.dumps(j['secondary']))
-    for sub, title in (('trace', 'bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-parity (incl. the 500-step set-up training)'),
-                       ('trace_eval', 'bench.py --steps 20 --warmup 5 --only-timed --weights xavier (the evaluate() replays alone)'),
-                       ('trace_l1', 'bench.py --steps 10 --warmup 3 --only-timed --workload transe_l1_fb15k237 --weights xavier (TransE-L1 evaluate() replays)')):
+    titles = {'trace': 'bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-parity (incl. the 500-step set-up training)',
+              'trace_eval': 'bench.py --steps 20 --warmup 5 --only-timed (the evaluate() replays alone; trained weights: the '
+                            'set-up training shows as score_fwd / bwd rows)',
+              'trace_l1': 'bench.py --only-timed --workload transe_l1_fb15k237 --weights xavier (TransE-L1 evaluate() replays)'}
+    subs = sorted(os.path.basename(d) for d in glob.glob(os.path.join(out, 'trace*')) if os.path.isdir(d))
+    for sub in subs:
+        title = titles.get(sub, 'bench.py --only-timed: %s (see tools/profile_round.sh)' % sub[len('trace_'):])
         stats = glob.glob(os.path.join(out, sub, '*kernel_stats.csv')) + glob.glob(os.path.join(out, sub, '*', '*kernel_stats.csv'))
         if stats:
             print('\n## kernel-trace --stats: %s\n' % title)
             print('| kernel | calls | total ms | avg us | % |')
             print('|---|---|---|---|---|')
-            for r in list(csv.DictReader(open(stats[0])))[:40]:
+            for r in list(csv.DictReader(open(stats[0])))[:(40 if sub in ('trace', 'trace_eval') else 16)]:
                 print('| %s | %s | %.3f | %.2f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                           float(r['AverageNs']) / 1e3, r['Percentage']))
     print('\n## PMC counters, mean per launch of the dominant kernels\n')
@@ -57,6 +61,7 @@ def main(out):
     for d in sorted(glob.glob(os.path.join(out, 'pmc*'))):
         if not os.path.isdir(d):
             continue
+        print('| **%s** | | | |' % os.path.basename(d))
         for f in glob.glob(os.path.join(d, '*counter_collection.csv')) + glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
