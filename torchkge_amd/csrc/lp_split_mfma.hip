@@ -1351,8 +1351,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                             int32_t qid;
                             if (GS) qid = p.members[(cur_q0 + (e & 255u)) * GS + ((e >> 8) & 3u)];
                             else qid = p.col_q ? p.col_q[cur_q0 + (e & 255u)] : (int32_t)(cur_q0 + (e & 255u));
-                            p.list[2 * pos] = qid;
-                            p.list[2 * pos + 1] = (int32_t)(c0 + (e >> (GS ? 10 : 8)));
+                            // (one 8-byte store per pair: consecutive lanes fill consecutive entries)
+                            reinterpret_cast<int2 *>(p.list)[pos] = make_int2(qid, (int32_t)(c0 + (e >> (GS ? 10 : 8))));
                         } else {
                             *p.overflow = 1.0f;
                         }

@@ -47,11 +47,17 @@ COALESCE_LIST_BYTES = 2 << 30
 # size).  A batch is cut into as many row tiles as it takes, so b_size never decides whether the score exchange fits.
 SCORE_TILE_BYTES = int(os.environ.get('KGE_SCORE_TILE_BYTES', 256 << 20))
 DEDUPE_QUERIES = os.environ.get('KGE_DEDUPE_QUERIES', '1') != '0'    # count kernel on distinct query rows (ColumnPlan)
+# ... on the one-product level too?  There the matrix work a shared row saves is a third of what it was, and the grouped
+# columns' multi-pass epilogue costs what it always did (measured r04, cfg2: 0.631 ms per evaluate without columns, 0.649 with).
+DEDUPE_LEVEL1 = os.environ.get('KGE_DEDUPE_LEVEL1', '1') != '0'
 # One-product level of the split prefilter (model.split_level = 'auto'): an evaluation whose three-product sweep re-scored
 # at most LEVEL1_ENTER pairs per query hands the NEXT one to the one-product sweep (a third of the matrix work, ~4x the
 # re-scored pairs); one whose one-product sweep re-scored more than LEVEL1_LEAVE per query hands it back.  Break-even on
 # cfg2: ~24 extra pairs per query (0.25 ms of count kernel against ~4 G exact pair scores / s).
-LEVEL1_ENTER, LEVEL1_LEAVE = 6.0, 30.0
+LEVEL1_ENTER, LEVEL1_LEAVE = 4.0, 30.0
+# (measured: the one-product sweep re-scores ~5.8x the pairs of the three-product one -- entering at <= 4 predicts <= 23 --;
+#  an evaluator that had to LEAVE level 1 does not try again until the three-product count has halved: no flip-flopping
+#  between two captured graphs on a model that sits at the boundary)
 
 
 class HipRankEngine(object):
@@ -288,7 +294,10 @@ class LinkPredictionEvaluator(object):
         # fact (the ranks are written straight to it); static like the plans.
         self._perm = None
         self._level = 0         # level of the split prefilter the next evaluation runs (see LEVEL1_ENTER)
+        self._level1_max = LEVEL1_ENTER     # three-product re-scored pairs per query below which level 1 is (re-)entered
+        self._level0_seen = None            # ... the last such count observed on level 0
         self.last_rescored_per_query = None
+        self._graph_cache = {}  # key -> (graph, static state): the two levels' captures are both kept
 
     def _internal_batch(self, b_size, n_local):
         """Batch the fused kernels see.  In the reference ``b_size`` only bounds the (b, N, d) temporaries
@@ -421,7 +430,8 @@ class LinkPredictionEvaluator(object):
             seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
         xkw = self._xkw(sharded)
         by_scores = sharded and self.exchange == 'scores'
-        if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores:
+        lvl1 = hasattr(self.model, '_use_level1') and self.model._split_level == 1 and self.model._use_level1()
+        if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and (DEDUPE_LEVEL1 or not lvl1):
             xkw['cols'] = plan.cols     # (entity shards too: the columns are a property of the queries, not of the candidates)
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
         if by_scores:
@@ -757,6 +767,12 @@ class LinkPredictionEvaluator(object):
                 run(heads, tails, rels, out, fl)
             else:
                 # the whole evaluate() as ONE hipGraph: ~20 short launches per batch replayed without host gaps
+                if self._graph_key != key and key in self._graph_cache:
+                    # (e.g. the other level of the split prefilter, captured earlier: switch back without a new capture)
+                    if self._graph_key is not None and self._graph is not None:
+                        self._graph_cache[self._graph_key] = (self._graph, self._graph_static)
+                    self._graph, self._graph_static = self._graph_cache.pop(key)
+                    self._graph_key, self._graph_src = key, None
                 if self._graph_key != key:
                     hh_, tt_, rr_ = facts()
                     st = {'h': hh_.clone(), 't': tt_.clone(), 'r': rr_.clone(),
@@ -805,6 +821,7 @@ class LinkPredictionEvaluator(object):
                         warnings.warn('torchkge_amd: hipGraph capture of evaluate() failed (%s); running eagerly' % (exc,))
                         self.graph = False
                         self._graph = self._graph_static = self._graph_key = None
+                        self._graph_cache = {}
                         torch.cuda.synchronize(device)
                         flat, out, fl = alloc_out()
                         run(*facts(), out, fl)
@@ -814,6 +831,9 @@ class LinkPredictionEvaluator(object):
                             gc.enable()
                     if g is not None:
                         st['targets_cat'] = getattr(self.engine, '_targets_cat', None)   # baked into the graph too
+                        if self._graph_key is not None and self._graph is not None:
+                            # keep ONE earlier capture (the other split level); older ones go -- outside any capture
+                            self._graph_cache = {self._graph_key: (self._graph, self._graph_static)}
                         self._graph, self._graph_static, self._graph_key = g, st, key
                         self._graph_src = None
                 if self._graph_key == key:
@@ -860,11 +880,14 @@ class LinkPredictionEvaluator(object):
                     # level policy for the NEXT evaluation, from the pairs this one re-scored (flags[2])
                     per_q = rescored / (2.0 * n_local)
                     self.last_rescored_per_query = per_q
-                    if level_now == 0 and per_q <= LEVEL1_ENTER and getattr(self.model, 'split_level', 0) == 'auto' \
-                            and rescored > 0:
-                        self._level = 1
+                    if level_now == 0 and rescored > 0:
+                        self._level0_seen = per_q
+                        if per_q <= min(LEVEL1_ENTER, self._level1_max) and getattr(self.model, 'split_level', 0) == 'auto':
+                            self._level = 1
                     elif level_now == 1 and per_q > LEVEL1_LEAVE:
                         self._level = 0
+                        if self._level0_seen is not None:       # do not come back before the model has changed a lot
+                            self._level1_max = 0.5 * self._level0_seen
                 if not redo:
                     break
                 res = None
