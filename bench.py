@@ -754,6 +754,9 @@ def main():
                 # batch's COLUMNS (distinct query rows) where the evaluator's plan carries a ColumnPlan
                 pl = (getattr(ev, '_plans', None) or {}).get((0, int(h.shape[0])))
                 cols = getattr(pl, 'cols', None)
+                if int(getattr(model, '_split_level', 0)) == 1 and model._use_level1() and not \
+                        (tk.evaluation.DEDUPE_LEVEL1 and getattr(model, 'lp_dedupe_level1', True)):
+                    cols = None     # (as evaluate() does on the one-product level: Model.lp_dedupe_level1)
                 prob = model.lp_problem(h, t, r, 'both', cols=cols) if cols is not None else model.lp_problem_both(h, t, r)
             if prob is not None:
                 true = torch.cat([t, h])

@@ -47,8 +47,9 @@ COALESCE_LIST_BYTES = 2 << 30
 # size).  A batch is cut into as many row tiles as it takes, so b_size never decides whether the score exchange fits.
 SCORE_TILE_BYTES = int(os.environ.get('KGE_SCORE_TILE_BYTES', 256 << 20))
 DEDUPE_QUERIES = os.environ.get('KGE_DEDUPE_QUERIES', '1') != '0'    # count kernel on distinct query rows (ColumnPlan)
-# ... on the one-product level too?  There the matrix work a shared row saves is a third of what it was, and the grouped
-# columns' multi-pass epilogue costs what it always did (measured r04, cfg2: 0.631 ms per evaluate without columns, 0.649 with).
+# ... on the one-product level too (measured r04, same box, ms per evaluate with / without columns on level 1: TransE 0.648 /
+# 0.632, ComplEx 0.479 / 0.479, DistMult 2.642 / 2.667, TransH 0.813 / 0.838 -- profiles/r04/dedupe_level1_ab.txt): yes,
+# except where the model opts out (Model.lp_dedupe_level1; TransE does).  KGE_DEDUPE_LEVEL1=0 switches it off everywhere.
 DEDUPE_LEVEL1 = os.environ.get('KGE_DEDUPE_LEVEL1', '1') != '0'
 # One-product level of the split prefilter (model.split_level = 'auto'): an evaluation whose three-product sweep re-scored
 # at most LEVEL1_ENTER pairs per query hands the NEXT one to the one-product sweep (a third of the matrix work, ~4x the
@@ -431,7 +432,10 @@ class LinkPredictionEvaluator(object):
         xkw = self._xkw(sharded)
         by_scores = sharded and self.exchange == 'scores'
         lvl1 = hasattr(self.model, '_use_level1') and self.model._split_level == 1 and self.model._use_level1()
-        if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and (DEDUPE_LEVEL1 or not lvl1):
+        # (one-product level: the matrix work a shared row saves is a third of what it was, the grouped columns' multi-pass
+        # epilogue costs what it always did -- models say whether columns still pay there: lp_dedupe_level1)
+        if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and \
+                ((DEDUPE_LEVEL1 and getattr(self.model, 'lp_dedupe_level1', True)) or not lvl1):
             xkw['cols'] = plan.cols     # (entity shards too: the columns are a property of the queries, not of the candidates)
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
         if by_scores:

@@ -57,6 +57,9 @@ class TransEModel(TranslationModel):
     # the evaluator may hand lp_problem(side='both') a ColumnPlan: the fused query pipeline then writes one split row
     # per DISTINCT query row of the batch and the count kernel sweeps columns instead of queries
     lp_dedupe_queries = True
+    # ... but not on the one-product level of the split prefilter: at d = 200 a shared row saves 4 MFMA groups per tile,
+    # less than the grouped columns' multi-pass epilogue costs (evaluation.DEDUPE_LEVEL1: 0.632 vs 0.648 ms per evaluate)
+    lp_dedupe_level1 = False
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight]
