@@ -118,12 +118,22 @@ def all_to_all_rows(local, recv, group=None):
         return False
     assert P == world and local.shape[0] == world * m and local.is_contiguous() and recv.is_contiguous()
     key = (backend_name(group), local.device.type)
-    if key[0] == 'nccl':
+    if key[0] == 'nccl' and key not in _A2A_FALLBACK:
         if world > 1:       # grouped send / recv per peer; zero-sized entries (the own block) are skipped by the backend
             none = local.new_empty(0)
-            dist.all_to_all([recv[j] if j != rank else none for j in range(world)],
-                            [local[j * m:(j + 1) * m] if j != rank else none for j in range(world)], group=group)
+            try:
+                dist.all_to_all([recv[j] if j != rank else none for j in range(world)],
+                                [local[j * m:(j + 1) * m] if j != rank else none for j in range(world)], group=group)
+            except (RuntimeError, ValueError, NotImplementedError):
+                # a build that rejects zero-sized entries (argument validation: nothing was sent): the equal-split form,
+                # own block included -- the caller may still read its own block from `local`
+                _A2A_FALLBACK.add(key)
+                dist.all_to_all_single(recv.view(world * m, per), local, group=group)
+                return True
         return False
+    if key[0] == 'nccl':
+        dist.all_to_all_single(recv.view(world * m, per), local, group=group)
+        return True
     if key not in _A2A_FALLBACK:
         try:
             dist.all_to_all_single(recv.view(world * m, per), local, group=group)
