@@ -14,9 +14,10 @@ Metric = link-prediction triples scored / second (whole job, all ranks).
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
   --scaling strong --shard entities  (default) the ONE dataset-sized job BASELINE.json names with the entity
                    tables row-sharded: every rank scores ITS N/P candidates for all test triples and the ranks meet
-                   in the exchange north_star names -- the partial score tiles, as an all-to-all in which every rank
-                   receives (and ranks) only the rows of its 2B/P queries (--exchange scores, the headline) -- or in
-                   one all-reduce of the (3, 2B) partial rank counts (--exchange counts; timed beside the headline).
+                   in one all-reduce of the (3, 2B) partial rank counts (--exchange counts, the headline: the
+                   evaluator's own default) -- or in the exchange north_star names, the partial score tiles, as an
+                   all-to-all in which every rank receives (and ranks) only the rows of its 2B/P queries (--exchange
+                   scores; timed beside the headline: it needs the exact fp32 score GEMM and 595 MB per link at N = 2).
   --scaling weak --shard entities  the entity table grows to N dataset-sized shards (also reported beside a
                    strong run: weak_mode).
   --scaling weak --shard queries   independent replicas: every rank evaluates its own
@@ -82,10 +83,11 @@ def parse():
     ap.add_argument('--shard', default='entities', choices=['entities', 'queries'],
                     help='N>1: what is partitioned across ranks (weak+queries = independent replicas)')
     ap.add_argument('--exchange', default=None, choices=['counts', 'scores'],
-                    help="entity shards: what the ranks exchange.  Default for N>1: 'scores' = the partial (2B, N/P) score "
-                         "tiles north_star names, exchanged as an RCCL all-to-all of row blocks (every rank receives and "
-                         "ranks only its 2B/P queries); the other exchange is timed beside it at the same b_size "
-                         "(other_exchange).  'counts' = one all-reduce of 3 x 2B int32 per batch, bit-identical ranks")
+                    help="entity shards: what the ranks exchange.  Default: 'counts' = one all-reduce of 3 x 2B int32 per batch "
+                         "behind the f16 prefilter (the evaluator's own default).  'scores' = the partial (2B, N/P) score tiles "
+                         "north_star names, exchanged as an RCCL all-to-all of row blocks (every rank receives and ranks only "
+                         "its 2B/P queries; bit-identical ranks).  The other exchange is timed beside the headline at the same "
+                         "b_size (other_exchange)")
     ap.add_argument('--no-weak', action='store_true', help='N>1 strong run: skip the secondary weak-scaling measurement')
     ap.add_argument('--tables', default='sharded', choices=['sharded', 'replicated'],
                     help='entity shards: each rank HOLDS only its rows of the entity tables (default) or a full replica')
@@ -394,7 +396,8 @@ def _sample_power(run, device, seconds=1.6):
 
 def _measure_traffic(args, kernel_sym, extra_out=None):
     """HBM-side bytes per launch of the dominant kernel, measured in THIS run: bench.py re-runs itself (timed loop only,
-    eager launches, Xavier weights: the count kernel's traffic does not depend on the weights) under
+    eager launches, the SAME weights and split level as the headline: the uncertain-pair list a model leaves is part of
+    the kernel's writes) under
     ``rocprofv3 --pmc <counter> --kernel-trace`` once per counter -- FETCH_SIZE (3 TCC slots) and WRITE_SIZE (2) do
     not fit one pass -- and averages the counter over the launches of `kernel_sym`.  FETCH_SIZE / WRITE_SIZE are in
     KB; gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> 2 x FETCH_SIZE.
@@ -416,8 +419,8 @@ def _measure_traffic(args, kernel_sym, extra_out=None):
     for ctrs in passes:
         d = tempfile.mkdtemp(prefix='kge_pmc_', dir='/tmp')
         cmd = [rp, '--pmc'] + list(ctrs) + ['--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 't', '--', sys.executable,
-               os.path.abspath(__file__), '--only-timed', '--no-graph', '--no-traffic', '--weights',
-               'xavier' if args.weights == 'trained' else args.weights, '--steps', '3', '--warmup', '0',
+               os.path.abspath(__file__), '--only-timed', '--no-graph', '--no-traffic', '--weights', args.weights,
+               '--steps', '3', '--warmup', '0',
                '--settle-ms', '0', '--workload', args.workload, '--batch', str(args.batch), '--kg', args.kg, '--l2-mode', args.l2_mode,
                '--split-level', str(getattr(args, 'level_used', args.split_level))]
         cmd += (['--no-split'] if args.no_split else []) + (['--materialize'] if args.materialize else []) \
@@ -426,7 +429,9 @@ def _measure_traffic(args, kernel_sym, extra_out=None):
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'KGE_FORCE_COLLECTIVES'):
             env.pop(k, None)
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if args.train_steps is not None:
+                cmd += ['--train-steps', str(args.train_steps)]
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             got = {}        # per (counter, kernel NAME): the count kernel may run as two instantiations per launch
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):      # (single / grouped columns)
                 for r in csv.DictReader(open(f)):
@@ -483,7 +488,12 @@ def main():
     n_ent1, n_rel, n_train, n_valid, n_test = orc.DATASET_SHAPES[shape]
     multi = world > 1 or forced
     if args.exchange is None:
-        args.exchange = 'scores' if (multi and args.shard == 'entities') else 'counts'
+        # N > 1 headline = the exchange the evaluator itself defaults to: the all-reduce of the (3, 2B) partial rank counts
+        # behind the f16 prefilter.  The score exchange north_star names (all-to-all of the partial score tiles) is measured
+        # beside it at the same b_size (other_exchange): it needs the EXACT fp32 score GEMM (>= 1.5 ms of fp32 MFMA peak for
+        # this job on one GPU) and moves (P-1)/P^2 * 2B*N*4 bytes per rank -- 595 MB over ONE xGMI link at N = 2 (7.8 ms
+        # modelled against 0.63 ms for the whole single-GPU evaluation) -- so it cannot strong-scale a job this small.
+        args.exchange = 'counts'
     # weak scaling over entity shards (default for N > 1): the entity table grows to N
     # dataset-sized shards, each GPU scores ITS shard for every test triple and the ranks
     # exchange partial results over RCCL -- per-GPU work is fixed as N grows.
@@ -754,8 +764,7 @@ def main():
                 # batch's COLUMNS (distinct query rows) where the evaluator's plan carries a ColumnPlan
                 pl = (getattr(ev, '_plans', None) or {}).get((0, int(h.shape[0])))
                 cols = getattr(pl, 'cols', None)
-                if int(getattr(model, '_split_level', 0)) == 1 and model._use_level1() and not \
-                        (tk.evaluation.DEDUPE_LEVEL1 and getattr(model, 'lp_dedupe_level1', True)):
+                if model._use_level1() and not (tk.evaluation.DEDUPE_LEVEL1 and getattr(model, 'lp_dedupe_level1', True)):
                     cols = None     # (as evaluate() does on the one-product level: Model.lp_dedupe_level1)
                 prob = model.lp_problem(h, t, r, 'both', cols=cols) if cols is not None else model.lp_problem_both(h, t, r)
             if prob is not None:
@@ -896,7 +905,7 @@ def main():
             roof['peak_is'] = 'v_sad_u16 issue rate (39.3 T lane-instructions/s); frac_fp32_equivalent = 3K flop per pair against the fp32 VALU peak'
         if pmc:
             pm = {'source': 'rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass spawned by this run '
-                            '(eager launches, Xavier weights), summed over the kernel\'s instantiations per evaluate'}
+                            '(eager launches, same weights and split level), summed over the kernel\'s instantiations per evaluate'}
             pm.update(pmc)
             if 'SQ_INSTS_MFMA' in pmc and split:
                 pm['executed_TFLOPs_from_SQ_INSTS_MFMA'] = round(pmc['SQ_INSTS_MFMA'] * 32768 / kern_s / 1e12, 2)

@@ -6,7 +6,7 @@ run() {
   if [ $rc -ne 0 ]; then echo "FAILED rc=$rc"; tail -15 /tmp/dry.err; fi
   tail -1 /tmp/dry.out | grep -o '^{"metric\|"value": [0-9.e+]*\|ms_per_step[^,]*\|"scaling": "[^"]*"\|filtered_mrr[^,]*\|"workload": "[^"]*"\|"parallelism": "[^"]*"\|hip_graph[^,]*\|"layout": "[^"]*"\|bytes_this_rank[^,}]*\|"collective_time": {[^}]*}\|"other_exchange": {[^}]*}[^}]*}\|"weak_mode": {[^}]*}[^}]*}' | paste -s -d' '
 }
-echo "default (strong scaling of the cfg2 job, row-sharded tables, all-gather of score tiles; counts + weak mode beside it)"; run
+echo "default (strong scaling of the cfg2 job, row-sharded tables, counts all-reduce; score all-to-all + weak mode beside it)"; run
 echo default-xavier; run --weights xavier
 echo strong-entities-counts; run --exchange counts --weights xavier --no-weak
 echo strong-replicated-tables; run --tables replicated --weights xavier --exchange counts

@@ -2,7 +2,7 @@
 # RCCL smoke on a single-GPU box: one rank, sharded code paths and collectives forced on.
 export HSA_ENABLE_IPC_MODE_LEGACY=0 KGE_FORCE_COLLECTIVES=1
 run() { timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary "$@" 2>&1 | tail -1 | cut -c1-2400; }
-echo "default (strong, all-gather of score tiles)"; run
+echo "default (strong, counts all-reduce; score all-to-all beside it)"; run
 echo strong-entities-counts; run --exchange counts --no-weak
 echo strong-queries; run --shard queries
 echo weak; run --scaling weak --exchange counts

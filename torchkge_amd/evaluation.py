@@ -431,7 +431,7 @@ class LinkPredictionEvaluator(object):
             seg_lo, seg_hi, true_idx, targets = eng.lookup_both(index_t, index_h, h, t, r)
         xkw = self._xkw(sharded)
         by_scores = sharded and self.exchange == 'scores'
-        lvl1 = hasattr(self.model, '_use_level1') and self.model._split_level == 1 and self.model._use_level1()
+        lvl1 = hasattr(self.model, '_use_level1') and self.model._use_level1()      # (the policy's choice, or a forced level)
         # (one-product level: the matrix work a shared row saves is a third of what it was, the grouped columns' multi-pass
         # epilogue costs what it always did -- models say whether columns still pay there: lp_dedupe_level1)
         if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and \
