@@ -97,8 +97,6 @@ struct SplitParams {
     // == query); members: [column][GSETS] query ids (< 0: unused set) for the grouped launch (template GS > 0).
     const int32_t *col_q, *members;
     int q_panels, c_tiles;
-    int panel_bytes;      // RP (resident query panel, LV = 1): bytes of the panel region; last_compact: its last stage holds
-    int last_compact;     // ONE k16 unit and is stored as 192 rows x 32 bytes (else every stage is 192 x 128)
     int qg;               // query panels interleaved under one sweep of the candidate tiles (work order)
     int64_t n_items;
     int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 4 no epilogue,
@@ -831,29 +829,19 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
 // row holds FOUR units, and a stage is four MFMA groups qh*eh instead of 2 x 3 -- a third of the matrix work and half
 // the operand bytes per (pair, unit); same tile, same LDS-DMA staging and swizzle, same epilogue against thresholds
 // that carry the operands' measured f16 residuals (split_thr_l2_hi).  p.units / p.stages then count hi units / 4-unit stages.
-// RP (with LV = 1, plain thresholds, one query per column): the query panel is RESIDENT in LDS.  At 32 bytes per unit a
-// 192-row panel is 78 KiB at d = 200 (three 128-byte stages + a compact 32-byte last one): it fits beside the candidate
-// double buffer, is loaded once per sweep of the candidate tiles, and the per-stage L2 -> LDS stream shrinks from
-// 57 KiB to the 32 KiB of candidate rows (-43 %): the stream, not the matrix pipe, bounds the one-product level.
-template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0, bool RP = false>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
+template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0>   // PM: 0 plain thresholds, 1 TransH projection term, 2 TransD
 __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const SplitParams p)
 {
     static_assert(GS == 0 || GS == GSETS, "grouped columns carry GSETS threshold sets");
-    static_assert(!RP || (LV == 1 && PM == 0 && GS == 0), "resident panel: one-product level, plain thresholds, single columns");
     const int dbg = DBG ? p.dbg : 0;                                // probes compile away in the product kernel
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int MT = TC / 32 / (NWAVES / 2);                      // 32x32 candidate tiles per wave
     constexpr int EJ = TC * 8 / NTHREADS, QJ = TQ * 8 / NTHREADS;   // staged 16-byte chunks per thread
     constexpr int SROWS = NTHREADS / 8;                             // rows covered by one staging pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS map: [stage 0][stage 1] of (candidate rows | query rows) -- or, RP: [E stage 0][E stage 1][query panel] --, then
-    // the tile's uncertain-pair buffer and the per-panel arrays
-    constexpr int PANEL_OFF = 2 * E_STAGE_BYTES;
-    const int lds_tail = RP ? PANEL_OFF + p.panel_bytes : 2 * STAGE_BYTES;
-    constexpr int BUF_BYTES = RP ? E_STAGE_BYTES : STAGE_BYTES;      // distance of the two stage buffers
-    int *unc_cnt = reinterpret_cast<int *>(smem + lds_tail);
-    unsigned *unc_list = reinterpret_cast<unsigned *>(smem + lds_tail + 16);
-    float4 *pthr = reinterpret_cast<float4 *>(smem + lds_tail + 16 + UNC_CAP * 4);   // PM: per query of the panel
+    int *unc_cnt = reinterpret_cast<int *>(smem + 2 * STAGE_BYTES);
+    unsigned *unc_list = reinterpret_cast<unsigned *>(smem + 2 * STAGE_BYTES + 16);
+    float4 *pthr = reinterpret_cast<float4 *>(smem + 2 * STAGE_BYTES + 16 + UNC_CAP * 4);   // PM: per query of the panel
     int *prow = reinterpret_cast<int *>(pthr + TQ);
     float2 *gthr = reinterpret_cast<float2 *>(prow + TQ);                  // GS: [set][TQ] thresholds ...
     int *gcnt = reinterpret_cast<int *>(gthr + (GS ? GS : 1) * TQ);         // ... [set][TQ] counters ...
@@ -911,25 +899,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                                          (__attribute__((address_space(3))) void *)l, 16, 0, 0);
     };
 
-    // RP: the whole query panel (every stage of the 192 rows) into its resident region; called by all waves, ends with a
-    // block-wide barrier
-    auto load_q_panel = [&](int64_t q0) __attribute__((always_inline)) {
-        const char *src = p.Qs + (q0 + srow) * p.row_bytes + sch * 16;
-        const int full = p.last_compact ? p.stages - 1 : p.stages;
-        for (int st = 0; st < full; ++st) {
-            char *dst = smem + PANEL_OFF + st * Q_STAGE_BYTES + wid * 1024;
-#pragma unroll
-            for (int j = 0; j < QJ; ++j) dma(src + st * 128 + j * rstep, dst + j * SROWS * 128);
-        }
-        if (p.last_compact && wid < TQ / 32) {    // 32 rows x 32 bytes per instruction: lane -> (row, 16-byte half)
-            const int row = wid * 32 + (lane >> 1);
-            dma(p.Qs + (q0 + row) * p.row_bytes + (p.stages - 1) * 128 + (lane & 1) * 16,
-                smem + PANEL_OFF + (p.stages - 1) * Q_STAGE_BYTES + wid * 1024);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-
     // fragment addressing: row r of a tile, chunk (u*4 + piece*2 + half) ^ ((r>>1)&7)
     const int sw = (l31 >> 1) & 7;
     const int a_row = (wr * (MT * 32) + l31) * 128;
@@ -944,10 +913,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     unsigned h_off[4];      // LV = 1: the hi fragment of unit j of a stage is chunk 2 j + half
 #pragma unroll
     for (int j = 0; j < 4; ++j) h_off[j] = lds0 + a_row + ((j * 2 + half) ^ sw) * 16;
-    // RP: query fragments come from the resident panel -- stage s at PANEL_OFF + s * Q_STAGE_BYTES in the stage layout,
-    // the compact last stage as 192 rows x 32 bytes
-    const unsigned q_delta = __builtin_amdgcn_readfirstlane(PANEL_OFF + (wc * 96) * 128 - wr * (MT * 32) * 128);
-    const unsigned qc_addr = lds0 + PANEL_OFF + (wc * 96 + l31) * 32 + half * 16;
     // the query fragments sit a wave-uniform distance behind the candidate fragments (scalar register)
     const unsigned b_delta = __builtin_amdgcn_readfirstlane(b_row - a_row);
 
@@ -1024,15 +989,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     }
     load_panel(cur_q0);
     pf_new_item();
-    if (RP) load_q_panel(cur_q0);
     {   // stage 0 of the first tile
         char *nE = smem + wid * 1024, *nQ = nE + E_STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < EJ; ++j) dma(pfE + j * rstep, nE + j * SROWS * 128);
-        if (!RP) {
 #pragma unroll
-            for (int j = 0; j < QJ; ++j) dma(pfQ + j * rstep, nQ + j * SROWS * 128);
-        }
+        for (int j = 0; j < QJ; ++j) dma(pfQ + j * rstep, nQ + j * SROWS * 128);
         if (++pf_s == S) {
             pf_s = 0;
             if (++pf_it < nitems) pf_new_item();
@@ -1069,22 +1031,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         KGE_DSR(BH[1], bh_, 4096); KGE_DSR(BH[2], bh_, 8192);                                       \
         asm volatile("" :: "v"(ah_), "v"(bh_));                                                     \
     }
-#define KGE_HLOAD_RP(AH, BH, BASE, J, QST) /* RP: A from the stage buffer, B from stage QST of the resident panel */ \
-    {                                                                                               \
-        const unsigned ah_ = (BASE) + h_off[J];                                                     \
-        const unsigned bh_ = h_off[J] + q_delta + (unsigned)(QST) * Q_STAGE_BYTES;                  \
-        KGE_DSR(AH[0], ah_, 0); KGE_DSR(BH[0], bh_, 0); KGE_DSR(AH[1], ah_, 4096);                  \
-        KGE_DSR(BH[1], bh_, 4096); KGE_DSR(BH[2], bh_, 8192);                                       \
-        asm volatile("" :: "v"(ah_), "v"(bh_));                                                     \
-    }
-#define KGE_HLOAD_RPC(AH, BH, BASE, QST) /* RP, compact last stage (one unit, 32-byte rows) */      \
-    {                                                                                               \
-        const unsigned ah_ = (BASE) + h_off[0];                                                     \
-        const unsigned bh_ = qc_addr + (unsigned)(QST) * Q_STAGE_BYTES;                             \
-        KGE_DSR(AH[0], ah_, 0); KGE_DSR(BH[0], bh_, 0); KGE_DSR(AH[1], ah_, 4096);                  \
-        KGE_DSR(BH[1], bh_, 1024); KGE_DSR(BH[2], bh_, 2048);                                       \
-        asm volatile("" :: "v"(ah_), "v"(bh_));                                                     \
-    }
 #define KGE_HWAIT(AH, BH)                                                                           \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(AH[0]), "+v"(AH[1]), "+v"(BH[0]), "+v"(BH[1]), "+v"(BH[2]) :: "memory");
 #define KGE_SMMA_P(A, B, C) /* one of the three split products over the wave's MT x NT tiles, given C */ \
@@ -1108,14 +1054,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16;
 
     f16x8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
-    if (RP) {
-        if (p.last_compact && p.stages == 1) { KGE_HLOAD_RPC(ah0, bh0, 0u, 0) } else { KGE_HLOAD_RP(ah0, bh0, 0u, 0, 0) }
-    } else if (LV == 1) { KGE_HLOAD(ah0, bh0, 0u, 0) } else { KGE_SLOAD(ah0, al0, bh0, bl0, 0u, 0) }
+    if (LV == 1) { KGE_HLOAD(ah0, bh0, 0u, 0) } else { KGE_SLOAD(ah0, al0, bh0, bl0, 0u, 0) }
     int it = 0, s = 0;
     for (int g = 0; g < G; ++g) {
         const int buf = g & 1;
         const bool more = g + 1 < G;
-        const unsigned sb = buf * BUF_BYTES, sb_next = (buf ^ 1) * BUF_BYTES;
+        const unsigned sb = buf * STAGE_BYTES, sb_next = (buf ^ 1) * STAGE_BYTES;
         const int nunits = min(2, p.units - 2 * s);
         const bool two = nunits == 2;              // the last stage of a tile may hold a single k16 unit
         // In the product kernel the LDS-DMA pieces are issued unconditionally (after the block's last
@@ -1126,63 +1070,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
         // groups: an LDS-DMA instruction holds the issuing wave for 60+ cycles, which hides behind
         // matrix work only if the pieces are spread over the stage (and the other wave of the SIMD
         // is in its MFMAs)
-        char *nE = smem + (buf ^ 1) * BUF_BYTES + wid * 1024, *nQ = nE + E_STAGE_BYTES;
+        char *nE = smem + (buf ^ 1) * STAGE_BYTES + wid * 1024, *nQ = nE + E_STAGE_BYTES;
         const char *gE = pfE + pf_s * 128, *gQ = pfQ + pf_s * 128;
 
         // (grouped columns: on a tile's last stage the next stage's first fragments are fetched AFTER the multi-pass
         // epilogue -- their registers are what its temporaries need; the LDS buffer stays valid through the next stage)
         const bool defer_frag = GS != 0 && s == S - 1;
-        // RP: does the NEXT tile belong to another query panel?  (block-uniform; its first fragments then wait for the
-        // panel reload behind this tile's epilogue)
-        bool panel_switch = false;
-        if (RP && s == S - 1 && more) {
-            int qp_n, ct_n;
-            item_qp_ct(it + 1, qp_n, ct_n);
-            panel_switch = (int64_t)qp_n * TQ != cur_q0;
-        }
-        if constexpr (RP) {
-            // as the LV = 1 stage below, without the query pieces of the stream: the B fragments come from the resident panel
-            const int nu = min(4, p.units - 4 * s);
-            const bool clast = p.last_compact && s == S - 1;        // this stage of the panel is the compact one (nu == 1)
-            const int s_nx = (s + 1 == S) ? 0 : s + 1;
-            const bool cnext = p.last_compact && s_nx == S - 1;
-            KGE_HWAIT(ah0, bh0)
-            if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
-            __builtin_amdgcn_sched_barrier(0);
-            const char *gE1 = gE + rstep;
-            if (pf) { dma(gE, nE); dma(gE1, nE + SROWS * 128); }
-            __builtin_amdgcn_sched_barrier(0);
-            KGE_HLOAD_RP(ah1, bh1, sb, 1, clast ? 0 : s)
-            asm volatile("" :: "v"(gE), "v"(gE1));
-            __builtin_amdgcn_sched_barrier(0);
-            KGE_HWAIT(ah1, bh1)
-            if (nu > 1) { KGE_SMMA_PA(ah1, bh1) }
-            __builtin_amdgcn_sched_barrier(0);
-            if (pf) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
-            if (more && pf) {
-                if (++pf_s == S) {
-                    pf_s = 0;
-                    if (++pf_it < nitems) pf_new_item();
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            KGE_HLOAD_RP(ah0, bh0, sb, 2, clast ? 0 : s)
-            __builtin_amdgcn_sched_barrier(0);
-            KGE_HWAIT(ah0, bh0)
-            if (nu > 2) { KGE_SMMA_PA(ah0, bh0) }
-            __builtin_amdgcn_sched_barrier(0);
-            KGE_HLOAD_RP(ah1, bh1, sb, 3, clast ? 0 : s)
-            __builtin_amdgcn_sched_barrier(0);
-            KGE_HWAIT(ah1, bh1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next stage landed in LDS
-            __syncthreads();
-            if (more && !panel_switch) {
-                if (cnext) { KGE_HLOAD_RPC(ah0, bh0, sb_next, s_nx) } else { KGE_HLOAD_RP(ah0, bh0, sb_next, 0, s_nx) }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (nu > 3) { KGE_SMMA_PA(ah1, bh1) }
-            __builtin_amdgcn_sched_barrier(0);
-        } else if constexpr (LV == 1) {
+        if constexpr (LV == 1) {
             // ONE product per k16 unit, four units per stage: [u0] dma E0 E1 | frag u1 [u1] dma E2 E3 | frag u2 [u2] dma Q |
             // frag u3 -- barrier -- frag u0 of the next stage [u3].  Every fragment overwrite has an LDS wait (or an MFMA
             // group) between it and the MFMAs that last read those registers.
@@ -1477,10 +1371,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                     flush_counts(cur_q0);
                     cur_q0 = next_q0;
                     load_panel(cur_q0);
-                    if (RP) {   // the new panel into its resident region, then the next tile's first fragments
-                        load_q_panel(cur_q0);
-                        if (p.last_compact && S == 1) { KGE_HLOAD_RPC(ah0, bh0, sb_next, 0) } else { KGE_HLOAD_RP(ah0, bh0, sb_next, 0, 0) }
-                    }
                 }
             }
         }
@@ -1489,8 +1379,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
 #undef KGE_SMMA_PA
 #undef KGE_SMMA_P
 #undef KGE_HLOAD
-#undef KGE_HLOAD_RP
-#undef KGE_HLOAD_RPC
 #undef KGE_HWAIT
 #undef KGE_SLOAD
 #undef KGE_SWAIT
@@ -1522,36 +1410,20 @@ __global__ __launch_bounds__(64, 2) void split_recheck_kernel(const kge_lp_desc 
     }
 }
 
-constexpr int SMEM_LIMIT = 160 * 1024;    // LDS per CU (gfx950)
-
-template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0, bool RP = false>
+template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
-    auto k = lp_split_count_kernel<NWAVES, DBG, PM, GS, LV, RP>;
-    // RP: [2 candidate stages][resident query panel][uncertain-pair buffer] (+ slack for the unused per-panel arrays' base)
-    const int smem = RP ? 2 * E_STAGE_BYTES + p.panel_bytes + 16 + UNC_CAP * 4 + 64 : SMEM_BYTES;
+    auto k = lp_split_count_kernel<NWAVES, DBG, PM, GS, LV>;
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, RP ? SMEM_LIMIT : SMEM_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NWAVES), smem, s, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NWAVES), SMEM_BYTES, s, p);
     KGE_CHECK_LAUNCH();
     return 0;
-}
-
-// Resident query panel (RP): does a 192-row panel of `stages` 4-unit stages fit beside the candidate double buffer?
-// Every stage in the 128-byte-row layout, or -- when the last stage holds ONE unit -- that one as 32-byte rows.
-inline bool split_panel_fits(int units, int stages, int *panel_bytes, int *last_compact)
-{
-    const int fixed = 2 * E_STAGE_BYTES + 16 + UNC_CAP * 4 + 64;
-    if (fixed + stages * Q_STAGE_BYTES <= SMEM_LIMIT) { *panel_bytes = stages * Q_STAGE_BYTES; *last_compact = 0; return true; }
-    const int nu_last = units - 4 * (stages - 1);
-    const int compact = (stages - 1) * Q_STAGE_BYTES + TQ * 32;
-    if (nu_last == 1 && fixed + compact <= SMEM_LIMIT) { *panel_bytes = compact; *last_compact = 1; return true; }
-    return false;
 }
 
 int split_num_cus()
@@ -1722,10 +1594,6 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     p.overflow = overflow;
     p.col_q = nullptr; p.members = nullptr;
     p.c_tiles = (int)((d->N + TC - 1) / TC);
-    p.panel_bytes = 0; p.last_compact = 0;
-    // one-product level, plain thresholds, one query per column: keep the query panel resident in LDS where it fits
-    const bool rp = lv1 && !proj && kge_env_int("KGE_SPLIT_RP", 1) != 0 &&
-                    split_panel_fits(p.units, p.stages, &p.panel_bytes, &p.last_compact);
     p.dbg = kge_env_int("KGE_SPLIT_DBG", 0);
     // Query panels interleaved under one sweep of the candidate tiles (work order, see the kernel).  Measured r03
     // (profiles/r03/split_work_order_sweep.txt): at K = 200 (172 KiB per panel) 16 panels per XCD cut the L2-miss
@@ -1747,8 +1615,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
             p.n_items = (int64_t)p.q_panels * p.c_tiles;
             const int grid = (int)(p.n_items < slots ? p.n_items : slots);
             rc = lv1 ? (pm == 1 ? launch_split<8, false, 1, 0, 1>(p, grid, s)
-                                : (pm == 2 ? launch_split<8, false, 2, 0, 1>(p, grid, s)
-                                           : (rp ? launch_split<8, false, 0, 0, 1, true>(p, grid, s) : launch_split<8, false, 0, 0, 1>(p, grid, s))))
+                                : (pm == 2 ? launch_split<8, false, 2, 0, 1>(p, grid, s) : launch_split<8, false, 0, 0, 1>(p, grid, s)))
                      : (pm == 1 ? launch_split<8, false, 1>(p, grid, s)
                                 : (pm == 2 ? launch_split<8, false, 2>(p, grid, s) : launch_split<8, false, 0>(p, grid, s)));
             if (rc) return rc;
@@ -1772,7 +1639,6 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
     if (lv1 && d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1, 0, 1>(p, grid, s);
     if (lv1 && d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2, 0, 1>(p, grid, s);
-    if (lv1 && rp) return launch_split<8, false, 0, 0, 1, true>(p, grid, s);
     if (lv1) return launch_split<8, false, 0, 0, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2>(p, grid, s);
