@@ -32,11 +32,18 @@
  *   kge_filter_lookup +          utils/modeling.py:53-102 (get_true_targets / filter_scores)
  *   kge_filter_scores
  *   kge_filtered_rank_from_scores  get_rank(scores) + get_rank(filter_scores(scores))
- *                                  evaluation.py:292-300
+ *   kge_filtered_rank_from_tiles   evaluation.py:292-300 (_from_tiles: on the rank-major score tiles of the
+ *                                  entity-sharded path's score all-to-all, kge_hip_coll.h)
  *   kge_lp_pair_scores,          the fused form of evaluation.py:290-300 that never
  *   kge_lp_count_ge,               materialises the (B,N) score matrix
  *   kge_lp_filter_sub,
  *   kge_rank_finalize
+ *   kge_lp_split_rows / _count /   the same rank count through the certified f16 MFMA prefilter + exact recheck
+ *   _recheck, kge_lp_hi_rows,      (three products per k16 unit, or ONE on planar hi operands: kge_split_args.level);
+ *   kge_lp_query_pipeline          kge_lp_sad_* for TransE-L1
+ *   kge_filter_index_build,      the dict-of-sets filter structures of data_structures.py:386-397 as a device CSR, and
+ *   kge_filter_plan_build,         the evaluator's static per-batch plans, built by rocPRIM sorts / scans
+ *   kge_column_plan_build / _emit
  *   kge_topk                     the sort + top_k slice of inference.py:148-150, :243-245
  *   kge_corrupt_scatter          BernoulliNegativeSampler.corrupt_batch / Uniform...
  *                                  sampling.py:313-325 and :206-221 (the integer scatter)
