@@ -130,7 +130,10 @@ class HipRankEngine(object):
         all-candidates count and its exact recheck on the current stream (fork / join by events: captured into the
         hipGraph of evaluate() as two parallel branches)."""
         out = torch.zeros(3, prob.B + pad, dtype=torch.int32, device=s_true.device)
-        if aux is None:
+        # (only beside the split-prefilter count kernel -- one persistent workgroup per CU that leaves 30 KB of LDS and a
+        # fifth of the registers free; the fp32 tile kernel runs TWO workgroups per CU and loses one of them to a
+        # co-resident kernel's LDS: measured 2.44 -> 3.37 ms per evaluate with --no-split)
+        if aux is None or getattr(prob, 'split', None) is None:
             prob.count_ge(s_true, out[0])
             prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
             return out
@@ -309,6 +312,7 @@ class LinkPredictionEvaluator(object):
         # GPU; measured r04, same box: TransE 0.629 -> 0.619 ms, DistMult / FB15k 2.607 -> 2.536, ComplEx / TransH +-0:
         # profiles/r04/overlap_filter_ab.txt).  KGE_OVERLAP_FILTER=0 keeps everything on one stream.
         self.overlap_filter = os.environ.get('KGE_OVERLAP_FILTER', '1') == '1'
+        self._n_evaluations = 0
         self._level = 0         # level of the split prefilter the next evaluation runs (see LEVEL1_ENTER)
         self._level1_max = LEVEL1_ENTER     # three-product re-scored pairs per query below which level 1 is (re-)entered
         self._level0_seen = None            # ... the last such count observed on level 0
@@ -472,7 +476,9 @@ class LinkPredictionEvaluator(object):
         kw = {'plan': plan} if plan is not None else {}
         if ride:
             kw['pad'] = 2
-        if self.overlap_filter and not sharded and isinstance(eng, HipRankEngine) and s_true.is_cuda:
+        # (from the evaluator's SECOND evaluation on: creating and first using a stream costs ~60 ms of the first call)
+        if self.overlap_filter and self._n_evaluations > 0 and not sharded and isinstance(eng, HipRankEngine) \
+                and s_true.is_cuda:
             if self._aux_stream is None:
                 self._aux_stream = torch.cuda.Stream(s_true.device)
             kw['aux'] = self._aux_stream
@@ -777,7 +783,7 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, one_graph, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                       level_now, getattr(self.model, 'split_level', None),
+                       level_now, getattr(self.model, 'split_level', None), self.overlap_filter and self._n_evaluations > 0,
                        tuple(p_.data_ptr() for p_ in params), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))
@@ -929,6 +935,7 @@ class LinkPredictionEvaluator(object):
         self.rank_true_heads, self.rank_true_tails = res[0], res[1]
         self.filt_rank_true_heads, self.filt_rank_true_tails = res[2], res[3]
         self.evaluated = True
+        self._n_evaluations += 1
 
     # -- metrics (evaluation.py:310-425) --------------------------------------
     def _check(self):
