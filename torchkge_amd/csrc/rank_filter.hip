@@ -760,11 +760,42 @@ __global__ __launch_bounds__(RB) void topk_chunk_reg_kernel(float *__restrict__ 
         int li[KMAX];
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) { lv[j] = -INFINITY; li[j] = EMPTY; }
-        for (int64_t c = lane; c < C; c += 64) {
-            const float v = row[c];
-            const bool real = ids ? ids[c] >= 0 : true;
+        // Wave-wide pruning threshold: after 16 / 64 / 256 full iterations the k-th best entry of the 64 lists is selected
+        // (on copies).  Every later element has a LARGER id than all entries seen so far (iteration t covers ids
+        // [64 t, 64 t + 63]), so one whose score does not exceed that k-th score already has k entries ahead of it in
+        // the (score descending, id ascending) order and can never be selected: after the first thousand columns only
+        // ~k ln(C / 1024) elements per ROW still run the insertion chain, and the scan is bandwidth bound.
+        float tau = 0.f;
+        bool tau_on = false;
+        auto refresh_tau = [&]() __attribute__((always_inline)) {    // (every lane active)
+            float cv[KMAX];
+            int ci[KMAX];
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) { cv[j] = lv[j]; ci[j] = li[j]; }
+            float bv = -INFINITY;
+            int bi = EMPTY;
+            for (int j = 0; j < k; ++j) {
+                bv = cv[0];
+                bi = ci[0];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (oi != EMPTY && (bi == EMPTY || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                }
+                if (bi != EMPTY && ci[0] == bi) {
+#pragma unroll
+                    for (int q = 0; q + 1 < KMAX; ++q) { cv[q] = cv[q + 1]; ci[q] = ci[q + 1]; }
+                    cv[KMAX - 1] = -INFINITY;
+                    ci[KMAX - 1] = EMPTY;
+                }
+            }
+            tau_on = bi != EMPTY;       // k real entries exist: their k-th score prunes
+            tau = bv;
+        };
+        auto visit = [&](float v, int64_t c, bool real) __attribute__((always_inline)) {
             // enters the list iff it beats the list's last entry (strictly, or at equal score by the smaller column)
-            if (real && (v > lv[KMAX - 1] || (v == lv[KMAX - 1] && (int)c < li[KMAX - 1]))) {
+            if (real && (!tau_on || v > tau) && (v > lv[KMAX - 1] || (v == lv[KMAX - 1] && (int)c < li[KMAX - 1]))) {
                 float cv = v;
                 int ci = (int)c;
 #pragma unroll
@@ -778,7 +809,25 @@ __global__ __launch_bounds__(RB) void topk_chunk_reg_kernel(float *__restrict__ 
                     ci = ti;
                 }
             }
+        };
+        // full steps of UN iterations (every lane active): the UN loads are issued together, then visited in id order
+        constexpr int UN = 8;
+        int64_t t = 0;                                  // iteration = 64 consecutive columns
+        const int64_t t_full = C / (64 * UN) * UN;      // iterations covered by full steps
+        for (; t < t_full; t += UN) {
+            if (t == 16 || t == 64 || t == 256) refresh_tau();
+            float v[UN];
+            bool real[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t c = (t + u) * 64 + lane;
+                v[u] = row[c];
+                real[u] = ids ? ids[c] >= 0 : true;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) visit(v[u], (t + u) * 64 + lane, real[u]);
         }
+        for (int64_t c = t * 64 + lane; c < C; c += 64) visit(row[c], c, ids ? ids[c] >= 0 : true);
         for (int j = 0; j < k; ++j) {
             float bv = lv[0];
             int bi = li[0];
