@@ -110,28 +110,20 @@ def all_to_all_rows(local, recv, group=None):
     """Score tile (P * m, per) of this rank -- rows [j*m, (j+1)*m) are the queries rank j ranks -- ->
     recv (P, m, per): tile p = the scores rank p computed for THIS rank's m queries (rank-major, no re-layout).
     ONE all-to-all: (P-1)/P of one local tile per rank on the fabric.  Returns True when recv[rank] was filled as
-    well, False when the own block was left where the scorer wrote it (local[rank*m : (rank+1)*m]) -- RCCL: the own
-    block is not part of the exchange at all, the rank kernel reads it in place."""
+    well, False when the own block was left where the scorer wrote it (local[rank*m : (rank+1)*m]) -- a world of one:
+    nothing is exchanged, the rank kernel reads the block in place."""
     world, rank = world_and_rank(group)
     P, m, per = recv.shape
     if not multi(world):
         return False
     assert P == world and local.shape[0] == world * m and local.is_contiguous() and recv.is_contiguous()
     key = (backend_name(group), local.device.type)
-    if key[0] == 'nccl' and key not in _A2A_FALLBACK:
-        if world > 1:       # grouped send / recv per peer; zero-sized entries (the own block) are skipped by the backend
-            none = local.new_empty(0)
-            try:
-                dist.all_to_all([recv[j] if j != rank else none for j in range(world)],
-                                [local[j * m:(j + 1) * m] if j != rank else none for j in range(world)], group=group)
-            except (RuntimeError, ValueError, NotImplementedError):
-                # a build that rejects zero-sized entries (argument validation: nothing was sent): the equal-split form,
-                # own block included -- the caller may still read its own block from `local`
-                _A2A_FALLBACK.add(key)
-                dist.all_to_all_single(recv.view(world * m, per), local, group=group)
-                return True
+    if world == 1:          # (forced collectives on a world of one: nothing to exchange, the own block is ranked in place)
         return False
     if key[0] == 'nccl':
+        # RCCL: the plain equal-split all-to-all (the own block travels as a device copy inside the collective: 1/P of
+        # one local tile).  A grouped send / recv form with a zero-sized own entry would save that copy, but it is a
+        # far less travelled path of the backend and cannot be exercised on the one-GPU boxes this engine is built on.
         dist.all_to_all_single(recv.view(world * m, per), local, group=group)
         return True
     if key not in _A2A_FALLBACK:

@@ -522,9 +522,9 @@ class LinkPredictionEvaluator(object):
             loc = torch.empty(world * m, per, dtype=torch.float32, device=dev)     # rows >= q1 - q0 / columns >= the
             eng.score_rows(prob, q0, q1, loc)                                      # shard's width: never read
             recv = torch.empty(world, m, per, dtype=torch.float32, device=dev)
-            # (RCCL: the own block is not exchanged -- the rank kernel reads it from `loc`; the choice is a property of
-            # the backend, so it is the same when this call is recorded into graph segments and replayed)
-            in_place = kdist.backend_name(self.group) == 'nccl' or not kdist.multi(world)
+            # (a world of one -- forced collectives -- exchanges nothing: the rank kernel reads the own block from `loc`;
+            # a property of the process group, so it is the same when this call is recorded into graph segments)
+            in_place = world == 1
             self._collective(lambda a_=loc, b_=recv: kdist.all_to_all_rows(a_, b_, self.group))
             my0 = q0 + rank * m
             rows = min(m, q1 - my0)
