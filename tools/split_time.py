@@ -10,13 +10,21 @@ from tools.split_dev import problem  # noqa: E402
 
 B, N, K = 32768, 14541, 200
 E, q, t = problem(B, N, K)
-guard = torch.zeros(4, device='cuda')
+guard = torch.zeros(8, device='cuda')
+if os.environ.get('TAIL'):      # thresholds in the sparse upper tail (a fitted model): the true entity is the query's neighbour
+    q = (E[t] + 0.5 * torch.nn.functional.normalize(torch.randn_like(q), dim=1)).contiguous()
 en = _hip.row_sqnorm(E, max_io=guard[1:2])
 qn = _hip.row_sqnorm(q, max_io=guard[0:1])
 prob = _hip.LpProblem(_hip.LP_L2_EXPAND, q, E, qn=qn, en=en)
 st = prob.pair_scores(t)
-_Es, _e2 = _hip.split_table(E, aug=en)
-prob.split = {'Es': _Es, 'e2pref': None if os.environ.get('NO_PREF') else _e2, 'enmax': guard[1:2], 'overflow': guard[2:3]}
+LEVEL = int(os.environ.get('LEVEL', '0'))      # 1: the one-product level (planar hi operands)
+if LEVEL == 1:
+    _Eh, _de2 = _hip.hi_table(E, aug=en)
+    prob.split = {'Es': _Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'level': 1, 'de2max': _de2,
+                  'list_stat': guard[6:7]}
+else:
+    _Es, _e2 = _hip.split_table(E, aug=en)
+    prob.split = {'Es': _Es, 'e2pref': None if os.environ.get('NO_PREF') else _e2, 'enmax': guard[1:2], 'overflow': guard[2:3]}
 _hip.SPLIT_EPS_SCALE = float(os.environ.get('EPS', '1'))
 prep = prob.split_prepare()
 raw = torch.zeros(B, dtype=torch.int32, device='cuda')
@@ -41,6 +49,6 @@ for name, fn in (('count', count), ('recheck', recheck)):
         fn()
     b.record()
     torch.cuda.synchronize()
-    print('%s dbg=%s waves=%s: %.3f ms (pairs listed %d)' % (
-        name, os.environ.get('KGE_SPLIT_DBG', '0'), os.environ.get('KGE_SPLIT_WAVES', '8'),
+    print('%s level=%d dbg=%s waves=%s: %.3f ms (pairs listed %d)' % (
+        name, LEVEL, os.environ.get('KGE_SPLIT_DBG', '0'), os.environ.get('KGE_SPLIT_WAVES', '8'),
         a.elapsed_time(b) / 10, int(nl.item())))

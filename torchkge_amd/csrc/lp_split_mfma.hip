@@ -1081,13 +1081,14 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             // frag u3 -- barrier -- frag u0 of the next stage [u3].  Every fragment overwrite has an LDS wait (or an MFMA
             // group) between it and the MFMAs that last read those registers.
             const int nu = min(4, p.units - 4 * s);
+            const bool frag = !DBG || !(dbg & 16);      // (probe: no fragment loads after the first)
+            const char *gE1 = gE + rstep;
             KGE_HWAIT(ah0, bh0)
             if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
             __builtin_amdgcn_sched_barrier(0);
-            const char *gE1 = gE + rstep;
             if (pf) { dma(gE, nE); dma(gE1, nE + SROWS * 128); }
             __builtin_amdgcn_sched_barrier(0);
-            KGE_HLOAD(ah1, bh1, sb, 1)
+            if (frag) { KGE_HLOAD(ah1, bh1, sb, 1) }
             asm volatile("" :: "v"(gE), "v"(gE1));
             __builtin_amdgcn_sched_barrier(0);
             KGE_HWAIT(ah1, bh1)
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             __builtin_amdgcn_sched_barrier(0);
             if (pf) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
             __builtin_amdgcn_sched_barrier(0);
-            KGE_HLOAD(ah0, bh0, sb, 2)
+            if (frag) { KGE_HLOAD(ah0, bh0, sb, 2) }
             __builtin_amdgcn_sched_barrier(0);
             KGE_HWAIT(ah0, bh0)
             if (nu > 2) { KGE_SMMA_PA(ah0, bh0) }
@@ -1108,12 +1109,12 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            KGE_HLOAD(ah1, bh1, sb, 3)
+            if (frag) { KGE_HLOAD(ah1, bh1, sb, 3) }
             __builtin_amdgcn_sched_barrier(0);
             KGE_HWAIT(ah1, bh1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next stage landed in LDS
-            __syncthreads();
-            if (more && !defer_frag) { KGE_HLOAD(ah0, bh0, sb_next, 0) }
+            if (!DBG || !(dbg & 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next stage landed in LDS
+            if (!DBG || !(dbg & 32)) __syncthreads();
+            if (more && !defer_frag && frag) { KGE_HLOAD(ah0, bh0, sb_next, 0) }
             __builtin_amdgcn_sched_barrier(0);
             if (nu > 3) { KGE_SMMA_PA(ah1, bh1) }
             __builtin_amdgcn_sched_barrier(0);
@@ -1639,7 +1640,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     const int grid = (int)(p.n_items < slots ? p.n_items : slots);
     if (lv1 && d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1, 0, 1>(p, grid, s);
     if (lv1 && d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2, 0, 1>(p, grid, s);
-    if (lv1) return launch_split<8, false, 0, 0, 1>(p, grid, s);
+    if (lv1) return p.dbg ? launch_split<8, true, 0, 0, 1>(p, grid, s) : launch_split<8, false, 0, 0, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJH) return launch_split<8, false, 1>(p, grid, s);
     if (d->mode == KGE_LP_L2_PROJD) return launch_split<8, false, 2>(p, grid, s);
     return p.dbg ? launch_split<8, true, 0>(p, grid, s) : launch_split<8, false, 0>(p, grid, s);
