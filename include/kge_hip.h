@@ -238,6 +238,10 @@ int kge_ewise(int op, const float *a, const float *b, const float *c, const floa
  * (device scalar, atomically -- the evaluator's "was the norm expansion safe" guard) */
 int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, float *max_io,
                    kge_stream_t stream);
+/* The same norms in ANY summation order (a few ulps of a K-term sum away from the chain): for values that only bound an
+ * error or fix an operand scale -- the DOT modes of the split prefilter -- never for a value that enters a score. */
+int kge_row_sqnorm_any_order(const float *X, int64_t ld, int64_t rows, int K, float *out, float *max_io,
+                             kge_stream_t stream);
 /* out[i] = scale * chain_k X[i,k]*Y[i,k] */
 int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t rows, int K, float scale,
                 float *out, kge_stream_t stream);

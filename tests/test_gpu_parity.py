@@ -1640,3 +1640,23 @@ def test_evaluator_level_policy_and_identical_ranks(hip, kind):
     finally:
         evm.LEVEL1_ENTER, evm.LEVEL1_LEAVE = old
         m.split_level = 'auto'
+
+
+@pytest.mark.parametrize('rows,K', [(1, 4), (6268, 200), (40943, 200), (300, 17), (129, 513), (65536, 400)])
+def test_bound_only_row_norms_match_the_chain_to_rounding(hip, rows, K):
+    """kge_row_sqnorm_any_order (16 lanes per row, any summation order: bounds / scales of the DOT-mode prefilter) against the
+    sequential chain: equal to a few ulps of a K-term sum, maximum folded into the device scalar."""
+    g = torch.Generator().manual_seed(rows + K)
+    X = (torch.randn(rows, K, generator=g) * 2).cuda()
+    m = torch.zeros(2, device='cuda')
+    a = hip.row_sqnorm(X, max_io=m[0:1])
+    b = hip.row_sqnorm(X, max_io=m[1:2], bound_only=True)
+    ref = (X.double() ** 2).sum(1)
+    assert float(((b.double() - ref).abs() / ref.clamp_min(1e-30)).max()) < 1e-6
+    assert float(((a - b).abs() / a.clamp_min(1e-30)).max()) < 1e-5
+    assert abs(float(m[0]) - float(m[1])) <= 1e-5 * float(m[0]) and float(m[1]) == float(b.max())
+    Xs = X[:, :K - 1] if K > 1 else X          # a strided view (ld != K): the scalar path
+    if K > 1:
+        c = hip.row_sqnorm(Xs, K=K - 1, bound_only=True)
+        refs = (Xs.double() ** 2).sum(1)
+        assert float(((c.double() - refs).abs() / refs.clamp_min(1e-30)).max()) < 1e-6

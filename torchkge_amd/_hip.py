@@ -76,6 +76,7 @@ _SIGNATURES = {
     'kge_relation_scores_proj': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
+    'kge_row_sqnorm_any_order': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     'kge_row_dot': [_vp, _vp, _i64, _i64, _int, ctypes.c_float, _vp, _vp],
     'kge_gather_rows': [_vp, _i64, _vp, _i64, _int, _vp, _vp],
     'kge_normalize_rows': [_vp, _i64, _i64, _int, _vp],
@@ -130,7 +131,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 24        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 25        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -585,7 +586,13 @@ def padded_cols(n):
     return int(load_library().kge_lp_split_rows_padded(n, 0))
 
 
-def row_sqnorm(X, K=None, max_io=None):
+FAST_BOUND_NORMS = os.environ.get('KGE_FAST_BOUND_NORMS', '1') == '1'
+
+
+def row_sqnorm(X, K=None, max_io=None, bound_only=False):
+    """Squared row norms by the sequential fmaf chain (the contract of every value that enters a score) -- or, with
+    ``bound_only`` (the result only bounds an error / fixes an operand scale: the DOT modes of the split prefilter), in
+    any summation order by the bandwidth-bound kernel (kge_row_sqnorm_any_order)."""
     lib = load_library()
     require_cuda(X)
     X = f32c(X)
@@ -593,7 +600,10 @@ def row_sqnorm(X, K=None, max_io=None):
     K = X.shape[1] if K is None else K
     out = torch.empty(rows, dtype=torch.float32, device=X.device)
     with _on(X.device):
-        _check(lib.kge_row_sqnorm(_p(X), ld, rows, K, _p(out), _p(max_io), _stream()), 'kge_row_sqnorm')
+        if bound_only and FAST_BOUND_NORMS:
+            _check(lib.kge_row_sqnorm_any_order(_p(X), ld, rows, K, _p(out), _p(max_io), _stream()), 'kge_row_sqnorm_any_order')
+        else:
+            _check(lib.kge_row_sqnorm(_p(X), ld, rows, K, _p(out), _p(max_io), _stream()), 'kge_row_sqnorm')
     return out
 
 
@@ -775,8 +785,9 @@ class LpProblem(object):
                 extra['q_dn2'], extra['q_dn2_per_query'] = self.pre['q_dn2'], True
         elif int(self.desc.mode) == LP_DOT:
             qmax = torch.zeros(2, dtype=torch.float32, device=self.device)
-            qn0 = row_sqnorm(A0, K=K, max_io=qmax[0:1])
-            qn1 = row_sqnorm(A1, max_io=qmax[1:2]) if A1 is not None else None
+            # (DOT mode: the norms bound the error band and fix the operands' scale; no score contains them)
+            qn0 = row_sqnorm(A0, K=K, max_io=qmax[0:1], bound_only=True)
+            qn1 = row_sqnorm(A1, max_io=qmax[1:2], bound_only=True) if A1 is not None else None
             qn = qn0 if qn1 is None else qn0 + qn1
             cols = self.cols
             if level == 1:      # one-product level: planar hi rows (per column when the batch has a ColumnPlan) + residuals

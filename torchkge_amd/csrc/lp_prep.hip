@@ -258,6 +258,62 @@ __global__ __launch_bounds__(64) void row_sqnorm_staged_kernel(const float *__re
         if (lane == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), m);
     }
 }
+// Squared row norms in ANY summation order (bounds and scales only -- the DOT modes of the split prefilter; no score
+// contains them, so the sequential chain of the reference is not needed): 16 lanes per row, float4 loads, four rows of a
+// lane group in flight, a shuffle tree; the maximum leaves the block as ONE atomic (same-address atomics serialise in
+// the L2: one per wavefront of a 40 k-row table cost more than the sweep itself).
+__global__ __launch_bounds__(256) void row_sqnorm_any_kernel(const float *__restrict__ X, int64_t ld, int64_t rows, int K,
+                                                             float *out, float *max_io)
+{
+    __shared__ unsigned wmax[4];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const bool vec = (K % 4 == 0) && (ld % 4 == 0) && ((size_t)X & 15) == 0;
+    float big = 0.f;
+    for (int64_t r0 = (int64_t)blockIdx.x * 64; r0 < rows; r0 += (int64_t)gridDim.x * 64) {    // 64 rows per block and step
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            for (int k = sub * 4; k < K; k += 64) {
+                float4 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r = min(r0 + grp * 4 + j, rows - 1);
+                    t[j] = *reinterpret_cast<const float4 *>(X + r * ld + k);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = fmaf(t[j].x, t[j].x, acc[j]); acc[j] = fmaf(t[j].y, t[j].y, acc[j]);
+                    acc[j] = fmaf(t[j].z, t[j].z, acc[j]); acc[j] = fmaf(t[j].w, t[j].w, acc[j]);
+                }
+            }
+        } else {
+            for (int k = sub; k < K; k += 16)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = X[min(r0 + grp * 4 + j, rows - 1) * ld + k];
+                    acc[j] = fmaf(x, x, acc[j]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = acc[j];
+            a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 1, 64);
+            const int64_t r = r0 + grp * 4 + j;
+            if (r < rows) {
+                if (sub == 0) out[r] = a;
+                big = __uint_as_float(max(__float_as_uint(big), __float_as_uint(a)));
+            }
+        }
+    }
+    if (max_io) {
+        unsigned m = __float_as_uint(big);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+    }
+}
+
 __global__ void row_dot_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t ld,
                                int64_t rows, int K, float scale, float *out)
 {
@@ -365,6 +421,19 @@ extern "C" int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, f
         hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, ld, rows, K,
                            out, max_io);
     }
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int kge_row_sqnorm_any_order(const float *X, int64_t ld, int64_t rows, int K, float *out, float *max_io,
+                                        kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!X || !out) return KGE_EINVAL;
+    const int64_t blocks = (rows + 63) / 64;
+    hipLaunchKernelGGL(row_sqnorm_any_kernel, dim3((int)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, kge_s(stream),
+                       X, ld, rows, K, out, max_io);
     KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -336,9 +336,9 @@ class Model(Module):
         key = '%d_%d' % (c_base, T0.shape[0])
 
         def norms():
-            en0 = _hip.row_sqnorm(T0, max_io=g[1:2])
+            en0 = _hip.row_sqnorm(T0, max_io=g[1:2], bound_only=True)      # (only the maxima are used: the operands' scale)
             if T1 is not None:
-                _hip.row_sqnorm(T1, max_io=g[5:6])
+                _hip.row_sqnorm(T1, max_io=g[5:6], bound_only=True)
             del en0
             return True
         srcs = [T0] + ([T1] if T1 is not None else [])
