@@ -198,38 +198,42 @@ __global__ void row_sqnorm_kernel(const float *__restrict__ X, int64_t ld, int64
         if ((threadIdx.x & 63) == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), m);
     }
 }
-// The same chains with the rows fetched cooperatively: a wavefront owns 64 rows,
-// loads them 40 k at a time as 160-byte segments (10 lanes x float4 per row, all
-// loads of a chunk in flight) and hands each lane its row through LDS (stride 44
-// floats, conflict-free b128).  ~5x faster than 64 lanes striding 64 rows.
-__global__ __launch_bounds__(64) void row_sqnorm_staged_kernel(const float *__restrict__ X, int64_t ld, int64_t rows,
-                                                               int K, float *out, float *max_io)
+// The same chains with the rows fetched cooperatively: a wavefront owns RPW rows (64, or 16 for tables of a few
+// ten thousand rows: the chains are latency bound, 16 rows per wavefront put four times as many wavefronts in flight --
+// 14,541 rows are 228 wavefronts of 64, less than one per CU), loads them KGE_PS_KC k at a time as 16-byte pieces (all
+// loads of a chunk in flight) and hands lane r its row through LDS (conflict-free b128).  Same chain, same bits.
+template <int RPW, int NW>      // NW independent wavefronts per block, each on its own LDS slice: they share the final atomic
+__global__ __launch_bounds__(64 * NW) void row_sqnorm_staged_kernel(const float *__restrict__ X, int64_t ld, int64_t rows,
+                                                                    int K, float *out, float *max_io)
 {
-    __shared__ __attribute__((aligned(16))) float xs[64 * KGE_PS_LD];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float xs_all[NW * RPW * KGE_PS_LD];
+    __shared__ unsigned wmax[NW];
+    constexpr int NP = KGE_PS_KC / 4, ITS = RPW * NP / 64;      // pieces per row chunk; load passes per full chunk
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *xs = xs_all + wv * RPW * KGE_PS_LD;
     float big = 0.f;
-    const int64_t ngroups = (rows + 63) >> 6;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int64_t row0 = grp * 64;
+    const int64_t ngroups = (rows + RPW - 1) / RPW;
+    for (int64_t grp = (int64_t)blockIdx.x * NW + wv; grp < ngroups; grp += (int64_t)gridDim.x * NW) {
+        const int64_t row0 = grp * RPW;
         float acc = 0.f;
         for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {   // K % 4 == 0, ld % 4 == 0, X 16-byte aligned (checked by the host)
             const int kc = min(KGE_PS_KC, K - k0);
             const int pieces = kc >> 2;
             if (kc == KGE_PS_KC) {
-                float4 v[KGE_PS_KC / 4];
+                float4 v[ITS];
 #pragma unroll
-                for (int it = 0; it < KGE_PS_KC / 4; ++it) {
-                    const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
+                for (int it = 0; it < ITS; ++it) {
+                    const int idx = lane + 64 * it, rr = idx / NP, pc = idx % NP;
                     const int64_t r = min(row0 + rr, rows - 1);
                     v[it] = *reinterpret_cast<const float4 *>(X + r * ld + k0 + pc * 4);
                 }
 #pragma unroll
-                for (int it = 0; it < KGE_PS_KC / 4; ++it) {
-                    const int idx = lane + 64 * it, rr = idx / (KGE_PS_KC / 4), pc = idx % (KGE_PS_KC / 4);
+                for (int it = 0; it < ITS; ++it) {
+                    const int idx = lane + 64 * it, rr = idx / NP, pc = idx % NP;
                     *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) = v[it];
                 }
             } else {
-                for (int idx = lane; idx < 64 * pieces; idx += 64) {
+                for (int idx = lane; idx < RPW * pieces; idx += 64) {
                     const int rr = idx / pieces, pc = idx - rr * pieces;
                     const int64_t r = min(row0 + rr, rows - 1);
                     *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) =
@@ -237,25 +241,38 @@ __global__ __launch_bounds__(64) void row_sqnorm_staged_kernel(const float *__re
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            const float *x = xs + lane * KGE_PS_LD;
-            for (int k = 0; k < kc; k += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(x + k);
-                acc = fmaf(t.x, t.x, acc);
-                acc = fmaf(t.y, t.y, acc);
-                acc = fmaf(t.z, t.z, acc);
-                acc = fmaf(t.w, t.w, acc);
+            if (lane < RPW) {
+                const float *x = xs + lane * KGE_PS_LD;
+                for (int k = 0; k < kc; k += 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(x + k);
+                    acc = fmaf(t.x, t.x, acc);
+                    acc = fmaf(t.y, t.y, acc);
+                    acc = fmaf(t.z, t.z, acc);
+                    acc = fmaf(t.w, t.w, acc);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
-        if (row0 + lane < rows) {
+        if (lane < RPW && row0 + lane < rows) {
             out[row0 + lane] = acc;
             big = __uint_as_float(max(__float_as_uint(big), __float_as_uint(acc)));
         }
     }
-    if (max_io) {
+    if (max_io) {       // one atomic per block (same-address atomics serialise in the L2)
         unsigned m = __float_as_uint(big);
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-        if (lane == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), m);
+        if (NW == 1) {
+            if (lane == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), m);
+        } else {
+            if (lane == 0) wmax[wv] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned mm = wmax[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) mm = max(mm, wmax[w]);
+                kge_atomic_max_u32(reinterpret_cast<unsigned *>(max_io), mm);
+            }
+        }
     }
 }
 // Squared row norms in ANY summation order (bounds and scales only -- the DOT modes of the split prefilter; no score
@@ -326,20 +343,21 @@ __global__ void row_dot_kernel(const float *__restrict__ X, const float *__restr
 }
 
 // the same chain with both rows staged cooperatively (see row_sqnorm_staged_kernel)
+template <int RPW>
 __global__ __launch_bounds__(64) void row_dot_staged_kernel(const float *__restrict__ X, const float *__restrict__ Y,
                                                             int64_t ld, int64_t rows, int K, float scale, float *out)
 {
-    __shared__ __attribute__((aligned(16))) float xs[64 * KGE_PS_LD];
-    __shared__ __attribute__((aligned(16))) float ys[64 * KGE_PS_LD];
+    __shared__ __attribute__((aligned(16))) float xs[RPW * KGE_PS_LD];
+    __shared__ __attribute__((aligned(16))) float ys[RPW * KGE_PS_LD];
     const int lane = threadIdx.x;
-    const int64_t ngroups = (rows + 63) >> 6;
+    const int64_t ngroups = (rows + RPW - 1) / RPW;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int64_t row0 = grp * 64;
+        const int64_t row0 = grp * RPW;
         float acc = 0.f;
         for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {   // K % 4 == 0, ld % 4 == 0, 16-byte aligned (checked by the host)
             const int kc = min(KGE_PS_KC, K - k0);
             const int pieces = kc >> 2;
-            for (int idx = lane; idx < 64 * pieces; idx += 64) {
+            for (int idx = lane; idx < RPW * pieces; idx += 64) {
                 const int rr = idx / pieces, pc = idx - rr * pieces;
                 const int64_t r = min(row0 + rr, rows - 1);
                 *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) =
@@ -348,17 +366,19 @@ __global__ __launch_bounds__(64) void row_dot_staged_kernel(const float *__restr
                     *reinterpret_cast<const float4 *>(Y + r * ld + k0 + pc * 4);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            const float *x = xs + lane * KGE_PS_LD, *y = ys + lane * KGE_PS_LD;
-            for (int k = 0; k < kc; k += 4) {
-                const float4 a = *reinterpret_cast<const float4 *>(x + k), b = *reinterpret_cast<const float4 *>(y + k);
-                acc = fmaf(a.x, b.x, acc);
-                acc = fmaf(a.y, b.y, acc);
-                acc = fmaf(a.z, b.z, acc);
-                acc = fmaf(a.w, b.w, acc);
+            if (lane < RPW) {
+                const float *x = xs + lane * KGE_PS_LD, *y = ys + lane * KGE_PS_LD;
+                for (int k = 0; k < kc; k += 4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(x + k), b = *reinterpret_cast<const float4 *>(y + k);
+                    acc = fmaf(a.x, b.x, acc);
+                    acc = fmaf(a.y, b.y, acc);
+                    acc = fmaf(a.z, b.z, acc);
+                    acc = fmaf(a.w, b.w, acc);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
-        if (row0 + lane < rows) out[row0 + lane] = scale * acc;
+        if (lane < RPW && row0 + lane < rows) out[row0 + lane] = scale * acc;
     }
 }
 
@@ -407,6 +427,9 @@ __global__ __launch_bounds__(WPB * 64) void normalize_rows_kernel(float *X, int6
 
 } // namespace
 
+// rows up to which the staged chain kernels run 16 rows per wavefront (131,072 rows = 8,192 wavefronts: 32 per CU)
+static const int64_t KGE_ROWS_SMALL = 131072;
+
 extern "C" int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, float *out, float *max_io,
                               kge_stream_t stream)
 {
@@ -414,9 +437,17 @@ extern "C" int kge_row_sqnorm(const float *X, int64_t ld, int64_t rows, int K, f
     if (rows == 0) return 0;
     if (!X || !out) return KGE_EINVAL;
     if (K % 4 == 0 && ld % 4 == 0 && kge_aligned16(X)) {
-        const int64_t groups = (rows + 63) / 64;
-        hipLaunchKernelGGL(row_sqnorm_staged_kernel, dim3((int)(groups < 256 * 14 ? groups : 256 * 14)), dim3(64), 0,
-                           kge_s(stream), X, ld, rows, K, out, max_io);
+        // (latency-bound chains: 16 rows per wavefront until that fills the chip several times over)
+        if (rows <= KGE_ROWS_SMALL) {
+            const int64_t blocks = (rows + 63) / 64;        // 4 wavefronts x 16 rows
+            auto k = row_sqnorm_staged_kernel<16, 4>;
+            hipLaunchKernelGGL(k, dim3((int)blocks), dim3(256), 0, kge_s(stream), X, ld, rows, K, out, max_io);
+        } else {
+            const int64_t groups = (rows + 63) / 64;
+            auto k = row_sqnorm_staged_kernel<64, 1>;
+            hipLaunchKernelGGL(k, dim3((int)(groups < 256 * 14 ? groups : 256 * 14)), dim3(64), 0,
+                               kge_s(stream), X, ld, rows, K, out, max_io);
+        }
     } else {
         hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, ld, rows, K,
                            out, max_io);
@@ -445,9 +476,14 @@ extern "C" int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t r
     if (rows == 0) return 0;
     if (!X || !Y || !out) return KGE_EINVAL;
     if (K % 4 == 0 && ld % 4 == 0 && kge_aligned16(X) && kge_aligned16(Y)) {
-        const int64_t groups = (rows + 63) / 64;
-        hipLaunchKernelGGL(row_dot_staged_kernel, dim3((int)(groups < 256 * 14 ? groups : 256 * 14)), dim3(64), 0,
-                           kge_s(stream), X, Y, ld, rows, K, scale, out);
+        if (rows <= KGE_ROWS_SMALL) {
+            const int64_t groups = (rows + 15) / 16;
+            hipLaunchKernelGGL(row_dot_staged_kernel<16>, dim3((int)groups), dim3(64), 0, kge_s(stream), X, Y, ld, rows, K, scale, out);
+        } else {
+            const int64_t groups = (rows + 63) / 64;
+            hipLaunchKernelGGL(row_dot_staged_kernel<64>, dim3((int)(groups < 256 * 14 ? groups : 256 * 14)), dim3(64), 0,
+                               kge_s(stream), X, Y, ld, rows, K, scale, out);
+        }
     } else {
         hipLaunchKernelGGL(row_dot_kernel, dim3(grid_threads(rows, 64)), dim3(64), 0, kge_s(stream), X, Y, ld, rows, K, scale, out);
     }
