@@ -11,6 +11,25 @@ Q="--no-cpu-baseline --no-full-parity --no-traffic"
 P="--no-cpu-baseline --no-traffic"          # (full-split parity ON: every workload's parity_full_split is recorded)
 T="--no-cpu-baseline"                       # (... and the run's own PMC passes: traffic, SQ_INSTS_MFMA, MFMA busy)
 b() { name=$1; shift; timeout 600 python $R/bench.py "$@" 2>$OUT/$name.err | tail -1 > $OUT/bench_$name.json; [ -s $OUT/bench_$name.json ] && rm -f $OUT/$name.err; }
+tr() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o bench -- python $R/bench.py --only-timed "$@" > $OUT/trace_$name.log 2>&1; }
+finish() {
+  cd $R
+  python tools/summarize_profiles.py $OUT > $OUT/SUMMARY.md 2>&1
+  # keep what gets committed small: the kernel-stats / counter CSVs and logs, not the raw traces
+  find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
+  du -sh $OUT; head -30 $OUT/SUMMARY.md | cut -c1-400
+}
+# bash tools/profile_round.sh r04 <workload> ...: refresh the bench line + the evaluate-only kernel trace of the named
+# workloads only (after a change that touches just them); SUMMARY.md is then rebuilt here from the merged directory
+if [ $# -gt 1 ]; then
+  shift
+  for w in "$@"; do
+    case $w in transh_fb15k237) t=transh;; transd_fb15k237) t=transd;; transe_fb15k237) t=eval;; *) t=$w;; esac   # (trace names of the full run)
+    b $w --steps 10 --warmup 3 --workload $w $T; tr $t --steps 10 --warmup 3 --workload $w
+  done
+  find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
+  exit 0
+fi
 # the headline line exactly as the driver runs it (all legs on), then the variants
 b transe_fb15k237 --steps 20 --warmup 3
 b transe_fb15k237_three_products --steps 20 --warmup 3 --split-level 0 $T --no-secondary
@@ -30,7 +49,6 @@ timeout 1500 python $R/bench.py --workload complex_wikidata5m --no-secondary --b
 timeout 600 python $R/tools/topk_time.py --cfg5 2>/dev/null | grep "^{" > $OUT/topk_inference.jsonl
 timeout 300 python $R/tools/first_call.py 2>/dev/null | tail -1 > $OUT/first_call.json
 # per-kernel time of the bench command (the trained-weights set-up shows up as the score_fwd/bwd, key_* and optimiser rows)
-tr() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o bench -- python $R/bench.py --only-timed "$@" > $OUT/trace_$name.log 2>&1; }
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --steps 20 --warmup 5 $Q > $OUT/trace.log 2>&1
 # ... and of the timed loops alone (no roofline / f32 legs): what one evaluate() consists of, per workload
 tr eval --steps 20 --warmup 5
@@ -59,8 +77,4 @@ for pass in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 # ... and of the broadcast-subtract kernel (packed-FMA L2)
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmcdirect_SQ -o bench -- python $R/bench.py --only-timed --steps 2 --warmup 1 --weights xavier --settle-ms 0 --no-graph --l2-mode direct > $OUT/pmcdirect.log 2>&1
-cd $R
-python tools/summarize_profiles.py $OUT > $OUT/SUMMARY.md 2>&1
-# keep what gets committed small: the kernel-stats / counter CSVs and logs, not the raw traces
-find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
-du -sh $OUT; head -30 $OUT/SUMMARY.md | cut -c1-400
+finish
