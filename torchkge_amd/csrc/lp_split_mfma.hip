@@ -101,7 +101,8 @@ struct SplitParams {
     int64_t n_items;
     int dbg;              // env KGE_SPLIT_DBG (timing probes, wrong results): 1 no global loads, 4 no epilogue,
                           // 16 no LDS fragment reads, 32 no barriers, 128 every block streams tile (0,0),
-                          // 1024 hi*hi product only (one-product first level), 2048 half of the LDS-DMA pieces
+                          // 1024 hi*hi product only (one-product first level), 2048 half of the LDS-DMA pieces,
+                          // 4096 (LV = 1) cycle stamps of the stage phases into the head of the pair list
                           // (a planar hi table would move half the bytes)
 };
 
@@ -1056,7 +1057,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
     f16x8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
     if (LV == 1) { KGE_HLOAD(ah0, bh0, 0u, 0) } else { KGE_SLOAD(ah0, al0, bh0, bl0, 0u, 0) }
     int it = 0, s = 0;
+    // probe 4096 (DBG kernel, LV = 1): cycle stamps of the phases of the first KGE_TL_STAGES stages of block 0, waves 0 and 4
+    // (partners on one SIMD), written to the head of the pair list (combine with 64: no list flush) -- tools/split_timeline.py
+    constexpr int KGE_TL_STAGES = 48;
+    unsigned long long tsv[16];
+#define KGE_TS(I) if (DBG && tl) tsv[I] = __builtin_readcyclecounter();
     for (int g = 0; g < G; ++g) {
+        const bool tl = DBG && LV == 1 && (dbg & 4096) && bid == 0 && (wid == 0 || wid == 4) && g < KGE_TL_STAGES;
         const int buf = g & 1;
         const bool more = g + 1 < G;
         const unsigned sb = buf * STAGE_BYTES, sb_next = (buf ^ 1) * STAGE_BYTES;
@@ -1083,24 +1090,34 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
             const int nu = min(4, p.units - 4 * s);
             const bool frag = !DBG || !(dbg & 16);      // (probe: no fragment loads after the first)
             const char *gE1 = gE + rstep;
+            KGE_TS(0)
             KGE_HWAIT(ah0, bh0)
+            KGE_TS(1)
             if (s == 0) { KGE_SMMA_P(ah0, bh0, zero16) } else { KGE_SMMA_PA(ah0, bh0) }
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(2)
             if (pf) { dma(gE, nE); dma(gE1, nE + SROWS * 128); }
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(3)
             if (frag) { KGE_HLOAD(ah1, bh1, sb, 1) }
             asm volatile("" :: "v"(gE), "v"(gE1));
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(4)
             KGE_HWAIT(ah1, bh1)
+            KGE_TS(5)
             if (nu > 1) { KGE_SMMA_PA(ah1, bh1) }
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(6)
             if (pf) { dma(gE + 2 * rstep, nE + 2 * SROWS * 128); dma(gE + 3 * rstep, nE + 3 * SROWS * 128); }
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(7)
             if (frag) { KGE_HLOAD(ah0, bh0, sb, 2) }
             __builtin_amdgcn_sched_barrier(0);
             KGE_HWAIT(ah0, bh0)
+            KGE_TS(8)
             if (nu > 2) { KGE_SMMA_PA(ah0, bh0) }
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(9)
             if (pf) { dma(gQ, nQ); dma(gQ + rstep, nQ + SROWS * 128); dma(gQ + 2 * rstep, nQ + 2 * SROWS * 128); }
             if (more && pf) {
                 if (++pf_s == S) {
@@ -1109,15 +1126,20 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(10)
             if (frag) { KGE_HLOAD(ah1, bh1, sb, 3) }
             __builtin_amdgcn_sched_barrier(0);
             KGE_HWAIT(ah1, bh1)
+            KGE_TS(11)
             if (!DBG || !(dbg & 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next stage landed in LDS
+            KGE_TS(12)
             if (!DBG || !(dbg & 32)) __syncthreads();
+            KGE_TS(13)
             if (more && !defer_frag && frag) { KGE_HLOAD(ah0, bh0, sb_next, 0) }
             __builtin_amdgcn_sched_barrier(0);
             if (nu > 3) { KGE_SMMA_PA(ah1, bh1) }
             __builtin_amdgcn_sched_barrier(0);
+            KGE_TS(14)
         } else {
             // (this stage's first k16 fragments were fetched behind the previous stage's barrier, below)
             KGE_SWAIT(ah0, al0, bh0, bl0)
@@ -1375,8 +1397,17 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void lp_split_count_kernel(const Sp
                 }
             }
         }
+        if (DBG && tl) {
+            tsv[15] = __builtin_readcyclecounter();     // (behind the epilogue of a tile's last stage)
+            if (lane == 0) {
+                unsigned long long *o = reinterpret_cast<unsigned long long *>(p.list) + ((wid >> 2) * KGE_TL_STAGES + g) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] = tsv[i];
+            }
+        }
         if (++s == S) { s = 0; ++it; }
     }
+#undef KGE_TS
 #undef KGE_SMMA_PA
 #undef KGE_SMMA_P
 #undef KGE_HLOAD
