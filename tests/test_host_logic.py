@@ -474,3 +474,14 @@ def test_internal_batch_of_the_fused_evaluator():
     finally:
         ev.COALESCE_BATCH = old
         _M.n_ent = 14541
+
+
+def test_documented_abi_version_is_the_bindings():
+    """INTEGRATION.md / DESIGN.md state the ABI version a maintainer binds against: the one the binding checks."""
+    import re
+    from torchkge_amd import _hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = re.search(r'kge_abi_version\(\)` \(currently \*\*(\d+)\*\*', open(os.path.join(root, 'INTEGRATION.md')).read())
+    assert m and int(m.group(1)) == _hip.ABI_VERSION
+    m = re.search(r'`include/kge_hip.h` \(ABI (\d+)\)', open(os.path.join(root, 'DESIGN.md')).read())
+    assert m and int(m.group(1)) == _hip.ABI_VERSION
