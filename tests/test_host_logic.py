@@ -485,3 +485,18 @@ def test_documented_abi_version_is_the_bindings():
     assert m and int(m.group(1)) == _hip.ABI_VERSION
     m = re.search(r'`include/kge_hip.h` \(ABI (\d+)\)', open(os.path.join(root, 'DESIGN.md')).read())
     assert m and int(m.group(1)) == _hip.ABI_VERSION
+
+
+def test_every_profile_file_the_documents_cite_exists():
+    """DESIGN.md / README.md / INTEGRATION.md / tools/README.md quote measurements by file: every `profiles/rNN/...` path they
+    name is a committed file (or a glob that matches one)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for doc in ('DESIGN.md', 'README.md', 'INTEGRATION.md', os.path.join('tools', 'README.md')):
+        text = open(os.path.join(root, doc)).read()
+        for path in set(re.findall(r'profiles/r0\d/[A-Za-z0-9_.*-]+', text)):
+            path = path.rstrip('.,)')
+            if not glob.glob(os.path.join(root, path)) and not glob.glob(os.path.join(root, path + '*')):
+                missing.append((doc, path))
+    assert not missing, missing
