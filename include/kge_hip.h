@@ -500,6 +500,14 @@ typedef struct kge_split_args {
     const float *q_dn2;
     const int64_t *q_dn2_index;
     const float *de2max;
+    /* FREE-RUNNING one-product sweep (r05, level = 1 only).  es_frag = 1: Es is the FRAGMENT-MAJOR candidate table of
+     * kge_lp_hi_rows_frag -- [rows_padded / 32][kge_lp_hi_units(K)][64][16 bytes], the 1-KiB block of (32-row group, k16
+     * unit) holding chunk (row % 32) + 32 * (k / 8 % 2): the A operand of v_mfma_f32_32x32x16_f16 in lane order.  The
+     * count kernel then keeps a 96-query panel resident in LDS, every wavefront reads the fragments of ITS 64 candidate
+     * rows straight from global memory into registers and runs without block-wide barriers (lp_hi_stream.hip); same
+     * thresholds, same counts, same list.  Qs stays the planar operand.  Columns: col_q only (members must be NULL).
+     * K must satisfy kge_lp_hi_stream_supported(K). */
+    int32_t es_frag;
 } kge_split_args;
 int kge_lp_split_group_sets(void);
 
@@ -534,6 +542,13 @@ int kge_lp_hi_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_
                    int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
                    const float *norm2max1, void *out, float *dn2, float *dn2max, const int64_t *row_index,
                    kge_stream_t stream);
+/* The CANDIDATE operand of the free-running one-product sweep (kge_split_args.es_frag = 1): the values of
+ * kge_lp_hi_rows(is_query = 0) in FRAGMENT-MAJOR order, [rows_padded / 32][kge_lp_hi_units(K0 + K1)][64][16 bytes]
+ * (same byte count).  kge_lp_hi_stream_supported(K): 1 if that sweep handles K columns (else use the planar table). */
+int kge_lp_hi_rows_frag(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                        int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
+                        const float *norm2max1, void *out, float *dn2, float *dn2max, kge_stream_t stream);
+int kge_lp_hi_stream_supported(int K);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
 /* 1 if v_mfma_f32_32x32x16_f16 on the current device accumulates as the tighter error model assumes (two

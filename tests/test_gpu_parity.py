@@ -1086,12 +1086,14 @@ def test_split_prefilter_projection_modes_counts_equal_exact_counts(hip, mode_na
     assert float(guard[2]) == 0.0
     assert B <= int(prob.last_split[0].item()) <= 64 * B
     # ... and on the ONE-PRODUCT level (planar hi table, thresholds from the measured residuals; same epilogue)
-    Eh, de2 = hip.hi_table(dT, aug=en)
-    prob.split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'xabsmax': guard[3:4],
-                  'yabsmax': guard[4:5] if mode_name == 'D' else None, 'level': 1, 'de2max': de2}
-    got = prob.count_ge(st)
-    assert torch.equal(got, exact), int((got != exact).sum())
-    assert float(guard[2]) == 0.0 and B <= int(prob.last_split[0].item())
+    # ... and on the FREE-RUNNING one-product kernel (fragment-major candidate table, lp_hi_stream.hip; r05)
+    for frag in (False, True):
+        Eh, de2 = hip.hi_table(dT, aug=en, frag=frag)
+        prob.split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'xabsmax': guard[3:4],
+                      'yabsmax': guard[4:5] if mode_name == 'D' else None, 'level': 1, 'de2max': de2, 'es_frag': frag}
+        got = prob.count_ge(st)
+        assert torch.equal(got, exact), (frag, int((got != exact).sum()))
+        assert float(guard[2]) == 0.0 and B <= int(prob.last_split[0].item())
 
 
 @pytest.mark.parametrize('n0,n1,rows', [(1000, 0, 237), (32768, 32768, 14541), (5, 3, 2), (70000, 1, 1 << 20), (1, 0, 1)])
@@ -1478,9 +1480,11 @@ def test_device_built_index_and_plans_equal_the_torch_builds(hip, n_ent, n_rel, 
     assert torch.equal(hip.sort_perm(keys.cuda(), (B // 1000 + 1) * n_rel).cpu(), torch.argsort(keys, stable=True))
 
 
+@pytest.mark.parametrize('frag', [False, True])
 @pytest.mark.parametrize('B,N,K,cols_on', [(64, 300, 32, False), (1000, 3000, 200, False), (193, 257, 17, False), (5, 2, 1, False),
-                                           (700, 1500, 203, False), (1000, 3000, 200, True), (400, 5000, 64, True)])
-def test_split_one_product_level_counts_equal_exact_counts(hip, B, N, K, cols_on):
+                                           (700, 1500, 203, False), (1000, 3000, 200, True), (400, 5000, 64, True),
+                                           (3000, 20000, 200, False), (2500, 9000, 400, False), (300, 1100, 500, False)])
+def test_split_one_product_level_counts_equal_exact_counts(hip, B, N, K, cols_on, frag):
     """The ONE-PRODUCT level of the split prefilter (kge_split_args.level = 1: planar hi operands, one MFMA product per
     k16 unit, thresholds from the operands' measured f16 residuals) + exact recheck leave exactly the counts of the
     fp32 kernel -- TransE-L2 shaped problems, per query and over query columns (hub keys), also with the band shrunk."""
@@ -1508,10 +1512,12 @@ def test_split_one_product_level_counts_equal_exact_counts(hip, B, N, K, cols_on
     prob = hip.LpProblem(hip.LP_L2_EXPAND, dq, dE, qn=qn, en=en)
     st = prob.pair_scores(dt)
     exact = prob.count_ge(st)
-    Eh, de2 = hip.hi_table(dE, aug=en)
+    # frag: the FREE-RUNNING kernel (lp_hi_stream.hip, r05) on the fragment-major table -- it sweeps per query (grouped
+    # columns are dropped by split_prepare), single-query columns pass through col_q
+    Eh, de2 = hip.hi_table(dE, aug=en, frag=frag)
     assert 0.0 <= float(de2) < 1e-6 * float(guard[1])         # ||e - hi(e)|| ~ 2^-12 ||e|| (0 when every value is an f16)
     prob.split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'level': 1, 'de2max': de2,
-                  'list_stat': guard[6:7]}
+                  'list_stat': guard[6:7], 'es_frag': frag}
     prob.cols = cols
     try:
         # (the band's residual term bounds ACTUAL f16 rounding errors by Cauchy-Schwarz: tight at small K, so only a
@@ -1529,9 +1535,10 @@ def test_split_one_product_level_counts_equal_exact_counts(hip, B, N, K, cols_on
     assert float(guard[2]) == 0.0
 
 
+@pytest.mark.parametrize('frag', [False, True])
 @pytest.mark.parametrize('B,N,K,K1,scale', [(300, 1000, 64, 0, 1.0), (257, 700, 40, 40, 30.0), (100, 513, 17, 17, 1e-3),
-                                          (64, 300, 200, 200, 1.0)])
-def test_split_one_product_level_dot_mode(hip, B, N, K, K1, scale):
+                                          (64, 300, 200, 200, 1.0), (1200, 4100, 400, 0, 1.0)])
+def test_split_one_product_level_dot_mode(hip, B, N, K, K1, scale, frag):
     """The one-product level on KGE_LP_DOT problems (DistMult / ComplEx: two K-segments, operands with their own
     power-of-two scales, negative true scores, an all-zero query)."""
     g = torch.Generator().manual_seed(B * 7 + K + 1)
@@ -1552,9 +1559,9 @@ def test_split_one_product_level_dot_mode(hip, B, N, K, K1, scale):
     if T1 is not None:
         hip.row_sqnorm(T1, max_io=guard[5:6])
         nm1 = guard[5:6]
-    Eh, de2 = hip.hi_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=nm1)
+    Eh, de2 = hip.hi_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=nm1, frag=frag)
     prob.split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'enmax1': nm1, 'overflow': guard[2:3], 'level': 1,
-                  'de2max': de2, 'list_stat': guard[6:7]}
+                  'de2max': de2, 'list_stat': guard[6:7], 'es_frag': frag}
     try:
         for eps in ((1.0, 0.5) if K + K1 >= 200 else (1.0,)):
             hip.SPLIT_EPS_SCALE = eps

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torchkge_amd import _hip  # noqa: E402
 from tools.split_dev import problem  # noqa: E402
 
-B, N, K = 32768, 14541, 200
+B, N, K = int(os.environ.get('B', 32768)), int(os.environ.get('N', 14541)), int(os.environ.get('K', 200))
 E, q, t = problem(B, N, K)
 guard = torch.zeros(8, device='cuda')
 if os.environ.get('TAIL'):      # thresholds in the sparse upper tail (a fitted model): the true entity is the query's neighbour
@@ -19,9 +19,10 @@ prob = _hip.LpProblem(_hip.LP_L2_EXPAND, q, E, qn=qn, en=en)
 st = prob.pair_scores(t)
 LEVEL = int(os.environ.get('LEVEL', '0'))      # 1: the one-product level (planar hi operands)
 if LEVEL == 1:
-    _Eh, _de2 = _hip.hi_table(E, aug=en)
+    FRAG = os.environ.get('FRAG', '1') == '1'   # the free-running kernel (fragment-major candidate table)
+    _Eh, _de2 = _hip.hi_table(E, aug=en, frag=FRAG)
     prob.split = {'Es': _Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'level': 1, 'de2max': _de2,
-                  'list_stat': guard[6:7]}
+                  'list_stat': guard[6:7], 'es_frag': FRAG}
 else:
     _Es, _e2 = _hip.split_table(E, aug=en)
     prob.split = {'Es': _Es, 'e2pref': None if os.environ.get('NO_PREF') else _e2, 'enmax': guard[1:2], 'overflow': guard[2:3]}
@@ -49,6 +50,6 @@ for name, fn in (('count', count), ('recheck', recheck)):
         fn()
     b.record()
     torch.cuda.synchronize()
-    print('%s level=%d dbg=%s waves=%s: %.3f ms (pairs listed %d)' % (
-        name, LEVEL, os.environ.get('KGE_SPLIT_DBG', '0'), os.environ.get('KGE_SPLIT_WAVES', '8'),
-        a.elapsed_time(b) / 10, int(nl.item())))
+    print('%s level=%d frag=%s B=%d N=%d K=%d dbg=%s hs_waves=%s hs_qg=%s: %.3f ms (pairs listed %d)' % (
+        name, LEVEL, os.environ.get('FRAG', '1') if LEVEL == 1 else '-', B, N, K, os.environ.get('KGE_SPLIT_DBG', '0'),
+        os.environ.get('KGE_HS_WAVES', 'auto'), os.environ.get('KGE_HS_QG', 'auto'), a.elapsed_time(b) / 10, int(nl.item())))

@@ -49,6 +49,7 @@ class SplitArgs(ctypes.Structure):
         ('col_q', _vp), ('n_single_p', _i64), ('members', _vp), ('n_multi_p', _i64),
         ('q_cell_ss_index', _vp), ('q_cell_ss_ld', _i64),
         ('level', ctypes.c_int32), ('q_dn2', _vp), ('q_dn2_index', _vp), ('de2max', _vp),
+        ('es_frag', ctypes.c_int32),
     ]
 
 
@@ -90,6 +91,8 @@ _SIGNATURES = {
     'kge_lp_hi_units': [_int],
     'kge_lp_hi_rows': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _int, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
                        _vp, _vp],
+    'kge_lp_hi_rows_frag': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_hi_stream_supported': [_int],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
@@ -131,7 +134,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 25        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 26        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -468,7 +471,7 @@ def split_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nm
 
 
 def hi_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None, want_dn2=False,
-            dn2max=None, row_index=None):
+            dn2max=None, row_index=None, frag=False):
     """PLANAR hi operand of the one-product level (kge_lp_hi_rows): uint8 tensor [rows_p][hi_units][32 bytes] of
     [X | X1] (+ the per-row residuals ||x - hi(x)||^2 when want_dn2; their maximum folded into the device scalar
     dn2max).  Augmentation / scale conventions as split_rows."""
@@ -494,6 +497,12 @@ def hi_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nm
     rows_p = int(lib.kge_lp_split_rows_padded(rows, 1 if is_query else 0))
     out = torch.empty(max(rows_p, 1) * units_p * 32, dtype=torch.uint8, device=X.device)
     dn2 = torch.empty(max(rows, 1), dtype=torch.float32, device=X.device) if want_dn2 else None
+    if frag:        # candidates of the free-running sweep: the same values in fragment-major order (kge_lp_hi_rows_frag)
+        assert not is_query and row_index is None
+        with _on(X.device):
+            _check(lib.kge_lp_hi_rows_frag(_p(X), ld, K, _p(X1), ld1, K1, rows, aug_mode, _p(aug), aug_mul, _p(nmax0),
+                                           _p(nmax1), _p(out), _p(dn2), _p(dn2max), _stream()), 'kge_lp_hi_rows_frag')
+        return (out, dn2) if want_dn2 else out
     with _on(X.device):
         _check(lib.kge_lp_hi_rows(_p(X), ld, K, _p(X1), ld1, K1, rows, 1 if is_query else 0, aug_mode, _p(aug), aug_mul,
                                   _p(nmax0), _p(nmax1), _p(out), _p(dn2), _p(dn2max), _p(row_index), _stream()),
@@ -501,11 +510,19 @@ def hi_rows(X, K=None, is_query=False, aug=None, X1=None, K1=None, dot=False, nm
     return (out, dn2) if want_dn2 else out
 
 
-def hi_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None):
-    """Candidate operand of the one-product level: (Eh, de2max) -- the planar hi table and the device scalar
-    max_c ||e_c - hi(e_c)||^2 of its error band."""
+HI_STREAM = os.environ.get('KGE_HI_STREAM', '1') != '0'    # one-product level on the free-running kernel (lp_hi_stream.hip)
+
+
+def hi_stream_ok(K):
+    """Does the free-running one-product sweep (fragment-major candidate table, kge_split_args.es_frag) handle K columns?"""
+    return HI_STREAM and int(load_library().kge_lp_hi_stream_supported(int(K))) == 1
+
+
+def hi_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None, frag=False):
+    """Candidate operand of the one-product level: (Eh, de2max) -- the hi table (planar, or fragment-major for the
+    free-running sweep) and the device scalar max_c ||e_c - hi(e_c)||^2 of its error band."""
     de2 = torch.zeros(1, dtype=torch.float32, device=X.device)
-    Eh = hi_rows(X, K=K, aug=aug, X1=X1, K1=K1, dot=dot, nmax0=nmax0, nmax1=nmax1, dn2max=de2)
+    Eh = hi_rows(X, K=K, aug=aug, X1=X1, K1=K1, dot=dot, nmax0=nmax0, nmax1=nmax1, dn2max=de2, frag=frag)
     return Eh, de2
 
 
@@ -776,6 +793,8 @@ class LpProblem(object):
         A0, A1 = self.keep[0], self.keep[2]
         extra = {}
         level = int(self.split.get('level', 0))
+        if self.split.get('es_frag') and self.pre is None and self.cols is not None and self.cols.n_multi_p > 0:
+            self.cols = None        # the free-running sweep takes no grouped columns: per query (always valid)
         want_ss = self.split.get('e2pref') is not None and level == 0    # prefix-norm magnitude bound of the error band
         if self.pre is not None:
             assert int(self.pre.get('level', 0)) == level
@@ -856,6 +875,9 @@ class LpProblem(object):
             a.col_q, a.n_single_p = _p(cols.col_q), cols.n_single_p
             a.members, a.n_multi_p = _p(cols.members), cols.n_multi_p
         a.level = int(sp.get('level', 0))
+        a.es_frag = 1 if sp.get('es_frag') else 0
+        if a.es_frag:
+            assert a.level == 1 and (cols is None or cols.n_multi_p == 0), 'the free-running sweep takes no grouped columns'
         if a.level == 1:        # one-product level: the band needs the operands' measured f16 residuals
             a.de2max = _p(sp['de2max'])
             a.q_dn2 = _p(prep.get('q_dn2'))

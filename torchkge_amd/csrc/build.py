@@ -14,7 +14,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['score_triples.hip', 'lp_prep.hip', 'lp_gemm_mfma.hip', 'lp_split_mfma.hip', 'lp_direct.hip',
+SOURCES = ['score_triples.hip', 'lp_prep.hip', 'lp_gemm_mfma.hip', 'lp_split_mfma.hip', 'lp_hi_stream.hip', 'lp_direct.hip',
            'lp_l1_sad.hip', 'rank_filter.hip', 'corrupt.hip', 'key_sort.hip', 'index_build.hip']
 HEADERS = ['kge_common.h', os.path.join('..', '..', 'include', 'kge_hip.h')]
 LIB = os.path.join(HERE, 'libkge_hip.so')

@@ -293,3 +293,32 @@ static inline int kge_lp_desc_check(const kge_lp_desc *d)
     if (d->Wq && d->mode < KGE_LP_L1_DIRECT) return KGE_EINVAL;
     return 0;
 }
+
+// ---- free-running one-product count kernel (lp_hi_stream.hip), launched by kge_lp_split_count ----------------------
+struct kge_hi_stream_params {
+    const char *Ef;             // candidates: FRAGMENT-MAJOR hi table [rows_p / 32][units_p][64 lanes][16 B] (kge_lp_hi_rows, frag = 1)
+    const char *Qh;             // queries: planar hi operand [q_rows][q_row_bytes]
+    int64_t q_row_bytes;
+    int units, units_p;         // k16 units holding data / units per 32-row group of Ef
+    int64_t rows_p;             // candidate rows of Ef (a multiple of 64)
+    int64_t q_rows;             // rows of Qh (a multiple of 96)
+    int64_t B;                  // queries (thr / raw_count are indexed by query)
+    const float2 *thr;
+    const float4 *thr4;         // projection modes: (a_lo, a_hi, p_i, z_i)
+    const float *X;             // projection modes: X (n_rel, ldx)
+    int64_t ldx;
+    const int64_t *r_idx;
+    const float *yc;
+    int32_t *raw_count;
+    int32_t *list;
+    int32_t cap;
+    int32_t *list_count;
+    float *overflow;
+    const int32_t *col_q;       // optional: column -> query id (< 0: padding)
+    // filled by kge_hi_stream_launch
+    int q_panels, c_tiles, qg;  // qg: panels interleaved under one candidate sweep (a power of two dividing the blocks per XCD)
+    int64_t n_items;
+    int panel_bytes;
+};
+int kge_hi_stream_max_units(void);
+int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_t s);

@@ -1,0 +1,412 @@
+// The one-product level of the split prefilter as FREE-RUNNING wavefronts (r05).
+//
+// Same arithmetic as lp_split_count_kernel<.., LV = 1> (lp_split_mfma.hip): acc = sum over the k16 units of
+// hi(q) . hi(e) on v_mfma_f32_32x32x16_f16, compared with the two per-query thresholds (a_lo, a_hi); raw_count +=
+// #{acc >= a_lo}, pairs inside the band go to the list that kge_lp_split_recheck re-scores exactly.  What is different
+// is who waits for whom.  The r04 kernel stages both operands through a double-buffered LDS stage that all eight waves
+// of the block fill and read, one barrier per stage: the two waves of a SIMD run the same phase at the same time (MFMA
+// group, LDS-DMA issue, fragment wait, compare epilogue) and the matrix pipe idles through every phase but one
+// (profiles/r04/lv1_stall_counters.txt: 28-34 % busy, VALU and MFMA co-executing 3.7 % of the time).  Here
+//
+//   * the QUERY panel (96 queries x all k16 units, 32 B per unit + 16 B row padding: conflict-free ds_read_b128) is
+//     RESIDENT in LDS for a whole sweep of the candidate tiles -- loaded once per panel, read-only in between;
+//   * every wave owns 64 CANDIDATE rows of the tile and reads their MFMA fragments straight from global memory into
+//     registers: the candidate table is laid out FRAGMENT-MAJOR ([32-row group][k16 unit][lane][16 B], kge_lp_hi_rows
+//     with frag = 1), so one global_load_dwordx4 per (32 rows, unit) is a fully coalesced 1-KiB read that lands in the
+//     exact register layout of the A operand -- no LDS staging, no ds_read, no LDS-DMA for the streamed operand;
+//   * hence NO barrier in the tile loop: a wave's only dependencies are its own loads (vmcnt / lgkmcnt, placed by the
+//     compiler -- without LDS-DMA in the kernel hipcc's wait insertion is exact).  The waves drift apart, and while one
+//     wave of a SIMD runs its compare epilogue (VALU) or waits for fragments, its partner's MFMAs have the pipe;
+//   * uncertain pairs go to a per-WAVE list in LDS (ballot + mbcnt positions: no LDS atomics), flushed by the wave
+//     itself; the only block-wide synchronisation is the change of the query panel.
+//
+// Wave tile 64 candidates x 96 queries (2 x 3 MFMA tiles, 96 accumulator VGPRs) as before; a workgroup is NW waves x 64
+// rows of ONE panel: NW = 4 (256 threads, TWO workgroups per CU, panel <= 22 units) or NW = 8 (512 threads, one per CU).
+#include "kge_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int HS_TQ = 96;                       // queries per panel (MFMA columns = lanes, 3 tiles of 32)
+constexpr int HS_NT = 3, HS_MT = 2;
+constexpr int HS_WROWS = 64;                    // candidate rows per wave
+constexpr int HS_WLIST = 256;                   // uncertain pairs buffered per wave (int2 entries)
+constexpr int HS_PF = 3, HS_RING = 4;           // candidate fragments: units in flight / ring slots
+
+template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM>
+__global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_stream_params p)
+{
+    constexpr int NTHREADS = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int units = UNITS ? UNITS : p.units;
+    const int RS = units * 32 + 16;                                 // panel row stride (bytes): (2 units + 1) chunks, odd
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    char *panel = smem;
+    int2 *wlist = reinterpret_cast<int2 *>(smem + p.panel_bytes) + wid * HS_WLIST;
+    float4 *pthr = reinterpret_cast<float4 *>(smem + p.panel_bytes + NW * HS_WLIST * 8);     // PM: per query of the panel
+    int *prow = reinterpret_cast<int *>(pthr + HS_TQ);
+
+    // work order: as lp_split_count_kernel -- QG panels interleaved under a sweep of the candidate tiles, XCD x owns an
+    // eighth of the item list, its blocks take stride-nbx positions (nbx a multiple of QG: a block keeps its panel)
+    const int QG = p.qg;
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int nbx = (nb - xcd + 7) >> 3;
+    const int nx = nb < 8 ? nb : 8;
+    const int64_t x_begin = p.n_items * xcd / nx, x_end = p.n_items * (xcd + 1) / nx;
+    const int64_t item_begin = x_begin + loc;
+    const int nitems = item_begin < x_end ? (int)((x_end - item_begin + nbx - 1) / nbx) : 0;
+    if (nitems <= 0) return;
+    // item -> (query panel, candidate tile).  Panels are grouped: floor(P / QG) groups of QG panels, then one group per set
+    // bit of the remainder (sizes QG/2 .. 1); inside a group the items run (panel 0, tile 0) (panel 1, tile 0) .. so
+    // that a block stepping by nbx -- a multiple of every group size -- keeps ITS panel while the blocks of the XCD sweep
+    // the candidate tiles together (every tile enters the L2 once per group).
+    const int full_panels = (p.q_panels / QG) * QG;
+    const int full_items = full_panels * p.c_tiles;
+    auto item_qp_ct = [&](int i, int &qp, int &ct) __attribute__((always_inline)) {
+        int idx = (int)item_begin + i * nbx;
+        int base = 0, gsz = QG;
+        if (idx < full_items) {
+            const int per = QG * p.c_tiles, grp = idx / per;
+            idx -= grp * per;
+            base = grp * QG;
+        } else {
+            idx -= full_items;
+            base = full_panels;
+            const int rem = p.q_panels - full_panels;
+            gsz = 1;
+            for (int sz = QG >> 1; sz >= 1; sz >>= 1) {
+                if (rem & sz) {
+                    if (idx < sz * p.c_tiles) { gsz = sz; break; }
+                    idx -= sz * p.c_tiles;
+                    base += sz;
+                }
+            }
+        }
+        ct = idx / gsz;
+        qp = base + (idx - ct * gsz);
+    };
+
+    // candidate fragments of this wave: 32-row groups g, g + 1 of the fragment-major table
+    const int n_groups32 = (int)(p.rows_p >> 5);
+    const int64_t gstride = (int64_t)p.units_p << 10;               // bytes per 32-row group
+    auto tile_ptr = [&](int ct, bool &active) __attribute__((always_inline)) -> const char * {
+        int g = ct * (NW * 2) + wid * 2;
+        active = g + 1 < n_groups32;
+        g = min(g, n_groups32 - 2);                                 // (past the table: valid rows, results dropped)
+        return p.Ef + g * gstride;
+    };
+    const unsigned lane16 = lane * 16;
+
+    f32x16 acc[HS_MT][HS_NT];
+    f16x8 A[HS_RING][HS_MT], Bf[2][HS_NT];
+    int cnt[HS_NT] = {0, 0, 0};
+    float alo[HS_NT], ahi[HS_NT];
+    int qid[HS_NT];
+    int nlist = 0;                                                  // entries in this wave's LDS list (wave-uniform)
+
+    auto flush_list = [&]() __attribute__((always_inline)) {
+        if (nlist > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(p.list_count, nlist);
+            base = __builtin_amdgcn_readfirstlane(base);
+            for (int i = lane; i < nlist; i += 64) {
+                const int pos = base + i;
+                if ((unsigned)pos < (unsigned)p.cap) reinterpret_cast<int2 *>(p.list)[pos] = wlist[i];
+                else *p.overflow = 1.0f;
+            }
+            nlist = 0;
+        }
+    };
+    auto load_panel = [&](int64_t q0) __attribute__((always_inline)) {
+        // rows of the planar query operand -> LDS rows of stride RS
+        const int cpr = 2 * units;                                  // 16-byte chunks per row
+        const int total = HS_TQ * cpr;
+        for (int n = tid; n < total; n += NTHREADS) {
+            const int row = n / cpr, c = n - row * cpr;
+            const uint4 v = *reinterpret_cast<const uint4 *>(p.Qh + (q0 + row) * p.q_row_bytes + c * 16);
+            *reinterpret_cast<uint4 *>(panel + row * RS + c * 16) = v;
+        }
+        if (PM) {
+            if (tid < HS_TQ) {
+                const int64_t q = p.col_q ? (int64_t)p.col_q[q0 + tid] : q0 + tid;
+                pthr[tid] = q >= 0 ? p.thr4[q] : make_float4(INFINITY, INFINITY, 0.f, 0.f);
+                prow[tid] = (int)p.r_idx[min(max(q, (int64_t)0), p.B - 1)];
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < HS_NT; ++nt) {
+            const int64_t col = q0 + nt * 32 + l31;
+            int64_t q = p.col_q ? (int64_t)p.col_q[col] : col;
+            if (q >= p.B) q = -1;
+            float2 t = make_float2(INFINITY, INFINITY);
+            if (q >= 0) {
+                if (PM) { const float4 t4 = p.thr4[q]; t = make_float2(t4.x, t4.y); }
+                else t = p.thr[q];
+            }
+            alo[nt] = t.x; ahi[nt] = t.y; qid[nt] = (int)q;
+        }
+    };
+    auto flush_counts = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < HS_NT; ++nt) {
+            const int v = cnt[nt] + __shfl_xor(cnt[nt], 32, 64);
+            if (half == 0 && v != 0 && qid[nt] >= 0) atomicAdd(&p.raw_count[qid[nt]], v);
+            cnt[nt] = 0;
+        }
+    };
+
+    // fragment addresses inside the panel: row nt * 32 + l31, unit u, k-half `half`
+    const unsigned b_lane = (unsigned)(l31 * RS + half * 16);
+    auto load_B = [&](f16x8 (&dst)[HS_NT], int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < HS_NT; ++nt)
+            dst[nt] = *reinterpret_cast<const f16x8 *>(panel + b_lane + nt * 32 * RS + u * 32);
+    };
+    auto load_A = [&](f16x8 (&dst)[HS_MT], const char *tp, int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < HS_MT; ++mt)
+            dst[mt] = *reinterpret_cast<const f16x8 *>(tp + mt * gstride + (u << 10) + lane16);
+    };
+
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    int qp_cur, ct_cur;
+    item_qp_ct(0, qp_cur, ct_cur);
+    int64_t cur_q0 = (int64_t)qp_cur * HS_TQ;
+    load_panel(cur_q0);
+    bool act_cur;
+    const char *tp_cur = tile_ptr(ct_cur, act_cur);
+#pragma unroll
+    for (int u = 0; u < HS_PF; ++u)
+        if (u < units) load_A(A[u], tp_cur, u);
+    __syncthreads();
+    load_B(Bf[0], 0);
+
+    for (int it = 0; it < nitems; ++it) {
+        // ---- the K sweep of one wave tile: per unit 6 MFMAs, 3 ds_read_b128 (queries of the next unit), 2 global loads
+        // (candidates three units ahead) -- all register-to-register dependencies, waits placed by the compiler
+        if constexpr (UNITS != 0) {
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) {
+                if (u + 1 < UNITS) load_B(Bf[(u + 1) & 1], u + 1);
+                if (u + HS_PF < UNITS) load_A(A[(u + HS_PF) % HS_RING], tp_cur, u + HS_PF);
+#pragma unroll
+                for (int mt = 0; mt < HS_MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < HS_NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[u % HS_RING][mt], Bf[u & 1][nt],
+                                                                            u == 0 ? zero16 : acc[mt][nt], 0, 0, 0);
+                // interleave: one load behind each of the first five MFMAs of the unit
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        } else {
+            // any number of units: a runtime loop over groups of four (the ring's period), guards on the tail
+#pragma unroll
+            for (int mt = 0; mt < HS_MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < HS_NT; ++nt) acc[mt][nt] = zero16;
+            for (int u0 = 0; u0 < units; u0 += HS_RING) {
+#pragma unroll
+                for (int j = 0; j < HS_RING; ++j) {
+                    const int u = u0 + j;
+                    if (u < units) {
+                        if (u + 1 < units) load_B(Bf[(j + 1) & 1], u + 1);
+                        if (u + HS_PF < units) load_A(A[(j + HS_PF) % HS_RING], tp_cur, u + HS_PF);
+#pragma unroll
+                        for (int mt = 0; mt < HS_MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < HS_NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[j][mt], Bf[j & 1][nt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- the next item: its first candidate fragments fly under this tile's epilogue
+        const bool more = it + 1 < nitems;
+        int qp_next = qp_cur, ct_next = ct_cur;
+        if (more) item_qp_ct(it + 1, qp_next, ct_next);
+        bool act_next;
+        const char *tp_next = tile_ptr(ct_next, act_next);
+        const bool switching = qp_next != qp_cur;
+#pragma unroll
+        for (int u = 0; u < HS_PF; ++u)
+            if (u < units) load_A(A[u], tp_next, u);
+        if (!switching) load_B(Bf[0], 0);
+
+        // ---- compare epilogue (as lp_split_count_kernel: w = v - a_lo, sign bits -> popcount, band test on the bits)
+        if (act_cur) {
+            const int64_t c0 = (int64_t)ct_cur * (NW * HS_WROWS) + wid * HS_WROWS;
+            int cl_base = 4 * half;
+            asm volatile("" : "+v"(cl_base));
+#pragma unroll
+            for (int nt = 0; nt < HS_NT; ++nt) {
+                float lo_n = alo[nt], hi_n = ahi[nt], p_n = 0.f, z_n = 0.f;
+                const float *xrow = nullptr;
+                if (PM) {
+                    const float4 t4 = pthr[nt * 32 + l31];
+                    p_n = t4.z; z_n = t4.w;
+                    xrow = p.X + (int64_t)prow[nt * 32 + l31] * p.ldx + c0 + 4 * half;
+                }
+                const f32x2 nlo2 = {-lo_n, -lo_n};
+                const float hwf = hi_n - lo_n;
+                const unsigned hwb = hwf >= 0.f ? __float_as_uint(hwf) : 0u;
+                unsigned smask = 0u;
+#pragma unroll
+                for (int mt = 0; mt < HS_MT; ++mt) {
+                    float4 x4[4], y4[4];
+                    if (PM) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            x4[g4] = *reinterpret_cast<const float4 *>(xrow + mt * 32 + 8 * g4);
+                            if (PM == 2) y4[g4] = *reinterpret_cast<const float4 *>(p.yc + c0 + 4 * half + mt * 32 + 8 * g4);
+                        }
+                    }
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        float vq[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vq[e] = acc[mt][nt][g4 * 4 + e];
+                            if (PM) {
+                                const float xe = e == 0 ? x4[g4].x : (e == 1 ? x4[g4].y : (e == 2 ? x4[g4].z : x4[g4].w));
+                                float corr;
+                                if (PM == 1) {
+                                    corr = xe * fmaf(xe, z_n, p_n);
+                                } else {
+                                    const float ye = e == 0 ? y4[g4].x : (e == 1 ? y4[g4].y : (e == 2 ? y4[g4].z : y4[g4].w));
+                                    corr = ye * fmaf(ye, z_n, fmaf(2.0f, xe, p_n));
+                                }
+                                vq[e] = fmaf(corr, -8388608.0f, vq[e]);
+                            }
+                        }
+                        const f32x2 w01 = (f32x2){vq[0], vq[1]} + nlo2, w23 = (f32x2){vq[2], vq[3]} + nlo2;
+                        const unsigned b0 = __float_as_uint(w01.x), b1 = __float_as_uint(w01.y);
+                        const unsigned b2 = __float_as_uint(w23.x), b3 = __float_as_uint(w23.y);
+                        smask = __builtin_amdgcn_alignbit(smask, b0, 31);
+                        smask = __builtin_amdgcn_alignbit(smask, b1, 31);
+                        smask = __builtin_amdgcn_alignbit(smask, b2, 31);
+                        smask = __builtin_amdgcn_alignbit(smask, b3, 31);
+                        const unsigned mq = min(min(min(b0, b1), b2), b3);
+                        if (__ballot(mq <= hwb)) {      // some lane holds an uncertain pair among these 4 rows
+                            const unsigned bb[4] = {b0, b1, b2, b3};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool unc = bb[e] <= hwb;
+                                const unsigned long long m = __ballot(unc);
+                                if (m) {
+                                    if (nlist + 64 > HS_WLIST) flush_list();
+                                    const int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                    if (unc) wlist[pos] = make_int2(qid[nt], (int)(c0 + cl_base + mt * 32 + e + 8 * g4));
+                                    nlist += __popcll(m);
+                                }
+                            }
+                        }
+                    }
+                }
+                cnt[nt] += 32 - __popc(smask);
+            }
+        }
+
+        // ---- query panel change (block-uniform): the only block-wide synchronisation of the sweep
+        if (switching) {
+            flush_counts();
+            __syncthreads();                    // every wave is done reading the old panel
+            cur_q0 = (int64_t)qp_next * HS_TQ;
+            load_panel(cur_q0);
+            __syncthreads();
+            load_B(Bf[0], 0);
+        }
+        qp_cur = qp_next; ct_cur = ct_next; tp_cur = tp_next; act_cur = act_next;
+    }
+    flush_counts();
+    flush_list();
+}
+
+template <int NW, int UNITS, int PM>
+int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
+{
+    auto k = lp_hi_stream_kernel<NW, UNITS, PM>;
+    static int attr_smem = 0;   // per instantiation
+    if (smem > attr_smem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NW, int PM>
+int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
+{
+    if (p.units == 13) return hs_launch<NW, 13, PM>(p, grid, smem, s);
+    if (p.units == 26) return hs_launch<NW, 26, PM>(p, grid, smem, s);
+    return hs_launch<NW, 0, PM>(p, grid, smem, s);
+}
+
+} // namespace
+
+int kge_hi_stream_max_units(void) { return 32; }
+
+// p.units, p.units_p, p.rows_p, p.B, pointers filled by the caller (kge_lp_split_count); this fills the work order
+int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_t s)
+{
+    if (p.units <= 0 || p.units > 32 || p.rows_p % 64 != 0 || p.rows_p < 64) return KGE_EINVAL;
+    const int RS = p.units * 32 + 16;
+    p.panel_bytes = (HS_TQ * RS + 15) / 16 * 16;
+    // two 4-wave workgroups per CU while two panels (+ lists) fit the LDS; else one 8-wave workgroup
+    const int extra = HS_TQ * 20;
+    const int smem4 = p.panel_bytes + 4 * HS_WLIST * 8 + extra, smem8 = p.panel_bytes + 8 * HS_WLIST * 8 + extra;
+    int nw = 2 * smem4 <= 160 * 1024 - 2048 ? 4 : 8;
+    const int force = kge_env_int("KGE_HS_WAVES", 0);
+    if (force == 4 && smem4 <= 160 * 1024) nw = 4;
+    if (force == 8) nw = 8;
+    if (nw == 8 && smem8 > 160 * 1024) return KGE_EUNSUPPORTED;
+    const int tile_rows = nw * HS_WROWS;
+    p.q_panels = (int)((p.q_rows + HS_TQ - 1) / HS_TQ);
+    p.c_tiles = (int)((p.rows_p + tile_rows - 1) / tile_rows);
+    p.n_items = (int64_t)p.q_panels * p.c_tiles;
+    if (p.n_items == 0) return 0;
+    const int per_cu = nw == 4 ? 2 : 1;
+    const int64_t slots = (int64_t)num_cus * per_cu;
+    int grid = (int)(p.n_items < slots ? p.n_items : slots);
+    // panels interleaved under one candidate sweep: the largest power of two (<= 64) dividing the blocks per XCD, so that
+    // a block keeps its panel for a whole sweep; small launches run panel-major
+    p.qg = 1;
+    if (grid >= 8 && p.n_items >= slots) {
+        grid -= grid % 8;
+        const int nbx = grid / 8;
+        while (p.qg < 64 && nbx % (p.qg * 2) == 0) p.qg *= 2;
+        const int cap_qg = kge_env_int("KGE_HS_QG", 64);
+        while (p.qg > cap_qg && p.qg > 1) p.qg /= 2;
+    }
+    const int smem = nw == 4 ? smem4 : smem8;
+    if (nw == 4) {
+        if (pm == 1) return hs_dispatch_units<4, 1>(p, grid, smem, s);
+        if (pm == 2) return hs_dispatch_units<4, 2>(p, grid, smem, s);
+        return hs_dispatch_units<4, 0>(p, grid, smem, s);
+    }
+    if (pm == 1) return hs_dispatch_units<8, 1>(p, grid, smem, s);
+    if (pm == 2) return hs_dispatch_units<8, 2>(p, grid, smem, s);
+    return hs_dispatch_units<8, 0>(p, grid, smem, s);
+}

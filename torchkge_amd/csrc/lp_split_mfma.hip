@@ -236,6 +236,9 @@ struct HiRowsParams {
     float *dn2;               // optional (rows)
     float *dn2max;            // optional device scalar, max folded in
     const int64_t *row_index;
+    int frag;                 // 1: FRAGMENT-MAJOR output [rows_p / 32][units_p][64][16 B] -- chunk (row % 32) + 32 * k-half of
+                              // the 1-KiB block of (32-row group, unit): the A operand of v_mfma_f32_32x32x16_f16 in lane
+                              // order, one coalesced global_load_dwordx4 per block (lp_hi_stream.hip)
 };
 
 __global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
@@ -309,8 +312,13 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
                 }
                 hi.h[e] = h;
             }
-            uint4 *o = p.out + (row * p.units_p + u) * 2;
-            o[0] = hi.v[0]; o[1] = hi.v[1];
+            if (p.frag) {
+                uint4 *o = p.out + (((row >> 5) * p.units_p + u) << 6) + (row & 31);
+                o[0] = hi.v[0]; o[32] = hi.v[1];
+            } else {
+                uint4 *o = p.out + (row * p.units_p + u) * 2;
+                o[0] = hi.v[0]; o[1] = hi.v[1];
+            }
         }
         dn += __shfl_xor(dn, 8, 64);    // the 16 lanes of a row sit in one aligned group of the wavefront
         dn += __shfl_xor(dn, 4, 64);
@@ -1513,10 +1521,10 @@ extern "C" int kge_lp_split_rows(const float *X0, int64_t ld0, int K0, const flo
 /* units of a PLANAR hi operand (one-product level): k16 units of K + 2 columns, rounded up to 4 (one 128-byte stage) */
 extern "C" int kge_lp_hi_units(int K) { return (int)round_up((K + 2 + 15) / 16, 4); }
 
-extern "C" int kge_lp_hi_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
-                              int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
-                              const float *norm2max1, void *out, float *dn2, float *dn2max, const int64_t *row_index,
-                              kge_stream_t stream)
+static int hi_rows_impl(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                        int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
+                        const float *norm2max1, void *out, float *dn2, float *dn2max, const int64_t *row_index,
+                        int frag, kge_stream_t stream)
 {
     if (rows < 0 || K0 <= 0 || K1 < 0 || ld0 < K0 || (K1 > 0 && ld1 < K1) || aug_mode < 1 || aug_mode > 4) return KGE_EINVAL;
     if (rows == 0 && is_query) return 0;
@@ -1531,11 +1539,36 @@ extern "C" int kge_lp_hi_rows(const float *X0, int64_t ld0, int K0, const float 
     p.units_p = kge_lp_hi_units(K0 + K1);
     p.out = reinterpret_cast<uint4 *>(out);
     p.dn2 = dn2; p.dn2max = dn2max; p.row_index = row_index;
+    p.frag = frag;
     const int64_t blocks = p.rows_p / 16;
     if (blocks == 0) return 0;
     hipLaunchKernelGGL(hi_rows_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int kge_lp_hi_rows(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                              int is_query, int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
+                              const float *norm2max1, void *out, float *dn2, float *dn2max, const int64_t *row_index,
+                              kge_stream_t stream)
+{
+    return hi_rows_impl(X0, ld0, K0, X1, ld1, K1, rows, is_query, aug_mode, aug, aug_mul, norm2max0, norm2max1, out, dn2,
+                        dn2max, row_index, 0, stream);
+}
+
+/* the CANDIDATE operand of the free-running one-product kernel: same values, fragment-major layout (kge_split_args.es_frag) */
+extern "C" int kge_lp_hi_rows_frag(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                                   int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
+                                   const float *norm2max1, void *out, float *dn2, float *dn2max, kge_stream_t stream)
+{
+    return hi_rows_impl(X0, ld0, K0, X1, ld1, K1, rows, 0, aug_mode, aug, aug_mul, norm2max0, norm2max1, out, dn2, dn2max,
+                        nullptr, 1, stream);
+}
+
+/* 1 if kge_lp_split_count takes a fragment-major candidate table (es_frag = 1) for K columns on the one-product level */
+extern "C" int kge_lp_hi_stream_supported(int K)
+{
+    return (K + 2 + 15) / 16 <= kge_hi_stream_max_units() ? 1 : 0;
 }
 
 extern "C" int kge_lp_split_prefix_max(const float *cell_ss, int64_t rows, int is_query, int units_p, float *e2pref,
@@ -1634,6 +1667,25 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     // are within noise with 4 ahead -> 16 while 16 panels stay below ~3 MiB, else 4.
     p.qg = kge_env_int("KGE_SPLIT_QG", (int64_t)TQ * p.row_bytes * 16 <= (3 << 20) ? 16 : 4);
     const int slots = split_num_cus();
+    if (a->es_frag) {
+        // the free-running one-product kernel (lp_hi_stream.hip): fragment-major candidate table, resident query panel
+        if (!lv1 || a->members || a->n_multi_p > 0 || units > kge_hi_stream_max_units()) return KGE_EINVAL;
+        kge_hi_stream_params h;
+        h.Ef = reinterpret_cast<const char *>(Es);
+        h.Qh = reinterpret_cast<const char *>(Qs);
+        h.q_row_bytes = p.row_bytes;
+        h.units = units; h.units_p = units_p;
+        h.rows_p = kge_lp_split_rows_padded(d->N, 0);
+        h.q_rows = a->col_q ? a->n_single_p : Bp;
+        if (a->col_q && (a->n_single_p <= 0 || a->n_single_p % TQ)) return KGE_EINVAL;
+        h.B = d->B;
+        h.thr = p.thr; h.thr4 = p.thr4;
+        h.X = p.X; h.ldx = p.ldx; h.r_idx = p.r_idx; h.yc = p.yc;
+        h.raw_count = raw_count; h.list = list; h.cap = cap; h.list_count = list_count; h.overflow = overflow;
+        h.col_q = a->col_q;
+        const int pm = d->mode == KGE_LP_L2_PROJH ? 1 : (d->mode == KGE_LP_L2_PROJD ? 2 : 0);
+        return kge_hi_stream_launch(h, pm, slots, s);
+    }
     if (a->col_q || a->members) {
         // Columns instead of queries: Qs holds n_single_p rows that carry one query each (col_q), then n_multi_p rows
         // that carry up to GSETS queries of one key each (members); both counts multiples of the query panel.

@@ -453,8 +453,10 @@ class LinkPredictionEvaluator(object):
         lvl1 = hasattr(self.model, '_use_level1') and self.model._use_level1()      # (the policy's choice, or a forced level)
         # (one-product level: the matrix work a shared row saves is a third of what it was, the grouped columns' multi-pass
         # epilogue costs what it always did -- models say whether columns still pay there: lp_dedupe_level1)
-        if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and \
-                ((DEDUPE_LEVEL1 and getattr(self.model, 'lp_dedupe_level1', True)) or not lvl1):
+        # (... and the free-running one-product kernel sweeps per query: no columns there)
+        lvl1_cols = DEDUPE_LEVEL1 and getattr(self.model, 'lp_dedupe_level1', True) and \
+            not (hasattr(self.model, '_level1_stream') and self.model._level1_stream())
+        if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and (lvl1_cols or not lvl1):
             xkw['cols'] = plan.cols     # (entity shards too: the columns are a property of the queries, not of the candidates)
         prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
         if by_scores:

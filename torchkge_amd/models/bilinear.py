@@ -100,6 +100,9 @@ class ComplExModel(BilinearModel):
     def _d_rel(self):
         return self.emb_dim
 
+    def _lp_width(self):
+        return 2 * self.emb_dim
+
     def normalize_parameters(self):
         """No normalisation for ComplEx (bilinear.py:475-480)."""
         pass

@@ -316,6 +316,17 @@ class Model(Module):
     split_level = 'auto'
     _split_level = 0        # what the running evaluation uses (set by the evaluator)
 
+    # the one-product level on the FREE-RUNNING count kernel (lp_hi_stream.hip: fragment-major candidate table, resident
+    # query panel, no block-wide barriers) wherever it handles the GEMM's width; it sweeps per query (no query columns)
+    lp_hi_stream = True
+
+    def _lp_width(self):
+        """Columns of the all-candidates GEMM (ComplEx: 2 d)."""
+        return self._d_rel
+
+    def _level1_stream(self):
+        return bool(self.lp_hi_stream) and _hip.hi_stream_ok(self._lp_width())
+
     def _use_level1(self):
         lv = self.split_level
         want = self._split_level == 1 if lv == 'auto' else int(lv) == 1
@@ -346,9 +357,11 @@ class Model(Module):
         nm1 = g[5:6] if T1 is not None else None
         if self._use_level1() and c_base == 0 and T0.shape[0] == self.n_ent:
             # one-product level (see TransEModel._fused_query_problem): planar hi table + its residual maximum
-            Eh, de2 = self._cache.get('ehd_' + key, srcs, lambda: _hip.hi_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=nm1))
+            frag = self._level1_stream()
+            Eh, de2 = self._cache.get('ehd%d_' % frag + key, srcs,
+                                      lambda: _hip.hi_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=nm1, frag=frag))
             prob.split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'level': 1,
-                          'de2max': de2, 'list_stat': g[6:7]}
+                          'de2max': de2, 'list_stat': g[6:7], 'es_frag': frag}
             return prob
         Es, e2 = self._cache.get('esd_' + key, srcs, lambda: _hip.split_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=nm1))
         prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'list_stat': g[6:7]}
@@ -499,8 +512,9 @@ class TranslationModel(Model):
         prob.split = {'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': g[3:4], 'yabsmax': g[4:5] if yc is not None else None,
                       'list_stat': g[6:7]}
         if self._use_level1():      # one-product level (see TransEModel._fused_query_problem)
-            Eh, de2 = self._cache.get('eh_' + key, [table], lambda: _hip.hi_table(table, K=Kq, aug=en))
-            prob.split.update({'Es': Eh, 'e2pref': None, 'level': 1, 'de2max': de2})
+            frag = self._level1_stream() and prob.desc.c_base == 0 and table.shape[0] == self.n_ent
+            Eh, de2 = self._cache.get('eh%d_' % frag + key, [table], lambda: _hip.hi_table(table, K=Kq, aug=en, frag=frag))
+            prob.split.update({'Es': Eh, 'e2pref': None, 'level': 1, 'de2max': de2, 'es_frag': frag})
         else:
             Es, e2 = self._cache.get('es_' + key, [table], lambda: _hip.split_table(table, K=Kq, aug=en))
             prob.split.update({'Es': Es, 'e2pref': e2})

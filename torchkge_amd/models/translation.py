@@ -125,11 +125,12 @@ class TransEModel(TranslationModel):
         if self._use_level1():
             # one-product level of the split prefilter (a fitted model: the true entities sit in the sparse upper tail,
             # the 8x wider band still holds few pairs): planar hi table, thresholds from the measured f16 residuals
-            Eh, de2 = self._cache.get('eh_' + key, [E], lambda: _hip.hi_table(E, aug=en))
+            frag = self._level1_stream() and (cols is None or cols.n_multi_p == 0)
+            Eh, de2 = self._cache.get('eh%d_' % frag + key, [E], lambda: _hip.hi_table(E, aug=en, frag=frag))
             pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], cols=cols, level=1,
                                          de2max=de2)
             split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'overflow': g[2:3], 'level': 1, 'de2max': de2,
-                     'list_stat': g[6:7]}
+                     'list_stat': g[6:7], 'es_frag': frag}
         else:
             Es, e2 = self._cache.get('es_' + key, [E], lambda: _hip.split_table(E, aug=en))
             pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2, cols=cols)
