@@ -508,6 +508,9 @@ typedef struct kge_split_args {
      * thresholds, same counts, same list.  Qs stays the planar operand.  Columns: col_q only (members must be NULL).
      * K must satisfy kge_lp_hi_stream_supported(K). */
     int32_t es_frag;
+    /* es_frag = 1, optional: true_idx[i] = GLOBAL id of the entity whose exact score IS s_true[i] (the evaluator's true
+     * entity).  That pair is counted and can never be taken back by the recheck, so the sweep does not list it. */
+    const int64_t *true_idx;
 } kge_split_args;
 int kge_lp_split_group_sets(void);
 
@@ -549,6 +552,12 @@ int kge_lp_hi_rows_frag(const float *X0, int64_t ld0, int K0, const float *X1, i
                         int aug_mode, const float *aug, float aug_mul, const float *norm2max0,
                         const float *norm2max1, void *out, float *dn2, float *dn2max, kge_stream_t stream);
 int kge_lp_hi_stream_supported(int K);
+/* Candidate-table preparation of the L2 one-product sweep in ONE pass over the table: en[row] = ||X[row]||^2 by
+ * kge_row_sqnorm's sequential chain (same bits), *en_max_io = max(*en_max_io, max en), out = the fragment-major hi table
+ * of kge_lp_hi_rows_frag(aug_mode 1, aug = en, aug_mul = -0.5), *dn2max_io = max(*dn2max_io, max_row ||x - hi(x)||^2).
+ * KGE_EUNSUPPORTED unless K % 4 == 0, ld % 4 == 0 and X is 16-byte aligned (then: the separate entry points). */
+int kge_lp_table_prep_l2(const float *X, int64_t ld, int64_t rows, int K, float *en, float *en_max_io, void *out,
+                         float *dn2max_io, kge_stream_t stream);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
 /* 1 if v_mfma_f32_32x32x16_f16 on the current device accumulates as the tighter error model assumes (two

@@ -1667,3 +1667,23 @@ def test_bound_only_row_norms_match_the_chain_to_rounding(hip, rows, K):
         c = hip.row_sqnorm(Xs, K=K - 1, bound_only=True)
         refs = (Xs.double() ** 2).sum(1)
         assert float(((c.double() - refs).abs() / refs.clamp_min(1e-30)).max()) < 1e-6
+
+
+@pytest.mark.parametrize('N,K', [(14541, 200), (257, 64), (1000, 12), (5, 4), (4097, 400)])
+def test_table_prep_l2_equals_the_separate_kernels(hip, N, K):
+    """kge_lp_table_prep_l2 (r05: norms + fragment-major hi table + residual maximum in one pass) == kge_row_sqnorm (bit for
+    bit: the scores contain en) + kge_lp_hi_rows_frag (byte for byte) + its residual maximum (a bound: equal up to the
+    summation order)."""
+    g = torch.Generator().manual_seed(N + K)
+    E = (torch.nn.functional.normalize(torch.randn(N, K, generator=g), dim=1) * 1.3).cuda()
+    guard = torch.zeros(8, device='cuda')
+    en_ref = hip.row_sqnorm(E, max_io=guard[1:2])
+    Eh_ref, de2_ref = hip.hi_table(E, aug=en_ref, frag=True)
+    g2 = torch.zeros(8, device='cuda')
+    got = hip.table_prep_l2(E, g2[1:2], g2[7:8])
+    assert got is not None
+    en, Eh = got
+    assert torch.equal(en, en_ref) and float(g2[1]) == float(guard[1])
+    assert torch.equal(Eh, Eh_ref)
+    assert abs(float(g2[7]) - float(de2_ref)) <= 3e-4 * float(de2_ref) + 1e-30
+    assert float(g2[7]) >= float(de2_ref) * (1 - 1e-5)

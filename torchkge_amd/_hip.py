@@ -49,7 +49,7 @@ class SplitArgs(ctypes.Structure):
         ('col_q', _vp), ('n_single_p', _i64), ('members', _vp), ('n_multi_p', _i64),
         ('q_cell_ss_index', _vp), ('q_cell_ss_ld', _i64),
         ('level', ctypes.c_int32), ('q_dn2', _vp), ('q_dn2_index', _vp), ('de2max', _vp),
-        ('es_frag', ctypes.c_int32),
+        ('es_frag', ctypes.c_int32), ('true_idx', _vp),
     ]
 
 
@@ -93,6 +93,7 @@ _SIGNATURES = {
                        _vp, _vp],
     'kge_lp_hi_rows_frag': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_hi_stream_supported': [_int],
+    'kge_lp_table_prep_l2': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
@@ -526,6 +527,28 @@ def hi_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1
     return Eh, de2
 
 
+def table_prep_l2(E, emax_io, de2max_io):
+    """Candidate side of the L2 one-product sweep in ONE launch (kge_lp_table_prep_l2): (en, Ef) -- the squared row norms
+    (kge_row_sqnorm's chain, same bits; maximum folded into emax_io) and the fragment-major hi table (residual maximum
+    folded into de2max_io).  None when the table's shape / alignment needs the separate kernels."""
+    lib = load_library()
+    require_cuda(E, emax_io, de2max_io)
+    E = f32c(E)
+    rows, K, ld = E.shape[0], E.shape[1], E.stride(0)
+    if K % 4 or ld % 4 or E.data_ptr() % 16 or rows == 0:
+        return None
+    units_p = int(lib.kge_lp_hi_units(K))
+    rows_p = int(lib.kge_lp_split_rows_padded(rows, 0))
+    en = torch.empty(rows, dtype=torch.float32, device=E.device)
+    out = torch.empty(rows_p * units_p * 32, dtype=torch.uint8, device=E.device)
+    with _on(E.device):
+        rc = int(lib.kge_lp_table_prep_l2(_p(E), ld, rows, K, _p(en), _p(emax_io), _p(out), _p(de2max_io), _stream()))
+    if rc == KGE_EUNSUPPORTED:
+        return None
+    _check(rc, 'kge_lp_table_prep_l2')
+    return en, out
+
+
 def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None, level=0, de2max=None):
     """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
     s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
@@ -696,6 +719,7 @@ class LpProblem(object):
         self.sad = None         # TransE-L1: {'Ei', 'emax', 'rmax', 'overflow'} -> counts via the u16 SAD prefilter
         self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
         self.cols = None        # filter_index.ColumnPlan of a both-sides batch: split count over distinct query rows
+        self.split_true = None  # (s_true tensor, true ids): the thresholds are the exact scores of these pairs (evaluator)
 
     def scores(self, out=None):
         lib = load_library()
@@ -878,6 +902,10 @@ class LpProblem(object):
         a.es_frag = 1 if sp.get('es_frag') else 0
         if a.es_frag:
             assert a.level == 1 and (cols is None or cols.n_multi_p == 0), 'the free-running sweep takes no grouped columns'
+            # s_true IS the exact score of (query, split_true entity): the sweep need not list that pair
+            st_true = getattr(self, 'split_true', None)
+            if st_true is not None and st_true[0] is s_true:
+                a.true_idx = _p(i64c(st_true[1]))
         if a.level == 1:        # one-product level: the band needs the operands' measured f16 residuals
             a.de2max = _p(sp['de2max'])
             a.q_dn2 = _p(prep.get('q_dn2'))

@@ -315,6 +315,8 @@ struct kge_hi_stream_params {
     int32_t *list_count;
     float *overflow;
     const int32_t *col_q;       // optional: column -> query id (< 0: padding)
+    const int64_t *true_idx;    // optional: GLOBAL id of the entity whose exact score is the query's threshold s_true ...
+    int64_t c_base;             // ... local candidate c is global entity c_base + c
     // filled by kge_hi_stream_launch
     int q_panels, c_tiles, qg;  // qg: panels interleaved under one candidate sweep (a power of two dividing the blocks per XCD)
     int64_t n_items;

@@ -33,10 +33,13 @@ namespace {
 constexpr int HS_TQ = 96;                       // queries per panel (MFMA columns = lanes, 3 tiles of 32)
 constexpr int HS_NT = 3, HS_MT = 2;
 constexpr int HS_WROWS = 64;                    // candidate rows per wave
-constexpr int HS_WLIST = 256;                   // uncertain pairs buffered per wave (int2 entries)
+constexpr int HS_WLIST = 384;                   // uncertain pairs buffered per wave (int2 entries)
 constexpr int HS_PF = 3, HS_RING = 4;           // candidate fragments: units in flight / ring slots
 
-template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM>
+// PROBE (timing probes, wrong results; env KGE_HS_PROBE, instantiated for <4, 13, 0> only): 1 no compare epilogue, 2 every
+// wave streams the table's first rows (cache-hot candidates), 4 no query-fragment reads in the K sweep, 8 no candidate loads
+// in the K sweep, 16 no MFMAs
+template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM, int PROBE = 0>
 __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_stream_params p)
 {
     constexpr int NTHREADS = 64 * NW;
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         int g = ct * (NW * 2) + wid * 2;
         active = g + 1 < n_groups32;
         g = min(g, n_groups32 - 2);                                 // (past the table: valid rows, results dropped)
+        if (PROBE & 2) g = wid * 2;
         return p.Ef + g * gstride;
     };
     const unsigned lane16 = lane * 16;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     f16x8 A[HS_RING][HS_MT], Bf[2][HS_NT];
     int cnt[HS_NT] = {0, 0, 0};
     float alo[HS_NT], ahi[HS_NT];
-    int qid[HS_NT];
+    int qid[HS_NT], tru[HS_NT];                                     // query id / its true candidate (local index; -1: none)
     int nlist = 0;                                                  // entries in this wave's LDS list (wave-uniform)
 
     auto flush_list = [&]() __attribute__((always_inline)) {
@@ -149,6 +153,9 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                 else t = p.thr[q];
             }
             alo[nt] = t.x; ahi[nt] = t.y; qid[nt] = (int)q;
+            // the pair (query, its true entity) scores s_true exactly: it is counted (acc >= a_lo) and a re-score could
+            // never take it back -- it need not be listed (a tenth of a fitted model's list)
+            tru[nt] = (p.true_idx && q >= 0) ? (int)(p.true_idx[q] - p.c_base) : -1;
         }
     };
     auto flush_counts = [&]() __attribute__((always_inline)) {
@@ -195,8 +202,22 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         if constexpr (UNITS != 0) {
 #pragma unroll
             for (int u = 0; u < UNITS; ++u) {
-                if (u + 1 < UNITS) load_B(Bf[(u + 1) & 1], u + 1);
-                if (u + HS_PF < UNITS) load_A(A[(u + HS_PF) % HS_RING], tp_cur, u + HS_PF);
+                if (u + 1 < UNITS && !(PROBE & 4)) load_B(Bf[(u + 1) & 1], u + 1);
+                if (u + HS_PF < UNITS && !(PROBE & 8)) load_A(A[(u + HS_PF) % HS_RING], tp_cur, u + HS_PF);
+                if (PROBE & 16) {
+                    if (u == 0) {
+#pragma unroll
+                        for (int mt = 0; mt < HS_MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < HS_NT; ++nt) acc[mt][nt] = zero16;
+                    }
+                    // (keep the loads alive)
+#pragma unroll
+                    for (int mt = 0; mt < HS_MT; ++mt) acc[mt][0][0] += (float)A[u % HS_RING][mt][0];
+#pragma unroll
+                    for (int nt = 0; nt < HS_NT; ++nt) acc[0][nt][1] += (float)Bf[u & 1][nt][0];
+                    continue;
+                }
 #pragma unroll
                 for (int mt = 0; mt < HS_MT; ++mt)
 #pragma unroll
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         if (!switching) load_B(Bf[0], 0);
 
         // ---- compare epilogue (as lp_split_count_kernel: w = v - a_lo, sign bits -> popcount, band test on the bits)
-        if (act_cur) {
+        if (act_cur && !(PROBE & 1)) {
             const int64_t c0 = (int64_t)ct_cur * (NW * HS_WROWS) + wid * HS_WROWS;
             int cl_base = 4 * half;
             asm volatile("" : "+v"(cl_base));
@@ -271,16 +292,18 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                 unsigned smask = 0u;
 #pragma unroll
                 for (int mt = 0; mt < HS_MT; ++mt) {
+#pragma unroll
+                    for (int gh = 0; gh < 2; ++gh) {       // (the projection gathers two quads at a time: register budget)
                     float4 x4[4], y4[4];
                     if (PM) {
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
+                        for (int g4 = 2 * gh; g4 < 2 * gh + 2; ++g4) {
                             x4[g4] = *reinterpret_cast<const float4 *>(xrow + mt * 32 + 8 * g4);
                             if (PM == 2) y4[g4] = *reinterpret_cast<const float4 *>(p.yc + c0 + 4 * half + mt * 32 + 8 * g4);
                         }
                     }
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
+                    for (int g4 = 2 * gh; g4 < 2 * gh + 2; ++g4) {
                         float vq[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -306,25 +329,42 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                         smask = __builtin_amdgcn_alignbit(smask, b3, 31);
                         const unsigned mq = min(min(min(b0, b1), b2), b3);
                         if (__ballot(mq <= hwb)) {      // some lane holds an uncertain pair among these 4 rows
+                            // (kept SMALL: this block is unrolled 24 times; capacity is checked once per tile below --
+                            // an entry past the buffer raises the overflow flag, like UNC_CAP of lp_split_count_kernel)
                             const unsigned bb[4] = {b0, b1, b2, b3};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const bool unc = bb[e] <= hwb;
+                                const int cand = (int)c0 + cl_base + mt * 32 + e + 8 * g4;
+                                const bool unc = bb[e] <= hwb && cand != tru[nt];
                                 const unsigned long long m = __ballot(unc);
                                 if (m) {
-                                    if (nlist + 64 > HS_WLIST) flush_list();
                                     const int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                    if (unc) wlist[pos] = make_int2(qid[nt], (int)(c0 + cl_base + mt * 32 + e + 8 * g4));
+                                    if (unc && pos < HS_WLIST) wlist[pos] = make_int2(qid[nt], cand);
                                     nlist += __popcll(m);
                                 }
                             }
                         }
                     }
+                    }
                 }
                 cnt[nt] += 32 - __popc(smask);
             }
         }
+
+        if (PROBE & 1) {        // (probe: the accumulators stay alive through one add each)
+#pragma unroll
+            for (int mt = 0; mt < HS_MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < HS_NT; ++nt) cnt[nt] += __float_as_int(acc[mt][nt][5]) & 1;
+        }
+        // the list buffer: a tile that outran it raises the overflow flag (the caller redoes the count on the next level down);
+        // flushed while >= 2/3 of it is free for the next tile (a density of 4 % of the tile's pairs: UNC_CAP's)
+        if (nlist > HS_WLIST) {
+            if (lane == 0) *p.overflow = 1.0f;
+            nlist = HS_WLIST;
+        }
+        if (nlist >= HS_WLIST / 3) flush_list();
 
         // ---- query panel change (block-uniform): the only block-wide synchronisation of the sweep
         if (switching) {
@@ -341,10 +381,10 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     flush_list();
 }
 
-template <int NW, int UNITS, int PM>
+template <int NW, int UNITS, int PM, int PROBE = 0>
 int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 {
-    auto k = lp_hi_stream_kernel<NW, UNITS, PM>;
+    auto k = lp_hi_stream_kernel<NW, UNITS, PM, PROBE>;
     static int attr_smem = 0;   // per instantiation
     if (smem > attr_smem) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -359,6 +399,19 @@ int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 template <int NW, int PM>
 int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 {
+    if (NW == 4 && PM == 0 && p.units == 13) {
+        switch (kge_env_int("KGE_HS_PROBE", 0)) {
+        case 1: return hs_launch<4, 13, 0, 1>(p, grid, smem, s);
+        case 2: return hs_launch<4, 13, 0, 2>(p, grid, smem, s);
+        case 4: return hs_launch<4, 13, 0, 4>(p, grid, smem, s);
+        case 8: return hs_launch<4, 13, 0, 8>(p, grid, smem, s);
+        case 12: return hs_launch<4, 13, 0, 12>(p, grid, smem, s);
+        case 13: return hs_launch<4, 13, 0, 13>(p, grid, smem, s);
+        case 16: return hs_launch<4, 13, 0, 16>(p, grid, smem, s);
+        case 17: return hs_launch<4, 13, 0, 17>(p, grid, smem, s);
+        default: break;
+        }
+    }
     if (p.units == 13) return hs_launch<NW, 13, PM>(p, grid, smem, s);
     if (p.units == 26) return hs_launch<NW, 26, PM>(p, grid, smem, s);
     return hs_launch<NW, 0, PM>(p, grid, smem, s);

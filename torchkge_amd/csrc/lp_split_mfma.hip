@@ -337,6 +337,137 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
     }
 }
 
+// ---- candidate-table preparation of the L2 one-product sweep in ONE pass (r05) -----------------------------------
+// What kge_row_sqnorm (en, its maximum) + a zero-fill + kge_lp_hi_rows_frag (hi table, residual maximum) do in three
+// launches with the table read twice: a 256-thread block stages 16 rows in LDS; lanes 0..15 run the rows' sequential
+// ||e||^2 chains (row_sqnorm_kernel's: acc = fmaf(x_k, x_k, acc), k ascending -- the score contains en, same bits)
+// while all threads convert the data units to f16 hi parts (thread = row + 16 * unit: a unit's 16 rows are one 256-byte
+// run of the fragment-major table) and sum their residuals; the two augmentation columns follow once en is known.
+struct TablePrepParams {
+    const float *X;
+    int64_t ld, rows, rows_p;
+    int K, units_p;
+    float *en;                // (rows)
+    float *en_max;            // device scalar, max folded in
+    uint4 *out;               // fragment-major hi table
+    float *dn2max;            // device scalar, max folded in
+};
+
+__global__ __launch_bounds__(256) void table_prep_l2_kernel(const TablePrepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float tp_smem[];
+    const int K = p.K, LDS_LD = ((K + 3) & ~3) + 4;         // (row stride: 16-byte aligned, 4 floats of padding)
+    float *xs = tp_smem;                                    // [16][LDS_LD]
+    float *dnp = xs + 16 * LDS_LD;                          // [16][17] partial residual sums
+    float *ens = dnp + 16 * 17;                             // [16]
+    __shared__ unsigned bmax[2];
+    const int tid = threadIdx.x, r = tid & 15, uu = tid >> 4;
+    const float scale = (float)(1 << SPLIT_SCALE_LOG2);
+    const float inv2 = 1.0f / (scale * scale);
+    const int units_d = (K + 15) >> 4;                      // units that hold data columns
+    float emax_b = 0.f, dmax_b = 0.f;
+    for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < p.rows_p; r0 += (int64_t)gridDim.x * 16) {
+        // stage the 16 rows (rows past the table: zeros)
+        const int nv = K >> 2;                              // float4 per row (K % 4 == 0, checked by the host)
+        for (int idx = tid; idx < 16 * nv; idx += 256) {
+            const int rr = idx / nv, c = idx - rr * nv;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + rr < p.rows) v = *reinterpret_cast<const float4 *>(p.X + (r0 + rr) * p.ld + c * 4);
+            *reinterpret_cast<float4 *>(xs + rr * LDS_LD + c * 4) = v;
+        }
+        __syncthreads();
+        const int64_t row = r0 + r;
+        const bool real = row < p.rows;
+        if (tid < 16) {                                     // the sequential chain of ||e||^2
+            const float *x = xs + r * LDS_LD;
+            float acc = 0.f;
+            for (int k = 0; k < K; k += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(x + k);
+                acc = fmaf(t.x, t.x, acc);
+                acc = fmaf(t.y, t.y, acc);
+                acc = fmaf(t.z, t.z, acc);
+                acc = fmaf(t.w, t.w, acc);
+            }
+            ens[r] = acc;
+            if (real) {
+                p.en[row] = acc;
+                emax_b = __uint_as_float(max(__float_as_uint(emax_b), __float_as_uint(acc)));
+            }
+        }
+        // data units: hi parts + residuals (the units holding an augmentation column are finished below)
+        float dn = 0.f;
+        for (int u = uu; u < p.units_p; u += 16) {
+            const int k0 = u * 16;
+            if (k0 + 16 <= K) {
+                union { _Float16 h[16]; uint4 v[2]; } hi;
+                const float *x = xs + r * LDS_LD + k0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float xsj = x[e] * scale;
+                    const _Float16 h = (_Float16)xsj;
+                    const float d = xsj - (float)h;
+                    dn = fmaf(d, d, dn);
+                    hi.h[e] = h;
+                }
+                uint4 *o = p.out + (((row >> 5) * p.units_p + u) << 6) + (row & 31);
+                o[0] = hi.v[0]; o[32] = hi.v[1];
+            }
+        }
+        dnp[r * 17 + uu] = dn;
+        __syncthreads();
+        // units that straddle / follow K: data tail, the two augmentation columns (hi and lo of -||e||^2/2), zeros
+        for (int u = (K >> 4) + uu; u < p.units_p; u += 16) {
+            const int k0 = u * 16;
+            union { _Float16 h[16]; uint4 v[2]; } hi;
+            float dt = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + e;
+                float a = 0.f;
+                if (k < K) {
+                    a = xs[r * LDS_LD + k] * scale;
+                    const float d = a - (float)(_Float16)a;
+                    dt = fmaf(d, d, dt);
+                } else if (k == K || k == K + 1) {
+                    if (real) {
+                        const float full = ens[r] * -0.5f * scale;
+                        const _Float16 fh = (_Float16)full;
+                        a = k == K ? (float)fh : (float)(_Float16)(full - (float)fh);
+                    } else {
+                        a = -65504.f;                       // padding candidate: can never count
+                    }
+                }
+                hi.h[e] = (_Float16)a;
+            }
+            if (u == (K >> 4)) dnp[r * 17 + 16] = dt;           // (the one unit that may hold a data tail; always present)
+            uint4 *o = p.out + (((row >> 5) * p.units_p + u) << 6) + (row & 31);
+            o[0] = hi.v[0]; o[32] = hi.v[1];
+        }
+        __syncthreads();
+        if (tid < 16 && real) {
+            float t = 0.f;
+            for (int j = 0; j < 17; ++j) t += dnp[r * 17 + j];
+            t *= inv2 * 1.0002f;                            // (fp32 summation error, any order: K * 2^-24 relative)
+            dmax_b = fmaxf(dmax_b, t);
+        }
+        __syncthreads();
+    }
+    // one atomic per block for each maximum
+    if (tid < 64) {
+        unsigned m0 = __float_as_uint(emax_b), m1 = __float_as_uint(dmax_b);
+        for (int off = 8; off > 0; off >>= 1) {
+            m0 = max(m0, (unsigned)__shfl_xor((int)m0, off, 64));
+            m1 = max(m1, (unsigned)__shfl_xor((int)m1, off, 64));
+        }
+        if (tid == 0) { bmax[0] = m0; bmax[1] = m1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (p.en_max) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.en_max), bmax[0]);
+        if (p.dn2max) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.dn2max), bmax[1]);
+    }
+}
+
 // e2pref[u] = max over rows of the squared norm of the row's first (u+1)*16 data columns: with the
 // same prefix norms of a query, || q[:k] || * sqrt(e2pref) bounds every partial sum the MFMA
 // accumulator holds while it works through unit u (Cauchy-Schwarz on the prefix) -- the error band
@@ -1571,6 +1702,36 @@ extern "C" int kge_lp_hi_stream_supported(int K)
     return (K + 2 + 15) / 16 <= kge_hi_stream_max_units() ? 1 : 0;
 }
 
+/* Candidate-table preparation of the L2 one-product sweep in one pass: en[row] = ||X[row]||^2 by kge_row_sqnorm's
+ * sequential chain (same bits), *en_max_io = max(., max en), the fragment-major hi table of kge_lp_hi_rows_frag(aug_mode 1,
+ * aug = en, aug_mul = -0.5) and *dn2max_io = max(., max_row ||x - hi(x)||^2) -- one launch, the table read once.
+ * K % 4 == 0, ld % 4 == 0, X 16-byte aligned (else KGE_EUNSUPPORTED: use the separate entry points). */
+extern "C" int kge_lp_table_prep_l2(const float *X, int64_t ld, int64_t rows, int K, float *en, float *en_max_io,
+                                    void *out, float *dn2max_io, kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!X || !en || !out) return KGE_EINVAL;
+    if (K % 4 != 0 || ld % 4 != 0 || !kge_aligned16(X) || K > 8192) return KGE_EUNSUPPORTED;
+    TablePrepParams p;
+    p.X = X; p.ld = ld; p.rows = rows; p.rows_p = kge_lp_split_rows_padded(rows, 0);
+    p.K = K; p.units_p = kge_lp_hi_units(K);
+    p.en = en; p.en_max = en_max_io; p.out = reinterpret_cast<uint4 *>(out); p.dn2max = dn2max_io;
+    const int lds_ld = ((K + 3) & ~3) + 4;
+    const int smem = (16 * lds_ld + 16 * 17 + 16) * 4;
+    const int64_t blocks = p.rows_p / 16;
+    auto k = table_prep_l2_kernel;
+    static int attr_smem = 0;
+    if (smem > 48 * 1024 && smem > attr_smem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL(k, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), smem, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_lp_split_prefix_max(const float *cell_ss, int64_t rows, int is_query, int units_p, float *e2pref,
                                        kge_stream_t stream)
 {
@@ -1683,6 +1844,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
         h.X = p.X; h.ldx = p.ldx; h.r_idx = p.r_idx; h.yc = p.yc;
         h.raw_count = raw_count; h.list = list; h.cap = cap; h.list_count = list_count; h.overflow = overflow;
         h.col_q = a->col_q;
+        h.true_idx = a->true_idx; h.c_base = d->c_base;
         const int pm = d->mode == KGE_LP_L2_PROJH ? 1 : (d->mode == KGE_LP_L2_PROJD ? 2 : 0);
         return kge_hi_stream_launch(h, pm, slots, s);
     }

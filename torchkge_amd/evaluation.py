@@ -106,7 +106,10 @@ class HipRankEngine(object):
     def true_scores(prob, true_idx):
         if prob.pre is not None and prob.pre.get('true_idx') is None:
             prob.pre['true_idx'] = true_idx     # both-sides batch: the fused query pipeline scored exactly these pairs
-        return prob.pair_scores(true_idx)
+        st = prob.pair_scores(true_idx)
+        if hasattr(prob, 'split_true'):
+            prob.split_true = (st, true_idx)    # (the count sweep need not list the pairs whose score IS the threshold)
+        return st
 
     uses_plans = True       # per-batch FilterPlan (segments + grouping), built once per evaluator
 
@@ -339,14 +342,17 @@ class LinkPredictionEvaluator(object):
             # free; re-decided only when the memory now free would shrink the batch by 2x or more.
             # (Sharded evaluators keep the rank-independent formula: every rank must cut the same batches.)
             try:
-                dev = getattr(self, '_dev', None) or next(self.model.parameters()).device
-                free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                k_q = 2 * int(getattr(self.model, 'emb_dim', 0) or 0) + 64
-                now = max(1, int((free // 4) // (16 * per_query + 2 * 4 * 4 * k_q)))
-                now = 1 << (now.bit_length() - 1)
                 kept = getattr(self, '_mem_fit', None)
-                if kept is None or now * 2 <= kept:
-                    self._mem_fit = kept = now
+                # (hipMemGetInfo + the allocator's statistics cost ~30 us of host time with the GPU idle in front of a
+                # 0.5 ms step: asked on the first evaluation and every 32nd one after it)
+                if kept is None or self._n_evaluations % 32 == 0:
+                    dev = getattr(self, '_dev', None) or next(self.model.parameters()).device
+                    free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                    k_q = 2 * int(getattr(self.model, 'emb_dim', 0) or 0) + 64
+                    now = max(1, int((free // 4) // (16 * per_query + 2 * 4 * 4 * k_q)))
+                    now = 1 << (now.bit_length() - 1)
+                    if kept is None or now * 2 <= kept:
+                        self._mem_fit = kept = now
                 fit = min(fit, kept)
             except Exception:
                 pass

@@ -121,12 +121,24 @@ class TransEModel(TranslationModel):
         E = _hip.f32c(tabs[0])
         g = self._lp_guard
         key = '0_%d' % E.shape[0]
-        en = self._cache.get('en_' + key, [E], lambda: _hip.row_sqnorm(E, max_io=g[1:2]))
-        if self._use_level1():
+        lvl1 = self._use_level1()
+        frag = lvl1 and self._level1_stream() and (cols is None or cols.n_multi_p == 0)
+        prep = None
+        if frag:
+            # the candidate side of the free-running sweep in ONE launch: ||e||^2 (the reference chain), the fragment-major
+            # hi table and its residual maximum (guard slot 7, zeroed with the guard) -- kge_lp_table_prep_l2
+            prep = self._cache.get('tp_' + key, [E], lambda: _hip.table_prep_l2(E, g[1:2], g[7:8]))
+        if prep is not None:
+            en = self._cache.get('en_' + key, [E], lambda: prep[0])
+        else:
+            en = self._cache.get('en_' + key, [E], lambda: _hip.row_sqnorm(E, max_io=g[1:2]))
+        if lvl1:
             # one-product level of the split prefilter (a fitted model: the true entities sit in the sparse upper tail,
             # the 8x wider band still holds few pairs): planar hi table, thresholds from the measured f16 residuals
-            frag = self._level1_stream() and (cols is None or cols.n_multi_p == 0)
-            Eh, de2 = self._cache.get('eh%d_' % frag + key, [E], lambda: _hip.hi_table(E, aug=en, frag=frag))
+            if prep is not None:
+                Eh, de2 = prep[1], g[7:8]
+            else:
+                Eh, de2 = self._cache.get('eh%d_' % frag + key, [E], lambda: _hip.hi_table(E, aug=en, frag=frag))
             pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], cols=cols, level=1,
                                          de2max=de2)
             split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'overflow': g[2:3], 'level': 1, 'de2max': de2,
