@@ -338,6 +338,48 @@ def full_split_parity(info, tables, kg, kg_test, ev_ranks, device, b=256, tol=2e
                            'oracle.lp_evaluate = reference algorithm on ATen GPU ops, b_size=%d' % b, secs)
 
 
+def _load_reference():
+    """The REAL reference package, staged by oracle/Makefile as the git-ignored oracle/_ref/torchkge (it travels to the GPU
+    box with the snapshot).  None when absent.  Only bench.py's cpu_baseline leg uses it."""
+    ref_root = os.path.join(ROOT, 'oracle', '_ref')
+    if not os.path.isdir(os.path.join(ref_root, 'torchkge')):
+        return None
+    if ref_root not in sys.path:
+        sys.path.insert(0, ref_root)
+    try:
+        import torchkge            # noqa: F401  (the reference; this repo's package is torchkge_amd)
+        return torchkge
+    except Exception:
+        return None
+
+
+def reference_evaluator(ref, kind, p, tables, n_ent, n_rel, heads, tails, rels, dict_of_heads, dict_of_tails):
+    """torchkge's own model + KnowledgeGraph + LinkPredictionEvaluator (evaluation.py:207-308) on CPU tensors holding
+    `tables`, for the given facts; the filter dictionaries are the full graph's."""
+    from collections import defaultdict
+    d = tables[0].shape[1]
+    if kind == 'transe':
+        m, names = ref.models.TransEModel(d, n_ent, n_rel, dissimilarity_type='L%d' % p), ['ent_emb', 'rel_emb']
+    elif kind == 'distmult':
+        m, names = ref.models.DistMultModel(d, n_ent, n_rel), ['ent_emb', 'rel_emb']
+    elif kind == 'complex':
+        m, names = ref.models.ComplExModel(d, n_ent, n_rel), ['re_ent_emb', 'im_ent_emb', 're_rel_emb', 'im_rel_emb']
+    elif kind == 'transh':
+        m, names = ref.models.TransHModel(d, n_ent, n_rel), ['ent_emb', 'rel_emb', 'norm_vect']
+    elif kind == 'transd':
+        m, names = ref.models.TransDModel(d, tables[1].shape[1], n_ent, n_rel), ['ent_emb', 'rel_emb', 'ent_proj_vect',
+                                                                                 'rel_proj_vect']
+    else:
+        raise ValueError(kind)
+    m.load_state_dict({n + '.weight': t.clone() for n, t in zip(names, tables)}, strict=False)
+    kg_ref = ref.data_structures.KnowledgeGraph(
+        kg={'heads': heads.clone(), 'tails': tails.clone(), 'relations': rels.clone()},
+        ent2ix={i: i for i in range(n_ent)}, rel2ix={i: i for i in range(n_rel)},
+        dict_of_heads=defaultdict(set, dict_of_heads), dict_of_tails=defaultdict(set, dict_of_tails),
+        dict_of_rels=defaultdict(set))
+    return ref.evaluation.LinkPredictionEvaluator(m, kg_ref)
+
+
 def _flush_c_stdio():
     """RCCL writes a banner through C stdio; on a piped stdout it would otherwise surface after the JSON line."""
     try:
@@ -1000,7 +1042,20 @@ def main():
         th, tt_, tr = kg_test.head_idx.cpu(), kg_test.tail_idx.cpu(), kg_test.relations.cpu()
         dh, dtl = kg.dict_of_heads, kg.dict_of_tails
 
+        ref_pkg = _load_reference()
+        # TransH / TransD: the reference's evaluate_projections loops over all N entities in Python and caches an (R, N, d)
+        # tensor (2.76 GB at cfg2's shape) -- timed as part of its evaluate(), as a user would pay it
+        use_ref = ref_pkg is not None
+
         def cpu_run(off, bs, ties=False):
+            if use_ref and not ties:
+                evr = reference_evaluator(ref_pkg, kind, p, tables, n_ent_full, info['n_rel'], th[off:off + bs],
+                                          tt_[off:off + bs], tr[off:off + bs], dh, dtl)
+                c0 = time.perf_counter()
+                with torch.no_grad():
+                    evr.evaluate(b_size=bs, verbose=False)
+                return time.perf_counter() - c0, (evr.rank_true_heads, evr.rank_true_tails, evr.filt_rank_true_heads,
+                                                  evr.filt_rank_true_tails)
             c0 = time.perf_counter()
             o = orc.lp_evaluate(kind, tables, th[off:off + bs], tt_[off:off + bs], tr[off:off + bs], dh, dtl, bs, p,
                                 tie_tol=2e-5 if ties else None)
@@ -1017,12 +1072,20 @@ def main():
         torch.set_num_threads(best_thr)
         sweep, best, off = {}, None, 0
         cpu_r, gpu_r, ties_all = [], [], []
+        ref_vs_port_diff = 0
         for bs in (32, 64, 128, 256):           # the reference is strongly non-monotonic in b
             if off + bs > n_test:
                 break
             if bs > 32:
                 cpu_run(off, bs)                        # untimed first touch of this size's temporaries
-            dt_, (rh, rt, frh, frt, ties) = cpu_run(off, bs, ties=True)
+            if use_ref:
+                # the timed run is the REFERENCE's own evaluate(); its ranks must equal the port's (which also supplies
+                # the tie intervals the GPU ranks are judged by)
+                dt_, (rrh, rrt, rfrh, rfrt) = cpu_run(off, bs)
+                _, (rh, rt, frh, frt, ties) = cpu_run(off, bs, ties=True)
+                ref_vs_port_diff += int((torch.stack([rrh, rrt, rfrh, rfrt]) != torch.stack([rh, rt, frh, frt])).sum())
+            else:
+                dt_, (rh, rt, frh, frt, ties) = cpu_run(off, bs, ties=True)
             sweep[bs] = round(bs * 2 * n_ent_full / dt_, 1)
             if best is None or sweep[bs] > sweep[best]:
                 best = bs
@@ -1036,11 +1099,16 @@ def main():
         mo = orc.lp_metrics(*cpu_r, 10)
         mg = orc.lp_metrics(*gpu_r, 10)
         cpu = {'value': sweep[best], 'unit': 'triples_scored/s',
-               'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'port',
-               'sample': 'one batch per b_size in {32,64,128,256} (%d of %d test triples; each size run twice, the second timed), '
-                         'oracle.lp_evaluate = the reference algorithm on torch CPU ops (no autograd graph: measured 1.27x '
-                         'faster than the real reference in the build container, BASELINE.md); value = the best b_size (%d) '
-                         'at the best thread count (%d)' % (off, n_test, best, best_thr),
+               'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'reference' if use_ref else 'port',
+               'sample': ('one batch per b_size in {32,64,128,256} (%d of %d test triples; each size run twice, the second timed), '
+                          % (off, n_test)) +
+                         ('torchkge %s itself (staged from /root/reference as oracle/_ref by oracle/Makefile): its models, '
+                          'KnowledgeGraph and LinkPredictionEvaluator.evaluate on CPU tensors with this run\'s tables; '
+                          % getattr(ref_pkg, '__version__', '?') if use_ref else
+                          'oracle.lp_evaluate = the reference algorithm on torch CPU ops (oracle/_ref absent: no autograd graph, '
+                          'measured 1.27x faster than the real reference in the build container, BASELINE.md); ') +
+                         'value = the best b_size (%d) at the best thread count (%d)' % (best, best_thr),
+               'reference_ranks_differing_from_port': ref_vs_port_diff if use_ref else None,
                'b_size_sweep': sweep, 'thread_sweep_b32': thread_sweep,
                'ranks_equal_to_gpu': n_diff == 0, 'ranks_differing': n_diff, 'ranks_compared': int(cpu_r.numel()),
                'gpu_ranks_within_reference_tie_interval_2e-5': in_tie,

@@ -556,8 +556,13 @@ int kge_lp_hi_stream_supported(int K);
  * kge_row_sqnorm's sequential chain (same bits), *en_max_io = max(*en_max_io, max en), out = the fragment-major hi table
  * of kge_lp_hi_rows_frag(aug_mode 1, aug = en, aug_mul = -0.5), *dn2max_io = max(*dn2max_io, max_row ||x - hi(x)||^2).
  * KGE_EUNSUPPORTED unless K % 4 == 0, ld % 4 == 0 and X is 16-byte aligned (then: the separate entry points). */
+int kge_lp_table_prep_blocks(int64_t rows);
 int kge_lp_table_prep_l2(const float *X, int64_t ld, int64_t rows, int K, float *en, float *en_max_io, void *out,
-                         float *dn2max_io, kge_stream_t stream);
+                         float *dn2max_io,
+                         float *block_max /* optional, 2 * kge_lp_table_prep_blocks(rows) floats: the blocks leave their two
+                                             maxima there INSTEAD of folding them into the scalars (hundreds of same-address
+                                             atomics serialise); pass it on to kge_lp_query_pipeline, which reduces them */,
+                         kge_stream_t stream);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
 /* 1 if v_mfma_f32_32x32x16_f16 on the current device accumulates as the tighter error model assumes (two
@@ -580,7 +585,10 @@ int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const
                           int level /* 1: Qs is the PLANAR hi operand and thr the thresholds of the one-product level */,
                           const float *de2max /* level 1: device scalar >= max_c ||e_c - hi(e_c)||^2 (kge_lp_hi_rows) */,
                           float *q_dn2 /* level 1, optional out: ||q_i - hi(q_i)||^2 per query (kge_split_args.q_dn2) */,
-                          kge_stream_t stream);
+                          const float *tp_block_max /* optional: the block maxima of kge_lp_table_prep_l2; the kernel then
+                                                       folds them into *emax and *de2max (written through the const
+                                                       pointers) before using the two scalars */,
+                          int tp_blocks, kge_stream_t stream);
 /* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
 int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,

@@ -1687,3 +1687,9 @@ def test_table_prep_l2_equals_the_separate_kernels(hip, N, K):
     assert torch.equal(Eh, Eh_ref)
     assert abs(float(g2[7]) - float(de2_ref)) <= 3e-4 * float(de2_ref) + 1e-30
     assert float(g2[7]) >= float(de2_ref) * (1 - 1e-5)
+    # deferred maxima: per-block values instead of the atomics; their maxima are the two scalars
+    g3 = torch.zeros(8, device='cuda')
+    en3, Eh3, bm = hip.table_prep_l2(E, g3[1:2], g3[7:8], deferred_max=True)
+    assert torch.equal(en3, en_ref) and torch.equal(Eh3, Eh_ref) and float(g3[1]) == 0.0 and float(g3[7]) == 0.0
+    nb = bm.shape[0] // 2
+    assert float(bm[:nb].max()) == float(guard[1]) and float(bm[nb:].max()) == float(g2[7])

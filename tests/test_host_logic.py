@@ -500,3 +500,18 @@ def test_every_profile_file_the_documents_cite_exists():
             if not glob.glob(os.path.join(root, path)) and not glob.glob(os.path.join(root, path + '*')):
                 missing.append((doc, path))
     assert not missing, missing
+
+
+def test_names_the_engine_leaves_out_behave_like_absent_attributes():
+    """the module-level __getattr__ of the package raises an AttributeError subclass -- hasattr / getattr with
+    a default work as for any missing attribute, `from ... import` fails with ImportError, plain access says what to use."""
+    import torchkge_amd as tk
+    import torchkge_amd.utils as tku
+    for mod, name in ((tk, 'RelationInference'), (tk, 'PositionalNegativeSampler'), (tk, 'TripletClassificationEvaluator'),
+                      (tku, 'Trainer'), (tku, 'TrainDataLoader')):
+        assert not hasattr(mod, name) and getattr(mod, name, None) is None
+        with pytest.raises(AttributeError, match='does not provide'):
+            getattr(mod, name)
+    with pytest.raises(ImportError):
+        from torchkge_amd import RelationInference  # noqa: F401
+    assert not hasattr(tk, 'no_such_name')

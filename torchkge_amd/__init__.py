@@ -3,7 +3,7 @@
 hot path, behind torchkge's own Python interfaces.  See DESIGN.md."""
 __version__ = '0.1.0'
 
-from .exceptions import NotYetEvaluatedError
+from .exceptions import NotYetEvaluatedError, NotProvidedError
 from .utils import MarginLoss, LogisticLoss
 from .utils import l1_dissimilarity, l2_dissimilarity
 from .data_structures import KnowledgeGraph, SmallKG
@@ -24,5 +24,5 @@ _NOT_PROVIDED = {
 
 def __getattr__(name):
     if name in _NOT_PROVIDED:
-        raise ImportError('torchkge_amd does not provide torchkge.%s: %s (see INTEGRATION.md)' % (name, _NOT_PROVIDED[name]))
+        raise NotProvidedError('torchkge_amd does not provide torchkge.%s: %s (see INTEGRATION.md)' % (name, _NOT_PROVIDED[name]))
     raise AttributeError('module %r has no attribute %r' % (__name__, name))

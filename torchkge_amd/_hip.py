@@ -93,7 +93,8 @@ _SIGNATURES = {
                        _vp, _vp],
     'kge_lp_hi_rows_frag': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_hi_stream_supported': [_int],
-    'kge_lp_table_prep_l2': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_table_prep_l2': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_table_prep_blocks': [_i64],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
@@ -103,7 +104,7 @@ _SIGNATURES = {
     'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
     'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
-                              _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp],
+                              _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -527,10 +528,12 @@ def hi_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1
     return Eh, de2
 
 
-def table_prep_l2(E, emax_io, de2max_io):
+def table_prep_l2(E, emax_io, de2max_io, deferred_max=False):
     """Candidate side of the L2 one-product sweep in ONE launch (kge_lp_table_prep_l2): (en, Ef) -- the squared row norms
     (kge_row_sqnorm's chain, same bits; maximum folded into emax_io) and the fragment-major hi table (residual maximum
-    folded into de2max_io).  None when the table's shape / alignment needs the separate kernels."""
+    folded into de2max_io).  ``deferred_max``: (en, Ef, block_max) -- the two maxima stay per block (no same-address
+    atomics) until lp_query_pipeline(tp_bmax=block_max) folds them into the scalars.  None when the table's shape /
+    alignment needs the separate kernels."""
     lib = load_library()
     require_cuda(E, emax_io, de2max_io)
     E = f32c(E)
@@ -541,15 +544,16 @@ def table_prep_l2(E, emax_io, de2max_io):
     rows_p = int(lib.kge_lp_split_rows_padded(rows, 0))
     en = torch.empty(rows, dtype=torch.float32, device=E.device)
     out = torch.empty(rows_p * units_p * 32, dtype=torch.uint8, device=E.device)
+    bm = torch.empty(2 * int(lib.kge_lp_table_prep_blocks(rows)), dtype=torch.float32, device=E.device) if deferred_max else None
     with _on(E.device):
-        rc = int(lib.kge_lp_table_prep_l2(_p(E), ld, rows, K, _p(en), _p(emax_io), _p(out), _p(de2max_io), _stream()))
+        rc = int(lib.kge_lp_table_prep_l2(_p(E), ld, rows, K, _p(en), _p(emax_io), _p(out), _p(de2max_io), _p(bm), _stream()))
     if rc == KGE_EUNSUPPORTED:
         return None
     _check(rc, 'kge_lp_table_prep_l2')
-    return en, out
+    return (en, out, bm) if deferred_max else (en, out)
 
 
-def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None, level=0, de2max=None):
+def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None, level=0, de2max=None, tp_bmax=None):
     """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
     s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
     the threshold kernel.  ``cols`` (filter_index.ColumnPlan): the split rows are written per COLUMN
@@ -577,7 +581,8 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
                                          split_accum_model(), SPLIT_EPS_SCALE, _p(out['Q']), _p(out['qn']),
                                          _p(out['s_true']), _p(out['Qs']), _p(out['thr']), _p(out['n_list']),
                                          _p(None if level == 1 else e2pref), _p(None if cols is None else cols.qs_row),
-                                         level, _p(de2max), _p(out.get('q_dn2')), _stream()),
+                                         level, _p(de2max), _p(out.get('q_dn2')), _p(tp_bmax),
+                                         0 if tp_bmax is None else tp_bmax.shape[0] // 2, _stream()),
                'kge_lp_query_pipeline')
     return out
 

@@ -351,6 +351,10 @@ struct TablePrepParams {
     float *en_max;            // device scalar, max folded in
     uint4 *out;               // fragment-major hi table
     float *dn2max;            // device scalar, max folded in
+    float *block_max;         // optional [2][gridDim.x]: the blocks' two maxima as plain stores INSTEAD of the atomics -- ~900
+                              // same-address device-scope atomics per scalar serialise for ~50 us at the end of the kernel
+                              // (measured in situ: 65 against 14 us); the consumer (kge_lp_query_pipeline) reduces them
+    int dbg;                  // env KGE_TP_DBG (timing probes, wrong results): 1 no norm chain, 2 no conversions, 4 no table reads
 };
 
 __global__ __launch_bounds__(256) void table_prep_l2_kernel(const TablePrepParams p)
@@ -372,13 +376,13 @@ __global__ __launch_bounds__(256) void table_prep_l2_kernel(const TablePrepParam
         for (int idx = tid; idx < 16 * nv; idx += 256) {
             const int rr = idx / nv, c = idx - rr * nv;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + rr < p.rows) v = *reinterpret_cast<const float4 *>(p.X + (r0 + rr) * p.ld + c * 4);
+            if (r0 + rr < p.rows && !(p.dbg & 4)) v = *reinterpret_cast<const float4 *>(p.X + (r0 + rr) * p.ld + c * 4);
             *reinterpret_cast<float4 *>(xs + rr * LDS_LD + c * 4) = v;
         }
         __syncthreads();
         const int64_t row = r0 + r;
         const bool real = row < p.rows;
-        if (tid < 16) {                                     // the sequential chain of ||e||^2
+        if (tid < 16 && !(p.dbg & 1)) {                     // the sequential chain of ||e||^2
             const float *x = xs + r * LDS_LD;
             float acc = 0.f;
             for (int k = 0; k < K; k += 4) {
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256) void table_prep_l2_kernel(const TablePrepParam
         float dn = 0.f;
         for (int u = uu; u < p.units_p; u += 16) {
             const int k0 = u * 16;
-            if (k0 + 16 <= K) {
+            if (k0 + 16 <= K && !(p.dbg & 2)) {
                 union { _Float16 h[16]; uint4 v[2]; } hi;
                 const float *x = xs + r * LDS_LD + k0;
 #pragma unroll
@@ -463,8 +467,13 @@ __global__ __launch_bounds__(256) void table_prep_l2_kernel(const TablePrepParam
     }
     __syncthreads();
     if (tid == 0) {
-        if (p.en_max) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.en_max), bmax[0]);
-        if (p.dn2max) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.dn2max), bmax[1]);
+        if (p.block_max) {
+            p.block_max[blockIdx.x] = __uint_as_float(bmax[0]);
+            p.block_max[gridDim.x + blockIdx.x] = __uint_as_float(bmax[1]);
+        } else {
+            if (p.en_max) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.en_max), bmax[0]);
+            if (p.dn2max) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.dn2max), bmax[1]);
+        }
     }
 }
 
@@ -769,6 +778,9 @@ struct QueryPipeParams {
     const float *de2max;            // level 1: device scalar >= max_c ||e_c - hi(e_c)||^2
     float *q_dn2;                   // level 1, optional: ||q_i - hi(q_i)||^2 per query (for a later kge_lp_split_count
                                     // that recomputes the thresholds: thr_ready = 0)
+    const float *tp_bmax;           // optional [2][tp_blocks]: the block maxima kge_lp_table_prep_l2 left instead of its atomics:
+    int tp_blocks;                  // every block reduces them (emax, de2max), block 0 stores the two scalars
+    float *emax_out, *de2max_out;
 };
 
 template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
@@ -786,7 +798,31 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
     float *qs = qs_all + wv * QPW * LD, *ts = ts_all + wv * QPW * LD;
     const int d = p.d, kpad = p.units_p * 16;
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
-    const float em = *p.emax;
+    float em, de2m = 0.f;
+    if (p.tp_bmax) {        // the table preparation's block maxima -> the two scalars (values >= 0: ordered like their bits)
+        __shared__ unsigned red[8];
+        unsigned m0 = 0u, m1 = 0u;
+        for (int j = threadIdx.x; j < p.tp_blocks; j += 256) {
+            m0 = max(m0, __float_as_uint(p.tp_bmax[j]));
+            m1 = max(m1, __float_as_uint(p.tp_bmax[p.tp_blocks + j]));
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 = max(m0, (unsigned)__shfl_xor((int)m0, off, 64));
+            m1 = max(m1, (unsigned)__shfl_xor((int)m1, off, 64));
+        }
+        if (lane == 0) { red[wv] = m0; red[4 + wv] = m1; }
+        __syncthreads();
+        m0 = max(max(red[0], red[1]), max(red[2], red[3]));
+        m1 = max(max(red[4], red[5]), max(red[6], red[7]));
+        // (folded into what the scalars already hold -- the guard vector is zeroed per evaluation, other shards may add)
+        em = __uint_as_float(max(m0, __float_as_uint(*p.emax)));
+        de2m = __uint_as_float(max(m1, p.de2max ? __float_as_uint(*p.de2max) : 0u));
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *p.emax_out = em; if (p.de2max_out) *p.de2max_out = de2m; }
+    } else {
+        em = *p.emax;
+        if (p.level == 1) de2m = *p.de2max;
+    }
     float qbig = 0.f;
     const int64_t ngroups = (p.Bp + QPW - 1) / QPW;
     for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
@@ -941,7 +977,7 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                     const float inv2 = 1.0f / ((float)(1 << SPLIT_SCALE_LOG2) * (float)(1 << SPLIT_SCALE_LOG2));
                     const float dq2 = dn * inv2 * 1.0001f;
                     if (p.q_dn2) p.q_dn2[i] = dq2;
-                    p.thr[i] = split_thr_l2_hi(qn, st, em, d, p.units, p.c_acc, p.eps_scale, dq2, *p.de2max);
+                    p.thr[i] = split_thr_l2_hi(qn, st, em, d, p.units, p.c_acc, p.eps_scale, dq2, de2m);
                 } else {
                     p.thr[i] = split_thr_l2(qn, st, em, d, p.units, p.c_acc, p.eps_scale, amag);
                 }
@@ -1706,8 +1742,14 @@ extern "C" int kge_lp_hi_stream_supported(int K)
  * sequential chain (same bits), *en_max_io = max(., max en), the fragment-major hi table of kge_lp_hi_rows_frag(aug_mode 1,
  * aug = en, aug_mul = -0.5) and *dn2max_io = max(., max_row ||x - hi(x)||^2) -- one launch, the table read once.
  * K % 4 == 0, ld % 4 == 0, X 16-byte aligned (else KGE_EUNSUPPORTED: use the separate entry points). */
+extern "C" int kge_lp_table_prep_blocks(int64_t rows)
+{
+    const int64_t blocks = kge_lp_split_rows_padded(rows, 0) / 16;
+    return (int)(blocks < 65536 ? blocks : 65536);
+}
+
 extern "C" int kge_lp_table_prep_l2(const float *X, int64_t ld, int64_t rows, int K, float *en, float *en_max_io,
-                                    void *out, float *dn2max_io, kge_stream_t stream)
+                                    void *out, float *dn2max_io, float *block_max, kge_stream_t stream)
 {
     if (rows < 0 || K <= 0 || ld < K) return KGE_EINVAL;
     if (rows == 0) return 0;
@@ -1717,6 +1759,8 @@ extern "C" int kge_lp_table_prep_l2(const float *X, int64_t ld, int64_t rows, in
     p.X = X; p.ld = ld; p.rows = rows; p.rows_p = kge_lp_split_rows_padded(rows, 0);
     p.K = K; p.units_p = kge_lp_hi_units(K);
     p.en = en; p.en_max = en_max_io; p.out = reinterpret_cast<uint4 *>(out); p.dn2max = dn2max_io;
+    p.block_max = block_max;
+    p.dbg = kge_env_int("KGE_TP_DBG", 0);
     const int lds_ld = ((K + 3) & ~3) + 4;
     const int smem = (16 * lds_ld + 16 * 17 + 16) * 4;
     const int64_t blocks = p.rows_p / 16;
@@ -1983,7 +2027,7 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
                                      const float *emax, float *qmax_io, int accum_model, float eps_scale, float *Q,
                                      float *qn, float *s_true, void *Qs, float *thr, int32_t *list_count,
                                      const float *e2pref, const int32_t *qs_row, int level, const float *de2max,
-                                     float *q_dn2, kge_stream_t stream)
+                                     float *q_dn2, const float *tp_block_max, int tp_blocks, kge_stream_t stream)
 {
     if (level != 0 && level != 1) return KGE_EINVAL;
     if (level == 1 && !de2max) return KGE_EINVAL;
@@ -2000,6 +2044,9 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     p.c_acc = accum_model == 1 ? 1.25f : 2.0f; p.eps_scale = eps_scale;
     p.units = (d + 1 + 15) / 16; p.units_p = kge_lp_split_units(d, 1);
     p.level = level; p.de2max = de2max; p.q_dn2 = q_dn2;
+    p.tp_bmax = tp_block_max; p.tp_blocks = tp_blocks;
+    p.emax_out = const_cast<float *>(emax); p.de2max_out = const_cast<float *>(de2max);
+    if (tp_block_max && tp_blocks <= 0) return KGE_EINVAL;
     if (level == 1) { p.units = (d + 2 + 15) / 16; p.units_p = kge_lp_hi_units(d); }
     p.Q = Q; p.qn = qn; p.s_true = s_true;
     p.thr = reinterpret_cast<float2 *>(thr);

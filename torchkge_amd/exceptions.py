@@ -39,3 +39,11 @@ class SplitabilityError(_KgeError):
 
 class NoPreTrainedVersionError(_KgeError):
     pass
+
+
+class NotProvidedError(AttributeError):
+    """A name of the reference that this engine leaves out (outside SURVEY.md section 8's hot path).  Raised by the
+    packages' module-level ``__getattr__``.  It IS an AttributeError, so ``hasattr(torchkge_amd, name)`` is False and
+    ``getattr(torchkge_amd, name, default)`` gives the default, as for any absent attribute; attribute access
+    (``torchkge_amd.RelationInference``) shows the message that says what to use instead, and ``from torchkge_amd import
+    name`` fails with Python's own ImportError."""

@@ -81,9 +81,16 @@ class FilterIndex(object):
         v = torch.as_tensor(values, dtype=torch.int64).to(dev)
         if key1.numel() == 0:
             return cls(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int32), device)
+        # the ids are ALWAYS checked against the bounds (one reduction launch + one sync per index build): the pack kernel
+        # ORs the value into the low bits of the key and the radix sort looks at exactly the declared bits, so an id outside
+        # [0, bound) -- a kg whose tensors disagree with ent2ix -- would silently merge or mis-sort filter lists.
+        # (kge_i64_max3 compares as unsigned: a negative id comes back as a negative Python int here)
+        m1, m2, m3 = _hip.i64_max3(key1, key2, v)
         if n_key1 is None or n_key2 is None or n_values is None:
-            m1, m2, m3 = _hip.i64_max3(key1, key2, v)
             n_key1, n_key2, n_values = m1 + 1, m2 + 1, m3 + 1
+        if min(m1, m2, m3) < 0 or m1 >= n_key1 or m2 >= n_key2 or m3 >= n_values:
+            raise ValueError('filter index: ids outside [0, bound): max ids (%d, %d, %d) against bounds (%d, %d, %d) '
+                             '(negative ids read as negative maxima)' % (m1, m2, m3, n_key1, n_key2, n_values))
         if not (0 < n_key2 <= KEY2_SPAN and 0 < n_values < (1 << 31) and n_key1 > 0):
             raise ValueError('filter index: ids out of range (negative, or a relation id >= 2**31)')
         built = _hip.filter_index_build(key1, key2, v, int(n_key1), int(n_key2), int(n_values), KEY2_SPAN)

@@ -127,7 +127,9 @@ class TransEModel(TranslationModel):
         if frag:
             # the candidate side of the free-running sweep in ONE launch: ||e||^2 (the reference chain), the fragment-major
             # hi table and its residual maximum (guard slot 7, zeroed with the guard) -- kge_lp_table_prep_l2
-            prep = self._cache.get('tp_' + key, [E], lambda: _hip.table_prep_l2(E, g[1:2], g[7:8]))
+            # (its two maxima stay per block -- hundreds of same-address atomics would serialise -- and every query
+            # pipeline launch folds them into guard[1] / guard[7] on its way in: idempotent, 2 x 912 floats)
+            prep = self._cache.get('tp_' + key, [E], lambda: _hip.table_prep_l2(E, g[1:2], g[7:8], deferred_max=True))
         if prep is not None:
             en = self._cache.get('en_' + key, [E], lambda: prep[0])
         else:
@@ -139,8 +141,9 @@ class TransEModel(TranslationModel):
                 Eh, de2 = prep[1], g[7:8]
             else:
                 Eh, de2 = self._cache.get('eh%d_' % frag + key, [E], lambda: _hip.hi_table(E, aug=en, frag=frag))
+            tp_bmax = prep[2] if prep is not None else None
             pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], cols=cols, level=1,
-                                         de2max=de2)
+                                         de2max=de2, tp_bmax=tp_bmax)
             split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'overflow': g[2:3], 'level': 1, 'de2max': de2,
                      'list_stat': g[6:7], 'es_frag': frag}
         else:

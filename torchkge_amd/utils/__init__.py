@@ -1,4 +1,5 @@
 # -*- coding: utf-8 -*-
+from ..exceptions import NotProvidedError
 from .data import DataLoader, get_n_batches
 from .dissimilarities import l1_dissimilarity, l2_dissimilarity
 from .losses import MarginLoss, LogisticLoss, BinaryCrossEntropyLoss
@@ -8,7 +9,7 @@ from .operations import get_rank, get_mask, get_bernoulli_probs, get_tph, get_hp
 
 def __getattr__(name):
     if name in ('Trainer', 'TrainDataLoader'):
-        raise ImportError('torchkge_amd.utils does not provide %s (torchkge/utils/training.py is host glue outside the hot '
+        raise NotProvidedError('torchkge_amd.utils does not provide %s (torchkge/utils/training.py is host glue outside the hot '
                           'path): write the tutorial loop around Model.forward -- sampler.corrupt_batch, model(h, t, r, nh, '
                           'nt), criterion, backward, optimizer.step -- see tests/test_reference_style.py and INTEGRATION.md'
                           % name)
