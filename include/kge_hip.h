@@ -315,11 +315,13 @@ int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const int32_t *fou
 int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
                            int64_t *out, int64_t ld, int64_t off, const int64_t *pos /* optional: fact j of the
                            evaluation goes to column pos[j] (facts processed in another order, e.g. sorted by relation) */,
-                           const float *guard /* optional, with flags: >= 7 device floats [max ||q||^2, max ||e||^2, overflow,
-                           .., .., .., re-scored pairs] */,
+                           float *guard /* optional, with flags: 8 device floats [max ||q||^2, max ||e||^2, overflow,
+                           .., .., .., re-scored pairs, ..] */,
                            float *flags /* optional, 3 floats: flags[0] = guard[0] + guard[1], flags[1] = guard[2], flags[2] =
                            guard[6] (the evaluation's guard decisions and the split prefilter's re-scored pair count, written
                            behind the ranks by the same launch) */,
+                           int zero_guard /* with flags: the 8 guard floats are zeroed after they were read -- the next
+                           evaluation finds them clean and needs no fill of its own */,
                            kge_stream_t stream);
 
 /* generic: every query has its own candidate matrix cand[i] (N,K) at
@@ -588,7 +590,9 @@ int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const
                           const float *tp_block_max /* optional: the block maxima of kge_lp_table_prep_l2; the kernel then
                                                        folds them into *emax and *de2max (written through the const
                                                        pointers) before using the two scalars */,
-                          int tp_blocks, kge_stream_t stream);
+                          int tp_blocks,
+                          int32_t *zero_i32 /* optional: zero_n int32 zeroed by this launch (the batch's rank counters) */,
+                          int64_t zero_n, kge_stream_t stream);
 /* *max_io = max(*max_io, max_i |x[i]|) -- device scalar, zero it first */
 int kge_absmax(const float *x, int64_t n, float *max_io, kge_stream_t stream);
 int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,

@@ -1693,3 +1693,50 @@ def test_table_prep_l2_equals_the_separate_kernels(hip, N, K):
     assert torch.equal(en3, en_ref) and torch.equal(Eh3, Eh_ref) and float(g3[1]) == 0.0 and float(g3[7]) == 0.0
     nb = bm.shape[0] // 2
     assert float(bm[:nb].max()) == float(guard[1]) and float(bm[nb:].max()) == float(g2[7])
+
+
+def test_fresh_evaluators_share_what_was_learned_about_model_and_graph(hip):
+    """The reference idiom builds LinkPredictionEvaluator(model, kg) anew per validation (evaluation.py:252-262): plans,
+    level and the captured hipGraph are kept per (model, kg, options) at module level, so the THIRD fresh evaluator
+    replays; ranks identical throughout; share_state=False (or other options) keeps a private state; the state dies with
+    the model."""
+    import gc
+    import torchkge_amd as tk
+    from torchkge_amd import evaluation as evm
+    n_ent, n_rel, d = 4000, 11, 64
+    tables = orc.init_tables('transe', n_ent, n_rel, d, seed=5)
+    m = build_model('transe', 2, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples(n_ent, n_rel, 30000, seed=9)
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(28000, 2000))
+    ref = None
+    states = []
+    for i in range(4):
+        ev = tk.LinkPredictionEvaluator(m, kg_test)
+        ev.evaluate(512, verbose=False)
+        ranks = [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]
+        if ref is None:
+            ref = ranks
+        for a, b in zip(ref, ranks):
+            assert torch.equal(a, b)
+        states.append(ev._st)
+        assert ev._n_evaluations == i + 1
+    assert all(s_ is states[0] for s_ in states)
+    assert states[0]._graph is not None and states[0]._aux_stream is not None      # captured by the second, replayed since
+    priv = tk.LinkPredictionEvaluator(m, kg_test, share_state=False)
+    assert priv._st is not states[0] and priv._n_evaluations == 0
+    other = tk.LinkPredictionEvaluator(m, kg_test, graph=False)                   # other options: another state
+    assert other._st is not states[0]
+    # a guard vector dirtied outside an evaluation (a guarded section opened by hand) is zeroed again before the replay
+    g = m.lp_guard_begin(torch.device('cuda', 0))
+    g.fill_(3.0)
+    m.lp_guard_end()
+    ev = tk.LinkPredictionEvaluator(m, kg_test)
+    ev.evaluate(512, verbose=False)
+    for a, b in zip(ref, [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]):
+        assert torch.equal(a, b)
+    n_before = len(evm._STATES)
+    del ev, priv, other, states, m
+    gc.collect()
+    assert len(evm._STATES) < n_before

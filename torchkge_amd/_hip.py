@@ -104,14 +104,14 @@ _SIGNATURES = {
     'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
     'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
-                              _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp],
+                              _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _i64, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     'kge_lp_filter_sub_planned': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                                   _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
-    'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
     'kge_get_rank': [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     'kge_filter_lookup': [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -553,7 +553,8 @@ def table_prep_l2(E, emax_io, de2max_io, deferred_max=False):
     return (en, out, bm) if deferred_max else (en, out)
 
 
-def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None, level=0, de2max=None, tp_bmax=None):
+def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None, level=0, de2max=None, tp_bmax=None,
+                      zero_counts=False):
     """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
     s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
     the threshold kernel.  ``cols`` (filter_index.ColumnPlan): the split rows are written per COLUMN
@@ -576,13 +577,16 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
            'n_list': torch.empty(1, dtype=torch.int32, device=dev)}
     if level == 1:      # (the residuals ||q - hi(q)||^2: a later split_count that recomputes the thresholds needs them)
         out['q_dn2'] = torch.empty(Bq, dtype=torch.float32, device=dev)
+    if zero_counts:     # the batch's (3, Bq) rank counters, zeroed by this launch (no fill node of their own)
+        out['counts'] = torch.empty(3, Bq, dtype=torch.int32, device=dev)
     with _on(dev):
         _check(lib.kge_lp_query_pipeline(side, _p(E), _p(R), d, _p(h), _p(t), _p(r), B, _p(en), _p(emax), _p(qmax_io),
                                          split_accum_model(), SPLIT_EPS_SCALE, _p(out['Q']), _p(out['qn']),
                                          _p(out['s_true']), _p(out['Qs']), _p(out['thr']), _p(out['n_list']),
                                          _p(None if level == 1 else e2pref), _p(None if cols is None else cols.qs_row),
                                          level, _p(de2max), _p(out.get('q_dn2')), _p(tp_bmax),
-                                         0 if tp_bmax is None else tp_bmax.shape[0] // 2, _stream()),
+                                         0 if tp_bmax is None else tp_bmax.shape[0] // 2, _p(out.get('counts')),
+                                         3 * Bq if zero_counts else 0, _stream()),
                'kge_lp_query_pipeline')
     return out
 
@@ -1014,7 +1018,7 @@ def rank_finalize(raw, sub, found):
     return rank, filt
 
 
-def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=None):
+def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=None, zero_guard=False):
     """kge_rank_finalize_both: the ranks of a 2B-query batch into the (4, n) int64 result matrix
     `out` (rows: head raw, tail raw, head filtered, tail filtered) at columns off .. off + B - 1."""
     lib = load_library()
@@ -1024,7 +1028,8 @@ def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=No
         raise RuntimeError('rank_finalize_both: out must be a (4, n) int64 matrix with unit column stride')
     with _on(raw.device):
         _check(lib.kge_rank_finalize_both(_p(raw), _p(sub), _p(found), B, _p(out), out.stride(0), off, _p(pos),
-                                          _p(guard if flags is not None else None), _p(flags), _stream()),
+                                          _p(guard if flags is not None else None), _p(flags),
+                                          1 if (zero_guard and flags is not None) else 0, _stream()),
                'kge_rank_finalize_both')
     return out
 

@@ -81,14 +81,19 @@ def build(force=False, verbose=False):
         # (-lrccl resolves to whichever librccl.so.1 the process has loaded first -- torch's own when the host is Python)
         # Optional: a box without the RCCL headers / library still gets the single-GPU core (libkge_hip.so); the sharded
         # path through the C-ABI (torchkge_amd/_hip_coll.py) then fails loudly when it is first used.
-        try:
+        # Optional ONLY where RCCL itself is missing: a box without its header / library still gets the single-GPU core
+        # (libkge_hip.so) and the sharded path through the C-ABI fails loudly on first use.  Where RCCL is installed a
+        # compile error in collectives.hip is an error (it used to be downgraded to a warning).
+        have_rccl = any(os.path.exists(os.path.join(d, 'rccl', 'rccl.h')) or os.path.exists(os.path.join(d, 'rccl.h'))
+                        for d in ('/opt/rocm/include',)) and \
+            any(os.path.exists(os.path.join('/opt/rocm/lib', n)) for n in ('librccl.so', 'librccl.so.1'))
+        if have_rccl:
             run([hipcc] + FLAGS + ['-shared', '-o', COLL_LIB, cs, '-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib'])
-        except RuntimeError as exc:
+        else:
             import warnings
             if os.path.exists(COLL_LIB):
                 os.remove(COLL_LIB)
-            warnings.warn('torchkge_amd: libkge_hip_coll.so not built (RCCL headers / library missing?): %s'
-                          % str(exc).splitlines()[-1])
+            warnings.warn('torchkge_amd: libkge_hip_coll.so not built: RCCL header / library not found under /opt/rocm')
     return LIB
 
 

@@ -781,6 +781,8 @@ struct QueryPipeParams {
     const float *tp_bmax;           // optional [2][tp_blocks]: the block maxima kge_lp_table_prep_l2 left instead of its atomics:
     int tp_blocks;                  // every block reduces them (emax, de2max), block 0 stores the two scalars
     float *emax_out, *de2max_out;
+    int32_t *zero_i32;              // optional: zero_n int32 zeroed by this launch (the batch's rank counters)
+    int64_t zero_n;
 };
 
 template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
@@ -798,6 +800,7 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
     float *qs = qs_all + wv * QPW * LD, *ts = ts_all + wv * QPW * LD;
     const int d = p.d, kpad = p.units_p * 16;
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < p.zero_n; j += (int64_t)gridDim.x * 256) p.zero_i32[j] = 0;
     float em, de2m = 0.f;
     if (p.tp_bmax) {        // the table preparation's block maxima -> the two scalars (values >= 0: ordered like their bits)
         __shared__ unsigned red[8];
@@ -2027,7 +2030,8 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
                                      const float *emax, float *qmax_io, int accum_model, float eps_scale, float *Q,
                                      float *qn, float *s_true, void *Qs, float *thr, int32_t *list_count,
                                      const float *e2pref, const int32_t *qs_row, int level, const float *de2max,
-                                     float *q_dn2, const float *tp_block_max, int tp_blocks, kge_stream_t stream)
+                                     float *q_dn2, const float *tp_block_max, int tp_blocks, int32_t *zero_i32,
+                                     int64_t zero_n, kge_stream_t stream)
 {
     if (level != 0 && level != 1) return KGE_EINVAL;
     if (level == 1 && !de2max) return KGE_EINVAL;
@@ -2047,6 +2051,8 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     p.tp_bmax = tp_block_max; p.tp_blocks = tp_blocks;
     p.emax_out = const_cast<float *>(emax); p.de2max_out = const_cast<float *>(de2max);
     if (tp_block_max && tp_blocks <= 0) return KGE_EINVAL;
+    if (zero_n < 0 || (zero_n > 0 && !zero_i32)) return KGE_EINVAL;
+    p.zero_i32 = zero_i32; p.zero_n = zero_n;
     if (level == 1) { p.units = (d + 2 + 15) / 16; p.units_p = kge_lp_hi_units(d); }
     p.Q = Q; p.qn = qn; p.s_true = s_true;
     p.thr = reinterpret_cast<float2 *>(thr);

@@ -581,7 +581,7 @@ __global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int3
 __global__ void rank_finalize_both_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
                                           const int32_t *__restrict__ found, int64_t B, int64_t *out, int64_t ld,
                                           int64_t off, const int64_t *__restrict__ pos,
-                                          const float *__restrict__ guard, float *flags)
+                                          float *__restrict__ guard, float *flags, int zero_guard)
 {
     // the evaluation's two guard decisions ride the last finalize (instead of an add + a copy node of their own):
     // flags[0] = max ||q||^2 + max ||e||^2 (norm-expansion guard), flags[1] = overflow of the uncertain-pair list
@@ -589,6 +589,12 @@ __global__ void rank_finalize_both_kernel(const int32_t *__restrict__ raw, const
         flags[0] = guard[0] + guard[1];
         flags[1] = guard[2];
         flags[2] = guard[6];        // pairs the split prefilter re-scored in this evaluation (kge_lp_split_recheck list_stat)
+        // ... and the guard vector is left ZEROED for the next evaluation (nobody reads it after this point): the next
+        // evaluate() starts without a fill node of its own
+        if (zero_guard) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) guard[j] = 0.f;
+        }
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
         const bool tail = i < B;
@@ -1135,14 +1141,14 @@ extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const i
 }
 
 extern "C" int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
-                                      int64_t *out, int64_t ld, int64_t off, const int64_t *pos, const float *guard,
-                                      float *flags, kge_stream_t stream)
+                                      int64_t *out, int64_t ld, int64_t off, const int64_t *pos, float *guard,
+                                      float *flags, int zero_guard, kge_stream_t stream)
 {
     if (B < 0 || off < 0 || ld < off + B) return KGE_EINVAL;
     if (B == 0) return 0;
     if (!raw || !sub || !found || !out || (flags && !guard)) return KGE_EINVAL;
     hipLaunchKernelGGL(rank_finalize_both_kernel, dim3(grid1d(2 * B, 256)), dim3(256), 0, kge_s(stream), raw, sub,
-                       found, B, out, ld, off, pos, guard, flags);
+                       found, B, out, ld, off, pos, guard, flags, (flags && zero_guard) ? 1 : 0);
     KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -27,6 +27,7 @@ all-reduce of 3*B values, bit-identical ranks).  ``shard='queries'`` splits the
 facts instead (no data-path collective, ranks all-gathered once at the end).
 """
 import os
+import weakref
 
 import torch
 from tqdm.autonotebook import tqdm
@@ -132,7 +133,11 @@ class HipRankEngine(object):
         ``aux`` (a HIP stream): the filter correction -- which needs the true scores only -- runs there, beside the
         all-candidates count and its exact recheck on the current stream (fork / join by events: captured into the
         hipGraph of evaluate() as two parallel branches)."""
-        out = torch.zeros(3, prob.B + pad, dtype=torch.int32, device=s_true.device)
+        pre_counts = prob.pre.pop('counts', None) if getattr(prob, 'pre', None) is not None else None
+        if pre_counts is not None and pad == 0 and tuple(pre_counts.shape) == (3, prob.B):
+            out = pre_counts        # zeroed by the fused query pipeline's launch: no fill node
+        else:
+            out = torch.zeros(3, prob.B + pad, dtype=torch.int32, device=s_true.device)
         # (only beside the split-prefilter count kernel -- one persistent workgroup per CU that leaves 30 KB of LDS and a
         # fifth of the registers free; the fp32 tile kernel runs TWO workgroups per CU and loses one of them to a
         # co-resident kernel's LDS: measured 2.44 -> 3.37 ms per evaluate with --no-split)
@@ -155,10 +160,13 @@ class HipRankEngine(object):
     writes_flags = True     # finalize_both(guard=, flags=): the guard decisions are written by the same launch
 
     @staticmethod
-    def finalize_both(counts, out, off, pos=None, guard=None, flags=None):
+    def finalize_both(counts, out, off, pos=None, guard=None, flags=None, zero_guard=False):
         """Ranks of a 2B-query batch into the (4, n) result matrix at columns off..off+B-1 (or pos[off..]);
-        ``flags`` (2 floats behind the ranks): [max ||q||^2 + max ||e||^2, list overflow] from the guard vector."""
-        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off, pos, guard, flags)
+        ``flags`` (2 floats behind the ranks): [max ||q||^2 + max ||e||^2, list overflow] from the guard vector;
+        ``zero_guard``: the launch leaves the guard vector zeroed for the next evaluation."""
+        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off, pos, guard, flags, zero_guard)
+
+    zeroes_guard = True     # finalize_both(zero_guard=True) exists
 
     @staticmethod
     def local_scores(prob):
@@ -230,6 +238,54 @@ class _GraphSegments(object):
                 x()
 
 
+class _EvalState(object):
+    """What an evaluator LEARNS about (model, knowledge graph): the static per-batch plans, the captured hipGraphs, the level
+    of the split prefilter, the second stream.  The reference idiom builds ``LinkPredictionEvaluator(model, kg)`` anew for
+    every validation (evaluation.py:252-262, docs/tutorials): the state is therefore kept per (model, kg, options) at
+    module level -- weakly keyed on the model, so it dies with it -- and a NEW evaluator on the same pair replays the
+    graph its predecessor captured instead of paying first-call prices again."""
+
+    SHARED = ('_plans', '_plan_stamp', '_plan_refs', '_plan_gen', '_perm', '_qmap', '_graph', '_graph_static', '_graph_key',
+              '_graph_src', '_graph_seen', '_graph_cache', '_aux_stream', '_n_evaluations', '_level', '_level1_max',
+              '_level0_seen', '_mem_fit', '_graph_failed')
+
+    def __init__(self):
+        self._plans = self._plan_stamp = self._plan_refs = self._perm = self._qmap = None
+        self._plan_gen = 0
+        self._graph = self._graph_static = self._graph_key = self._graph_src = self._graph_seen = None
+        self._graph_cache = {}  # key -> (graph, static state): the two levels' captures are both kept
+        self._aux_stream = None
+        self._n_evaluations = 0
+        self._level = 0         # level of the split prefilter the next evaluation runs (see LEVEL1_ENTER)
+        self._level1_max = LEVEL1_ENTER     # three-product re-scored pairs per query below which level 1 is (re-)entered
+        self._level0_seen = None            # ... the last such count observed on level 0
+        self._mem_fit = None
+        self._graph_failed = False
+        self.kg_ref = None
+
+
+_STATES = weakref.WeakKeyDictionary()       # model -> {(id(kg), options): _EvalState}
+SHARE_STATE = os.environ.get('KGE_SHARE_EVAL_STATE', '1') != '0'
+
+
+def _shared_state(model, kg, cfg):
+    """The _EvalState of (model, kg, cfg) -- created on first use; None when the pair cannot be weakly referenced."""
+    try:
+        per_model = _STATES.setdefault(model, {})
+        key = (id(kg), cfg)
+        st = per_model.get(key)
+        if st is not None and st.kg_ref() is kg:
+            return st
+        for k in [k for k, v in per_model.items() if v.kg_ref() is None]:    # graphs that are gone (id() may be reused)
+            del per_model[k]
+        st = _EvalState()
+        st.kg_ref = weakref.ref(kg)
+        per_model[key] = st
+        return st
+    except TypeError:
+        return None
+
+
 class LinkPredictionEvaluator(object):
     """Evaluate a model by link prediction (evaluation.py:207-425).
 
@@ -263,7 +319,7 @@ class LinkPredictionEvaluator(object):
 
     def __init__(self, model, knowledge_graph, fused=True, shard=None, exchange='counts',
                  group=None, engine=None, graph=None, overlap=False, both_sides=True, query_exchange='evaluate',
-                 coalesce=None, graph_collectives=None):
+                 coalesce=None, graph_collectives=None, share_state=None):
         self.model = model
         # entity shards + hipGraph: capture the RCCL collectives INSIDE the one graph of evaluate() (thread-local capture
         # mode: the process-group watchdog thread keeps querying events) instead of cutting the capture at every
@@ -284,43 +340,41 @@ class LinkPredictionEvaluator(object):
         self.fused, self.shard, self.exchange, self.group = fused, shard, exchange, group
         self.engine = engine if engine is not None else HipRankEngine()
         self.graph = graph if engine is None else False   # replay evaluate() as one hipGraph (see above)
-        self._graph = self._graph_static = self._graph_key = self._graph_src = self._graph_seen = None
         self.overlap = overlap                      # two-stream overlap of the short kernels (single GPU, fused)
-        self._aux_stream = None
         # both sides of a batch as ONE 2B-query problem (single GPU, fused): every latency-bound short
         # kernel of a batch runs once instead of twice, the all-candidates count kernel sees 2B queries
         self.both_sides = both_sides
         self._cut = None        # set while evaluate() is being captured as graph segments (see _GraphSegments)
         # per-batch FilterPlans (filter segments, true ids, grouping): a function of the test facts and the filter
         # index only, kept across evaluate() calls; _plan_stamp tells when they went stale
-        self._plans = None
-        self._plan_stamp = None
-        self._plan_refs = None
-        self._plan_gen = 0
         self._ctimes = None     # collective_timing(): (start, end) event pairs of the data-path collectives
         self._fl, self._fl_done = None, False
         # row-sharded models: the distinct entities of the test facts and the facts re-indexed into that list
         # (static like the plans); their rows are exchanged ONCE per evaluate() (query_exchange='evaluate') instead
         # of the (2B, K) query rows of every batch ('batch')
         self.query_exchange = query_exchange
-        self._qmap = None
         self._qb = None
         self._shard_flags = None
         # models whose count kernel gathers a per-(relation, candidate) table in its epilogue (TransH / TransD) ask for
         # the facts of a batch to be PROCESSED sorted by relation: the queries of a wavefront then share one or two
         # relation rows of that table instead of 32 different ones.  _perm[j] = original position of the j-th processed
         # fact (the ranks are written straight to it); static like the plans.
-        self._perm = None
         # the filter correction of a both-sides batch on a second stream, beside the count kernel and its recheck (single
         # GPU; measured r04, same box: TransE 0.629 -> 0.619 ms, DistMult / FB15k 2.607 -> 2.536, ComplEx / TransH +-0:
         # profiles/r04/overlap_filter_ab.txt).  KGE_OVERLAP_FILTER=0 keeps everything on one stream.
         self.overlap_filter = os.environ.get('KGE_OVERLAP_FILTER', '1') == '1'
-        self._n_evaluations = 0
-        self._level = 0         # level of the split prefilter the next evaluation runs (see LEVEL1_ENTER)
-        self._level1_max = LEVEL1_ENTER     # three-product re-scored pairs per query below which level 1 is (re-)entered
-        self._level0_seen = None            # ... the last such count observed on level 0
         self.last_rescored_per_query = None
-        self._graph_cache = {}  # key -> (graph, static state): the two levels' captures are both kept
+        # everything learned about (model, kg) -- plans, graphs, level, second stream: _EvalState, shared by the evaluators
+        # of the same pair and options (share_state=False, a custom engine or KGE_SHARE_EVAL_STATE=0: private)
+        share = SHARE_STATE if share_state is None else bool(share_state)
+        st = None
+        if share and engine is None:
+            cfg = (fused, shard, exchange, id(group) if group is not None else None, graph, overlap, both_sides,
+                   query_exchange, coalesce, self.graph_collectives, self.overlap_filter)
+            st = _shared_state(model, knowledge_graph, cfg)
+        self._st = st if st is not None else _EvalState()
+        if self._st._graph_failed:
+            self.graph = False
 
     def _internal_batch(self, b_size, n_local):
         """Batch the fused kernels see.  In the reference ``b_size`` only bounds the (b, N, d) temporaries
@@ -484,12 +538,8 @@ class LinkPredictionEvaluator(object):
         kw = {'plan': plan} if plan is not None else {}
         if ride:
             kw['pad'] = 2
-        # (from the evaluator's SECOND evaluation on: creating and first using a stream costs ~60 ms of the first call)
-        if self.overlap_filter and self._n_evaluations > 0 and not sharded and isinstance(eng, HipRankEngine) \
-                and s_true.is_cuda:
-            if self._aux_stream is None:
-                self._aux_stream = torch.cuda.Stream(s_true.device)
-            kw['aux'] = self._aux_stream
+        if self._use_aux and not sharded and isinstance(eng, HipRankEngine) and s_true.is_cuda:
+            kw['aux'] = self._aux_stream        # (created by evaluate(), outside any capture)
         counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, **kw)
         if ride:
             lim = float(self.model.L2_EXPAND_LIMIT)
@@ -503,6 +553,9 @@ class LinkPredictionEvaluator(object):
         if (last and guard is not None and not sharded and self._fl is not None and getattr(eng, 'writes_flags', False)):
             fkw = {'guard': guard, 'flags': self._fl}       # the last finalize also writes the two guard flags
             self._fl_done = True
+            if getattr(eng, 'zeroes_guard', False):         # ... and leaves the guard vector zeroed for the next evaluation
+                fkw['zero_guard'] = True
+                self._guard_zeroed = True
         if self._perm is not None:
             eng.finalize_both(counts[:, :n2] if ride else counts, out, off, self._perm, **fkw)
         else:
@@ -683,12 +736,23 @@ class LinkPredictionEvaluator(object):
         else:
             f_lo, f_hi = 0, kg.n_facts
 
+        # the filter correction on a second stream beside the count kernel (single GPU): from the second evaluation on --
+        # creating and first using a stream costs tens of ms in a fresh process -- or at once when the caller asked for an
+        # immediate capture (graph=True); the stream is created HERE, never inside a capture
+        self._use_aux = bool(self.overlap_filter and not sharded and device.type == 'cuda' and
+                             isinstance(self.engine, HipRankEngine) and (self._n_evaluations > 0 or self.graph is True))
+        if self._use_aux and self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(device)
         n_local = f_hi - f_lo
         b_size = self._internal_batch(b_size, n_local)
         index_h, index_t = self._filter_indices(device)
         guard = None
         if hasattr(self.model, 'lp_guard_begin') and not self._generic_model and device.type == 'cuda':
+            was_clean = bool(getattr(self.model, '_lp_guard_clean', False))
+            same_guard = getattr(self.model, '_lp_guard', None)
             guard = self.model.lp_guard_begin(device)   # TransE-L2: optimistic MFMA norm expansion
+            if was_clean and guard is not None and guard is same_guard:
+                object.__setattr__(self.model, '_lp_guard_clean', True)     # (zeroed by the last evaluation's finalize launch)
         session = self.model.lp_session() if hasattr(self.model, 'lp_session') else _NullCtx()
 
         try:
@@ -724,8 +788,13 @@ class LinkPredictionEvaluator(object):
 
             def run(heads, tails, rels, out, fl):
                 with session, torch.no_grad():
+                    self._guard_zeroed = False
                     if guard is not None and self.model._expand_ok is None:
-                        guard.zero_()
+                        # (clean when the previous evaluation's last finalize zeroed it -- Model._lp_guard_clean; replays
+                        # of a graph captured without this fill check the flag in front of the replay)
+                        if not getattr(self.model, '_lp_guard_clean', False):
+                            guard.zero_()
+                        object.__setattr__(self.model, '_lp_guard_clean', False)
                     n_batches = get_n_batches(n_local, b_size)
                     if by_scores:       # every rank writes only the columns of the queries it ranks
                         out.zero_()
@@ -767,6 +836,8 @@ class LinkPredictionEvaluator(object):
                         fl[1:2].copy_(guard[2:3])
                         fl[2:3].copy_(guard[6:7])
                     self._fl = None
+                    if guard is not None and self._guard_zeroed:
+                        object.__setattr__(self.model, '_lp_guard_clean', True)
 
             # one hipGraph when run() contains no collective (single GPU, query shards); graph segments with
             # the collectives between them for entity shards exchanging counts; eager otherwise
@@ -791,12 +862,16 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, one_graph, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                       level_now, getattr(self.model, 'split_level', None), self.overlap_filter and self._n_evaluations > 0,
+                       level_now, getattr(self.model, 'split_level', None), self.overlap_filter,
                        tuple(p_.data_ptr() for p_ in params), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))
-                if self.graph is None and self._graph_key != key and self._graph_seen != key:
-                    self._graph_seen = key      # 'auto': this eager call is the warm-up, the next one captures
+                if self.graph is None and self._graph_key != key and self._graph_seen != key and key not in self._graph_cache \
+                        and self._n_evaluations == 0:
+                    # 'auto', the FIRST evaluation of this (model, kg): eager -- it is the warm-up (and pays the process's
+                    # first-use costs once), the next one captures.  A later change of key (the other level of the split
+                    # prefilter, another b_size) warms up and captures in the same call: no second eager evaluation.
+                    self._graph_seen = key
                     use_graph = False
             if not use_graph:
                 heads, tails, rels = facts()
@@ -857,6 +932,7 @@ class LinkPredictionEvaluator(object):
                         import warnings
                         warnings.warn('torchkge_amd: hipGraph capture of evaluate() failed (%s); running eagerly' % (exc,))
                         self.graph = False
+                        self._graph_failed = True
                         self._graph = self._graph_static = self._graph_key = None
                         self._graph_cache = {}
                         torch.cuda.synchronize(device)
@@ -867,6 +943,8 @@ class LinkPredictionEvaluator(object):
                         if gc_was_on:
                             gc.enable()
                     if g is not None:
+                        st['zeroes_guard'] = bool(self._guard_zeroed)     # the captured run() ended with a guard-zeroing finalize
+                        st['needs_clean_guard'] = guard is not None
                         st['targets_cat'] = getattr(self.engine, '_targets_cat', None)   # baked into the graph too
                         if self._graph_key is not None and self._graph is not None:
                             # keep ONE earlier capture (the other split level); older ones go -- outside any capture
@@ -882,7 +960,14 @@ class LinkPredictionEvaluator(object):
                         st['t'].copy_(tt_, non_blocking=True)
                         st['r'].copy_(rr_, non_blocking=True)
                         self._graph_src = src
+                    if guard is not None and st.get('needs_clean_guard'):
+                        # the graph holds no fill of the guard vector: it relies on the previous evaluation's zeroing finalize
+                        if not getattr(self.model, '_lp_guard_clean', False):
+                            guard.zero_()
+                        object.__setattr__(self.model, '_lp_guard_clean', False)
                     self._graph.replay()
+                    if guard is not None and st.get('zeroes_guard'):
+                        object.__setattr__(self.model, '_lp_guard_clean', True)
                     flat, out, fl = st['out']
 
             res = None
@@ -908,6 +993,10 @@ class LinkPredictionEvaluator(object):
                     # the one-product level's wider band overflowed the list: this evaluation again on the three-product
                     # sweep (whose own flags are then checked like a first run's)
                     self._level = level_now = 0
+                    # (... and do not come back before the three-product count has halved -- as when LEAVING level 1: an
+                    # evaluator whose level-0 count sits below LEVEL1_ENTER would otherwise enter, overflow and redo on
+                    # every other evaluation)
+                    self._level1_max = 0.5 * (self._level0_seen if self._level0_seen is not None else LEVEL1_ENTER)
                     object.__setattr__(self.model, '_split_level', 0)
                     redo = check_again = True
                 elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
@@ -999,6 +1088,14 @@ class LinkPredictionEvaluator(object):
             int(self.mean_rank()[0]), int(self.mean_rank()[1])))
         print('MRR : {} \t\t Filt. MRR : {}'.format(
             round(self.mrr()[0], n_digits), round(self.mrr()[1], n_digits)))
+
+
+def _forward(name):
+    return property(lambda self: getattr(self._st, name), lambda self, v: setattr(self._st, name, v))
+
+
+for _n in _EvalState.SHARED:        # evaluator attributes that live in the (possibly shared) _EvalState
+    setattr(LinkPredictionEvaluator, _n, _forward(_n))
 
 
 class _NullCtx(object):

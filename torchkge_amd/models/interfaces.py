@@ -146,6 +146,7 @@ class Model(Module):
         # [1] max ||e||^2 (segment 0), [2] split-list overflow flag, [3] max |X|, [4] max |y_c| (projection
         # modes), [5] max ||e||^2 (segment 1)
         self._lp_guard = None
+        self._lp_guard_clean = False    # the guard vector is all zero (left so by the last evaluation's finalize launch)
         self._guard_on = False
         self._expand_ok = None      # TransE-L2 only: True/False forced by the evaluator, None: guarded
         self.split_filter = True    # fused rank counts via the f16-split prefilter + exact recheck
@@ -306,8 +307,12 @@ class Model(Module):
         _set(self, '_expand_ok', None)
         if not self._uses_guard():
             return None
+        # (whoever begins a guarded section may leave the vector dirty: the evaluator, which knows that its last finalize
+        # launch zeroed it, restores the flag right after this call)
+        _set(self, '_lp_guard_clean', False)
         if self._lp_guard is None or self._lp_guard.device != device:
             _set(self, '_lp_guard', torch.zeros(8, dtype=torch.float32, device=device))
+            _set(self, '_lp_guard_clean', True)
         _set(self, '_guard_on', True)
         return self._lp_guard
 

@@ -143,12 +143,13 @@ class TransEModel(TranslationModel):
                 Eh, de2 = self._cache.get('eh%d_' % frag + key, [E], lambda: _hip.hi_table(E, aug=en, frag=frag))
             tp_bmax = prep[2] if prep is not None else None
             pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], cols=cols, level=1,
-                                         de2max=de2, tp_bmax=tp_bmax)
+                                         de2max=de2, tp_bmax=tp_bmax, zero_counts=True)
             split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'overflow': g[2:3], 'level': 1, 'de2max': de2,
                      'list_stat': g[6:7], 'es_frag': frag}
         else:
             Es, e2 = self._cache.get('es_' + key, [E], lambda: _hip.split_table(E, aug=en))
-            pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2, cols=cols)
+            pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2, cols=cols,
+                                         zero_counts=True)
             split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'overflow': g[2:3], 'list_stat': g[6:7]}
         # (SIDE_BOTH: the evaluator fills in the concatenated true indices it gets from the filter lookup)
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
