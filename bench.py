@@ -338,6 +338,39 @@ def full_split_parity(info, tables, kg, kg_test, ev_ranks, device, b=256, tol=2e
                            'oracle.lp_evaluate = reference algorithm on ATen GPU ops, b_size=%d' % b, secs)
 
 
+def strong_scaling_model(n_test, n_ent, d, measured_ms_1gpu=None):
+    """Per-phase MODEL of one entity-sharded evaluate() of this job on P GPUs (exchange='counts', r05 path: fused query side
+    fed from the query-entity replicas, one-product level on every shard).  No multi-GPU box was available to any round, so
+    this is arithmetic on the single-GPU phase times measured in profiles/r05 (cfg2: timeline_transe_fb15k237.txt), scaled
+    by the work each phase does -- printed beside every measurement so that a measured curve can be held against it:
+      fixed      : host gap + graph launch + rank copy (0.075 ms), the query pipeline over all 2B queries (0.040 -- every rank
+                   builds every query row), finalize; does not shrink with P
+      1/P        : candidate-table preparation, the count sweep, its exact recheck, the filter correction's scoring
+      collectives: the replica all-gather of the U ~ 0.83 N distinct query entities' rows once per evaluate ((P-1)/P * U * d * 4 B
+                   per rank at 120 GB/s effective per direction) + two latency-bound all-reduces (true scores ride the
+                   replicas: none; counts + flags: one of 24 B x 2B) at ~25 us each on xGMI."""
+    pairs = 2.0 * n_test * n_ent
+    scale = pairs / (2.0 * 20466 * 14541) * (d / 200.0)         # the 1/P phases scale with pairs x width
+    qscale = (n_test / 20466.0) * (d / 200.0)
+    fixed = 0.075 + 0.040 * qscale + 0.003
+    per_p = (0.010 * (n_ent / 14541.0) * (d / 200.0) + 0.290 * scale + 0.070 * scale + 0.035 * qscale)
+    out = {}
+    for P in (1, 2, 4, 8):
+        coll = 0.0
+        if P > 1:
+            u_bytes = 0.83 * n_ent * d * 4.0
+            coll = (P - 1) / P * u_bytes / 120e9 * 1e3 + 2 * 0.025
+        out[str(P)] = round(fixed + per_p / P + coll, 4)
+    res = {'modelled_ms_per_evaluate': out,
+           'modelled_speedup_vs_1gpu': {k: round(out['1'] / v, 2) for k, v in out.items()},
+           'phases_ms_at_P1': {'fixed': round(fixed, 4), 'shrinks_as_1_over_P': round(per_p, 4)},
+           'note': 'a MODEL (single-GPU phase times of profiles/r05 scaled by work; collectives from link arithmetic), not a '
+                   'measurement: no multi-GPU node was available to any round'}
+    if measured_ms_1gpu is not None:
+        res['measured_ms_1gpu_this_run'] = round(measured_ms_1gpu, 4)
+    return res
+
+
 def _load_reference():
     """The REAL reference package, staged by oracle/Makefile as the git-ignored oracle/_ref/torchkge (it travels to the GPU
     box with the snapshot).  None when absent.  Only bench.py's cpu_baseline leg uses it."""
@@ -775,6 +808,42 @@ def main():
                      'collective_time': collective_ms(ev_w, args.batch, exchange='counts', n_ent_all=info_w['n_ent'])
                      if device.type == 'cuda' else None}
         del ev_w, m_w, kg_w, kg_test_w
+        torch.cuda.empty_cache()
+
+    # ... and BASELINE cfg4 -- the configuration named for 8 GPUs: DistMult d = 400 on the FB15k shape, entity table sharded --
+    # next to the default cfg2 job (strong scaling, counts exchange, trained-like weights from rank 0)
+    cfg4_mode = None
+    if multi and shard == 'entities' and args.workload == 'transe_fb15k237' and not args.no_weak and not args.materialize \
+            and args.tables == 'sharded':
+        from torchkge_amd import distributed as kd
+        m_4, _, kg_4, kg_test_4, info_4 = build_workload('distmult_fb15k', device, kg_kind=args.kg,
+                                                         weights=('trained' if rank == 0 else 'xavier'),
+                                                         train_cfg={'steps': 300})
+        for prm in m_4.parameters():
+            if args.backend == 'nccl':
+                dist.broadcast(prm.data, src=0)
+            else:
+                buf = prm.data.cpu()
+                dist.broadcast(buf, src=0)
+                prm.data.copy_(buf.to(device))
+        kg_test_4.head_idx, kg_test_4.tail_idx, kg_test_4.relations = (kg_test_4.head_idx.to(device), kg_test_4.tail_idx.to(device),
+                                                                       kg_test_4.relations.to(device))
+        kd.shard_model_(m_4)
+        ev_4 = tk.LinkPredictionEvaluator(m_4, kg_test_4, shard='entities', exchange='counts', graph=graph_arg,
+                                          graph_collectives=True if args.graph_collectives else None)
+        for _ in range(4):      # eager, (level switch +) capture, replays
+            ev_4.evaluate(args.batch, verbose=False)
+        n_4 = max(2, args.steps // 2)
+        el_4 = timed_steps(ev_4, args.batch, n_4)
+        cfg4_mode = {'workload': 'distmult dim=400 on the fb15k-shaped synthetic KG (N=%d, R=%d, test=%d): BASELINE cfg4'
+                                 % (info_4['n_ent'], info_4['n_rel'], info_4['n_test']),
+                     'scaling': 'strong', 'entity_shards': world, 'exchange': 'counts', 'weights': 'trained (rank 0, broadcast)',
+                     'steps': n_4, 'ms_per_step': round(el_4 / n_4 * 1e3, 4),
+                     'value': round(info_4['n_test'] * 2 * info_4['n_ent'] * n_4 / el_4, 1),
+                     'split_level': int(getattr(m_4, '_split_level', 0)),
+                     'filtered_hits_at_10': ev_4.hit_at_k(10)[1],
+                     'strong_scaling_model': strong_scaling_model(info_4['n_test'], info_4['n_ent'], 400)}
+        del ev_4, m_4, kg_4, kg_test_4
         torch.cuda.empty_cache()
 
     # the same evaluation with the rank counts on the fp32 MFMA kernel only (reported beside the headline)
@@ -1273,7 +1342,8 @@ def main():
             'first_evaluate_what': 'wall time of the first evaluate() of a fresh evaluator: device-side filter index, FilterPlans, '
                                    'MFMA self-test, eager launches, ranks to the host; cold_ms_per_step: 5 graph replays after a '
                                    '0.5 s idle gap, before the clock-settle phase',
-            'higher_is_better': True, 'scaling': args.scaling if multi else 'weak',
+            # (the contract's key; at N = 1 it only says which mode `--gpus N` would run: the default strong-scales this job)
+            'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': '%s dim=%d L%d on %s-shaped synthetic KG (N=%d, R=%d, test=%d), '
                                    'LinkPredictionEvaluator.evaluate(b_size=%d)' % (
@@ -1293,6 +1363,7 @@ def main():
                                 'filter_lists': flt_stats},
             'roofline': roof, 'cpu_baseline': cpu, 'parity_full_split': parity, 'secondary': sec,
             'fresh_evaluator_per_validation': fresh_loop,
+            'strong_scaling_model': strong_scaling_model(n_test, n_ent_full, d, elapsed / args.steps * 1e3 if world == 1 else None),
             'entity_tables': None if not multi else {
                 'query_rows': (None if getattr(model, '_row_shard', None) is None else
                                ('rows of the %d distinct entities of the test facts summed over the ranks once per evaluate()'
@@ -1301,7 +1372,7 @@ def main():
                 'layout': ('row-sharded: N/P rows per GPU, relation tables replicated' if (shard == 'entities' and args.tables == 'sharded')
                            else 'replicated'),
                 'bytes_full': table_bytes_full, 'bytes_this_rank': model.entity_table_bytes()},
-            'collective_time': headline_coll, 'other_exchange': other_x, 'weak_mode': weak_mode,
+            'collective_time': headline_coll, 'other_exchange': other_x, 'weak_mode': weak_mode, 'cfg4_mode': cfg4_mode,
             'f32_mfma_only': None if f32_only_ms is None else {
                 'ms_per_step': round(f32_only_ms, 4), 'value': round(total_units / f32_only_ms * 1e3, 1),
                 'ranks_identical_to_headline_run': True},

@@ -140,6 +140,28 @@ for exchange, graph, qx, co in (('counts', False, 'evaluate', None), ('counts', 
         if not torch.equal(a, b):
             ok = False
             print('MISMATCH', rank, kind, exchange, graph, qx, int((a != b).sum()), flush=True)
+# (r05) the ONE-PRODUCT level on entity shards: forced (split_level = 1) and through the policy ('auto': the re-scored pair
+# count rides the counts all-reduce, so every rank switches together) -- eager and as hipGraph segments
+if kind != 'transe_l1':
+    for lvl, graph in ((1, False), (1, True), ('auto', None)):
+        m.split_level = lvl
+        ev = tk.LinkPredictionEvaluator(m, kg_test, shard='entities', exchange='counts', graph=graph)
+        lv_seen = []
+        for _ in range(4):
+            ev.evaluate(b_size=256, verbose=False)
+            lv_seen.append(int(m._split_level))
+            got = [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]
+            for a, b in zip(want, got):
+                if not torch.equal(a, b):
+                    ok = False
+                    print('MISMATCH (level %%s)' %% lvl, rank, kind, graph, int((a != b).sum()), flush=True)
+        if lvl == 1 and lv_seen != [1, 1, 1, 1]:
+            ok = False
+            print('LEVEL NOT TAKEN', rank, kind, lv_seen, flush=True)
+        if ev.last_rescored_per_query is None or ev.last_rescored_per_query <= 0:
+            ok = False
+            print('NO RE-SCORED COUNT ON SHARDS', rank, kind, lvl, ev.last_rescored_per_query, flush=True)
+    m.split_level = 'auto'
 # top-k inference on the row-sharded model (per-shard tiles -> partial lists -> all-gather -> merge) == unsharded
 if kind in ('transe', 'transh', 'complex'):
     dh_, dt_, _ = orc.build_filter_dicts(h, t, r)

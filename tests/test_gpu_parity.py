@@ -1040,7 +1040,10 @@ def test_projection_modes_shards_concatenate_bit_identically(hip, kind):
                                                # queries in relation order (how the evaluator feeds these modes): a 192-query
                                                # panel then holds <= 8 relation runs and each tile stages their X segments in LDS
                                                ('H', 1000, 3000, 200, -37), ('D', 900, 2049, 200, -11), ('H', 400, 700, 64, -2),
-                                               ('D', 1500, 1300, 72, -160)])
+                                               ('D', 1500, 1300, 72, -160),
+                                               # (r05: sizes at which the SLP-packed projection epilogue of the free-running
+                                               # kernel went wrong for ~1 pair in 3e6 -- profiles/r05/pm_epilogue_slp_bisect.txt)
+                                               ('H', 20000, 3000, 200, -37), ('D', 12000, 14541, 200, 237)])
 def test_split_prefilter_projection_modes_counts_equal_exact_counts(hip, mode_name, B, N, K, R):
     """TransH / TransD projection modes through the f16-split prefilter (the per-pair term
     x(xz+p) resp. y(yz+2g+p) is added to the approximate accumulator in the epilogue):

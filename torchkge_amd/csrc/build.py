@@ -26,7 +26,12 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 # per-file extras.  lp_direct.hip: the SLP vectoriser turns the L1 inner loop (sub, then add |.|) into v_pk_add_f32
 # pairs -- which issue at HALF rate on gfx950 (tools/probe/valu_rate_probe.hip: 34 T vs 63 T lane-ops/s) and have no
 # abs modifier, so every element pays an extra v_and: 3 issue slots per element instead of 2.
-EXTRA_FLAGS = {'lp_direct.hip': ['-fno-slp-vectorize']}
+# lp_hi_stream.hip: with SLP on, the projection (TransH / TransD) epilogue of the free-running count kernel becomes
+# v_pk_fma_f32 / v_pk_mul_f32 chains -- and ~1 in 3e6 pairs then gets a grossly wrong projection term, differently from run
+# to run (tools/dbg_pm.py, profiles/r05/pm_epilogue_slp_bisect.txt: same source, -fno-slp-vectorize: 0 mismatches in every
+# run; the prefetch placement and an explicit vmcnt(0) do not matter).  Not root-caused; packed f32 ops are an anti-lever
+# beside MFMAs anyway (MI355X_MICROARCH.md), so the file is built without the SLP vectoriser.
+EXTRA_FLAGS = {'lp_direct.hip': ['-fno-slp-vectorize'], 'lp_hi_stream.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

@@ -375,6 +375,16 @@ class LinkPredictionEvaluator(object):
         self._st = st if st is not None else _EvalState()
         if self._st._graph_failed:
             self.graph = False
+        # the second stream is created HERE, at construction (its creation costs tens of ms in a fresh process: better in
+        # front of the first evaluation -- which pays the process's first-use costs anyway -- than as a spike inside the
+        # second or third one)
+        if self.overlap_filter and engine is None and self._st._aux_stream is None:
+            try:
+                dev0 = next(model.parameters()).device
+                if dev0.type == 'cuda':
+                    self._st._aux_stream = torch.cuda.Stream(dev0)
+            except (StopIteration, RuntimeError):
+                pass
 
     def _internal_batch(self, b_size, n_local):
         """Batch the fused kernels see.  In the reference ``b_size`` only bounds the (b, N, d) temporaries
@@ -522,7 +532,14 @@ class LinkPredictionEvaluator(object):
         if by_scores:
             return self._exchange_score_tiles(prob, h.shape[0], true_idx, seg_lo, seg_hi, targets, out, off)
         s_true = None
-        if sharded and self._qb is not None and hasattr(self.model, 'lp_true_scores_replica'):
+        if sharded and self._qb is not None and getattr(prob, 'pre', None) is not None and prob.pre.get('true_idx') is None:
+            # row-sharded tables, fused query side fed from the query-entity replicas (r05): the pipeline has scored
+            # exactly the (query, true entity) pairs -- on every rank, from the same rows: no collective
+            prob.pre['true_idx'] = true_idx
+            s_true = prob.pre['s_true']
+            if hasattr(prob, 'split_true'):
+                prob.split_true = (s_true, true_idx)
+        elif sharded and self._qb is not None and hasattr(self.model, 'lp_true_scores_replica'):
             # row-sharded tables: the true entities' rows are in the query-entity replicas, so every rank scores
             # the (query, true entity) pairs itself -- same rows, same chain, same bits: no collective
             s_true = self.model.lp_true_scores_replica(prob, self._qb)
@@ -537,7 +554,7 @@ class LinkPredictionEvaluator(object):
         ride = sharded and last and guard is not None and getattr(eng, 'flag_columns', False)
         kw = {'plan': plan} if plan is not None else {}
         if ride:
-            kw['pad'] = 2
+            kw['pad'] = 3
         if self._use_aux and not sharded and isinstance(eng, HipRankEngine) and s_true.is_cuda:
             kw['aux'] = self._aux_stream        # (created by evaluate(), outside any capture)
         counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, **kw)
@@ -545,10 +562,11 @@ class LinkPredictionEvaluator(object):
             lim = float(self.model.L2_EXPAND_LIMIT)
             counts[0, n2:n2 + 1] = ((guard[0:1] + guard[1:2]) > lim).to(torch.int32) if lim != float('inf') else 0
             counts[0, n2 + 1:n2 + 2] = (guard[2:3] > 0).to(torch.int32)
+            counts[0, n2 + 2:n2 + 3] = guard[6:7].to(torch.int32)      # pairs this shard re-scored (level policy: their SUM)
         if sharded:     # (the recorded call runs again at every graph replay: bind the tensor, not the name)
             self._collective(lambda c_=counts: kdist.all_reduce_sum(c_, self.group))
         if ride:
-            self._shard_flags = counts[0, n2:n2 + 2]
+            self._shard_flags = counts[0, n2:n2 + 3]
         fkw = {}
         if (last and guard is not None and not sharded and self._fl is not None and getattr(eng, 'writes_flags', False)):
             fkw = {'guard': guard, 'flags': self._fl}       # the last finalize also writes the two guard flags
@@ -829,6 +847,7 @@ class LinkPredictionEvaluator(object):
                         # entity shards: the flags came back summed over the ranks with the last batch's counts
                         fl[0:1].copy_(torch.where(self._shard_flags[0:1] > 0, float('inf'), 0.0))
                         fl[1:2].copy_(self._shard_flags[1:2].to(torch.float32))
+                        fl[2:3].copy_(self._shard_flags[2:3].to(torch.float32))
                     elif guard is not None and not self._fl_done:
                         # [max ||q||^2 + max ||e||^2, split-prefilter overflow] behind the ranks (the both-sides path
                         # has the last batch's finalize write them)
@@ -842,7 +861,11 @@ class LinkPredictionEvaluator(object):
             # one hipGraph when run() contains no collective (single GPU, query shards); graph segments with
             # the collectives between them for entity shards exchanging counts; eager otherwise
             # level of the split prefilter for THIS evaluation (single GPU, fused): decided by the previous one
-            level_now = self._level if (guard is not None and not kdist.multi(world) and both) else 0
+            # (entity shards exchanging counts: the re-scored pair count rides the counts all-reduce like the guard flags, so
+            # every rank takes the same decision -- r05; other multi-rank forms stay on the three-product level)
+            level_ok = (not kdist.multi(world)) or (sharded and both and not by_scores and
+                                                   getattr(self.engine, 'flag_columns', False))
+            level_now = self._level if (guard is not None and both and level_ok) else 0
             if hasattr(self.model, '_split_level'):
                 object.__setattr__(self.model, '_split_level', level_now)
             multi = kdist.multi(world)
@@ -900,7 +923,7 @@ class LinkPredictionEvaluator(object):
                     gc.disable()
                     try:
                         if self.graph is not None or self._graph_seen != key:
-                            side = torch.cuda.Stream(device)
+                            side = self._aux_stream if self._aux_stream is not None else torch.cuda.Stream(device)
                             side.wait_stream(torch.cuda.current_stream(device))
                             with torch.cuda.stream(side):            # warm-up outside capture (lazy inits, attribute sets)
                                 run(st['h'], st['t'], st['r'], st['out'][1], st['out'][2])
@@ -944,6 +967,7 @@ class LinkPredictionEvaluator(object):
                             gc.enable()
                     if g is not None:
                         st['zeroes_guard'] = bool(self._guard_zeroed)     # the captured run() ended with a guard-zeroing finalize
+                        st['shard_flags'] = self._shard_flags             # (entity shards: where the summed flags land)
                         st['needs_clean_guard'] = guard is not None
                         st['targets_cat'] = getattr(self.engine, '_targets_cat', None)   # baked into the graph too
                         if self._graph_key is not None and self._graph is not None:
@@ -966,6 +990,7 @@ class LinkPredictionEvaluator(object):
                             guard.zero_()
                         object.__setattr__(self.model, '_lp_guard_clean', False)
                     self._graph.replay()
+                    self._shard_flags = st.get('shard_flags')
                     if guard is not None and st.get('zeroes_guard'):
                         object.__setattr__(self.model, '_lp_guard_clean', True)
                     flat, out, fl = st['out']
@@ -1002,7 +1027,7 @@ class LinkPredictionEvaluator(object):
                 elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
                     self.model._split_ok = False
                     redo = True
-                elif n_local > 0 and not kdist.multi(world):
+                elif n_local > 0 and (not kdist.multi(world) or (level_ok and self._shard_flags is not None)):
                     # level policy for the NEXT evaluation, from the pairs this one re-scored (flags[2])
                     per_q = rescored / (2.0 * n_local)
                     self.last_rescored_per_query = per_q

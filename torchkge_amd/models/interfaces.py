@@ -360,7 +360,7 @@ class Model(Module):
         srcs = [T0] + ([T1] if T1 is not None else [])
         self._cache.get('esn_' + key, srcs, norms)       # the norm maxima fix the operands' scale: before either table
         nm1 = g[5:6] if T1 is not None else None
-        if self._use_level1() and c_base == 0 and T0.shape[0] == self.n_ent:
+        if self._use_level1():
             # one-product level (see TransEModel._fused_query_problem): planar hi table + its residual maximum
             frag = self._level1_stream()
             Eh, de2 = self._cache.get('ehd%d_' % frag + key, srcs,
@@ -517,7 +517,7 @@ class TranslationModel(Model):
         prob.split = {'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': g[3:4], 'yabsmax': g[4:5] if yc is not None else None,
                       'list_stat': g[6:7]}
         if self._use_level1():      # one-product level (see TransEModel._fused_query_problem)
-            frag = self._level1_stream() and prob.desc.c_base == 0 and table.shape[0] == self.n_ent
+            frag = self._level1_stream()
             Eh, de2 = self._cache.get('eh%d_' % frag + key, [table], lambda: _hip.hi_table(table, K=Kq, aug=en, frag=frag))
             prob.split.update({'Es': Eh, 'e2pref': None, 'level': 1, 'de2max': de2, 'es_frag': frag})
         else:

@@ -101,10 +101,14 @@ class TransEModel(TranslationModel):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
-        if (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
-                and self.split_filter and self._split_ok and ent_lo == 0 and ent_hi == self.n_ent
-                and self._row_shard is None and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0):
+        fusable = (self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
+                   and self.split_filter and self._split_ok and h_idx.shape[0] > 0 and self.emb_dim % 4 == 0)
+        if fusable and ent_lo == 0 and ent_hi == self.n_ent and self._row_shard is None:
             return self._fused_query_problem(h_idx, t_idx, r_idx, sd, tabs, cols if sd == _hip.SIDE_BOTH else None)
+        if fusable and qtabs is not None and self._row_shard == (ent_lo, ent_hi) and sd == _hip.SIDE_BOTH:
+            # ROW-SHARDED table with the replicas of the query entities' rows at hand (h_idx / t_idx index THEM): the same
+            # fused query side, fed from the replicas; candidates = this rank's rows
+            return self._fused_query_problem(h_idx, t_idx, r_idx, sd, tabs, None, qrep=_hip.f32c(qtabs[0]), c_base=ent_lo)
         Q0, _, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)
         prob = self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi),
                                            c_base=ent_lo)
@@ -114,13 +118,17 @@ class TransEModel(TranslationModel):
             else None
         return prob
 
-    def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs, cols=None):
-        """Inside evaluate(), unsharded: the whole query side of a batch (q, ||q||^2, true scores,
-        split queries, thresholds) from ONE kernel; the evaluator's pair_scores(true_idx) /
-        count_ge calls then find their inputs ready."""
+    def _fused_query_problem(self, h_idx, t_idx, r_idx, sd, tabs, cols=None, qrep=None, c_base=0):
+        """Inside evaluate(): the whole query side of a batch (q, ||q||^2, true scores, split queries, thresholds) from
+        ONE kernel; the evaluator's pair_scores(true_idx) / count_ge calls then find their inputs ready.
+        ``qrep`` (row-sharded tables, r05): replicas of the rows of the entities the queries mention -- the source and
+        true-entity rows are read from THEM (h_idx / t_idx index the replicas; same rows, same chains, same bits as the
+        owner shard's), while the candidate side -- norms, split / hi table, the bounds of the error band -- is this
+        rank's own rows ``tabs[0]`` = global entities [c_base, c_base + rows)."""
         E = _hip.f32c(tabs[0])
         g = self._lp_guard
-        key = '0_%d' % E.shape[0]
+        key = '%d_%d' % (c_base, E.shape[0])
+        Eq = E if qrep is None else qrep            # where the query pipeline reads e_src / e_true
         lvl1 = self._use_level1()
         frag = lvl1 and self._level1_stream() and (cols is None or cols.n_multi_p == 0)
         prep = None
@@ -134,6 +142,11 @@ class TransEModel(TranslationModel):
             en = self._cache.get('en_' + key, [E], lambda: prep[0])
         else:
             en = self._cache.get('en_' + key, [E], lambda: _hip.row_sqnorm(E, max_io=g[1:2]))
+
+        def enq():      # ||.||^2 of the rows the true scores are read from (replicas: their own chain norms, no maximum)
+            if qrep is None:
+                return en
+            return self._cache.get('en_replica', [qrep], lambda: _hip.row_sqnorm(qrep))
         if lvl1:
             # one-product level of the split prefilter (a fitted model: the true entities sit in the sparse upper tail,
             # the 8x wider band still holds few pairs): planar hi table, thresholds from the measured f16 residuals
@@ -142,18 +155,18 @@ class TransEModel(TranslationModel):
             else:
                 Eh, de2 = self._cache.get('eh%d_' % frag + key, [E], lambda: _hip.hi_table(E, aug=en, frag=frag))
             tp_bmax = prep[2] if prep is not None else None
-            pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], cols=cols, level=1,
+            pre = _hip.lp_query_pipeline(sd, Eq, tabs[1], h_idx, t_idx, r_idx, enq(), g[1:2], g[0:1], cols=cols, level=1,
                                          de2max=de2, tp_bmax=tp_bmax, zero_counts=True)
             split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'overflow': g[2:3], 'level': 1, 'de2max': de2,
                      'list_stat': g[6:7], 'es_frag': frag}
         else:
             Es, e2 = self._cache.get('es_' + key, [E], lambda: _hip.split_table(E, aug=en))
-            pre = _hip.lp_query_pipeline(sd, E, tabs[1], h_idx, t_idx, r_idx, en, g[1:2], g[0:1], e2pref=e2, cols=cols,
+            pre = _hip.lp_query_pipeline(sd, Eq, tabs[1], h_idx, t_idx, r_idx, enq(), g[1:2], g[0:1], e2pref=e2, cols=cols,
                                          zero_counts=True)
             split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'overflow': g[2:3], 'list_stat': g[6:7]}
         # (SIDE_BOTH: the evaluator fills in the concatenated true indices it gets from the filter lookup)
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
-        prob = _hip.LpProblem(_hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
+        prob = _hip.LpProblem(_hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en, c_base=c_base)
         prob.split = split
         prob.pre = pre
         return prob
