@@ -896,14 +896,16 @@ def main():
                 # batch's COLUMNS (distinct query rows) where the evaluator's plan carries a ColumnPlan
                 pl = (getattr(ev, '_plans', None) or {}).get((0, int(h.shape[0])))
                 cols = getattr(pl, 'cols', None)
-                if model._use_level1() and not (tk.evaluation.DEDUPE_LEVEL1 and getattr(model, 'lp_dedupe_level1', True)):
-                    cols = None     # (as evaluate() does on the one-product level: Model.lp_dedupe_level1)
+                if model._use_level1() and (not (tk.evaluation.DEDUPE_LEVEL1 and getattr(model, 'lp_dedupe_level1', True))
+                                            or model._level1_stream()):
+                    cols = None     # (as evaluate() does on the one-product level: Model.lp_dedupe_level1 / the free-running kernel)
                 prob = model.lp_problem(h, t, r, 'both', cols=cols) if cols is not None else model.lp_problem_both(h, t, r)
             if prob is not None:
                 true = torch.cat([t, h])
                 if prob.pre is not None:
                     prob.pre['true_idx'] = true
                 s_true = prob.pair_scores(true)
+                prob.split_true = (s_true, true)    # (as the evaluator: the sweep does not list the pairs whose score IS the threshold)
                 B = 2 * B
             else:
                 # (row-sharded tables: only rank 0 runs this timing leg, so the query exchange is skipped --
@@ -954,16 +956,23 @@ def main():
             level = int(prob.split.get('level', 0))      # 1: the one-product level (planar hi operands, one MFMA per k16 unit)
             k16 = ((K + 2 + 15) // 16 * 16) if level == 1 else ((K + 1 + 15) // 16 * 16)
             alg_flops, exec_flops = 2 * K, (1 if level == 1 else 3) * 2 * k16
-            kname = ('lp_split_count_kernel, LV = 1 (f16 hi operands, ONE v_mfma_f32_32x32x16_f16 product per k16 unit, fp32 '
-                     'accumulate; band from the measured f16 residuals)') if level == 1 else \
+            stream = bool(prob.split.get('es_frag'))    # r05: the free-running one-product kernel (lp_hi_stream.hip)
+            kname = ('lp_hi_stream_kernel (one-product level, r05: ONE v_mfma_f32_32x32x16_f16 product per k16 unit on f16 hi '
+                     'operands, fp32 accumulate; resident 96-query panel in LDS, candidate fragments straight from the '
+                     'fragment-major table into registers, no block-wide barriers in the tile loop; band from the measured f16 '
+                     'residuals)') if (level == 1 and stream) else \
+                ('lp_split_count_kernel, LV = 1 (f16 hi operands, ONE v_mfma_f32_32x32x16_f16 product per k16 unit, fp32 '
+                 'accumulate; band from the measured f16 residuals)') if level == 1 else \
                 'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)'
-            ksym = 'lp_split_count_kernel'
+            ksym = 'lp_hi_stream_kernel' if (level == 1 and stream) else 'lp_split_count_kernel'
             peak, bound = PEAK_F16_TFLOPS, 'mfma'
             # what the matrix cores EXECUTE: the sweep runs over the batch's COLUMNS (distinct query rows, padded to the
             # 192-column panel) x the candidates padded to the 256-row tile, three f16 products per k16 unit -- not over
             # (query, candidate) pairs (r03 multiplied by pairs and over-stated executed_frac: 0.51 where PMC says 0.39)
             mfma_cols = (cols.n_single_p + cols.n_multi_p) if cols is not None else (B + 191) // 192 * 192
             mfma_pairs = mfma_cols * ((n_ent + 255) // 256 * 256)
+            if level == 1 and stream:       # units are exact there (no padding of K to 64): ceil((K + 2) / 16) per pair
+                exec_flops = 2 * 16 * ((K + 2 + 15) // 16)
             extra = {'peak_is': 'dense f16 MFMA (the unit the kernel runs on)',
                      'executed_flops_per_column_pair': exec_flops,
                      'mfma_column_pairs_per_launch': int(mfma_pairs),

@@ -1712,7 +1712,10 @@ static int hi_rows_impl(const float *X0, int64_t ld0, int K0, const float *X1, i
     p.frag = frag;
     const int64_t blocks = p.rows_p / 16;
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(hi_rows_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, kge_s(stream), p);
+    // every block ends with ONE same-address atomic (dn2max), and those serialise at ~20-30 ns each (measured r05 on the
+    // fused table preparation: 1,824 of them cost 50 us): with a maximum to fold, two blocks per CU walk the rows
+    const int64_t cap = dn2max ? 2 * (int64_t)split_num_cus() : 65536;
+    hipLaunchKernelGGL(hi_rows_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -425,7 +425,7 @@ class LinkPredictionEvaluator(object):
     def _ensure_plans(self, kg, f_lo, f_hi, b_size, index_t, index_h, device):
         """Build (or keep) the FilterPlans of every batch of this evaluation, OUTSIDE any graph capture."""
         want_sort = bool(getattr(self.model, 'lp_sort_queries_by_relation', False))
-        stamp = (b_size, f_lo, f_hi, str(device), want_sort,
+        stamp = (b_size, f_lo, f_hi, str(device), want_sort, DEDUPE_QUERIES, getattr(self.model, 'lp_dedupe_queries', False),
                  tuple((x.data_ptr(), x._version, x.shape[0]) for x in (kg.head_idx, kg.tail_idx, kg.relations)),
                  tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t) for x in (ix.keys, ix.offsets, ix.targets)))
         # ... and the stamped tensors themselves (strong references, compared by identity): a data_ptr / shape stamp
