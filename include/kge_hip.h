@@ -229,6 +229,13 @@ int kge_relation_scores_proj(int kind, const float *E, const float *R, const flo
                              int d_ent, int d_rel, const int64_t *h, const int64_t *t, int64_t B,
                              int64_t n_rel, float *out, int64_t ldo, kge_stream_t stream);
 
+/* Per-query scalars of the projection modes (KGE_LP_L2_PROJH / _PROJD) in ONE launch: qn[i] = ||Q[i]||^2 and
+ * pz[i] = (scale * (Q[i] . W[r_idx[i]]), ||W[r_idx[i]]||^2 + z_add) -- kge_lp_desc.Wq of those modes (TransH: scale 2,
+ * z_add -2, W = the normal vectors; TransD: scale -2, z_add 0, W = the relation projection vectors) -- by the chains of
+ * kge_row_sqnorm / kge_row_dot (same bits as the six launches it replaces); *qmax_io = max(*qmax_io, max qn).
+ * KGE_EUNSUPPORTED unless K % 4 == 0, ldq % 4 == 0, ldw % 4 == 0 and Q, W are 16-byte aligned. */
+int kge_proj_query_stats(const float *Q, int64_t ldq, const float *W, int64_t ldw, const int64_t *r_idx, int64_t rows,
+                         int K, float scale, float z_add, float *qn, float *pz, float *qmax_io, kge_stream_t stream);
 /* out = op(a, b[, c, d]) elementwise over n floats (separate mul / add roundings,
  * as the reference's (re_h * re_r - im_h * im_r) etc., bilinear.py:514-522). */
 int kge_ewise(int op, const float *a, const float *b, const float *c, const float *d, int64_t n,
@@ -464,7 +471,8 @@ typedef struct kge_split_args {
     const float *qn0, *qn1;       /* KGE_LP_DOT: ||q_i||^2 per K-segment (qn1 NULL when K1 == 0); L2_EXPAND: desc.qn is used */
     const float *qmax0, *qmax1;   /* KGE_LP_DOT: device scalars >= max_i qn0 / qn1 (they fix the query operand's scale) */
     const float *emax0, *emax1;   /* device scalars >= max_c ||e_c||^2 per K-segment (emax1 NULL when K1 == 0) */
-    const float *xabsmax, *yabsmax; /* L2_PROJH/_PROJD: device scalars >= max |X[r,c]| (and >= max |yc[c]|, PROJD), see kge_absmax */
+    const float *xabsmax, *yabsmax; /* L2_PROJH/_PROJD: device scalars >= max |X[r,c]| (xabsmax NULL: the per-query bound
+                                     * ||w_i|| max||e|| is used) and >= max |yc[c]| (PROJD), see kge_absmax */
     int32_t accum_model;          /* 0: accumulation error bounded for ANY fp32 adder (2 * 2^-24 per product); 1: the
                                    * measured behaviour of gfx950, valid only if kge_mfma_f16_selftest() returned 1 */
     float eps_scale;              /* multiplies the error band (1.0 = the proven bound; tests shrink it) */
@@ -513,6 +521,11 @@ typedef struct kge_split_args {
     /* es_frag = 1, optional: true_idx[i] = GLOBAL id of the entity whose exact score IS s_true[i] (the evaluator's true
      * entity).  That pair is counted and can never be taken back by the recheck, so the sweep does not list it. */
     const int64_t *true_idx;
+    /* optional: the block maxima kge_lp_table_prep_l2 left instead of its atomics (2 * tp_blocks floats); the threshold
+     * kernel folds them into *emax0 and *de2max (written through the const pointers) before using the two scalars.
+     * Only with thr_ready = 0 and a one-segment problem. */
+    const float *tp_block_max;
+    int32_t tp_blocks;
 } kge_split_args;
 int kge_lp_split_group_sets(void);
 

@@ -49,7 +49,7 @@ class SplitArgs(ctypes.Structure):
         ('col_q', _vp), ('n_single_p', _i64), ('members', _vp), ('n_multi_p', _i64),
         ('q_cell_ss_index', _vp), ('q_cell_ss_ld', _i64),
         ('level', ctypes.c_int32), ('q_dn2', _vp), ('q_dn2_index', _vp), ('de2max', _vp),
-        ('es_frag', ctypes.c_int32), ('true_idx', _vp),
+        ('es_frag', ctypes.c_int32), ('true_idx', _vp), ('tp_block_max', _vp), ('tp_blocks', ctypes.c_int32),
     ]
 
 
@@ -76,6 +76,7 @@ _SIGNATURES = {
                             _vp, _vp, _vp],
     'kge_relation_scores_proj': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    'kge_proj_query_stats': [_vp, _i64, _vp, _i64, _vp, _i64, _int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp],
     'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     'kge_row_sqnorm_any_order': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     'kge_row_dot': [_vp, _vp, _i64, _i64, _int, ctypes.c_float, _vp, _vp],
@@ -375,6 +376,25 @@ def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=Fal
     return Q0, Q1, qn, Wq
 
 
+def proj_query_stats(Q, W, r_idx, scale, z_add, qmax_io=None):
+    """kge_proj_query_stats: (qn, pz) of a projection-mode problem in one launch -- ||Q_i||^2 and (scale * Q_i . W[r_i],
+    ||W[r_i]||^2 + z_add), the chains of row_sqnorm / row_dot (same bits).  None when shapes / alignment need the
+    separate kernels."""
+    lib = load_library()
+    require_cuda(Q, W, r_idx, qmax_io)
+    Q, W, r_idx = f32c(Q), f32c(W), i64c(r_idx)
+    rows, K = Q.shape
+    qn = torch.empty(rows, dtype=torch.float32, device=Q.device)
+    pz = torch.empty(rows, 2, dtype=torch.float32, device=Q.device)
+    with _on(Q.device):
+        rc = int(lib.kge_proj_query_stats(_p(Q), Q.stride(0), _p(W), W.stride(0), _p(r_idx), rows, K, float(scale), float(z_add),
+                                          _p(qn), _p(pz), _p(qmax_io), _stream()))
+    if rc == KGE_EUNSUPPORTED:
+        return None
+    _check(rc, 'kge_proj_query_stats')
+    return qn, pz
+
+
 def relation_scores_proj(kind, E, R, Wt, Ep, d_ent, d_rel, h, t):
     """(B, n_rel) scores of every relation for (h_i, ?, t_i) under the relation-specific projections of
     TransH / TransD (kge_relation_scores_proj)."""
@@ -528,7 +548,7 @@ def hi_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1
     return Eh, de2
 
 
-def table_prep_l2(E, emax_io, de2max_io, deferred_max=False):
+def table_prep_l2(E, emax_io, de2max_io, deferred_max=False, K=None):
     """Candidate side of the L2 one-product sweep in ONE launch (kge_lp_table_prep_l2): (en, Ef) -- the squared row norms
     (kge_row_sqnorm's chain, same bits; maximum folded into emax_io) and the fragment-major hi table (residual maximum
     folded into de2max_io).  ``deferred_max``: (en, Ef, block_max) -- the two maxima stay per block (no same-address
@@ -537,7 +557,8 @@ def table_prep_l2(E, emax_io, de2max_io, deferred_max=False):
     lib = load_library()
     require_cuda(E, emax_io, de2max_io)
     E = f32c(E)
-    rows, K, ld = E.shape[0], E.shape[1], E.stride(0)
+    rows, ld = E.shape[0], E.stride(0)
+    K = E.shape[1] if K is None else int(K)     # (TransD: the first d_r columns of the (N, d_e) table)
     if K % 4 or ld % 4 or E.data_ptr() % 16 or rows == 0:
         return None
     units_p = int(lib.kge_lp_hi_units(K))
@@ -908,6 +929,9 @@ class LpProblem(object):
             a.col_q, a.n_single_p = _p(cols.col_q), cols.n_single_p
             a.members, a.n_multi_p = _p(cols.members), cols.n_multi_p
         a.level = int(sp.get('level', 0))
+        tpb = sp.get('tp_bmax')
+        if tpb is not None and not a.thr_ready:     # block maxima of the fused table preparation: folded by the threshold kernel
+            a.tp_block_max, a.tp_blocks = _p(tpb), tpb.shape[0] // 2
         a.es_frag = 1 if sp.get('es_frag') else 0
         if a.es_frag:
             assert a.level == 1 and (cols is None or cols.n_multi_p == 0), 'the free-running sweep takes no grouped columns'

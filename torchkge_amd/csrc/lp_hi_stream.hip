@@ -35,10 +35,16 @@ constexpr int HS_NT = 3, HS_MT = 2;
 constexpr int HS_WROWS = 64;                    // candidate rows per wave
 constexpr int HS_WLIST = 384;                   // uncertain pairs buffered per wave (int2 entries)
 constexpr int HS_PF = 3, HS_RING = 4;           // candidate fragments: units in flight / ring slots
+#ifndef HS_SCALAR_SUB
+#define HS_SCALAR_SUB 1                         /* epilogue: w = v - a_lo as four v_sub_f32 instead of two v_pk_add_f32 (-3 %) */
+#endif
+#ifndef HS_TEST8
+#define HS_TEST8 1                              /* epilogue: the uncertain-pair test per 8 elements instead of per 4 (-1 %) */
+#endif
 
 // PROBE (timing probes, wrong results; env KGE_HS_PROBE, instantiated for <4, 13, 0> only): 1 no compare epilogue, 2 every
 // wave streams the table's first rows (cache-hot candidates), 4 no query-fragment reads in the K sweep, 8 no candidate loads
-// in the K sweep, 16 no MFMAs
+// in the K sweep, 16 no MFMAs; 32 / 64 / 96: VALID results, epilogue variants (scalar subtracts / test per 8 elements / both)
 template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM, int PROBE = 0>
 __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_stream_params p)
 {
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                             if (PM == 2) y4[g4] = *reinterpret_cast<const float4 *>(p.yc + c0 + 4 * half + mt * 32 + 8 * g4);
                         }
                     }
+                    unsigned bq[2][4];          // bit patterns of w = v - a_lo of the two quads of this half tile
 #pragma unroll
                     for (int g4 = 2 * gh; g4 < 2 * gh + 2; ++g4) {
                         float vq[4];
@@ -320,28 +327,48 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                                 vq[e] = fmaf(corr, -8388608.0f, vq[e]);
                             }
                         }
-                        const f32x2 w01 = (f32x2){vq[0], vq[1]} + nlo2, w23 = (f32x2){vq[2], vq[3]} + nlo2;
-                        const unsigned b0 = __float_as_uint(w01.x), b1 = __float_as_uint(w01.y);
-                        const unsigned b2 = __float_as_uint(w23.x), b3 = __float_as_uint(w23.y);
+                        unsigned b0, b1, b2, b3;
+                        if (HS_SCALAR_SUB || (PROBE & 32)) {        // four v_sub_f32 (same values: one rounding each)
+                            b0 = __float_as_uint(vq[0] - lo_n); b1 = __float_as_uint(vq[1] - lo_n);
+                            b2 = __float_as_uint(vq[2] - lo_n); b3 = __float_as_uint(vq[3] - lo_n);
+                        } else {
+                            const f32x2 w01 = (f32x2){vq[0], vq[1]} + nlo2, w23 = (f32x2){vq[2], vq[3]} + nlo2;
+                            b0 = __float_as_uint(w01.x); b1 = __float_as_uint(w01.y);
+                            b2 = __float_as_uint(w23.x); b3 = __float_as_uint(w23.y);
+                        }
                         smask = __builtin_amdgcn_alignbit(smask, b0, 31);
                         smask = __builtin_amdgcn_alignbit(smask, b1, 31);
                         smask = __builtin_amdgcn_alignbit(smask, b2, 31);
                         smask = __builtin_amdgcn_alignbit(smask, b3, 31);
-                        const unsigned mq = min(min(min(b0, b1), b2), b3);
-                        if (__ballot(mq <= hwb)) {      // some lane holds an uncertain pair among these 4 rows
-                            // (kept SMALL: this block is unrolled 24 times; capacity is checked once per tile below --
-                            // an entry past the buffer raises the overflow flag, like UNC_CAP of lp_split_count_kernel)
-                            const unsigned bb[4] = {b0, b1, b2, b3};
+                        bq[g4 & 1][0] = b0; bq[g4 & 1][1] = b1; bq[g4 & 1][2] = b2; bq[g4 & 1][3] = b3;
+                    }
+                    // uncertain pairs (0 <= w <= band width, as unsigned bit patterns): tested per quad, or per PAIR of quads
+                    // (HS_TEST8: half the ballots and branches; the listing below then walks 8 elements)
+                    const unsigned mq0 = min(min(min(bq[0][0], bq[0][1]), bq[0][2]), bq[0][3]);
+                    const unsigned mq1 = min(min(min(bq[1][0], bq[1][1]), bq[1][2]), bq[1][3]);
+                    const bool test8 = HS_TEST8 || (PROBE & 64);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int cand = (int)c0 + cl_base + mt * 32 + e + 8 * g4;
-                                const bool unc = bb[e] <= hwb && cand != tru[nt];
-                                const unsigned long long m = __ballot(unc);
-                                if (m) {
-                                    const int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                    if (unc && pos < HS_WLIST) wlist[pos] = make_int2(qid[nt], cand);
-                                    nlist += __popcll(m);
+                    for (int hq = 0; hq < 2; ++hq) {
+                        if (test8 && hq == 1) break;
+                        const unsigned mq = test8 ? min(mq0, mq1) : (hq == 0 ? mq0 : mq1);
+                        if (__ballot(mq <= hwb)) {      // some lane holds an uncertain pair among these rows
+                            // (kept SMALL: unrolled 12 / 24 times; capacity is checked once per tile below -- an entry
+                            // past the buffer raises the overflow flag, like UNC_CAP of lp_split_count_kernel)
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq) {
+                                if (!test8 && qq != hq) continue;
+                                const int g4 = 2 * gh + qq;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int cand = (int)c0 + cl_base + mt * 32 + e + 8 * g4;
+                                    const bool unc = bq[qq][e] <= hwb && cand != tru[nt];
+                                    const unsigned long long m = __ballot(unc);
+                                    if (m) {
+                                        const int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                        if (unc && pos < HS_WLIST) wlist[pos] = make_int2(qid[nt], cand);
+                                        nlist += __popcll(m);
+                                    }
                                 }
                             }
                         }
@@ -409,6 +436,9 @@ int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, hipStre
         case 13: return hs_launch<4, 13, 0, 13>(p, grid, smem, s);
         case 16: return hs_launch<4, 13, 0, 16>(p, grid, smem, s);
         case 17: return hs_launch<4, 13, 0, 17>(p, grid, smem, s);
+        case 32: return hs_launch<4, 13, 0, 32>(p, grid, smem, s);     // (valid results: epilogue variants)
+        case 64: return hs_launch<4, 13, 0, 64>(p, grid, smem, s);
+        case 96: return hs_launch<4, 13, 0, 96>(p, grid, smem, s);
         default: break;
         }
     }

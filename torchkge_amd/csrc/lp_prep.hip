@@ -65,8 +65,10 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
                     for (int k = lane; k < dr; k += 64) q1[k] = 0.f;
                 } else if (p.kind == KGE_TRANSH || p.kind == KGE_TRANSD) {
                     const float *w = (p.kind == KGE_TRANSH ? p.t2 : p.t3) + ri * dr;
-                    float *wq = p.Wq + i * dr;
-                    for (int k = lane; k < dr; k += 64) wq[k] = w[k];
+                    if (p.Wq) {
+                        float *wq = p.Wq + i * dr;
+                        for (int k = lane; k < dr; k += 64) wq[k] = w[k];
+                    }
                 }
                 continue;
             }
@@ -106,11 +108,11 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
             float a = 0.f;
             for (int k = lane; k < dr; k += 64) a = fmaf(e[k], w[k], a);
             a = wave_sum(a);
-            float *wq = p.Wq + i * dr;
+            float *wq = p.Wq ? p.Wq + i * dr : nullptr;
             for (int k = lane; k < dr; k += 64) {
                 const float pe = e[k] - a * w[k]; // translation.py:281
                 q0[k] = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
-                wq[k] = w[k];
+                if (wq) wq[k] = w[k];
             }
             break;
         }
@@ -120,11 +122,11 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
             float sc = 0.f;
             for (int k = lane; k < de; k += 64) sc = fmaf(ep[k], e[k], sc);
             sc = wave_sum(sc);
-            float *wq = p.Wq + i * dr;
+            float *wq = p.Wq ? p.Wq + i * dr : nullptr;
             for (int k = lane; k < dr; k += 64) {
                 const float pe = sc * rp[k] + e[k]; // translation.py:646
                 q0[k] = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
-                wq[k] = rp[k];
+                if (wq) wq[k] = rp[k];
             }
             break;
         }
@@ -382,6 +384,78 @@ __global__ __launch_bounds__(64) void row_dot_staged_kernel(const float *__restr
     }
 }
 
+// Per-query scalars of the projection modes (TransH / TransD) in ONE pass over the query rows: what kge_row_sqnorm(Q),
+// kge_row_dot(Q, W[r]) * scale, kge_row_sqnorm(W[r]) + z_add and the glue between them (a gather of the W rows, an add, a
+// stack) produce in six launches -- the SAME sequential chains (k ascending, one accumulator each), so the same bits:
+//   qn[i] = ||q_i||^2          pz[i] = (scale * (q_i . w_{r_i}),  ||w_{r_i}||^2 + z_add)
+// A wavefront owns 16 rows: rows of Q and the gathered rows of W staged through LDS, lanes 0..15 / 16..31 / 32..47 run the
+// three chains of row (lane & 15) side by side.  NW wavefronts per block share the final max ||q||^2 atomic.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void proj_query_stats_kernel(const float *__restrict__ Q, int64_t ldq,
+                                                                   const float *__restrict__ W, int64_t ldw,
+                                                                   const int64_t *__restrict__ r_idx, int64_t rows, int K,
+                                                                   float scale, float z_add, float *qn, float *pz,
+                                                                   float *qmax_io)
+{
+    constexpr int RPW = 16;
+    __shared__ __attribute__((aligned(16))) float xs_all[NW * RPW * KGE_PS_LD];
+    __shared__ __attribute__((aligned(16))) float ys_all[NW * RPW * KGE_PS_LD];
+    __shared__ unsigned wmax[NW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *xs = xs_all + wv * RPW * KGE_PS_LD, *ys = ys_all + wv * RPW * KGE_PS_LD;
+    const int row_l = lane & 15, chain = lane >> 4;        // chain 0: q.q, 1: q.w, 2: w.w (3: idle)
+    float big = 0.f;
+    const int64_t ngroups = (rows + RPW - 1) / RPW;
+    for (int64_t grp = (int64_t)blockIdx.x * NW + wv; grp < ngroups; grp += (int64_t)gridDim.x * NW) {
+        const int64_t row0 = grp * RPW;
+        float acc = 0.f;
+        for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {   // K % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned (host-checked)
+            const int kc = min(KGE_PS_KC, K - k0);
+            const int pieces = kc >> 2;
+            for (int idx = lane; idx < RPW * pieces; idx += 64) {
+                const int rr = idx / pieces, pc = idx - rr * pieces;
+                const int64_t r = min(row0 + rr, rows - 1);
+                *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) =
+                    *reinterpret_cast<const float4 *>(Q + r * ldq + k0 + pc * 4);
+                *reinterpret_cast<float4 *>(ys + rr * KGE_PS_LD + pc * 4) =
+                    *reinterpret_cast<const float4 *>(W + r_idx[r] * ldw + k0 + pc * 4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (chain < 3) {
+                const float *x = (chain == 2 ? ys : xs) + row_l * KGE_PS_LD;
+                const float *y = (chain == 0 ? xs : ys) + row_l * KGE_PS_LD;
+                for (int k = 0; k < kc; k += 4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(x + k), b = *reinterpret_cast<const float4 *>(y + k);
+                    acc = fmaf(a.x, b.x, acc);
+                    acc = fmaf(a.y, b.y, acc);
+                    acc = fmaf(a.z, b.z, acc);
+                    acc = fmaf(a.w, b.w, acc);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        const float uw = __shfl(acc, row_l + 16, 64), ww = __shfl(acc, row_l + 32, 64);
+        if (lane < RPW && row0 + lane < rows) {
+            qn[row0 + lane] = acc;
+            pz[2 * (row0 + lane)] = scale * uw;
+            pz[2 * (row0 + lane) + 1] = ww + z_add;
+            big = __uint_as_float(max(__float_as_uint(big), __float_as_uint(acc)));
+        }
+    }
+    if (qmax_io) {      // one atomic per block (same-address atomics serialise in the L2)
+        unsigned m = __float_as_uint(big);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if (lane == 0) wmax[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned mm = wmax[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mm = max(mm, wmax[w]);
+            kge_atomic_max_u32(reinterpret_cast<unsigned *>(qmax_io), mm);
+        }
+    }
+}
+
 __global__ void ewise_kernel(int op, const float *__restrict__ a, const float *__restrict__ b,
                              const float *__restrict__ c, const float *__restrict__ d, int64_t n, float *out)
 {
@@ -491,6 +565,24 @@ extern "C" int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t r
     return 0;
 }
 
+/* Per-query scalars of the projection modes in one launch: qn[i] = ||Q[i]||^2, pz[i] = (scale * (Q[i] . W[r_idx[i]]),
+ * ||W[r_idx[i]]||^2 + z_add) -- the chains of kge_row_sqnorm / kge_row_dot (same bits), *qmax_io = max(., max qn).
+ * KGE_EUNSUPPORTED unless K % 4 == 0, ldq % 4 == 0, ldw % 4 == 0 and both matrices are 16-byte aligned. */
+extern "C" int kge_proj_query_stats(const float *Q, int64_t ldq, const float *W, int64_t ldw, const int64_t *r_idx,
+                                    int64_t rows, int K, float scale, float z_add, float *qn, float *pz, float *qmax_io,
+                                    kge_stream_t stream)
+{
+    if (rows < 0 || K <= 0 || ldq < K || ldw < K) return KGE_EINVAL;
+    if (rows == 0) return 0;
+    if (!Q || !W || !r_idx || !qn || !pz) return KGE_EINVAL;
+    if (K % 4 || ldq % 4 || ldw % 4 || !kge_aligned16(Q) || !kge_aligned16(W)) return KGE_EUNSUPPORTED;
+    const int64_t blocks = (rows + 63) / 64;        // 4 wavefronts x 16 rows
+    hipLaunchKernelGGL(proj_query_stats_kernel<4>, dim3((int)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, kge_s(stream), Q, ldq,
+                       W, ldw, r_idx, rows, K, scale, z_add, qn, pz, qmax_io);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_ewise(int op, const float *a, const float *b, const float *c, const float *d, int64_t n,
                          float *out, kge_stream_t stream)
 {
@@ -544,8 +636,8 @@ extern "C" int kge_lp_prep_sharded(int kind, int side, const float *t0, const fl
     if (B == 0) return 0;
     if (!h || !t || !r || !Q0) return KGE_EINVAL;
     if (kind == KGE_COMPLEX && (!t2 || !t3 || !Q1)) return KGE_EINVAL;
-    if (kind == KGE_TRANSH && (!t2 || !Wq)) return KGE_EINVAL;
-    if (kind == KGE_TRANSD && (!t2 || !t3 || !Wq || d_ent < d_rel)) return KGE_EINVAL;
+    if (kind == KGE_TRANSH && !t2) return KGE_EINVAL;       // (Wq optional: NULL = the gathered rows are not needed)
+    if (kind == KGE_TRANSD && (!t2 || !t3 || d_ent < d_rel)) return KGE_EINVAL;
     if (kind != KGE_TRANSD && d_ent != d_rel) return KGE_EINVAL;
     PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq, ent_lo, ent_n};
     const int64_t nq = side == KGE_SIDE_BOTH ? 2 * B : B;

@@ -591,6 +591,9 @@ struct SplitThrParams {
     const float *q_dn2;             // ||q_i - hi(q_i)||^2, read at q_dn2_index[i] when given (query columns)
     const int64_t *q_dn2_index;
     const float *de2max;            // device scalar >= max_c ||e_c - hi(e_c)||^2
+    const float *tp_bmax;           // optional [2][tp_blocks]: block maxima left by kge_lp_table_prep_l2 (emax0, de2max): folded
+    int tp_blocks;                  // into the two scalars by every block on its way in, stored by block 0
+    float *emax_out, *de2max_out;
 };
 
 // (a_lo, a_hi) of the plain L2 expansion, unscaled half-width logic shared by split_thr_kernel and the fused
@@ -669,7 +672,31 @@ __global__ void split_thr_kernel(const SplitThrParams p)
 {
     const float two24_c = 5.9604645e-8f;
     const float two22 = 2.3841858e-7f;
-    const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
+    float em, de2m = 0.f;
+    if (p.tp_bmax) {        // (as query_pipeline_kernel: the table preparation's per-block maxima -> the two scalars)
+        __shared__ unsigned red[8];
+        unsigned m0 = 0u, m1 = 0u;
+        for (int j = threadIdx.x; j < p.tp_blocks; j += blockDim.x) {
+            m0 = max(m0, __float_as_uint(p.tp_bmax[j]));
+            m1 = max(m1, __float_as_uint(p.tp_bmax[p.tp_blocks + j]));
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 = max(m0, (unsigned)__shfl_xor((int)m0, off, 64));
+            m1 = max(m1, (unsigned)__shfl_xor((int)m1, off, 64));
+        }
+        const int wv_ = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[wv_] = m0; red[4 + wv_] = m1; }
+        __syncthreads();
+        m0 = max(max(red[0], red[1]), max(red[2], red[3]));
+        m1 = max(max(red[4], red[5]), max(red[6], red[7]));
+        em = __uint_as_float(max(m0, __float_as_uint(*p.emax0)));
+        de2m = __uint_as_float(max(m1, p.de2max ? __float_as_uint(*p.de2max) : 0u));
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *p.emax_out = em; if (p.de2max_out) *p.de2max_out = de2m; }
+    } else {
+        em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
+        if (p.level == 1) de2m = *p.de2max;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *p.list_count = 0;
         // non-finite norms (diverged embeddings): f16 operands would hold inf / NaN and the
@@ -703,7 +730,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
         }
         const float dq2 = p.level == 1 ? p.q_dn2[p.q_dn2_index ? p.q_dn2_index[i] : i] : 0.f;
         if (p.mode == KGE_LP_L2_EXPAND && p.level == 1) {
-            p.thr[i] = split_thr_l2_hi(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale, dq2, *p.de2max);
+            p.thr[i] = split_thr_l2_hi(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale, dq2, de2m);
         } else if (p.mode == KGE_LP_L2_EXPAND) {
             p.thr[i] = split_thr_l2(q, p.s_true[i], em, p.K, p.units, p.c_acc, p.eps_scale, amag);
         } else if (p.mode >= KGE_LP_L2_PROJH) {
@@ -712,7 +739,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float mag = qnrm * enrm + 0.5f * em;       // >= sum of |products|
             const float eps_dot = p.level == 1
                 ? split_acc_err(-1.0f, 0.5f * em, mag, p.units, p.c_acc, 16.0f) + split_chain_err(-1.0f, mag, p.K) +
-                  split_hi_resid(qnrm, enrm, 0.5f * em, dq2, *p.de2max) + 2.5e-7f * (qnrm + enrm) + 4e-9f
+                  split_hi_resid(qnrm, enrm, 0.5f * em, dq2, de2m) + 2.5e-7f * (qnrm + enrm) + 4e-9f
                 : split_acc_err(amag, 0.5f * em, mag, p.units, p.c_acc) + split_chain_err(amag, mag, p.K) +
                   eps_rel * mag + 2.5e-7f * (qnrm + enrm) + 4e-9f;
             const float eps_v = (2.0f * eps_dot + 4.0f * two22 * (q + em + fabsf(u))) * p.eps_scale;
@@ -722,7 +749,11 @@ __global__ void split_thr_kernel(const SplitThrParams p)
                 // + the projection term corr = x (x z + p)  resp.  y (y z + 2 g + p): it is computed exactly in fp32
                 // by both paths but enters in a different association -> a few ulps of its largest possible size
                 const float pi = p.pz[i * p.ldw], zi = p.pz[i * p.ldw + 1];
-                const float xm = *p.xabsmax, ym = p.mode == KGE_LP_L2_PROJD ? *p.yabsmax : 0.f;
+                // |X[r_i, c]| = |w_i . e_c| <= ||w_i|| max||e||  (Cauchy-Schwarz; ||w_i||^2 = z_i + 2 for TransH, z_i for TransD) when
+                // no measured maximum is given: the term below is 2^-22 of cmax, a looser bound costs nothing
+                const float wn2 = p.mode == KGE_LP_L2_PROJH ? zi + 2.0f : zi;
+                const float xm = p.xabsmax ? *p.xabsmax : sqrtf(fmaxf(wn2, 0.f) * em) * 1.000001f;
+                const float ym = p.mode == KGE_LP_L2_PROJD ? *p.yabsmax : 0.f;
                 const float cmax = p.mode == KGE_LP_L2_PROJH ? xm * (xm * fabsf(zi) + fabsf(pi))
                                                              : ym * (ym * fabsf(zi) + 2.0f * xm + fabsf(pi));
                 hw += 8.0f * two22 * cmax * p.eps_scale + two22 * cmax;
@@ -738,7 +769,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
             const float eps_dot = p.level == 1
                 ? (split_acc_err(-1.0f, 0.f, qnrm * enrm, p.units, p.c_acc, 16.0f) + split_chain_err(-1.0f, qnrm * enrm, p.K) +
-                   split_hi_resid(qnrm, enrm, 0.f, dq2, *p.de2max) + eps_abs) * p.eps_scale
+                   split_hi_resid(qnrm, enrm, 0.f, dq2, de2m) + eps_abs) * p.eps_scale
                 : (split_acc_err(amag, 0.f, qnrm * enrm, p.units, p.c_acc) +
                    split_chain_err(amag, qnrm * enrm, p.K) + straddle * qnrm * enrm +
                    eps_rel * qnrm * enrm + eps_abs) * p.eps_scale;
@@ -1805,7 +1836,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     if (!KGE_LP_IS_MFMA(d->mode)) return KGE_EINVAL;
     const bool proj = d->mode >= KGE_LP_L2_PROJH;
     if (d->B == 0 || d->N == 0) return 0;
-    if (proj && (!a || !a->xabsmax || (d->mode == KGE_LP_L2_PROJD && !a->yabsmax) || d->scal_ld % 4 != 0 ||
+    if (proj && (!a || (d->mode == KGE_LP_L2_PROJD && !a->yabsmax) || d->scal_ld % 4 != 0 ||
                  !kge_aligned16(d->scal)))
         return KGE_EINVAL;
     if (!a || !a->Qs || !a->Es || !s_true || !a->emax0 || !a->thr || !raw_count || !a->list || a->cap <= 0 ||
@@ -1840,6 +1871,9 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.ss_index = a->q_cell_ss_index; t.ss_ld = a->q_cell_ss_index ? a->q_cell_ss_ld : Bp;
     if (a->q_cell_ss_index && a->q_cell_ss_ld <= 0) return KGE_EINVAL;
     t.level = a->level; t.q_dn2 = a->q_dn2; t.q_dn2_index = a->q_dn2_index; t.de2max = a->de2max;
+    t.tp_bmax = a->tp_block_max; t.tp_blocks = a->tp_blocks;
+    t.emax_out = const_cast<float *>(a->emax0); t.de2max_out = const_cast<float *>(a->de2max);
+    if (a->tp_block_max && (a->tp_blocks <= 0 || a->emax1 || a->thr_ready)) return KGE_EINVAL;
     if (lv1) { t.q_cell_ss = nullptr; t.e2pref = nullptr; }
     t.list_count = a->list_count;
     t.overflow = a->overflow;

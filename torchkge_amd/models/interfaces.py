@@ -525,6 +525,58 @@ class TranslationModel(Model):
             prob.split.update({'Es': Es, 'e2pref': e2})
         return prob
 
+    def _proj_fast_problem(self, sd, h_idx, t_idx, r_idx, r_both, ent_lo, ent_hi, exchange, qtabs, spec):
+        """TransH / TransD inside evaluate() (guarded optimistic norm expansion + split prefilter), r05: the query side in
+        TWO launches -- kge_lp_prep (the query rows; the gathered W rows are not materialised) and kge_proj_query_stats
+        (||q||^2, p, z by the chains of the separate kernels: same bits) -- and, on the one-product level, the candidate
+        side in ONE (kge_lp_table_prep_l2: norms + fragment-major hi table + residual maximum, its two maxima folded by
+        the threshold kernel).  The measured max |X| (a kernel + a fill per evaluation) gives way to the per-query bound
+        ||w_i|| max||e|| inside the threshold kernel.  ``spec`` = (mode, W table, scale, z_add, K0, tables builder).
+        None: shapes / alignment need the general path."""
+        mode, Wt, scale, z_add, K0, build_side = spec
+        g = self._lp_guard
+        tabs = [x.data for x in self._tables()]
+        table = self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi)
+        Kq = table.shape[1] if K0 is None else K0
+        if Kq % 4 or table.stride(0) % 4 or table.data_ptr() % 16 or table.shape[0] == 0:
+            return None
+        Q0 = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)[0]
+        st = _hip.proj_query_stats(Q0, Wt, r_both, scale, z_add, qmax_io=g[0:1])
+        if st is None:
+            return None
+        qn, pz = st
+        key = '%d_%d' % (ent_lo, table.shape[0])
+        lvl1 = self._use_level1()
+        frag = lvl1 and self._level1_stream()
+        prep = None
+        if frag:
+            prep = self._cache.get('tp_' + key, [table], lambda: _hip.table_prep_l2(table, g[1:2], g[7:8], deferred_max=True, K=K0))
+        if prep is not None:
+            en = self._cache.get('en_' + key, [table], lambda: prep[0])
+        else:
+            en = self._cache.get('en_' + key, [table], lambda: _hip.row_sqnorm(table, K=K0, max_io=g[1:2]))
+        XT, yc = build_side(table, ent_lo, K0)
+        prob = _hip.LpProblem(mode, Q0, table, qn=qn, en=en, Wq=pz, scal=XT, r_idx=r_both, yc=yc, c_base=ent_lo, K0=K0)
+        split = {'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': None, 'yabsmax': None, 'list_stat': g[6:7]}
+        if yc is not None:
+            self._cache.get('ymax_' + key, [yc], lambda: _hip.absmax(yc, g[4:5]))
+            split['yabsmax'] = g[4:5]
+        if lvl1:
+            if prep is not None:
+                split.update({'Es': prep[1], 'e2pref': None, 'level': 1, 'de2max': g[7:8], 'es_frag': True, 'tp_bmax': prep[2]})
+            else:
+                Eh, de2 = self._cache.get('eh%d_' % frag + key, [table], lambda: _hip.hi_table(table, K=Kq, aug=en, frag=frag))
+                split.update({'Es': Eh, 'e2pref': None, 'level': 1, 'de2max': de2, 'es_frag': frag})
+        else:
+            Es, e2 = self._cache.get('es_' + key, [table], lambda: _hip.split_table(table, K=Kq, aug=en))
+            split.update({'Es': Es, 'e2pref': e2})
+        prob.split = split
+        return prob
+
+    def _proj_fast_ok(self):
+        return bool(self.dissimilarity_type == 'L2' and self.l2_mode == 'auto' and self._guard_on and self._expand_ok is None
+                    and self.split_filter and self._split_ok and getattr(self, 'lp_fast_proj', True))
+
     def _translational_problem(self, q, table, Wq=None, scal=None, r_idx=None, c_base=0, K0=None):
         """Problem for s[i,c] = -diss(q_i, table[c] (- a w_i))."""
         if self.dissimilarity_type == 'L2' and self.l2_mode in ('expand', 'auto') and \

@@ -237,17 +237,21 @@ class TransHModel(TranslationModel):
         """-||u - (e_c - x w)||^2 with x = e_c.w_{r_i}, expanded around the GEMM term u.e_c
         (KGE_LP_L2_PROJH): X[r, c] = W[r].E[c] is one small GEMM per evaluation, the
         per-query scalars are p = 2 u.w and z = ||w||^2 - 2."""
+        XT, _ = self._proj_side_tables(table, c_base, K0)
+        pz = torch.stack([_hip.row_dot(q, Wq, scale=2.0), _hip.row_sqnorm(Wq) - 2.0], dim=1).contiguous()
+        prob = _hip.LpProblem(_hip.LP_L2_PROJH, q, table, qn=qn, en=en, Wq=pz, scal=XT, r_idx=r_idx,
+                              c_base=c_base)
+        return self._attach_proj_split(prob, table, en, XT, None, K0)
+
+    def _proj_side_tables(self, table, c_base, K0):
+        """(X, None): X[r, c] = W[r].E[c] for the candidate rows, one small GEMM per evaluation."""
         W = _hip.f32c(self.norm_vect.weight.data)
         n = table.shape[0]
 
         def build():    # (n_rel, n) view of a row-padded buffer: the split kernel reads whole 256-candidate tiles
             buf = torch.zeros(W.shape[0], _hip.padded_cols(n), dtype=torch.float32, device=table.device)
             return _hip.LpProblem(_hip.LP_DOT, W, table).scores(buf[:, :n])
-        XT = self._cache.get('transh_aT_%d_%d' % (c_base, n), [table, W], build)
-        pz = torch.stack([_hip.row_dot(q, Wq, scale=2.0), _hip.row_sqnorm(Wq) - 2.0], dim=1).contiguous()
-        prob = _hip.LpProblem(_hip.LP_L2_PROJH, q, table, qn=qn, en=en, Wq=pz, scal=XT, r_idx=r_idx,
-                              c_base=c_base)
-        return self._attach_proj_split(prob, table, en, XT, None, K0)
+        return self._cache.get('transh_aT_%d_%d' % (c_base, n), [table, W], build), None
 
     def evaluate_projections(self):
         """Kept for API compatibility (translation.py:260-284); the engine needs
@@ -289,10 +293,18 @@ class TransHModel(TranslationModel):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
+        r_both = _both_r(r_idx, sd)
+        if self._proj_fast_ok() and h_idx.shape[0] > 0:
+            W = _hip.f32c(self.norm_vect.weight.data)
+            prob = self._proj_fast_problem(sd, h_idx, t_idx, r_idx, r_both, ent_lo, ent_hi, exchange, qtabs,
+                                           (_hip.LP_L2_PROJH, W, 2.0, -2.0, None, self._proj_side_tables))
+            if prob is not None:
+                prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
+                return prob
         Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_w=True)
         prob = self._translational_problem(Q0, self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), Wq=Wq,
                                            scal=lambda: self._a_matrix(ent_lo, ent_hi),
-                                           r_idx=_both_r(r_idx, sd), c_base=ent_lo)
+                                           r_idx=r_both, c_base=ent_lo)
         prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
         return prob
 
@@ -383,6 +395,14 @@ class TransDModel(TranslationModel):
         """-||u - (e'_c + y_c w)||^2, e' = e[:d_r], y_c = ep_c.e_c, expanded around the GEMM
         term u.e'_c (KGE_LP_L2_PROJD): G[r, c] = Rp[r].e'_c is one small GEMM per evaluation,
         the per-query scalars are p = -2 u.w and z = ||w||^2."""
+        GT, sigma = self._proj_side_tables(table, c_base, K0)
+        pz = torch.stack([_hip.row_dot(q, Wq, scale=-2.0), _hip.row_sqnorm(Wq)], dim=1).contiguous()
+        prob = _hip.LpProblem(_hip.LP_L2_PROJD, q, table, qn=qn, en=en, Wq=pz, scal=GT, r_idx=r_idx, yc=sigma,
+                              c_base=c_base, K0=K0)
+        return self._attach_proj_split(prob, table, en, GT, sigma, K0)
+
+    def _proj_side_tables(self, table, c_base, K0):
+        """(G, sigma): G[r, c] = Rp[r].E[c, :d_r] (one small GEMM per evaluation) and sigma[c] = Ep[c].E[c]."""
         lo, hi = c_base, c_base + table.shape[0]
         Rp = _hip.f32c(self.rel_proj_vect.weight.data)
         Ep = _hip.f32c(self.ent_proj_vect.weight.data)
@@ -398,10 +418,7 @@ class TransDModel(TranslationModel):
             return buf[:n]
         GT = self._cache.get('transd_gT_%d_%d' % (lo, hi), [table, Rp], build_g)
         sigma = self._cache.get('transd_sp_%d_%d' % (lo, hi), [table, Ep], build_s)
-        pz = torch.stack([_hip.row_dot(q, Wq, scale=-2.0), _hip.row_sqnorm(Wq)], dim=1).contiguous()
-        prob = _hip.LpProblem(_hip.LP_L2_PROJD, q, table, qn=qn, en=en, Wq=pz, scal=GT, r_idx=r_idx, yc=sigma,
-                              c_base=c_base, K0=K0)
-        return self._attach_proj_split(prob, table, en, GT, sigma, K0)
+        return GT, sigma
 
     def _handle_problem(self, q, cand, ent_lo=0, ent_hi=None):
         ent_hi = self.n_ent if ent_hi is None else ent_hi
@@ -411,7 +428,15 @@ class TransDModel(TranslationModel):
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None, cols=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         sd = _hip.side_code(side)
+        r_both = _both_r(r_idx, sd)
+        if self._proj_fast_ok() and h_idx.shape[0] > 0:
+            Rp = _hip.f32c(self.rel_proj_vect.weight.data)
+            prob = self._proj_fast_problem(sd, h_idx, t_idx, r_idx, r_both, ent_lo, ent_hi, exchange, qtabs,
+                                           (_hip.LP_L2_PROJD, Rp, -2.0, 0.0, self.rel_emb_dim, self._proj_side_tables))
+            if prob is not None:
+                prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
+                return prob
         Q0, _, _, Wq = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_w=True)
-        prob = self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=_both_r(r_idx, sd))
+        prob = self._problem(Q0, Wq, ent_lo, ent_hi, r_idx=r_both)
         prob.cols = cols if (sd == _hip.SIDE_BOTH and prob.split is not None) else None
         return prob
