@@ -219,6 +219,14 @@ int kge_lp_prep_sharded(int kind, int side, const float *t0, const float *t1, co
                         const float *t3, int d_ent, int d_rel, const int64_t *h, const int64_t *t,
                         const int64_t *r, int64_t B, int64_t ent_lo, int64_t ent_n, float *Q0, float *Q1,
                         float *qn, float *Wq, kge_stream_t stream);
+/* The same launch for the projection models (KGE_TRANSH / KGE_TRANSD, unsharded tables or replicas) with the PLANAR f16 hi
+ * operand of the query rows riding along (r05): Qh = what kge_lp_hi_rows(Q0, is_query = 1, aug_mode 2) builds in a launch of
+ * its own -- [Bp][hi_units_p][32 bytes], scale 2^12, augmentation columns 1, 1, rows [nq, Bp) zero -- and q_dn2[i] =
+ * ||q_i - hi(q_i)||^2 (optional).  Qh = NULL: exactly kge_lp_prep_sharded.  Wq may be NULL for these kinds. */
+int kge_lp_prep_hi(int kind, int side, const float *t0, const float *t1, const float *t2, const float *t3, int d_ent,
+                   int d_rel, const int64_t *h, const int64_t *t, const int64_t *r, int64_t B, int64_t ent_lo,
+                   int64_t ent_n, float *Q0, float *Q1, float *qn, float *Wq, void *Qh, int hi_units_p, int64_t Bp,
+                   float *q_dn2, kge_stream_t stream);
 
 /* Relation candidates of the projection models (relation prediction, `entities=False`;
  * TransH translation.py:252-256, TransD :621-626, scored as interfaces.py:261-272):

@@ -1743,3 +1743,33 @@ def test_fresh_evaluators_share_what_was_learned_about_model_and_graph(hip):
     del ev, priv, other, states, m
     gc.collect()
     assert len(evm._STATES) < n_before
+
+
+@pytest.mark.parametrize('kind,B,d_e,d_r', [('transh', 1000, 64, 64), ('transd', 777, 72, 48), ('transh', 5, 200, 200)])
+def test_projection_query_side_in_two_launches_equals_the_separate_kernels(hip, kind, B, d_e, d_r):
+    """r05: kge_lp_prep_hi (query rows + their planar f16 hi operand + residuals in one launch) and kge_proj_query_stats
+    (||q||^2, p, z in one launch) against the launches they replace: kge_lp_prep + kge_lp_hi_rows, and kge_row_sqnorm +
+    kge_row_dot (+ the add / stack glue) -- bit for bit (the residuals: a bound, equal up to the summation order)."""
+    n_ent, n_rel = 900, 13
+    tables = orc.init_tables(kind, n_ent, n_rel, d_e, seed=8, d_rel=(d_r if kind == 'transd' else None))
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    g = torch.Generator().manual_seed(B)
+    h = torch.randint(0, n_ent, (B,), generator=g).cuda(); t = torch.randint(0, n_ent, (B,), generator=g).cuda()
+    r = torch.randint(0, n_rel, (B,), generator=g).cuda()
+    tabs = [x.data for x in m._tables()]
+    k = hip.TRANSH if kind == 'transh' else hip.TRANSD
+    Q0, _, _, Wq = hip.lp_prep(k, hip.SIDE_BOTH, tabs, d_e, d_r, h, t, r, want_w=True)
+    Q0b, _, _, _, Qh, dn2 = hip.lp_prep(k, hip.SIDE_BOTH, tabs, d_e, d_r, h, t, r, want_hi=True)
+    assert torch.equal(Q0, Q0b)
+    Qh_ref, dn2_ref = hip.hi_rows(Q0, is_query=True, want_dn2=True)
+    assert torch.equal(Qh, Qh_ref)
+    assert torch.allclose(dn2, dn2_ref, rtol=3e-4, atol=0) and bool((dn2 >= dn2_ref * (1 - 1e-5)).all())
+    Wt = tabs[2] if kind == 'transh' else tabs[3]
+    rb = torch.cat([r, r])
+    scale, z_add = (2.0, -2.0) if kind == 'transh' else (-2.0, 0.0)
+    gq = torch.zeros(1, device='cuda')
+    qn, pz = hip.proj_query_stats(Q0, Wt, rb, scale, z_add, qmax_io=gq)
+    gq2 = torch.zeros(1, device='cuda')
+    qn_ref = hip.row_sqnorm(Q0, max_io=gq2)
+    pz_ref = torch.stack([hip.row_dot(Q0, Wq, scale=scale), hip.row_sqnorm(Wq) + z_add], dim=1)
+    assert torch.equal(qn, qn_ref) and torch.equal(pz, pz_ref) and float(gq) == float(gq2)

@@ -74,6 +74,8 @@ _SIGNATURES = {
                     _vp, _vp, _vp],
     'kge_lp_prep_sharded': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
                             _vp, _vp, _vp],
+    'kge_lp_prep_hi': [_int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                       _vp, _vp, _vp, _int, _i64, _vp, _vp],
     'kge_relation_scores_proj': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     'kge_proj_query_stats': [_vp, _i64, _vp, _i64, _vp, _i64, _int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp],
@@ -353,9 +355,11 @@ def side_code(side):
 
 
 def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=False,
-            want_q1=False, ent_lo=0, ent_n=-1):
+            want_q1=False, ent_lo=0, ent_n=-1, want_hi=False):
     """kge_lp_prep; ent_n >= 0: the entity tables hold only rows [ent_lo, ent_lo + ent_n) (kge_lp_prep_sharded:
-    rows of entities this shard does not own come back as zeros, to be summed over the shards)."""
+    rows of entities this shard does not own come back as zeros, to be summed over the shards).
+    want_hi (TransH / TransD, unsharded or replica tables): the same launch also writes the planar f16 hi operand of the
+    query rows and their residuals (kge_lp_prep_hi); returns (Q0, Q1, qn, Wq, Qh, q_dn2)."""
     lib = load_library()
     require_cuda(h, t, r, *tables)
     tabs = [f32c(x) for x in tables] + [None] * (4 - len(tables))
@@ -369,6 +373,17 @@ def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=Fal
     Q1 = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_q1 else None
     qn = torch.empty(B, dtype=torch.float32, device=dev) if want_qn else None
     Wq = torch.empty(B, d_rel, dtype=torch.float32, device=dev) if want_w else None
+    if want_hi:
+        assert ent_n < 0 and kind in (TRANSH, TRANSD)
+        units_p = int(lib.kge_lp_hi_units(d_rel))
+        Bp = int(lib.kge_lp_split_rows_padded(B, 1))
+        Qh = torch.empty(Bp * units_p * 32, dtype=torch.uint8, device=dev)
+        dn2 = torch.empty(B, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _check(lib.kge_lp_prep_hi(kind, side, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]), d_ent, d_rel, _p(h), _p(t),
+                                      _p(r), n_facts, ent_lo, ent_n, _p(Q0), _p(Q1), _p(qn), _p(Wq), _p(Qh), units_p, Bp,
+                                      _p(dn2), _stream()), 'kge_lp_prep_hi')
+        return Q0, Q1, qn, Wq, Qh, dn2
     with _on(dev):
         _check(lib.kge_lp_prep_sharded(kind, side, _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]),
                                        d_ent, d_rel, _p(h), _p(t), _p(r), n_facts, ent_lo, ent_n, _p(Q0), _p(Q1),
@@ -749,6 +764,7 @@ class LpProblem(object):
         self.sad = None         # TransE-L1: {'Ei', 'emax', 'rmax', 'overflow'} -> counts via the u16 SAD prefilter
         self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
         self.cols = None        # filter_index.ColumnPlan of a both-sides batch: split count over distinct query rows
+        self.pre_q = None       # (Qh, q_dn2): the queries' planar hi operand, already built (projection models, level 1)
         self.split_true = None  # (s_true tensor, true ids): the thresholds are the exact scores of these pairs (evaluator)
 
     def scores(self, out=None):
@@ -878,6 +894,9 @@ class LpProblem(object):
                 Qs = split_rows(A0, K=K, is_query=True, aug=qn, X1=A1, dot=True, nmax0=qmax[0:1],
                                 nmax1=qmax[1:2] if A1 is not None else None, cell_ss=want_ss)
                 extra = {'qn0': qn0, 'qn1': qn1, 'qmax': qmax}
+        elif level == 1 and getattr(self, 'pre_q', None) is not None and self.cols is None:
+            Qs, dn2 = self.pre_q        # (the projection models' query preparation wrote the hi operand in its own launch)
+            extra = {'cols': None, 'q_dn2': dn2}
         elif level == 1:                # L2 on the one-product level (non-fused query path)
             cols = self.cols
             Qs, dn2 = hi_rows(A0, K=K, is_query=True, want_dn2=True, row_index=None if cols is None else cols.rep)

@@ -34,6 +34,13 @@ struct PrepParams {
     int64_t B;
     float *Q0, *Q1, *Wq;
     int64_t ent_lo, ent_n;  // row-sharded entity tables: this rank holds rows [ent_lo, ent_lo + ent_n); ent_n < 0: whole tables
+    // optional (TransH / TransD, one-product level of the split prefilter, r05): the PLANAR f16 hi operand of the query rows
+    // ([Bp][hi_units_p][32 B], scale 2^12, two augmentation columns 1, 1 -- what kge_lp_hi_rows(is_query, aug_mode 2) builds
+    // from Q0 in a launch of its own) and ||q - hi(q)||^2 per query; rows [nq, Bp) are written as zeros
+    _Float16 *Qh;
+    int hi_units_p;
+    int64_t Bp;
+    float *q_dn2;
 };
 
 __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
@@ -45,7 +52,28 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
     const bool both = p.side == KGE_SIDE_BOTH;   // 2B queries: [0,B) tail side, [B,2B) head side
     const bool proj = p.side == KGE_SIDE_PROJ_H || p.side == KGE_SIDE_PROJ_T; // projection only, no relation term
     const int64_t nq = both ? 2 * p.B : p.B;
-    for (int64_t i = wave; i < nq; i += nwaves) {
+    const int hk = p.hi_units_p * 16;                       // f16 elements per row of Qh
+    const float hscale = 4096.0f;                           // (the L2 modes' fixed operand scale, SPLIT_SCALE_LOG2 = 12)
+    float dn_acc = 0.f;
+    // one hi element: k < dr data, k == dr / dr + 1 the augmentation columns (1, 1), zeros behind
+    auto emit_hi = [&](_Float16 *qh, int k, float val) __attribute__((always_inline)) {
+        const float xs = val * hscale;
+        const _Float16 hh = (_Float16)xs;
+        const float dd = xs - (float)hh;
+        dn_acc = fmaf(dd, dd, dn_acc);
+        qh[k] = hh;
+    };
+    const int64_t n_rows = p.Qh ? p.Bp : nq;
+    for (int64_t i = wave; i < n_rows; i += nwaves) {
+        _Float16 *qh = p.Qh ? p.Qh + i * hk : nullptr;
+        if (i >= nq) {      // padding rows of the hi operand
+            for (int k = lane; k < hk; k += 64) qh[k] = (_Float16)0.f;
+            continue;
+        }
+        if (qh) {
+            for (int k = dr + lane; k < hk; k += 64) qh[k] = (_Float16)((k == dr || k == dr + 1) ? hscale : 0.f);
+            dn_acc = 0.f;
+        }
         const bool tail = both ? i < p.B : p.side == KGE_SIDE_TAIL;
         const bool use_h = tail || p.side == KGE_SIDE_PROJ_H;
         const int64_t f = (both && i >= p.B) ? i - p.B : i;   // the fact this query belongs to
@@ -111,8 +139,10 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
             float *wq = p.Wq ? p.Wq + i * dr : nullptr;
             for (int k = lane; k < dr; k += 64) {
                 const float pe = e[k] - a * w[k]; // translation.py:281
-                q0[k] = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
+                const float val = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
+                q0[k] = val;
                 if (wq) wq[k] = w[k];
+                if (qh) emit_hi(qh, k, val);
             }
             break;
         }
@@ -125,11 +155,17 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
             float *wq = p.Wq ? p.Wq + i * dr : nullptr;
             for (int k = lane; k < dr; k += 64) {
                 const float pe = sc * rp[k] + e[k]; // translation.py:646
-                q0[k] = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
+                const float val = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
+                q0[k] = val;
                 if (wq) wq[k] = rp[k];
+                if (qh) emit_hi(qh, k, val);
             }
             break;
         }
+        }
+        if (qh && p.q_dn2) {    // ||q - hi(q)||^2, unscaled (a bound of the error band: any summation order, 1.0001 for it)
+            const float dn = wave_sum(dn_acc) * (1.0f / (hscale * hscale)) * 1.0001f;
+            if (lane == 0) p.q_dn2[i] = dn;
         }
     }
 }
@@ -629,6 +665,15 @@ extern "C" int kge_lp_prep_sharded(int kind, int side, const float *t0, const fl
                                    const int64_t *r, int64_t B, int64_t ent_lo, int64_t ent_n, float *Q0, float *Q1,
                                    float *qn, float *Wq, kge_stream_t stream)
 {
+    return kge_lp_prep_hi(kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, ent_lo, ent_n, Q0, Q1, qn, Wq, nullptr, 0, 0,
+                          nullptr, stream);
+}
+
+extern "C" int kge_lp_prep_hi(int kind, int side, const float *t0, const float *t1, const float *t2, const float *t3,
+                              int d_ent, int d_rel, const int64_t *h, const int64_t *t, const int64_t *r, int64_t B,
+                              int64_t ent_lo, int64_t ent_n, float *Q0, float *Q1, float *qn, float *Wq, void *Qh,
+                              int hi_units_p, int64_t Bp, float *q_dn2, kge_stream_t stream)
+{
     if (kind < KGE_TRANSE_L1 || kind > KGE_COMPLEX) return KGE_EINVAL;
     if (ent_n >= 0 && ent_lo < 0) return KGE_EINVAL;
     if (side < KGE_SIDE_TAIL || side > KGE_SIDE_BOTH) return KGE_EINVAL;
@@ -639,9 +684,13 @@ extern "C" int kge_lp_prep_sharded(int kind, int side, const float *t0, const fl
     if (kind == KGE_TRANSH && !t2) return KGE_EINVAL;       // (Wq optional: NULL = the gathered rows are not needed)
     if (kind == KGE_TRANSD && (!t2 || !t3 || d_ent < d_rel)) return KGE_EINVAL;
     if (kind != KGE_TRANSD && d_ent != d_rel) return KGE_EINVAL;
-    PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq, ent_lo, ent_n};
     const int64_t nq = side == KGE_SIDE_BOTH ? 2 * B : B;
-    hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(nq)), dim3(WPB * 64), 0, kge_s(stream), p);
+    if (Qh) {   // the hi operand rides the projection models' unsharded launch only
+        if ((kind != KGE_TRANSH && kind != KGE_TRANSD) || ent_n >= 0 || hi_units_p * 16 < d_rel + 2 || Bp < nq) return KGE_EINVAL;
+    }
+    PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq, ent_lo, ent_n,
+                 reinterpret_cast<_Float16 *>(Qh), hi_units_p, Bp, q_dn2};
+    hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(Qh ? Bp : nq)), dim3(WPB * 64), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     if (qn) return kge_row_sqnorm(Q0, d_rel, nq, d_rel, qn, nullptr, stream);
     return 0;

@@ -540,14 +540,17 @@ class TranslationModel(Model):
         Kq = table.shape[1] if K0 is None else K0
         if Kq % 4 or table.stride(0) % 4 or table.data_ptr() % 16 or table.shape[0] == 0:
             return None
-        Q0 = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)[0]
+        lvl1 = self._use_level1()
+        frag = lvl1 and self._level1_stream()
+        # (one-product level on unsharded tables / replicas: the query rows' planar hi operand rides the same launch)
+        hi_too = frag and (self._row_shard is None or qtabs is not None)
+        out = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, **({'want_hi': True} if hi_too else {}))
+        Q0 = out[0]
         st = _hip.proj_query_stats(Q0, Wt, r_both, scale, z_add, qmax_io=g[0:1])
         if st is None:
             return None
         qn, pz = st
         key = '%d_%d' % (ent_lo, table.shape[0])
-        lvl1 = self._use_level1()
-        frag = lvl1 and self._level1_stream()
         prep = None
         if frag:
             prep = self._cache.get('tp_' + key, [table], lambda: _hip.table_prep_l2(table, g[1:2], g[7:8], deferred_max=True, K=K0))
@@ -571,6 +574,8 @@ class TranslationModel(Model):
             Es, e2 = self._cache.get('es_' + key, [table], lambda: _hip.split_table(table, K=Kq, aug=en))
             split.update({'Es': Es, 'e2pref': e2})
         prob.split = split
+        if hi_too:
+            prob.pre_q = (out[4], out[5])
         return prob
 
     def _proj_fast_ok(self):

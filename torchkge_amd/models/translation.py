@@ -249,7 +249,11 @@ class TransHModel(TranslationModel):
         n = table.shape[0]
 
         def build():    # (n_rel, n) view of a row-padded buffer: the split kernel reads whole 256-candidate tiles
-            buf = torch.zeros(W.shape[0], _hip.padded_cols(n), dtype=torch.float32, device=table.device)
+            # (only the padding columns need the zeros -- the GEMM writes the rest: a strided fill of < 256 columns instead of
+            # one of the whole 13.8 MB buffer)
+            buf = torch.empty(W.shape[0], _hip.padded_cols(n), dtype=torch.float32, device=table.device)
+            if buf.shape[1] > n:
+                buf[:, n:].zero_()
             return _hip.LpProblem(_hip.LP_DOT, W, table).scores(buf[:, :n])
         return self._cache.get('transh_aT_%d_%d' % (c_base, n), [table, W], build), None
 
@@ -409,7 +413,9 @@ class TransDModel(TranslationModel):
         n = table.shape[0]
 
         def build_g():
-            buf = torch.zeros(Rp.shape[0], _hip.padded_cols(n), dtype=torch.float32, device=table.device)
+            buf = torch.empty(Rp.shape[0], _hip.padded_cols(n), dtype=torch.float32, device=table.device)
+            if buf.shape[1] > n:
+                buf[:, n:].zero_()
             return _hip.LpProblem(_hip.LP_DOT, Rp, table, K0=K0).scores(buf[:, :n])
 
         def build_s():
