@@ -36,6 +36,11 @@ def main(tag):
                                                     'trace_transd': 'transd_fb15k237', 'trace_transh': 'transh_fb15k237'}
                                                    .get(name, name[len('trace_'):]))
         shutil.copy(stats[0], os.path.join(dst, out))
+    for f in glob.glob(os.path.join(src, 'timeline_*.txt')):      # (r05) one evaluate() dispatch by dispatch, per workload
+        shutil.copy(f, dst)
+    for extra in ('level1_kernel_ab.txt', 'hi_stream_probes.txt', 'power_probe_hi_stream.txt', 'n2_dryrun_gloo.txt'):
+        if os.path.exists(os.path.join(src, extra)) and os.path.getsize(os.path.join(src, extra)) > 0:
+            shutil.copy(os.path.join(src, extra), dst)
     for extra in ('topk_inference.jsonl', 'first_call.json'):
         if os.path.exists(os.path.join(src, extra)) and os.path.getsize(os.path.join(src, extra)) > 0:
             shutil.copy(os.path.join(src, extra), dst)

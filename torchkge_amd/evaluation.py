@@ -47,6 +47,11 @@ COALESCE_LIST_BYTES = 2 << 30
 # exchange='scores': bytes of the local (rows, N/P) fp32 score tile of one all-to-all (the receive buffer has the same
 # size).  A batch is cut into as many row tiles as it takes, so b_size never decides whether the score exchange fits.
 SCORE_TILE_BYTES = int(os.environ.get('KGE_SCORE_TILE_BYTES', 256 << 20))
+# the count sweep enqueued IN FRONT of the filter correction of the second stream (its persistent workgroups then get every CU
+# from the start and the short filter kernels fill the leftover slots): per model (Model.lp_count_first; measured r05, same box,
+# alternating: TransE 0.502 -> 0.486 ms, DistMult 2.310 -> 2.330, TransH +-1 %: profiles/r05/count_first_ab.txt); the
+# environment switch forces it on or off everywhere
+COUNT_FIRST = {'0': False, '1': True}.get(os.environ.get('KGE_COUNT_FIRST', ''), None)
 DEDUPE_QUERIES = os.environ.get('KGE_DEDUPE_QUERIES', '1') != '0'    # count kernel on distinct query rows (ColumnPlan)
 # ... on the one-product level too (measured r04, same box, ms per evaluate with / without columns on level 1: TransE 0.648 /
 # 0.632, ComplEx 0.479 / 0.479, DistMult 2.642 / 2.667, TransH 0.813 / 0.838 -- profiles/r04/dedupe_level1_ab.txt): yes,
@@ -128,7 +133,7 @@ class HipRankEngine(object):
     flag_columns = True     # partial_counts(pad=k) appends k spare int32 columns (the guard flags ride the counts exchange)
 
     @staticmethod
-    def partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, plan=None, pad=0, aux=None):
+    def partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, plan=None, pad=0, aux=None, count_first=False):
         """int32 (3, B [+ pad]): raw >= counts, filter correction, found-true flag for this shard.
         ``aux`` (a HIP stream): the filter correction -- which needs the true scores only -- runs there, beside the
         all-candidates count and its exact recheck on the current stream (fork / join by events: captured into the
@@ -147,9 +152,14 @@ class HipRankEngine(object):
             return out
         main = torch.cuda.current_stream(s_true.device)
         aux.wait_stream(main)
-        with torch.cuda.stream(aux):
-            prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
-        prob.count_ge(s_true, out[0])
+        if count_first:
+            prob.count_ge(s_true, out[0])
+            with torch.cuda.stream(aux):
+                prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
+        else:
+            with torch.cuda.stream(aux):
+                prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
+            prob.count_ge(s_true, out[0])
         main.wait_stream(aux)
         return out
 
@@ -557,6 +567,7 @@ class LinkPredictionEvaluator(object):
             kw['pad'] = 3
         if self._use_aux and not sharded and isinstance(eng, HipRankEngine) and s_true.is_cuda:
             kw['aux'] = self._aux_stream        # (created by evaluate(), outside any capture)
+            kw['count_first'] = bool(getattr(self.model, 'lp_count_first', False)) if COUNT_FIRST is None else COUNT_FIRST
         counts = eng.partial_counts(prob, s_true, true_idx, seg_lo, seg_hi, targets, **kw)
         if ride:
             lim = float(self.model.L2_EXPAND_LIMIT)

@@ -60,6 +60,8 @@ class TransEModel(TranslationModel):
     # ... but not on the one-product level of the split prefilter: at d = 200 a shared row saves 4 MFMA groups per tile,
     # less than the grouped columns' multi-pass epilogue costs (evaluation.DEDUPE_LEVEL1: 0.632 vs 0.648 ms per evaluate)
     lp_dedupe_level1 = False
+    # the count sweep is enqueued in front of the second stream's filter correction (evaluation.COUNT_FIRST: -3 % here)
+    lp_count_first = True
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight]
