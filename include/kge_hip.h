@@ -534,6 +534,10 @@ typedef struct kge_split_args {
      * Only with thr_ready = 0 and a one-segment problem. */
     const float *tp_block_max;
     int32_t tp_blocks;
+    /* KGE_LP_DOT on level 1: 1 = the query operand Qs was built with PER-QUERY scales (kge_lp_dot_query_pipeline: row i scaled
+     * by the power of two that fits ||q_i||, not the batch maximum); qn0 then holds the total squared norm per query, qn1 /
+     * qmax0 / qmax1 are not read.  Matters only when the thresholds are recomputed (thr_ready = 0). */
+    int32_t q_scale_per_query;
 } kge_split_args;
 int kge_lp_split_group_sets(void);
 
@@ -592,6 +596,21 @@ int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const floa
  * passes of acc + 8 products, addends truncated 24 bits below the largest, one RNE rounding), 0 if not.
  * Launches a one-wave kernel on the null stream and synchronises: call once, outside any capture. */
 int kge_mfma_f16_selftest(void);
+/* DistMult / ComplEx query side of one batch on the ONE-PRODUCT level in one launch (r05) -- what kge_lp_prep,
+ * kge_lp_pair_scores (true scores), two kge_row_sqnorm_any_order passes, kge_lp_hi_rows(is_query) and the threshold kernel
+ * of kge_lp_split_count do separately (bilinear.py:247-267, :530-556 + evaluation.py:290-300): Q0 (and Q1 = the Im half,
+ * ComplEx: E1 / R1 / Q1 / emax1 non-NULL) bit-identical to kge_lp_prep, s_true bit-identical to kge_lp_pair_scores,
+ * qn = ||q_i||^2 (a bound: any summation order), Qh = the planar hi operand with PER-QUERY power-of-two scales, thr the
+ * thresholds that go with them, *list_count = 0, *overflow = 1 on non-finite norms; zero_n int32 at zero_i32 zeroed.
+ * emax0 / emax1 / de2max: device scalars of the candidate table (kge_row_sqnorm_any_order maxima, kge_lp_hi_rows[_frag]'s
+ * residual maximum), final when the launch runs.  Follow with kge_lp_split_count(level = 1, thr_ready = 1,
+ * q_scale_per_query = 1).  KGE_EINVAL unless d % 8 == 0 and the tables are 16-byte aligned (then: the separate kernels). */
+int kge_lp_dot_query_pipeline(int side, const float *E0, const float *E1, const float *R0, const float *R1, int d,
+                              const int64_t *h, const int64_t *t, const int64_t *r, int64_t B, const float *emax0,
+                              const float *emax1, const float *de2max, float *qmax_io, int accum_model, float eps_scale,
+                              float *Q0, float *Q1, float *qn, float *s_true, void *Qh, float *thr,
+                              float *q_dn2 /* optional */, int32_t *list_count, float *overflow, int32_t *zero_i32,
+                              int64_t zero_n, kge_stream_t stream);
 /* TransE-L2 query side of one batch in ONE launch -- what kge_lp_prep, kge_row_sqnorm (queries),
  * kge_lp_pair_scores (true scores), kge_lp_split_rows (queries) and the threshold kernel of
  * kge_lp_split_count do separately, with bit-identical outputs: Q (B,d), qn (B), s_true (B), Qs, thr

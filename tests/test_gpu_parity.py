@@ -1773,3 +1773,64 @@ def test_projection_query_side_in_two_launches_equals_the_separate_kernels(hip, 
     qn_ref = hip.row_sqnorm(Q0, max_io=gq2)
     pz_ref = torch.stack([hip.row_dot(Q0, Wq, scale=scale), hip.row_sqnorm(Wq) + z_add], dim=1)
     assert torch.equal(qn, qn_ref) and torch.equal(pz, pz_ref) and float(gq) == float(gq2)
+
+
+@pytest.mark.parametrize('kind,B,d,frag', [('distmult', 1000, 64, True), ('complex', 777, 40, True), ('complex', 333, 200, False),
+                                           ('distmult', 5, 400, True)])
+@pytest.mark.parametrize('side', ['both', 'tail', 'head'])
+def test_dot_query_side_in_one_launch_equals_the_separate_kernels(hip, kind, B, d, frag, side):
+    """r05: kge_lp_dot_query_pipeline (DistMult / ComplEx, one-product level: q, exact true scores, planar hi operand with
+    PER-QUERY scales, residuals, thresholds, zeroed counters in one launch) against kge_lp_prep + kge_lp_pair_scores (bit
+    for bit) and, through kge_lp_split_count + recheck, against the exact fp32 counts -- with the thresholds of the launch
+    (thr_ready) and with thresholds recomputed for other true scores (kge_split_args.q_scale_per_query)."""
+    n_ent, n_rel = 1500, 11
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=5)
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    g = torch.Generator().manual_seed(B + d)
+    h = torch.randint(0, n_ent, (B,), generator=g).cuda(); t = torch.randint(0, n_ent, (B,), generator=g).cuda()
+    r = torch.randint(0, n_rel, (B,), generator=g).cuda()
+    tabs = [hip.f32c(x.data) for x in m._tables()]
+    # rows of different magnitude, so that the per-query scales differ (moderately: the band of the one-product level is
+    # relative to ||q|| max||e||, and an untrained table with a few huge rows would put every small candidate inside it)
+    with torch.no_grad():
+        tabs[0][::7] *= 3.0
+        tabs[0][1::7] *= 0.2
+    cplx = kind == 'complex'
+    ent, rel = (tabs[:2], tabs[2:]) if cplx else (tabs[:1], tabs[1:])
+    sd = hip.side_code(side)
+    k = hip.COMPLEX if cplx else hip.DISTMULT
+    Q0, Q1, _, _ = hip.lp_prep(k, sd, tabs, d, d, h, t, r, want_q1=cplx) if cplx else hip.lp_prep(k, sd, tabs, d, d, h, t, r)
+    T0, T1 = ent[0], (ent[1] if cplx else None)
+    guard = torch.zeros(8, device='cuda')
+    hip.row_sqnorm(T0, max_io=guard[1:2], bound_only=True)
+    if cplx:
+        hip.row_sqnorm(T1, max_io=guard[5:6], bound_only=True)
+    nm1 = guard[5:6] if cplx else None
+    Eh, de2 = hip.hi_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=nm1, frag=frag)
+    split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'enmax1': nm1, 'overflow': guard[2:3], 'level': 1, 'de2max': de2,
+             'list_stat': guard[6:7], 'es_frag': frag}
+    pre = hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if cplx else None, h, t, r, guard[1:2], nm1, de2, guard[0:1],
+                                    guard[2:3], zero_counts=True)
+    assert torch.equal(pre['Q'], Q0) and (not cplx or torch.equal(pre['Q1'], Q1))
+    true = torch.cat([t, h]) if side == 'both' else (t if side == 'tail' else h)
+    ref = hip.LpProblem(hip.LP_DOT, Q0, T0, A1=Q1 if cplx else None, T1=T1)
+    st_ref = ref.pair_scores(true)
+    assert torch.equal(pre['s_true'].view(torch.int32), st_ref.view(torch.int32))
+    qn_ref = (Q0.double() ** 2).sum(1) + ((Q1.double() ** 2).sum(1) if cplx else 0)
+    assert torch.allclose(pre['qn'].double(), qn_ref, rtol=1e-5, atol=0)
+    assert int(pre['counts'].abs().sum()) == 0 and float(guard[0]) == float(pre['qn'].max())
+    exact = ref.count_ge(st_ref)
+    pre['true_idx'] = true
+    prob = hip.LpProblem(hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
+    prob.split, prob.pre = split, pre
+    st = prob.pair_scores(true)
+    assert st is pre['s_true']
+    got = prob.count_ge(st)
+    assert float(guard[2]) == 0.0, 'uncertain-pair list overflowed (%d pairs listed)' % int(prob.last_split[0])
+    assert torch.equal(got, exact), '%d of %d counts differ (max %d)' % (
+        int((got != exact).sum()), got.numel(), int((got - exact).abs().max()))
+    # other thresholds on the same prepared operands: the threshold kernel must use the per-query scales too
+    st2 = (st_ref * 0.5).contiguous()
+    got2 = prob.count_ge(st2)
+    assert float(guard[2]) == 0.0
+    assert torch.equal(got2, ref.count_ge(st2))

@@ -50,6 +50,7 @@ class SplitArgs(ctypes.Structure):
         ('q_cell_ss_index', _vp), ('q_cell_ss_ld', _i64),
         ('level', ctypes.c_int32), ('q_dn2', _vp), ('q_dn2_index', _vp), ('de2max', _vp),
         ('es_frag', ctypes.c_int32), ('true_idx', _vp), ('tp_block_max', _vp), ('tp_blocks', ctypes.c_int32),
+        ('q_scale_per_query', ctypes.c_int32),
     ]
 
 
@@ -108,6 +109,8 @@ _SIGNATURES = {
     'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _i64, _vp],
+    'kge_lp_dot_query_pipeline': [_int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, ctypes.c_float,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -139,7 +142,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 26        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 27        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -627,6 +630,39 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
     return out
 
 
+def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, qmax_io, overflow, zero_counts=False):
+    """DistMult (E1 = R1 = None) / ComplEx query side of one batch on the one-product level in one launch
+    (kge_lp_dot_query_pipeline): dict with Q (and Q1), qn, s_true, Qs (planar hi operand, PER-QUERY scales), thr, q_dn2,
+    n_list, counts -- Q / Q1 / s_true bit-identical to lp_prep + pair_scores."""
+    lib = load_library()
+    require_cuda(E0, R0, h, t, r, emax0, de2max, overflow)
+    E0, R0 = f32c(E0), f32c(R0)
+    E1, R1 = (None, None) if E1 is None else (f32c(E1), f32c(R1))
+    h, t, r = i64c(h), i64c(t), i64c(r)
+    B, d, dev = h.shape[0], E0.shape[1], E0.device
+    K = d if E1 is None else 2 * d
+    Bq = 2 * B if side == SIDE_BOTH else B
+    Bp = int(lib.kge_lp_split_rows_padded(Bq, 1))
+    units_p = int(lib.kge_lp_hi_units(K))
+    out = {'Q': torch.empty(Bq, d, dtype=torch.float32, device=dev),
+           'Q1': None if E1 is None else torch.empty(Bq, d, dtype=torch.float32, device=dev),
+           'qn': torch.empty(Bq, dtype=torch.float32, device=dev), 's_true': torch.empty(Bq, dtype=torch.float32, device=dev),
+           'Qs': torch.empty(Bp * units_p * 32, dtype=torch.uint8, device=dev), 'cols': None, 'level': 1,
+           'thr': torch.empty(4 * Bp, dtype=torch.float32, device=dev),
+           'q_dn2': torch.empty(Bq, dtype=torch.float32, device=dev),
+           'n_list': torch.empty(1, dtype=torch.int32, device=dev), 'q_scale_per_query': True}
+    if zero_counts:
+        out['counts'] = torch.empty(3, Bq, dtype=torch.int32, device=dev)
+    with _on(dev):
+        _check(lib.kge_lp_dot_query_pipeline(side, _p(E0), _p(E1), _p(R0), _p(R1), d, _p(h), _p(t), _p(r), B, _p(emax0),
+                                             _p(emax1), _p(de2max), _p(qmax_io), split_accum_model(), SPLIT_EPS_SCALE,
+                                             _p(out['Q']), _p(out['Q1']), _p(out['qn']), _p(out['s_true']), _p(out['Qs']),
+                                             _p(out['thr']), _p(out['q_dn2']), _p(out['n_list']), _p(overflow),
+                                             _p(out.get('counts')), 3 * Bq if zero_counts else 0, _stream()),
+               'kge_lp_dot_query_pipeline')
+    return out
+
+
 def sad_rows(X, emax, rmax, K=None, row_index=None):
     """16-bit fixed-point operand of the L1 prefilter (kge_lp_sad_rows): (rows, K padded to 8) uint16, scaled by
     32700 / (*emax + *rmax) (device scalars: max |x| of the entity and of the relation table)."""
@@ -872,6 +908,8 @@ class LpProblem(object):
                                          's_true_pre': self.pre['s_true'], 'cols': self.pre.get('cols')}
             if level == 1:      # per QUERY (the fused pipeline computes every query's residual itself)
                 extra['q_dn2'], extra['q_dn2_per_query'] = self.pre['q_dn2'], True
+            if self.pre.get('q_scale_per_query'):       # DOT pipeline: the hi operand carries per-query scales
+                extra['q_scale_per_query'], extra['qn0'] = True, self.pre['qn']
         elif int(self.desc.mode) == LP_DOT:
             qmax = torch.zeros(2, dtype=torch.float32, device=self.device)
             # (DOT mode: the norms bound the error band and fix the operands' scale; no score contains them)
@@ -951,6 +989,7 @@ class LpProblem(object):
         tpb = sp.get('tp_bmax')
         if tpb is not None and not a.thr_ready:     # block maxima of the fused table preparation: folded by the threshold kernel
             a.tp_block_max, a.tp_blocks = _p(tpb), tpb.shape[0] // 2
+        a.q_scale_per_query = 1 if prep.get('q_scale_per_query') else 0
         a.es_frag = 1 if sp.get('es_frag') else 0
         if a.es_frag:
             assert a.level == 1 and (cols is None or cols.n_multi_p == 0), 'the free-running sweep takes no grouped columns'

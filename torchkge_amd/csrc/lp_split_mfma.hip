@@ -594,6 +594,8 @@ struct SplitThrParams {
     const float *tp_bmax;           // optional [2][tp_blocks]: block maxima left by kge_lp_table_prep_l2 (emax0, de2max): folded
     int tp_blocks;                  // into the two scalars by every block on its way in, stored by block 0
     float *emax_out, *de2max_out;
+    int q_scale_per_query;          // DOT, level 1: the query operand of row i is scaled by split_scale(||q_i||^2), its own norm
+                                    // (kge_lp_dot_query_pipeline), not by the batch maximum's; qn0 then holds the total
 };
 
 // (a_lo, a_hi) of the plain L2 expansion, unscaled half-width logic shared by split_thr_kernel and the fused
@@ -762,7 +764,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
             }
         } else {
             // count c iff dot_c >= s_true; both operands carry their own power-of-two scale
-            const float qm = *p.qmax0 + (p.qmax1 ? *p.qmax1 : 0.f);
+            const float qm = p.q_scale_per_query ? q : *p.qmax0 + (p.qmax1 ? *p.qmax1 : 0.f);
             const float out_scale = split_scale(qm) * split_scale(em);
             const float st = p.s_true[i];
             const float sqk = sqrtf((float)p.K);
@@ -814,6 +816,8 @@ struct QueryPipeParams {
     float *emax_out, *de2max_out;
     int32_t *zero_i32;              // optional: zero_n int32 zeroed by this launch (the batch's rank counters)
     int64_t zero_n;
+    int dbg;                        // env KGE_QP_DBG (timing probes, wrong results): 1 no chains, 2 no split cells, 4 no Q store,
+                                    // 8 no row loads after the first chunk, 16 no block-maxima reduction, 32 no final atomic
 };
 
 template <int QPW>   // queries per wavefront: their chains run on lanes 0..QPW-1, loads / stores use all 64 lanes
@@ -827,13 +831,14 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
     __shared__ __attribute__((aligned(16))) float qs_all[4 * QPW * LD];
     __shared__ __attribute__((aligned(16))) float ts_all[4 * QPW * LD];
     __shared__ unsigned wmax[4];
+    __shared__ float dnp_all[4 * QPW * 8];          // level 1: residual sums per (row, 8-column group) of the current chunk
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float *qs = qs_all + wv * QPW * LD, *ts = ts_all + wv * QPW * LD;
+    float *qs = qs_all + wv * QPW * LD, *ts = ts_all + wv * QPW * LD, *dnp = dnp_all + wv * QPW * 8;
     const int d = p.d, kpad = p.units_p * 16;
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < p.zero_n; j += (int64_t)gridDim.x * 256) p.zero_i32[j] = 0;
     float em, de2m = 0.f;
-    if (p.tp_bmax) {        // the table preparation's block maxima -> the two scalars (values >= 0: ordered like their bits)
+    if (p.tp_bmax && !(p.dbg & 16)) {        // the table preparation's block maxima -> the two scalars (values >= 0: ordered like their bits)
         __shared__ unsigned red[8];
         unsigned m0 = 0u, m1 = 0u;
         for (int j = threadIdx.x; j < p.tp_blocks; j += 256) {
@@ -908,13 +913,13 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 q4.z = tl_ ? e4.z + r4.z : e4.z - r4.z;
                 q4.w = tl_ ? e4.w + r4.w : e4.w - r4.w;
                 const int64_t row = grp * QPW + rr;
-                if (row < p.B) *reinterpret_cast<float4 *>(p.Q + row * d + k0 + pc * 4) = q4;
+                if (row < p.B && !(p.dbg & 4)) *reinterpret_cast<float4 *>(p.Q + row * d + k0 + pc * 4) = q4;
                 *reinterpret_cast<float4 *>(qs + rr * LD + pc * 4) = q4;
                 *reinterpret_cast<float4 *>(ts + rr * LD + pc * 4) = t4;
             }
-            if (k0 + KC < kpad) KGE_QP_FETCH(k0 + KC)
+            if (k0 + KC < kpad && !(p.dbg & 8)) KGE_QP_FETCH(k0 + KC)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (kc > 0 && lane < QPW) {
+            if (kc > 0 && lane < QPW && !(p.dbg & 1)) {
                 const float *x = qs + lane * LD;
                 // row_sqnorm_kernel's chain; its value at the end of every k16 cell is the prefix squared norm
                 // of the magnitude sum (split_thr_kernel adds up cell sums instead: equal up to rounding, and
@@ -936,14 +941,6 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                     }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) qn = fmaf(xv[j], xv[j], qn);
-                    if (p.level == 1) {      // (independent of the two chains: fills their latency)
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            const float xsj = xv[j] * (float)(1 << SPLIT_SCALE_LOG2);
-                            const float dj = xsj - (float)(_Float16)xsj;
-                            dn = fmaf(dj, dj, dn);
-                        }
-                    }
 #pragma unroll
                     for (int b8 = 0; b8 < 16; b8 += 8) {
 #pragma unroll
@@ -957,22 +954,18 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 const int ktail = k;
                 for (; k < kc; ++k) {
                     qn = fmaf(x[k], x[k], qn);
-                    if (p.level == 1) {
-                        const float xsj = x[k] * (float)(1 << SPLIT_SCALE_LOG2);
-                        const float dj = xsj - (float)(_Float16)xsj;
-                        dn = fmaf(dj, dj, dn);
-                    }
                     if (p.e2pref && (((k0 + k) & 15) == 15 || k0 + k == d - 1))
                         amag = amag + sqrtf(qn * p.e2pref[(k0 + k) >> 4]);
                 }
                 if (ktail < kc) acc = lp_chain_dot(x + ktail, tt + ktail, kc - ktail, acc);   // the pair kernel's chain
             }
             // split cells of this chunk: 8 consecutive k of one row per lane and pass
-            const int ngr = min(KC, kpad - k0) >> 3;
+            const int ngr = (p.dbg & 2) ? 0 : min(KC, kpad - k0) >> 3;
             for (int idx = lane; idx < QPW * ngr; idx += 64) {
                 const int rr = idx / ngr, gq = idx - rr * ngr;
                 const int64_t row = grp * QPW + rr;
                 union { _Float16 h[8]; uint4 v; } hi, lo;
+                float dsum = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int k = k0 + gq * 8 + e;
@@ -981,8 +974,13 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                     xv *= (float)(1 << SPLIT_SCALE_LOG2);
                     const _Float16 hh = (_Float16)xv;
                     hi.h[e] = hh;
-                    lo.h[e] = (_Float16)(xv - (float)hh);
+                    const float dd = xv - (float)hh;             // exact in fp32 (0 in the augmentation / padding columns)
+                    lo.h[e] = (_Float16)dd;
+                    dsum = fmaf(dd, dd, dsum);
                 }
+                // level 1: the residual ||q - hi(q)||^2 is a BOUND of the error band (any summation order, 1.0001 for it):
+                // summed here on all 64 lanes -- on the chain lanes its 5 operations per element were 70 % of their work
+                if (p.level == 1) dnp[rr * 8 + gq] = dsum;
                 const int kk = k0 + gq * 8, u = kk >> 4, hf = (kk >> 3) & 1;
                 const int64_t dst = p.qs_row ? (row < p.B ? (int64_t)p.qs_row[row] : -1) : row;
                 if (dst >= 0 && p.level == 1) {      // planar hi operand: 32 bytes per unit
@@ -995,6 +993,8 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (p.level == 1 && lane < QPW)
+                for (int gq = 0; gq < ngr; ++gq) dn += dnp[lane * 8 + gq];
         }
 #undef KGE_QP_FETCH
         if (lane < QPW && i < p.Bp) {
@@ -1021,7 +1021,283 @@ __global__ __launch_bounds__(256) void query_pipeline_kernel(const QueryPipePara
             }
         }
     }
-    if (p.qmax_io) {    // one atomic per block (same-address atomics serialise at ~12 ns each)
+    if (p.qmax_io && !(p.dbg & 32)) {    // one atomic per block (same-address atomics serialise at ~12 ns each)
+        unsigned m = __float_as_uint(qbig);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if (lane == 0) wmax[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.qmax_io), max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+    }
+}
+
+// ---- fused query side of one DistMult / ComplEx batch on the one-product level (r05) ------------------------------
+// What lp_prep + pair_scores + two any-order norm passes + their sum + kge_lp_hi_rows(is_query) + the threshold kernel
+// (+ two fills) do in nine launches.  The DOT modes' operands carry a power-of-two scale taken from a squared-norm
+// MAXIMUM (arbitrary magnitudes, unlike the unit-ball rows of the L2 modes) -- batch-wide in the separate kernels, which
+// is what kept this side at two sweeps over Q with a device-wide reduction between them.  Here every query row carries
+// ITS OWN scale S_i = split_scale(||q_i||^2): the count kernels never see a scale (the thresholds of query i are
+// multiplied by S_i * S_e like its accumulators), the band only gets tighter (its absolute term then holds ||q_i|| where
+// it held max ||q||), and the guard column of the padding candidates is built from ||q_i|| alone.
+// Per group of QPW queries of a wavefront: (1) ||q||^2 in any order (a bound: 16 lanes per row, the source rows read
+// once -- they are read again, from the L1 / L2, by) (2) the TransE pipeline's chunk loop: q = e (x) r written for the
+// later exact kernels and staged in LDS with the true entity's rows, the exact true score by the pair kernel's chain
+// (one lane per query; segment [Re | Im] after segment), the planar f16 hi operand and its measured residual on all lanes.
+struct DotPipeParams {
+    int tail;                       // as QueryPipeParams
+    int64_t Bh;
+    const float *E0, *E1, *R0, *R1; // entity / relation tables (ComplEx: Re, Im; DistMult: E1 = R1 = NULL)
+    int d;                          // columns per segment (K = d resp. 2 d), d % 8 == 0
+    const int64_t *h, *t, *r;
+    int64_t B, Bp;
+    const float *emax0, *emax1;     // device scalars: max ||row||^2 of the candidate table's segments
+    const float *de2max;            // device scalar >= max_c ||e_c - hi(e_c)||^2
+    float *qmax_io;                 // device scalar, max ||q||^2 folded in (may be NULL)
+    float c_acc, eps_scale;
+    int units, units_p;
+    float *Q0, *Q1, *qn, *s_true, *q_dn2;
+    float2 *thr;
+    _Float16 *Qh;
+    int32_t *list_count;
+    float *overflow;
+    int32_t *zero_i32;
+    int64_t zero_n;
+};
+
+// thresholds of one DOT query on the one-product level, operand scales s_q (its own) and s_e
+__device__ __forceinline__ float2 split_thr_dot_hi(float q, float st, float em, int K, int units, float c_acc, float eps_scale,
+                                                   float dq2, float de2m, float qm, float s_q, float s_e)
+{
+    const float two22 = 2.3841858e-7f;
+    const float enrm = sqrtf(em) * 1.000001f, qnrm = sqrtf(q) * 1.000001f;
+    const float out_scale = s_q * s_e;
+    const float sqk = sqrtf((float)K);
+    const float eps_abs = 1.4901161e-8f * sqk * (sqrtf(qm) * enrm + sqrtf(em) * qnrm) + 1e-30f;
+    const float eps_dot = (split_acc_err(-1.0f, 0.f, qnrm * enrm, units, c_acc, 16.0f) + split_chain_err(-1.0f, qnrm * enrm, K) +
+                           split_hi_resid(qnrm, enrm, 0.f, dq2, de2m) + eps_abs) * eps_scale;
+    const float hw = eps_dot + two22 * fabsf(st);
+    return make_float2(split_nonzero_lo((st - hw) * out_scale), (st + hw) * out_scale);
+}
+
+template <int QPW, bool CPLX>
+__global__ __launch_bounds__(256) void dot_query_pipeline_kernel(const DotPipeParams p)
+{
+    constexpr int KC = 48, LD = 52;
+    __shared__ __attribute__((aligned(16))) float qs_all[4 * QPW * LD];
+    __shared__ __attribute__((aligned(16))) float ts_all[4 * QPW * LD];
+    __shared__ float dnp_all[4 * QPW * 8];
+    __shared__ float qn_all[4 * QPW], sc_all[4 * QPW];
+    __shared__ unsigned wmax[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *qs = qs_all + wv * QPW * LD, *ts = ts_all + wv * QPW * LD, *dnp = dnp_all + wv * QPW * 8;
+    float *qn_s = qn_all + wv * QPW, *sc_s = sc_all + wv * QPW;
+    const int d = p.d, nseg = CPLX ? 2 : 1, K = nseg * d, kpad = p.units_p * 16;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < p.zero_n; j += (int64_t)gridDim.x * 256) p.zero_i32[j] = 0;
+    const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f), de2m = *p.de2max;
+    const float s_e = split_scale(em);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !(em < INFINITY)) *p.overflow = 1.0f;
+    float qbig = 0.f;
+    const int nch_seg = (d + KC - 1) / KC, nch = nseg * nch_seg;
+    const int64_t ngroups = (p.Bp + QPW - 1) / QPW;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t i = grp * QPW + lane;
+        const bool valid = lane < QPW && i < p.B;
+        const int64_t ic = valid ? i : 0;
+        const bool tl = p.tail == 2 ? ic < p.Bh : p.tail == 1;
+        const int64_t fi = (p.tail == 2 && ic >= p.Bh) ? ic - p.Bh : ic;
+        const int64_t src = tl ? p.h[fi] : p.t[fi], tru = tl ? p.t[fi] : p.h[fi], ri = p.r[fi];
+        const int tli = tl ? 1 : 0;
+        // ---- (1) ||q||^2, any order: 16 lanes per row, four rows of the group at a time
+        {
+            const int sub = lane & 15;
+#pragma unroll 1
+            for (int rb = 0; rb < QPW; rb += 4) {
+                const int rr = rb + (lane >> 4);
+                const int64_t s_ = __shfl(src, rr, 64), r_ = __shfl(ri, rr, 64);
+                const bool tl_ = __shfl(tli, rr, 64) != 0;
+                float ss = 0.f;
+                for (int k = sub * 4; k < d; k += 64) {
+                    if (CPLX) {
+                        const float4 re = *reinterpret_cast<const float4 *>(p.E0 + s_ * d + k);
+                        const float4 im = *reinterpret_cast<const float4 *>(p.E1 + s_ * d + k);
+                        const float4 rr4 = *reinterpret_cast<const float4 *>(p.R0 + r_ * d + k);
+                        const float4 ir4 = *reinterpret_cast<const float4 *>(p.R1 + r_ * d + k);
+#define KGE_DP_SS(C)                                                                                         \
+    {                                                                                                        \
+        const float q0_ = tl_ ? re.C * rr4.C - im.C * ir4.C : rr4.C * re.C + ir4.C * im.C;                   \
+        const float q1_ = tl_ ? re.C * ir4.C + im.C * rr4.C : rr4.C * im.C - ir4.C * re.C;                   \
+        ss = fmaf(q0_, q0_, ss);                                                                             \
+        ss = fmaf(q1_, q1_, ss);                                                                             \
+    }
+                        KGE_DP_SS(x) KGE_DP_SS(y) KGE_DP_SS(z) KGE_DP_SS(w)
+#undef KGE_DP_SS
+                    } else {
+                        const float4 e4 = *reinterpret_cast<const float4 *>(p.E0 + s_ * d + k);
+                        const float4 r4 = *reinterpret_cast<const float4 *>(p.R0 + r_ * d + k);
+                        const float q0 = e4.x * r4.x, q1 = e4.y * r4.y, q2 = e4.z * r4.z, q3 = e4.w * r4.w;
+                        ss = fmaf(q0, q0, ss); ss = fmaf(q1, q1, ss); ss = fmaf(q2, q2, ss); ss = fmaf(q3, q3, ss);
+                    }
+                }
+                ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
+                if (sub == 0) qn_s[rr] = ss;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const float qn = lane < QPW ? qn_s[lane] : 0.f;
+        const float s_q = split_scale(qn);
+        if (lane < QPW) sc_s[lane] = s_q;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // ---- (2) the chunk loop
+        float acc = 0.f, dn = 0.f;
+        constexpr int NP = KC / 4, ITS = (QPW * NP + 63) / 64;
+        float4 pa[ITS], pb[ITS], pc_[ITS], pd[ITS], pt[ITS];
+#define KGE_DP_FETCH(C)                                                                                      \
+    {                                                                                                        \
+        const int sg_ = (C) / nch_seg, kk0_ = ((C) - sg_ * nch_seg) * KC;                                    \
+        const int pcs_ = max(0, min(KC, d - kk0_)) >> 2;                                                     \
+        const float *tt_ = (CPLX && sg_ != 0) ? p.E1 : p.E0;                                                 \
+        _Pragma("unroll") for (int it = 0; it < ITS; ++it) {                                                 \
+            const int idx = it * 64 + lane;                                                                  \
+            const bool act = idx < QPW * pcs_;                                                               \
+            const int rr = act ? idx / pcs_ : 0, pc = act ? idx - rr * pcs_ : 0;                             \
+            const int64_t s_ = __shfl(src, rr, 64), r_ = __shfl(ri, rr, 64), t_ = __shfl(tru, rr, 64);       \
+            if (act) {                                                                                       \
+                const int64_t ko_ = kk0_ + pc * 4;                                                           \
+                pa[it] = *reinterpret_cast<const float4 *>(p.E0 + s_ * d + ko_);                             \
+                pc_[it] = *reinterpret_cast<const float4 *>(p.R0 + r_ * d + ko_);                            \
+                if (CPLX) {                                                                                  \
+                    pb[it] = *reinterpret_cast<const float4 *>(p.E1 + s_ * d + ko_);                         \
+                    pd[it] = *reinterpret_cast<const float4 *>(p.R1 + r_ * d + ko_);                         \
+                }                                                                                            \
+                pt[it] = *reinterpret_cast<const float4 *>(tt_ + t_ * d + ko_);                              \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+        KGE_DP_FETCH(0)
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            const int sg = c / nch_seg, k0 = (c - sg * nch_seg) * KC;
+            const int kc = min(KC, d - k0), pieces = kc >> 2;
+            float *Qg = sg == 0 ? p.Q0 : p.Q1;
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int idx = it * 64 + lane;
+                const bool act = idx < QPW * pieces;
+                const int rr = act ? idx / pieces : 0, pc = act ? idx - rr * pieces : 0;
+                const bool tl_ = __shfl(tli, rr, 64) != 0;
+                if (!act) continue;
+                const float4 t4 = pt[it];
+                float4 q4;
+                if (CPLX) {      // lp_prep_kernel, bilinear.py:514-515 (tail) / :521-522 (head): the same operations
+                    const float4 re = pa[it], im = pb[it], rr4 = pc_[it], ir4 = pd[it];
+                    if (sg == 0) {
+                        q4.x = tl_ ? re.x * rr4.x - im.x * ir4.x : rr4.x * re.x + ir4.x * im.x;
+                        q4.y = tl_ ? re.y * rr4.y - im.y * ir4.y : rr4.y * re.y + ir4.y * im.y;
+                        q4.z = tl_ ? re.z * rr4.z - im.z * ir4.z : rr4.z * re.z + ir4.z * im.z;
+                        q4.w = tl_ ? re.w * rr4.w - im.w * ir4.w : rr4.w * re.w + ir4.w * im.w;
+                    } else {
+                        q4.x = tl_ ? re.x * ir4.x + im.x * rr4.x : rr4.x * im.x - ir4.x * re.x;
+                        q4.y = tl_ ? re.y * ir4.y + im.y * rr4.y : rr4.y * im.y - ir4.y * re.y;
+                        q4.z = tl_ ? re.z * ir4.z + im.z * rr4.z : rr4.z * im.z - ir4.z * re.z;
+                        q4.w = tl_ ? re.w * ir4.w + im.w * rr4.w : rr4.w * im.w - ir4.w * re.w;
+                    }
+                } else {         // bilinear.py:247-267
+                    const float4 e4 = pa[it], r4 = pc_[it];
+                    q4.x = e4.x * r4.x; q4.y = e4.y * r4.y; q4.z = e4.z * r4.z; q4.w = e4.w * r4.w;
+                }
+                const int64_t row = grp * QPW + rr;
+                if (row < p.B) *reinterpret_cast<float4 *>(Qg + row * d + k0 + pc * 4) = q4;
+                else q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(qs + rr * LD + pc * 4) = q4;
+                *reinterpret_cast<float4 *>(ts + rr * LD + pc * 4) = t4;
+            }
+            if (c + 1 < nch) KGE_DP_FETCH(c + 1)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (lane < QPW) {       // the exact true score: the pair kernel's chain (lp_chain_dot), continued over the segments
+                const float *x = qs + lane * LD, *tt = ts + lane * LD;
+                int k = 0;
+                for (; k + 16 <= kc; k += 16) {
+                    float xv[16], tv[16];
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const float4 v = *reinterpret_cast<const float4 *>(x + k + 4 * j4);
+                        const float4 w = *reinterpret_cast<const float4 *>(tt + k + 4 * j4);
+                        xv[4 * j4] = v.x; xv[4 * j4 + 1] = v.y; xv[4 * j4 + 2] = v.z; xv[4 * j4 + 3] = v.w;
+                        tv[4 * j4] = w.x; tv[4 * j4 + 1] = w.y; tv[4 * j4 + 2] = w.z; tv[4 * j4 + 3] = w.w;
+                    }
+#pragma unroll
+                    for (int b8 = 0; b8 < 16; b8 += 8) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc = fmaf(xv[b8 + j], tv[b8 + j], acc);
+                            acc = fmaf(xv[b8 + 4 + j], tv[b8 + 4 + j], acc);
+                        }
+                    }
+                }
+                if (k < kc) acc = lp_chain_dot(x + k, tt + k, kc - k, acc);     // (kc % 8 == 0: one more 8-block)
+            }
+            // the chunk's hi cells: 8 consecutive k of one row per lane and pass, the row's own scale
+            const int ngr = kc >> 3;
+            for (int idx = lane; idx < QPW * ngr; idx += 64) {
+                const int rr = idx / ngr, gq = idx - rr * ngr;
+                const int64_t row = grp * QPW + rr;
+                const float sc = sc_s[rr];
+                const float4 v0 = *reinterpret_cast<const float4 *>(qs + rr * LD + gq * 8);
+                const float4 v1 = *reinterpret_cast<const float4 *>(qs + rr * LD + gq * 8 + 4);
+                union { _Float16 h[8]; uint4 v; } hi;
+                float dsum = 0.f;
+#define KGE_DP_CV(E, X)                                                                                      \
+    {                                                                                                        \
+        const float xsj = (X) * sc;                                                                          \
+        const _Float16 hh = (_Float16)xsj;                                                                   \
+        const float dd = xsj - (float)hh;                                                                    \
+        dsum = fmaf(dd, dd, dsum);                                                                           \
+        hi.h[E] = hh;                                                                                        \
+    }
+                KGE_DP_CV(0, v0.x) KGE_DP_CV(1, v0.y) KGE_DP_CV(2, v0.z) KGE_DP_CV(3, v0.w)
+                KGE_DP_CV(4, v1.x) KGE_DP_CV(5, v1.y) KGE_DP_CV(6, v1.z) KGE_DP_CV(7, v1.w)
+#undef KGE_DP_CV
+                dnp[rr * 8 + gq] = dsum;
+                const int kk = sg * d + k0 + gq * 8, u = kk >> 4, hf = (kk >> 3) & 1;
+                if (row < p.Bp) reinterpret_cast<uint4 *>(p.Qh)[(row * p.units_p + u) * 2 + hf] = hi.v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (lane < QPW)
+                for (int gq = 0; gq < ngr; ++gq) dn += dnp[lane * 8 + gq];
+        }
+#undef KGE_DP_FETCH
+        // the cells behind the data: the guard column at K (see hi_rows_kernel, aug_mode 3 -- with this row's own norm), zeros
+        const int ntail = (kpad - K) >> 3;
+        for (int idx = lane; idx < QPW * ntail; idx += 64) {
+            const int rr = idx / ntail, g = idx - rr * ntail;
+            const int64_t row = grp * QPW + rr;
+            union { _Float16 h[8]; uint4 v; } hi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hi.h[e] = (_Float16)0.f;
+            if (g == 0 && row < p.B) {
+                const float qr = sqrtf(qn_s[rr]);
+                hi.h[0] = (_Float16)fmaxf(0.25f * (qr + qr * 0.00390625f) * sc_s[rr], 1.0f);
+            }
+            const int kk = K + g * 8, u = kk >> 4, hf = (kk >> 3) & 1;
+            if (row < p.Bp) reinterpret_cast<uint4 *>(p.Qh)[(row * p.units_p + u) * 2 + hf] = hi.v;
+        }
+        if (lane < QPW && i < p.Bp) {
+            if (valid) {
+                p.qn[i] = qn;
+                p.s_true[i] = acc;
+                const float dq2 = dn * (1.0f / (s_q * s_q)) * 1.0001f;
+                if (p.q_dn2) p.q_dn2[i] = dq2;
+                p.thr[i] = split_thr_dot_hi(qn, acc, em, K, p.units, p.c_acc, p.eps_scale, dq2, de2m, qn, s_q, s_e);
+                if (!(qn < INFINITY)) *p.overflow = 1.0f;
+                qbig = __uint_as_float(max(__float_as_uint(qbig), __float_as_uint(qn)));
+            } else {
+                p.thr[i] = make_float2(INFINITY, INFINITY);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // (qn_s / sc_s are rewritten by the next group)
+    }
+    if (p.qmax_io) {
         unsigned m = __float_as_uint(qbig);
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
         if (lane == 0) wmax[wv] = m;
@@ -1842,8 +2118,11 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     if (!a || !a->Qs || !a->Es || !s_true || !a->emax0 || !a->thr || !raw_count || !a->list || a->cap <= 0 ||
         !a->list_count || !a->overflow)
         return KGE_EINVAL;
-    if (d->mode == KGE_LP_DOT && (!a->qn0 || !a->qmax0 || (d->K1 > 0 && (!a->qn1 || !a->qmax1 || !a->emax1))))
+    const bool pq = a->q_scale_per_query != 0;     // (DOT, one-product level: per-query operand scales, qn0 = the total norm)
+    if (pq && (d->mode != KGE_LP_DOT || a->level != 1 || !a->qn0)) return KGE_EINVAL;
+    if (d->mode == KGE_LP_DOT && !pq && (!a->qn0 || !a->qmax0 || (d->K1 > 0 && (!a->qn1 || !a->qmax1 || !a->emax1))))
         return KGE_EINVAL;
+    if (d->mode == KGE_LP_DOT && d->K1 > 0 && !a->emax1) return KGE_EINVAL;
     if (d->B > INT32_MAX || d->N > INT32_MAX) return KGE_EINVAL;
     if (a->level != 0 && a->level != 1) return KGE_EINVAL;
     const bool lv1 = a->level == 1;     // one-product level: planar hi operands, plain thresholds
@@ -1856,9 +2135,10 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     SplitThrParams t;
     t.mode = d->mode;
     t.qn0 = d->mode != KGE_LP_DOT ? d->qn : a->qn0;
-    t.qn1 = (d->mode == KGE_LP_DOT && d->K1 > 0) ? a->qn1 : nullptr;
+    t.qn1 = (d->mode == KGE_LP_DOT && d->K1 > 0 && !pq) ? a->qn1 : nullptr;
     t.s_true = s_true;
-    t.qmax0 = a->qmax0; t.qmax1 = d->K1 > 0 ? a->qmax1 : nullptr;
+    t.qmax0 = a->qmax0; t.qmax1 = (d->K1 > 0 && !pq) ? a->qmax1 : nullptr;
+    t.q_scale_per_query = pq ? 1 : 0;
     t.emax0 = a->emax0; t.emax1 = (d->mode == KGE_LP_DOT && d->K1 > 0) ? a->emax1 : nullptr;
     t.B = d->B; t.Bp = Bp; t.K = K; t.units = units;
     t.eps_scale = a->eps_scale;
@@ -2062,6 +2342,47 @@ extern "C" int kge_mfma_f16_selftest(void)
  * bit-identical outputs.  Q (B,d), qn (B), s_true (B), Qs (split operand), thr (2*Bp floats), *list_count = 0.
  * The candidate table must be the whole entity table (no shard).  Then call kge_lp_split_count with
  * thr_ready = 1. */
+// The query side of one DistMult (E1 = R1 = NULL) / ComplEx batch on the one-product level in one launch, per-query operand
+// scales (dot_query_pipeline_kernel).  emax0 / emax1 / de2max must hold their final values when the launch runs.
+extern "C" int kge_lp_dot_query_pipeline(int side, const float *E0, const float *E1, const float *R0, const float *R1, int d,
+                                         const int64_t *h, const int64_t *t, const int64_t *r, int64_t B,
+                                         const float *emax0, const float *emax1, const float *de2max, float *qmax_io,
+                                         int accum_model, float eps_scale, float *Q0, float *Q1, float *qn, float *s_true,
+                                         void *Qh, float *thr, float *q_dn2, int32_t *list_count, float *overflow,
+                                         int32_t *zero_i32, int64_t zero_n, kge_stream_t stream)
+{
+    const bool both = side == KGE_SIDE_BOTH, cplx = E1 != nullptr;
+    if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD && !both) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
+    if (B == 0) return 0;
+    if (!E0 || !R0 || !h || !t || !r || !emax0 || !de2max || !Q0 || !qn || !s_true || !Qh || !thr || !list_count || !overflow)
+        return KGE_EINVAL;
+    if (cplx && (!R1 || !Q1 || !emax1)) return KGE_EINVAL;
+    if (!cplx && (R1 || Q1)) return KGE_EINVAL;
+    if (d % 8 != 0 || !kge_aligned16(E0) || !kge_aligned16(R0) || (cplx && (!kge_aligned16(E1) || !kge_aligned16(R1))))
+        return KGE_EINVAL;      // float4 staging, hi cells of 8 columns inside one segment
+    if (zero_n < 0 || (zero_n > 0 && !zero_i32)) return KGE_EINVAL;
+    DotPipeParams p;
+    p.tail = both ? 2 : (side == KGE_SIDE_TAIL ? 1 : 0);
+    p.Bh = B;
+    p.E0 = E0; p.E1 = E1; p.R0 = R0; p.R1 = R1; p.d = d; p.h = h; p.t = t; p.r = r;
+    p.B = both ? 2 * B : B; p.Bp = kge_lp_split_rows_padded(p.B, 1);
+    p.emax0 = emax0; p.emax1 = cplx ? emax1 : nullptr; p.de2max = de2max; p.qmax_io = qmax_io;
+    p.c_acc = accum_model == 1 ? 1.25f : 2.0f; p.eps_scale = eps_scale;
+    const int K = cplx ? 2 * d : d;
+    p.units = (K + 2 + 15) / 16; p.units_p = kge_lp_hi_units(K);
+    p.Q0 = Q0; p.Q1 = Q1; p.qn = qn; p.s_true = s_true; p.q_dn2 = q_dn2;
+    p.thr = reinterpret_cast<float2 *>(thr);
+    p.Qh = reinterpret_cast<_Float16 *>(Qh);
+    p.list_count = list_count; p.overflow = overflow;
+    p.zero_i32 = zero_i32; p.zero_n = zero_n;
+    const int64_t groups = (p.Bp + 15) / 16, blocks = (groups + 3) / 4;
+    const int grid = (int)(blocks < 256 * 16 ? blocks : 256 * 16);
+    if (cplx) hipLaunchKernelGGL((dot_query_pipeline_kernel<16, true>), dim3(grid), dim3(256), 0, kge_s(stream), p);
+    else hipLaunchKernelGGL((dot_query_pipeline_kernel<16, false>), dim3(grid), dim3(256), 0, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, int d, const int64_t *h,
                                      const int64_t *t, const int64_t *r, int64_t B, const float *en,
                                      const float *emax, float *qmax_io, int accum_model, float eps_scale, float *Q,
@@ -2090,6 +2411,7 @@ extern "C" int kge_lp_query_pipeline(int side, const float *E, const float *R, i
     if (tp_block_max && tp_blocks <= 0) return KGE_EINVAL;
     if (zero_n < 0 || (zero_n > 0 && !zero_i32)) return KGE_EINVAL;
     p.zero_i32 = zero_i32; p.zero_n = zero_n;
+    p.dbg = kge_env_int("KGE_QP_DBG", 0);
     if (level == 1) { p.units = (d + 2 + 15) / 16; p.units_p = kge_lp_hi_units(d); }
     p.Q = Q; p.qn = qn; p.s_true = s_true;
     p.thr = reinterpret_cast<float2 *>(thr);

@@ -69,6 +69,10 @@ class DistMultModel(BilinearModel):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
+        if ent_lo == 0 and ent_hi == self.n_ent and self._row_shard is None and exchange is None and qtabs is None:
+            prob = self._dot_fused_problem(sd, h_idx, t_idx, r_idx, [_hip.f32c(tabs[0])], [_hip.f32c(tabs[1])])
+            if prob is not None:
+                return prob
         Q0 = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs)[0]
         T0 = self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi)
         prob = self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, c_base=ent_lo), T0, c_base=ent_lo)
@@ -163,6 +167,11 @@ class ComplExModel(BilinearModel):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
+        if ent_lo == 0 and ent_hi == self.n_ent and self._row_shard is None and exchange is None and qtabs is None:
+            prob = self._dot_fused_problem(sd, h_idx, t_idx, r_idx, [_hip.f32c(tabs[0]), _hip.f32c(tabs[1])],
+                                           [_hip.f32c(tabs[2]), _hip.f32c(tabs[3])])
+            if prob is not None:
+                return prob
         Q0, Q1, _, _ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, want_q1=True)
         T0, T1 = self._cand_rows(_hip.f32c(tabs[0]), ent_lo, ent_hi), self._cand_rows(_hip.f32c(tabs[1]), ent_lo, ent_hi)
         prob = self._attach_dot_split(_hip.LpProblem(_hip.LP_DOT, Q0, T0, A1=Q1, T1=T1, c_base=ent_lo), T0, T1,

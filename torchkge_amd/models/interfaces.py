@@ -12,6 +12,8 @@ Added for the engine: ``lp_problem`` -- the descriptor of one all-candidates
 scoring problem straight from index vectors, which is what
 LinkPredictionEvaluator uses so that the (B, N) score matrix is never written.
 """
+import os
+
 import torch
 from torch.nn import Module
 
@@ -127,6 +129,10 @@ def _table_of(cand):
             (cand.stride(0) == 0 or cand.shape[0] == 1):
         return cand[0]
     return None
+
+
+# the DOT models' query side of a batch in one launch (kge_lp_dot_query_pipeline); KGE_DOT_FUSED=0: the separate kernels
+DOT_FUSED = os.environ.get('KGE_DOT_FUSED', '1') == '1'
 
 
 class Model(Module):
@@ -370,6 +376,31 @@ class Model(Module):
             return prob
         Es, e2 = self._cache.get('esd_' + key, srcs, lambda: _hip.split_table(T0, X1=T1, dot=True, nmax0=g[1:2], nmax1=nm1))
         prob.split = {'Es': Es, 'e2pref': e2, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'list_stat': g[6:7]}
+        return prob
+
+    def _dot_fused_problem(self, sd, h_idx, t_idx, r_idx, ent, rel):
+        """DistMult / ComplEx inside evaluate(), one-product level, whole tables on this GPU: the query side of the batch
+        from ONE launch (kge_lp_dot_query_pipeline: q, the exact true scores, the planar hi operand with per-query scales,
+        its residuals, the thresholds, zeroed rank counters) instead of nine; None when that path does not apply.
+        ``ent`` / ``rel``: [E] / [R] (DistMult) or [Re, Im] / [Re_r, Im_r] (ComplEx)."""
+        if not (DOT_FUSED and self._guard_on and self.split_filter and self._split_ok and self._use_level1()):
+            return None
+        d = ent[0].shape[1]
+        if h_idx.shape[0] == 0 or d % 8 != 0 or sd not in (_hip.SIDE_TAIL, _hip.SIDE_HEAD, _hip.SIDE_BOTH):
+            return None
+        T0, T1 = ent[0], (ent[1] if len(ent) > 1 else None)
+        shell = type('_Shell', (), {'split': None})()
+        self._attach_dot_split(shell, T0, T1)                   # candidate side (cached per evaluation): maxima, hi table
+        sp = shell.split
+        if sp is None or int(sp.get('level', 0)) != 1:
+            return None
+        g = self._lp_guard
+        pre = _hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if len(rel) > 1 else None, h_idx, t_idx, r_idx,
+                                         sp['enmax'], sp.get('enmax1'), sp['de2max'], g[0:1], sp['overflow'], zero_counts=True)
+        pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
+        prob = _hip.LpProblem(_hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
+        prob.split = sp
+        prob.pre = pre
         return prob
 
     def lp_problem_both(self, h_idx, t_idx, r_idx):
