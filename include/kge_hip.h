@@ -610,7 +610,21 @@ int kge_lp_dot_query_pipeline(int side, const float *E0, const float *E1, const 
                               const float *emax1, const float *de2max, float *qmax_io, int accum_model, float eps_scale,
                               float *Q0, float *Q1, float *qn, float *s_true, void *Qh, float *thr,
                               float *q_dn2 /* optional */, int32_t *list_count, float *overflow, int32_t *zero_i32,
-                              int64_t zero_n, kge_stream_t stream);
+                              int64_t zero_n,
+                              const float *dn_block_max /* optional: kge_lp_dot_table_prep's residual block maxima; the kernel
+                                                           folds them into *de2max (written through the const pointer) */,
+                              int dn_blocks, kge_stream_t stream);
+/* Candidate side of a DistMult / ComplEx problem on the one-product level in TWO launches (r05) -- what two
+ * kge_row_sqnorm_any_order passes, a zero-fill and kge_lp_hi_rows[_frag](aug_mode 4) do in four, with the table read twice
+ * instead of three times and no same-address atomics: (1) the squared-norm maxima of [X0 | X1] per block, (2) the hi table
+ * `out` (frag = 1: fragment-major, else planar), whose blocks fold (1) into *norm2max0_io / *norm2max1_io (values already
+ * there take part: other shards, an earlier call) and leave their residual maxima in dn_block_max
+ * [kge_lp_dot_table_prep_blocks(rows, 1)] -- hand those to kge_lp_dot_query_pipeline.  ws: 2 *
+ * kge_lp_dot_table_prep_blocks(rows, 0) floats. */
+int kge_lp_dot_table_prep_blocks(int64_t rows, int which);
+int kge_lp_dot_table_prep(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows, int frag,
+                          float *norm2max0_io, float *norm2max1_io, void *out, float *dn_block_max, float *ws,
+                          kge_stream_t stream);
 /* TransE-L2 query side of one batch in ONE launch -- what kge_lp_prep, kge_row_sqnorm (queries),
  * kge_lp_pair_scores (true scores), kge_lp_split_rows (queries) and the threshold kernel of
  * kge_lp_split_count do separately, with bit-identical outputs: Q (B,d), qn (B), s_true (B), Qs, thr

@@ -1777,12 +1777,13 @@ def test_projection_query_side_in_two_launches_equals_the_separate_kernels(hip, 
 
 @pytest.mark.parametrize('kind,B,d,frag', [('distmult', 1000, 64, True), ('complex', 777, 40, True), ('complex', 333, 200, False),
                                            ('distmult', 5, 400, True)])
-@pytest.mark.parametrize('side', ['both', 'tail', 'head'])
-def test_dot_query_side_in_one_launch_equals_the_separate_kernels(hip, kind, B, d, frag, side):
+@pytest.mark.parametrize('side,qpw', [('both', 4), ('both', 16), ('tail', 16), ('head', 4)])
+def test_dot_query_side_in_one_launch_equals_the_separate_kernels(hip, kind, B, d, frag, side, qpw, monkeypatch):
     """r05: kge_lp_dot_query_pipeline (DistMult / ComplEx, one-product level: q, exact true scores, planar hi operand with
     PER-QUERY scales, residuals, thresholds, zeroed counters in one launch) against kge_lp_prep + kge_lp_pair_scores (bit
     for bit) and, through kge_lp_split_count + recheck, against the exact fp32 counts -- with the thresholds of the launch
     (thr_ready) and with thresholds recomputed for other true scores (kge_split_args.q_scale_per_query)."""
+    monkeypatch.setenv('KGE_DQPIPE_QPW', str(qpw))      # queries per wavefront (the library picks 4 for small batches)
     n_ent, n_rel = 1500, 11
     tables = orc.init_tables(kind, n_ent, n_rel, d, seed=5)
     m = build_model(kind, 2, tables, n_ent, n_rel)
@@ -1807,10 +1808,17 @@ def test_dot_query_side_in_one_launch_equals_the_separate_kernels(hip, kind, B, 
         hip.row_sqnorm(T1, max_io=guard[5:6], bound_only=True)
     nm1 = guard[5:6] if cplx else None
     Eh, de2 = hip.hi_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=nm1, frag=frag)
-    split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'enmax1': nm1, 'overflow': guard[2:3], 'level': 1, 'de2max': de2,
-             'list_stat': guard[6:7], 'es_frag': frag}
-    pre = hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if cplx else None, h, t, r, guard[1:2], nm1, de2, guard[0:1],
-                                    guard[2:3], zero_counts=True)
+    # the candidate side in two launches (norm maxima per block, hi table + residual maxima per block): same table, same
+    # scalars -- the residual maximum once the query pipeline has folded the block maxima into its slot
+    g2 = torch.zeros(8, device='cuda')
+    Eh2, dnb, _ws = hip.dot_table_prep(T0, T1, g2[1:2], g2[5:6] if cplx else None, frag)
+    assert torch.equal(Eh2, Eh) and float(g2[1]) == float(guard[1]) and float(g2[5]) == float(guard[5])
+    assert float(dnb.max()) == float(de2)
+    split = {'Es': Eh2, 'e2pref': None, 'enmax': g2[1:2], 'enmax1': g2[5:6] if cplx else None, 'overflow': guard[2:3], 'level': 1,
+             'de2max': g2[7:8], 'list_stat': guard[6:7], 'es_frag': frag}
+    pre = hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if cplx else None, h, t, r, g2[1:2], g2[5:6] if cplx else None,
+                                    g2[7:8], guard[0:1], guard[2:3], zero_counts=True, dn_bmax=dnb)
+    assert float(g2[7]) == float(de2)
     assert torch.equal(pre['Q'], Q0) and (not cplx or torch.equal(pre['Q1'], Q1))
     true = torch.cat([t, h]) if side == 'both' else (t if side == 'tail' else h)
     ref = hip.LpProblem(hip.LP_DOT, Q0, T0, A1=Q1 if cplx else None, T1=T1)

@@ -15,7 +15,9 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 name = lambda r: r['Kernel_Name']
 fin = [i for i, r in enumerate(rows) if 'rank_finalize' in name(r)]
 # the last complete evaluate: from the dispatch after the second-to-last finalize to the last finalize
-a, b = fin[-2] + 1, fin[-1]
+import os
+back = int(os.environ.get('TL_BACK', '0'))       # TL_BACK=1: the evaluate (or batch) before the last one
+a, b = fin[-2 - back] + 1, fin[-1 - back]
 t0 = int(rows[a]['Start_Timestamp'])
 prev_end = None
 print('# one steady-state evaluate(): %d dispatches, %.1f us from the first start to the last end' % (

@@ -99,6 +99,7 @@ _SIGNATURES = {
     'kge_lp_hi_stream_supported': [_int],
     'kge_lp_table_prep_l2': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_table_prep_blocks': [_i64],
+    'kge_lp_dot_table_prep_blocks': [_i64, _int],
     'kge_lp_split_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SplitArgs), _vp, _vp, _vp],
     'kge_lp_split_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp],
     'kge_absmax': [_vp, _i64, _vp, _vp],
@@ -110,7 +111,8 @@ _SIGNATURES = {
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _i64, _vp],
     'kge_lp_dot_query_pipeline': [_int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, ctypes.c_float,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int, _vp],
+    'kge_lp_dot_table_prep': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -630,7 +632,31 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
     return out
 
 
-def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, qmax_io, overflow, zero_counts=False):
+def dot_table_prep(X0, X1, nmax0_io, nmax1_io, frag):
+    """Candidate side of a DOT problem on the one-product level in two launches (kge_lp_dot_table_prep): (Eh, dn_block_max) --
+    the hi table (fragment-major when ``frag``) and its residual maxima per block, to be folded by lp_dot_query_pipeline;
+    the squared-norm maxima of the table's segment(s) end up in nmax0_io / nmax1_io."""
+    lib = load_library()
+    require_cuda(X0, X1, nmax0_io, nmax1_io)
+    X0 = f32c(X0)
+    rows, K0 = X0.shape
+    K1, ld1 = 0, 0
+    if X1 is not None:
+        X1 = f32c(X1)
+        K1, ld1 = X1.shape[1], X1.stride(0)
+    units_p = int(lib.kge_lp_hi_units(K0 + K1))
+    rows_p = int(lib.kge_lp_split_rows_padded(rows, 0))
+    out = torch.empty(rows_p * units_p * 32, dtype=torch.uint8, device=X0.device)
+    ws = torch.empty(2 * int(lib.kge_lp_dot_table_prep_blocks(rows, 0)), dtype=torch.float32, device=X0.device)
+    dnb = torch.empty(int(lib.kge_lp_dot_table_prep_blocks(rows, 1)), dtype=torch.float32, device=X0.device)
+    with _on(X0.device):
+        _check(lib.kge_lp_dot_table_prep(_p(X0), X0.stride(0), K0, _p(X1), ld1, K1, rows, 1 if frag else 0, _p(nmax0_io),
+                                         _p(nmax1_io), _p(out), _p(dnb), _p(ws), _stream()), 'kge_lp_dot_table_prep')
+    return out, dnb, ws
+
+
+def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, qmax_io, overflow, zero_counts=False,
+                          dn_bmax=None):
     """DistMult (E1 = R1 = None) / ComplEx query side of one batch on the one-product level in one launch
     (kge_lp_dot_query_pipeline): dict with Q (and Q1), qn, s_true, Qs (planar hi operand, PER-QUERY scales), thr, q_dn2,
     n_list, counts -- Q / Q1 / s_true bit-identical to lp_prep + pair_scores."""
@@ -658,7 +684,8 @@ def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, q
                                              _p(emax1), _p(de2max), _p(qmax_io), split_accum_model(), SPLIT_EPS_SCALE,
                                              _p(out['Q']), _p(out['Q1']), _p(out['qn']), _p(out['s_true']), _p(out['Qs']),
                                              _p(out['thr']), _p(out['q_dn2']), _p(out['n_list']), _p(overflow),
-                                             _p(out.get('counts')), 3 * Bq if zero_counts else 0, _stream()),
+                                             _p(out.get('counts')), 3 * Bq if zero_counts else 0, _p(dn_bmax),
+                                             0 if dn_bmax is None else dn_bmax.shape[0], _stream()),
                'kge_lp_dot_query_pipeline')
     return out
 

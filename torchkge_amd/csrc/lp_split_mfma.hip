@@ -236,6 +236,9 @@ struct HiRowsParams {
     float *dn2;               // optional (rows)
     float *dn2max;            // optional device scalar, max folded in
     const int64_t *row_index;
+    const float *nm_bmax;     // optional [2][nm_blocks]: per-block squared-norm maxima of the two segments (dot_table_norm_max_kernel)
+    int nm_blocks;            //   -- every block folds them into *nmax0 / *nmax1 on its way in, block 0 stores the two scalars
+    float *dn_bmax;           // optional [gridDim.x]: the blocks' residual maxima as plain stores INSTEAD of the dn2max atomic
     int frag;                 // 1: FRAGMENT-MAJOR output [rows_p / 32][units_p][64][16 B] -- chunk (row % 32) + 32 * k-half of
                               // the 1-KiB block of (32-row group, unit): the A operand of v_mfma_f32_32x32x16_f16 in lane
                               // order, one coalesced global_load_dwordx4 per block (lp_hi_stream.hip)
@@ -245,7 +248,30 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
 {
     __shared__ unsigned bmax[4];
     float scale = (float)(1 << SPLIT_SCALE_LOG2), nmax = 0.f;
-    if (p.nmax0) {
+    if (p.nm_bmax) {        // (as query_pipeline_kernel: block maxima -> the two scalars, folded into what they hold)
+        __shared__ unsigned red[8];
+        unsigned m0 = 0u, m1 = 0u;
+        for (int j = threadIdx.x; j < p.nm_blocks; j += 256) {
+            m0 = max(m0, __float_as_uint(p.nm_bmax[j]));
+            m1 = max(m1, __float_as_uint(p.nm_bmax[p.nm_blocks + j]));
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 = max(m0, (unsigned)__shfl_xor((int)m0, off, 64));
+            m1 = max(m1, (unsigned)__shfl_xor((int)m1, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m0; red[4 + (threadIdx.x >> 6)] = m1; }
+        __syncthreads();
+        m0 = max(max(red[0], red[1]), max(red[2], red[3]));
+        m1 = max(max(red[4], red[5]), max(red[6], red[7]));
+        const float n0 = __uint_as_float(max(m0, __float_as_uint(*p.nmax0)));
+        const float n1 = p.nmax1 ? __uint_as_float(max(m1, __float_as_uint(*p.nmax1))) : 0.f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *const_cast<float *>(p.nmax0) = n0;
+            if (p.nmax1) *const_cast<float *>(p.nmax1) = n1;
+        }
+        nmax = n0 + n1;
+        scale = split_scale(nmax);
+    } else if (p.nmax0) {
         nmax = *p.nmax0 + (p.nmax1 ? *p.nmax1 : 0.f);
         scale = split_scale(nmax);
     }
@@ -328,12 +354,76 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
         if (real && tu_ == 0 && p.dn2) p.dn2[row] = dn;
         if (real) dmax = fmaxf(dmax, dn);
     }
-    if (p.dn2max) {
+    if (p.dn2max || p.dn_bmax) {
         unsigned m = __float_as_uint(dmax);
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
         if ((threadIdx.x & 63) == 0) bmax[threadIdx.x >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0) kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.dn2max), max(max(bmax[0], bmax[1]), max(bmax[2], bmax[3])));
+        if (threadIdx.x == 0) {
+            const unsigned mm = max(max(bmax[0], bmax[1]), max(bmax[2], bmax[3]));
+            if (p.dn_bmax) p.dn_bmax[blockIdx.x] = __uint_as_float(mm);
+            else kge_atomic_max_u32(reinterpret_cast<unsigned *>(p.dn2max), mm);
+        }
+    }
+}
+
+// Squared-norm maxima of the rows of one or two tables ([Re | Im] segments of a DOT candidate table) in ONE sweep, any
+// summation order (they fix the operand scale and bound the error band; no score contains them): row_sqnorm_any_kernel
+// for both segments without the per-row outputs, the blocks' maxima as plain stores (bmax[2][gridDim.x]) -- the consumer
+// (hi_rows_kernel, nm_bmax) reduces them: no same-address atomics, no zero-fill of the scalars.
+__global__ __launch_bounds__(256) void dot_table_norm_max_kernel(const float *__restrict__ X0, int64_t ld0, int K0,
+                                                                 const float *__restrict__ X1, int64_t ld1, int K1,
+                                                                 int64_t rows, float *bmax_out)
+{
+    __shared__ unsigned wmax[8];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    float big0 = 0.f, big1 = 0.f;
+    for (int sg = 0; sg < (X1 ? 2 : 1); ++sg) {
+        const float *X = sg ? X1 : X0;
+        const int64_t ld = sg ? ld1 : ld0;
+        const int K = sg ? K1 : K0;
+        const bool vec = (K % 4 == 0) && (ld % 4 == 0) && ((size_t)X & 15) == 0;
+        float big = 0.f;
+        for (int64_t r0 = (int64_t)blockIdx.x * 64; r0 < rows; r0 += (int64_t)gridDim.x * 64) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                for (int k = sub * 4; k < K; k += 64) {
+                    float4 t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const float4 *>(X + min(r0 + grp * 4 + j, rows - 1) * ld + k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = fmaf(t[j].x, t[j].x, acc[j]); acc[j] = fmaf(t[j].y, t[j].y, acc[j]);
+                        acc[j] = fmaf(t[j].z, t[j].z, acc[j]); acc[j] = fmaf(t[j].w, t[j].w, acc[j]);
+                    }
+                }
+            } else {
+                for (int k = sub; k < K; k += 16)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = X[min(r0 + grp * 4 + j, rows - 1) * ld + k];
+                        acc[j] = fmaf(x, x, acc[j]);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = acc[j];
+                a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 1, 64);
+                big = __uint_as_float(max(__float_as_uint(big), __float_as_uint(a)));   // (rows past the end repeat the last row)
+            }
+        }
+        if (sg) big1 = big; else big0 = big;
+    }
+    unsigned m0 = __float_as_uint(big0), m1 = __float_as_uint(big1);
+    for (int off = 32; off > 0; off >>= 1) {
+        m0 = max(m0, (unsigned)__shfl_xor((int)m0, off, 64));
+        m1 = max(m1, (unsigned)__shfl_xor((int)m1, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m0; wmax[4 + (threadIdx.x >> 6)] = m1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bmax_out[blockIdx.x] = __uint_as_float(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+        bmax_out[gridDim.x + blockIdx.x] = __uint_as_float(max(max(wmax[4], wmax[5]), max(wmax[6], wmax[7])));
     }
 }
 
@@ -1062,6 +1152,8 @@ struct DotPipeParams {
     float *overflow;
     int32_t *zero_i32;
     int64_t zero_n;
+    const float *dn_bmax;           // optional [dn_blocks]: block maxima of the candidate table's residuals (kge_lp_dot_table_prep):
+    int dn_blocks;                  // folded into *de2max by every block on its way in, stored by block 0
 };
 
 // thresholds of one DOT query on the one-product level, operand scales s_q (its own) and s_e
@@ -1094,7 +1186,22 @@ __global__ __launch_bounds__(256) void dot_query_pipeline_kernel(const DotPipePa
     const int d = p.d, nseg = CPLX ? 2 : 1, K = nseg * d, kpad = p.units_p * 16;
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < p.zero_n; j += (int64_t)gridDim.x * 256) p.zero_i32[j] = 0;
-    const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f), de2m = *p.de2max;
+    const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
+    float de2m;
+    if (p.dn_bmax) {
+        __shared__ unsigned red[4];
+        unsigned m = 0u;
+        for (int j = threadIdx.x; j < p.dn_blocks; j += 256) m = max(m, __float_as_uint(p.dn_bmax[j]));
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if (lane == 0) red[wv] = m;
+        __syncthreads();
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        de2m = __uint_as_float(max(m, __float_as_uint(*p.de2max)));
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<float *>(p.de2max) = de2m;
+    } else {
+        de2m = *p.de2max;
+    }
     const float s_e = split_scale(em);
     if (blockIdx.x == 0 && threadIdx.x == 0 && !(em < INFINITY)) *p.overflow = 1.0f;
     float qbig = 0.f;
@@ -2017,6 +2124,7 @@ static int hi_rows_impl(const float *X0, int64_t ld0, int K0, const float *X1, i
     p.out = reinterpret_cast<uint4 *>(out);
     p.dn2 = dn2; p.dn2max = dn2max; p.row_index = row_index;
     p.frag = frag;
+    p.nm_bmax = nullptr; p.nm_blocks = 0; p.dn_bmax = nullptr;
     const int64_t blocks = p.rows_p / 16;
     if (blocks == 0) return 0;
     // every block ends with ONE same-address atomic (dn2max), and those serialise at ~20-30 ns each (measured r05 on the
@@ -2043,6 +2151,44 @@ extern "C" int kge_lp_hi_rows_frag(const float *X0, int64_t ld0, int K0, const f
 {
     return hi_rows_impl(X0, ld0, K0, X1, ld1, K1, rows, 0, aug_mode, aug, aug_mul, norm2max0, norm2max1, out, dn2, dn2max,
                         nullptr, 1, stream);
+}
+
+/* Candidate side of a DOT problem on the one-product level in TWO launches (r05): the squared-norm maxima of the table's one
+ * or two segments in one sweep (block maxima, no atomics, no zero-fill), then the hi table (planar or fragment-major), whose
+ * blocks fold those maxima into *norm2max0_io / *norm2max1_io (block 0 stores the scalars) and leave their residual maxima
+ * per block in dn_block_max[kge_lp_dot_table_prep_blocks(rows, 1)] for kge_lp_dot_query_pipeline to fold into *de2max.
+ * ws: 2 * kge_lp_dot_table_prep_blocks(rows, 0) floats of scratch. */
+extern "C" int kge_lp_dot_table_prep_blocks(int64_t rows, int which)
+{
+    if (which == 0) { const int64_t b = (rows + 63) / 64; return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048); }
+    const int64_t b = kge_lp_split_rows_padded(rows, 0) / 16;
+    return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096);
+}
+
+extern "C" int kge_lp_dot_table_prep(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                                     int frag, float *norm2max0_io, float *norm2max1_io, void *out, float *dn_block_max,
+                                     float *ws, kge_stream_t stream)
+{
+    if (rows <= 0 || K0 <= 0 || K1 < 0 || ld0 < K0 || (K1 > 0 && ld1 < K1)) return KGE_EINVAL;
+    if (!X0 || (K1 > 0 && (!X1 || !norm2max1_io)) || !norm2max0_io || !out || !dn_block_max || !ws) return KGE_EINVAL;
+    const int nb = kge_lp_dot_table_prep_blocks(rows, 0);
+    hipLaunchKernelGGL(dot_table_norm_max_kernel, dim3(nb), dim3(256), 0, kge_s(stream), X0, ld0, K0,
+                       K1 > 0 ? X1 : nullptr, ld1, K1, rows, ws);
+    KGE_CHECK_LAUNCH();
+    HiRowsParams p;
+    p.X0 = X0; p.X1 = K1 > 0 ? X1 : nullptr; p.ld0 = ld0; p.ld1 = ld1; p.K0 = K0; p.K1 = K1;
+    p.rows = rows;
+    p.rows_p = kge_lp_split_rows_padded(rows, 0);
+    p.aug_mode = 4; p.aug = nullptr; p.aug_mul = 0.f;
+    p.nmax0 = norm2max0_io; p.nmax1 = K1 > 0 ? norm2max1_io : nullptr;
+    p.units_p = kge_lp_hi_units(K0 + K1);
+    p.out = reinterpret_cast<uint4 *>(out);
+    p.dn2 = nullptr; p.dn2max = nullptr; p.row_index = nullptr;
+    p.frag = frag ? 1 : 0;
+    p.nm_bmax = ws; p.nm_blocks = nb; p.dn_bmax = dn_block_max;
+    hipLaunchKernelGGL(hi_rows_kernel, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    return 0;
 }
 
 /* 1 if kge_lp_split_count takes a fragment-major candidate table (es_frag = 1) for K columns on the one-product level */
@@ -2349,8 +2495,10 @@ extern "C" int kge_lp_dot_query_pipeline(int side, const float *E0, const float 
                                          const float *emax0, const float *emax1, const float *de2max, float *qmax_io,
                                          int accum_model, float eps_scale, float *Q0, float *Q1, float *qn, float *s_true,
                                          void *Qh, float *thr, float *q_dn2, int32_t *list_count, float *overflow,
-                                         int32_t *zero_i32, int64_t zero_n, kge_stream_t stream)
+                                         int32_t *zero_i32, int64_t zero_n, const float *dn_block_max, int dn_blocks,
+                                         kge_stream_t stream)
 {
+    if (dn_block_max && dn_blocks <= 0) return KGE_EINVAL;
     const bool both = side == KGE_SIDE_BOTH, cplx = E1 != nullptr;
     if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD && !both) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
     if (B == 0) return 0;
@@ -2375,10 +2523,19 @@ extern "C" int kge_lp_dot_query_pipeline(int side, const float *E0, const float 
     p.Qh = reinterpret_cast<_Float16 *>(Qh);
     p.list_count = list_count; p.overflow = overflow;
     p.zero_i32 = zero_i32; p.zero_n = zero_n;
-    const int64_t groups = (p.Bp + 15) / 16, blocks = (groups + 3) / 4;
+    p.dn_bmax = dn_block_max; p.dn_blocks = dn_blocks;
+    // queries per wavefront: 16 -- or 4 for a small batch (the kernel is a latency chain per group: fewer than two groups of
+    // 16 per SIMD leave most of the chip idle while ~400 wavefronts walk 10 chunks each)
+    const int qpw = kge_env_int("KGE_DQPIPE_QPW", p.Bp / 16 < 2048 ? 4 : 16);
+    const int64_t groups = (p.Bp + qpw - 1) / qpw, blocks = (groups + 3) / 4;
     const int grid = (int)(blocks < 256 * 16 ? blocks : 256 * 16);
-    if (cplx) hipLaunchKernelGGL((dot_query_pipeline_kernel<16, true>), dim3(grid), dim3(256), 0, kge_s(stream), p);
-    else hipLaunchKernelGGL((dot_query_pipeline_kernel<16, false>), dim3(grid), dim3(256), 0, kge_s(stream), p);
+    if (qpw == 4) {
+        if (cplx) hipLaunchKernelGGL((dot_query_pipeline_kernel<4, true>), dim3(grid), dim3(256), 0, kge_s(stream), p);
+        else hipLaunchKernelGGL((dot_query_pipeline_kernel<4, false>), dim3(grid), dim3(256), 0, kge_s(stream), p);
+    } else {
+        if (cplx) hipLaunchKernelGGL((dot_query_pipeline_kernel<16, true>), dim3(grid), dim3(256), 0, kge_s(stream), p);
+        else hipLaunchKernelGGL((dot_query_pipeline_kernel<16, false>), dim3(grid), dim3(256), 0, kge_s(stream), p);
+    }
     KGE_CHECK_LAUNCH();
     return 0;
 }

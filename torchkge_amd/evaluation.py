@@ -42,7 +42,10 @@ from .utils.operations import get_rank
 
 
 # LinkPredictionEvaluator._internal_batch: facts per batch of the fused path / bound on a batch's uncertain-pair list
-COALESCE_BATCH = 32768
+# (r05: 32768 -> 65536 -- FB15k's 59,071 test facts as ONE batch of 118 k queries instead of two: DistMult 2.21 -> 2.14 ms per
+# evaluate, profiles/r05/dot_fused_ab.txt; the per-batch costs -- graph launch, read-back, the latency chains of the query side --
+# are paid once)
+COALESCE_BATCH = int(os.environ.get('KGE_COALESCE_BATCH', 65536))
 COALESCE_LIST_BYTES = 2 << 30
 # exchange='scores': bytes of the local (rows, N/P) fp32 score tile of one all-to-all (the receive buffer has the same
 # size).  A batch is cut into as many row tiles as it takes, so b_size never decides whether the score exchange fits.
@@ -322,7 +325,7 @@ class LinkPredictionEvaluator(object):
     coalesce: None | int -- the batch the fused kernels see.  In the reference ``b_size`` bounds the
         (b, N, d) temporaries; here ranks are per query and a small b_size only means many small
         launches, so the facts are processed ``max(b_size, coalesce)`` at a time (None: the module
-        default COALESCE_BATCH = 32768), never more than fits in a quarter of the FREE device memory
+        default COALESCE_BATCH = 65536), never more than fits in a quarter of the FREE device memory
         (uncertain-pair list + query buffers; single-GPU evaluators).  ``coalesce=0`` takes
         ``b_size`` literally -- the opt-out when b_size is the script's memory knob.
     """

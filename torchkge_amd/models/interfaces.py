@@ -389,14 +389,20 @@ class Model(Module):
         if h_idx.shape[0] == 0 or d % 8 != 0 or sd not in (_hip.SIDE_TAIL, _hip.SIDE_HEAD, _hip.SIDE_BOTH):
             return None
         T0, T1 = ent[0], (ent[1] if len(ent) > 1 else None)
-        shell = type('_Shell', (), {'split': None})()
-        self._attach_dot_split(shell, T0, T1)                   # candidate side (cached per evaluation): maxima, hi table
-        sp = shell.split
-        if sp is None or int(sp.get('level', 0)) != 1:
-            return None
         g = self._lp_guard
+        frag = self._level1_stream()
+        nm1 = g[5:6] if T1 is not None else None
+        # candidate side (cached per evaluation) in two launches: norm maxima per block, then the hi table whose blocks fold
+        # them into guard[1] / guard[5] and leave their residual maxima per block -- folded into guard[7] by every query
+        # pipeline launch on its way in (kge_lp_dot_table_prep; the guard vector is zeroed per evaluation)
+        srcs = [T0] + ([T1] if T1 is not None else [])
+        Eh, dnb, _ws = self._cache.get('dtp%d_0_%d' % (frag, T0.shape[0]), srcs,
+                                       lambda: _hip.dot_table_prep(T0, T1, g[1:2], nm1, frag))
+        sp = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'level': 1, 'de2max': g[7:8],
+              'list_stat': g[6:7], 'es_frag': frag}
         pre = _hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if len(rel) > 1 else None, h_idx, t_idx, r_idx,
-                                         sp['enmax'], sp.get('enmax1'), sp['de2max'], g[0:1], sp['overflow'], zero_counts=True)
+                                         sp['enmax'], nm1, sp['de2max'], g[0:1], sp['overflow'], zero_counts=True,
+                                         dn_bmax=dnb)
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
         prob.split = sp
