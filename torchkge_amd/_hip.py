@@ -1071,12 +1071,16 @@ class LpProblem(object):
         self.last_split = (n_list, (Qi, thr, lst))      # kept alive until the launches have run; tests read n_list
         return raw
 
-    def _count_ge_split(self, s_true, raw):
+    def _count_ge_split(self, s_true, raw, between=None):
         """Same counts as kge_lp_count_ge through the certified f16-split
         prefilter + exact recheck of the pairs inside the error band;
-        self.split = {'Es', 'enmax', 'overflow'} is set by the model."""
+        self.split = {'Es', 'enmax', 'overflow'} is set by the model.
+        ``between``: called after the sweep is enqueued and before the recheck (the evaluator forks its filter correction
+        there: beside the recheck instead of beside the sweep)."""
         prep = self.split_prepare()
         self.split_count(prep, s_true, raw)
+        if between is not None:
+            between()
         self.split_recheck(prep, s_true, raw)
         self.last_split = (prep['n_list'], prep)     # kept alive until the launches have run; tests read n_list
         return raw

@@ -154,6 +154,16 @@ class HipRankEngine(object):
             prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
             return out
         main = torch.cuda.current_stream(s_true.device)
+        if FILTER_BESIDE_RECHECK and prob.B > 0 and prob.N > 0:
+            # the filter correction forked BEHIND the count sweep, beside its exact recheck (both are short, L2-bound kernels;
+            # the sweep -- one or two persistent workgroups per CU -- then has the chip to itself)
+            def fork():
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    prob.filter_sub(s_true, true_idx, seg_lo, seg_hi, targets, out[1], out[2], grouped=True, plan=plan)
+            prob._count_ge_split(s_true, out[0], between=fork)
+            main.wait_stream(aux)
+            return out
         aux.wait_stream(main)
         if count_first:
             prob.count_ge(s_true, out[0])
@@ -210,6 +220,8 @@ def _to_host(t):
         return t
     host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host.copy_(t, non_blocking=True)
+    # (polling an event instead -- `while not ev.query()` -- was measured 2.4 % SLOWER per evaluate, r05:
+    # profiles/r05/host_wait_ab.txt; hipStreamSynchronize already spins)
     torch.cuda.current_stream(t.device).synchronize()
     return host
 
@@ -279,6 +291,8 @@ class _EvalState(object):
 
 _STATES = weakref.WeakKeyDictionary()       # model -> {(id(kg), options): _EvalState}
 SHARE_STATE = os.environ.get('KGE_SHARE_EVAL_STATE', '1') != '0'
+# the filter correction of the second stream beside the exact recheck (1) instead of beside the count sweep (0)
+FILTER_BESIDE_RECHECK = os.environ.get('KGE_FILTER_BESIDE_RECHECK', '0') == '1'
 
 
 def _shared_state(model, kg, cfg):
