@@ -538,6 +538,11 @@ typedef struct kge_split_args {
      * by the power of two that fits ||q_i||, not the batch maximum); qn0 then holds the total squared norm per query, qn1 /
      * qmax0 / qmax1 are not read.  Matters only when the thresholds are recomputed (thr_ready = 0). */
     int32_t q_scale_per_query;
+    /* es_frag = 1, col_q = NULL, optional (r05): kge_lp_split_regions(B) int32, ZEROED -- the sweep then leaves its uncertain pairs
+     * in REGIONS of `list` (cap / regions entries each), one per 32 consecutive queries, counts here; *list_count is not
+     * touched.  Follow with kge_lp_split_recheck_regions (which re-scores a region with its 32 query rows resident in LDS:
+     * half the row fetches of kge_lp_split_recheck).  Only when kge_lp_split_regions_supported(d). */
+    int32_t *region_count;
 } kge_split_args;
 int kge_lp_split_group_sets(void);
 
@@ -592,6 +597,13 @@ int kge_lp_table_prep_l2(const float *X, int64_t ld, int64_t rows, int K, float 
                          kge_stream_t stream);
 int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a, const float *s_true, int32_t *raw_count,
                        kge_stream_t stream);
+/* The exact recheck of a list cut into regions (kge_split_args.region_count): same decrements of raw_count as
+ * kge_lp_split_recheck; *list_stat += pairs re-scored, *list_count += pairs re-scored (both optional). */
+int kge_lp_split_regions(int64_t B);
+int kge_lp_split_regions_supported(const kge_lp_desc *d);
+int kge_lp_split_recheck_regions(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
+                                 const int32_t *region_count, int32_t *raw_count, float *list_stat, int32_t *list_count,
+                                 kge_stream_t stream);
 /* 1 if v_mfma_f32_32x32x16_f16 on the current device accumulates as the tighter error model assumes (two
  * passes of acc + 8 products, addends truncated 24 bits below the largest, one RNE rounding), 0 if not.
  * Launches a one-wave kernel on the null stream and synchronises: call once, outside any capture. */

@@ -1842,3 +1842,44 @@ def test_dot_query_side_in_one_launch_equals_the_separate_kernels(hip, kind, B, 
     got2 = prob.count_ge(st2)
     assert float(guard[2]) == 0.0
     assert torch.equal(got2, ref.count_ge(st2))
+
+
+@pytest.mark.parametrize('B,N,d', [(50, 300, 64), (700, 2100, 200), (1500, 900, 104)])
+@pytest.mark.parametrize('waves', [2, 4])
+def test_region_recheck_equals_the_global_list(hip, B, N, d, waves, monkeypatch):
+    """r05: the free-running sweep leaves its uncertain pairs in REGIONS of the list (one per 32 consecutive queries,
+    kge_split_args.region_count) and kge_lp_split_recheck_regions re-scores a region with its query rows resident in LDS --
+    the same counts, the same number of listed pairs as the one global list + kge_lp_split_recheck, and the exact counts;
+    a second sweep on the same operands (other thresholds) starts from zeroed region counters."""
+    monkeypatch.setenv('KGE_RECHECK_REGION_WAVES', str(waves))
+    g = torch.Generator().manual_seed(B + d)
+    E = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=1).cuda()
+    R = (0.3 * torch.randn(5, d, generator=g)).cuda()
+    h = torch.randint(0, N, (B,), generator=g).cuda(); t = torch.randint(0, N, (B,), generator=g).cuda()
+    h[: B // 3] = h[0]                  # a hub: many queries share their row (and their uncertain candidates)
+    r = torch.randint(0, 5, (B,), generator=g).cuda()
+    true = torch.cat([t, h])
+    got, listed = {}, {}
+    for regions in (False, True):
+        guard = torch.zeros(8, device='cuda')
+        en, Ef, tpb = hip.table_prep_l2(E, guard[1:2], guard[7:8], deferred_max=True)
+        pre = hip.lp_query_pipeline(hip.SIDE_BOTH, E, R, h, t, r, en, guard[1:2], guard[0:1], level=1, de2max=guard[7:8],
+                                    tp_bmax=tpb, zero_counts=True, regions=regions)
+        assert (pre.get('region_count') is not None) == regions
+        pre['true_idx'] = true
+        prob = hip.LpProblem(hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
+        prob.split = {'Es': Ef, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'level': 1, 'de2max': guard[7:8],
+                      'list_stat': guard[6:7], 'es_frag': True}
+        prob.pre = pre
+        st = prob.pair_scores(true)
+        got[regions] = prob.count_ge(st).clone()
+        assert float(guard[2]) == 0.0
+        listed[regions] = (int(prob.last_split[0]), float(guard[6]))
+        if regions:
+            assert int(pre['region_count'].sum()) == listed[True][0]
+            st2 = (st - 0.05).contiguous()
+            ref = hip.LpProblem(hip.LP_L2_EXPAND, pre['Q'], E, qn=pre['qn'], en=en)
+            assert torch.equal(prob.count_ge(st2), ref.count_ge(st2))
+            assert torch.equal(got[True], ref.count_ge(st))
+    assert torch.equal(got[False], got[True])
+    assert listed[False] == listed[True] and listed[True][0] > 0

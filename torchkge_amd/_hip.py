@@ -50,7 +50,7 @@ class SplitArgs(ctypes.Structure):
         ('q_cell_ss_index', _vp), ('q_cell_ss_ld', _i64),
         ('level', ctypes.c_int32), ('q_dn2', _vp), ('q_dn2_index', _vp), ('de2max', _vp),
         ('es_frag', ctypes.c_int32), ('true_idx', _vp), ('tp_block_max', _vp), ('tp_blocks', ctypes.c_int32),
-        ('q_scale_per_query', ctypes.c_int32),
+        ('q_scale_per_query', ctypes.c_int32), ('region_count', _vp),
     ]
 
 
@@ -106,6 +106,9 @@ _SIGNATURES = {
     'kge_lp_count_ge_cols': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     'kge_topk_chunk': [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp],
     'kge_lp_sad_rows': [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_split_recheck_regions': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_split_regions': [_i64],
+    'kge_lp_split_regions_supported': [ctypes.POINTER(LpDesc)],
     'kge_lp_sad_count': [ctypes.POINTER(LpDesc), ctypes.POINTER(SadArgs), _vp, _vp, _vp],
     'kge_lp_sad_recheck': [ctypes.POINTER(LpDesc), _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
@@ -144,7 +147,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 27        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 28        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -594,8 +597,20 @@ def table_prep_l2(E, emax_io, de2max_io, deferred_max=False, K=None):
     return (en, out, bm) if deferred_max else (en, out)
 
 
+# the uncertain-pair list of the free-running sweep cut into regions of 32 queries, re-scored with the region's query rows
+# resident in LDS (kge_lp_split_recheck_regions); KGE_REGION_RECHECK=0: the one global list
+REGION_RECHECK = os.environ.get('KGE_REGION_RECHECK', '1') == '1'
+
+
+def _counts_and_regions(Bq, dev, regions):
+    """(counts (3, Bq) int32, region counters or None, int32 elements to zero): ONE buffer, zeroed by the pipeline's launch."""
+    nreg = int(load_library().kge_lp_split_regions(Bq)) if regions else 0
+    buf = torch.empty(3 * Bq + nreg, dtype=torch.int32, device=dev)
+    return buf[:3 * Bq].view(3, Bq), (buf[3 * Bq:] if nreg else None), 3 * Bq + nreg
+
+
 def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=None, level=0, de2max=None, tp_bmax=None,
-                      zero_counts=False):
+                      zero_counts=False, regions=False):
     """TransE-L2 query side of one batch in one launch (kge_lp_query_pipeline): dict with Q, qn,
     s_true, Qs, thr, n_list -- bit-identical to lp_prep + row_sqnorm + pair_scores + split_rows +
     the threshold kernel.  ``cols`` (filter_index.ColumnPlan): the split rows are written per COLUMN
@@ -618,8 +633,10 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
            'n_list': torch.empty(1, dtype=torch.int32, device=dev)}
     if level == 1:      # (the residuals ||q - hi(q)||^2: a later split_count that recomputes the thresholds needs them)
         out['q_dn2'] = torch.empty(Bq, dtype=torch.float32, device=dev)
-    if zero_counts:     # the batch's (3, Bq) rank counters, zeroed by this launch (no fill node of their own)
-        out['counts'] = torch.empty(3, Bq, dtype=torch.int32, device=dev)
+    zero_n = 0
+    if zero_counts:     # the batch's (3, Bq) rank counters (+ the list's region counters), zeroed by this launch (no fill node)
+        out['counts'], out['region_count'], zero_n = _counts_and_regions(Bq, dev, regions and level == 1 and cols is None
+                                                                         and REGION_RECHECK)
     with _on(dev):
         _check(lib.kge_lp_query_pipeline(side, _p(E), _p(R), d, _p(h), _p(t), _p(r), B, _p(en), _p(emax), _p(qmax_io),
                                          split_accum_model(), SPLIT_EPS_SCALE, _p(out['Q']), _p(out['qn']),
@@ -627,7 +644,7 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
                                          _p(None if level == 1 else e2pref), _p(None if cols is None else cols.qs_row),
                                          level, _p(de2max), _p(out.get('q_dn2')), _p(tp_bmax),
                                          0 if tp_bmax is None else tp_bmax.shape[0] // 2, _p(out.get('counts')),
-                                         3 * Bq if zero_counts else 0, _stream()),
+                                         zero_n, _stream()),
                'kge_lp_query_pipeline')
     return out
 
@@ -656,7 +673,7 @@ def dot_table_prep(X0, X1, nmax0_io, nmax1_io, frag):
 
 
 def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, qmax_io, overflow, zero_counts=False,
-                          dn_bmax=None):
+                          dn_bmax=None, regions=False):
     """DistMult (E1 = R1 = None) / ComplEx query side of one batch on the one-product level in one launch
     (kge_lp_dot_query_pipeline): dict with Q (and Q1), qn, s_true, Qs (planar hi operand, PER-QUERY scales), thr, q_dn2,
     n_list, counts -- Q / Q1 / s_true bit-identical to lp_prep + pair_scores."""
@@ -677,14 +694,15 @@ def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, q
            'thr': torch.empty(4 * Bp, dtype=torch.float32, device=dev),
            'q_dn2': torch.empty(Bq, dtype=torch.float32, device=dev),
            'n_list': torch.empty(1, dtype=torch.int32, device=dev), 'q_scale_per_query': True}
+    zero_n = 0
     if zero_counts:
-        out['counts'] = torch.empty(3, Bq, dtype=torch.int32, device=dev)
+        out['counts'], out['region_count'], zero_n = _counts_and_regions(Bq, dev, regions and REGION_RECHECK)
     with _on(dev):
         _check(lib.kge_lp_dot_query_pipeline(side, _p(E0), _p(E1), _p(R0), _p(R1), d, _p(h), _p(t), _p(r), B, _p(emax0),
                                              _p(emax1), _p(de2max), _p(qmax_io), split_accum_model(), SPLIT_EPS_SCALE,
                                              _p(out['Q']), _p(out['Q1']), _p(out['qn']), _p(out['s_true']), _p(out['Qs']),
                                              _p(out['thr']), _p(out['q_dn2']), _p(out['n_list']), _p(overflow),
-                                             _p(out.get('counts')), 3 * Bq if zero_counts else 0, _p(dn_bmax),
+                                             _p(out.get('counts')), zero_n, _p(dn_bmax),
                                              0 if dn_bmax is None else dn_bmax.shape[0], _stream()),
                'kge_lp_dot_query_pipeline')
     return out
@@ -935,6 +953,8 @@ class LpProblem(object):
                                          's_true_pre': self.pre['s_true'], 'cols': self.pre.get('cols')}
             if level == 1:      # per QUERY (the fused pipeline computes every query's residual itself)
                 extra['q_dn2'], extra['q_dn2_per_query'] = self.pre['q_dn2'], True
+            if self.pre.get('region_count') is not None and self.split.get('es_frag') and extra['cols'] is None:
+                extra['region_count'] = self.pre['region_count']
             if self.pre.get('q_scale_per_query'):       # DOT pipeline: the hi operand carries per-query scales
                 extra['q_scale_per_query'], extra['qn0'] = True, self.pre['qn']
         elif int(self.desc.mode) == LP_DOT:
@@ -1018,6 +1038,16 @@ class LpProblem(object):
             a.tp_block_max, a.tp_blocks = _p(tpb), tpb.shape[0] // 2
         a.q_scale_per_query = 1 if prep.get('q_scale_per_query') else 0
         a.es_frag = 1 if sp.get('es_frag') else 0
+        rcnt = prep.get('region_count') if a.es_frag else None
+        if rcnt is not None and not int(lib.kge_lp_split_regions_supported(ctypes.byref(self.desc))):
+            rcnt = prep['region_count'] = None
+        if rcnt is not None:
+            if self.pre.get('regions_used'):        # a second sweep on the same operands: the counters start from zero again
+                rcnt.zero_()
+                if a.thr_ready:
+                    prep['n_list'].zero_()
+            self.pre['regions_used'] = True
+            a.region_count = _p(rcnt)
         if a.es_frag:
             assert a.level == 1 and (cols is None or cols.n_multi_p == 0), 'the free-running sweep takes no grouped columns'
             # s_true IS the exact score of (query, split_true entity): the sweep need not list that pair
@@ -1037,6 +1067,12 @@ class LpProblem(object):
     def split_recheck(self, prep, s_true, raw):
         """kge_lp_split_recheck: exact re-scoring of the pairs inside the error band."""
         lib = load_library()
+        if prep.get('region_count') is not None:        # the sweep left its pairs region by region
+            with _on(self.device):
+                _check(lib.kge_lp_split_recheck_regions(ctypes.byref(self.desc), _p(s_true), _p(prep['list']), prep['cap'],
+                                                        _p(prep['region_count']), _p(raw), _p(self.split.get('list_stat')),
+                                                        _p(prep['n_list']), _stream()), 'kge_lp_split_recheck_regions')
+            return raw
         with _on(self.device):
             _check(lib.kge_lp_split_recheck(ctypes.byref(self.desc), _p(s_true), _p(prep['list']), prep['cap'],
                                             _p(prep['n_list']), _p(raw), _p(self.split.get('list_stat')), _stream()),

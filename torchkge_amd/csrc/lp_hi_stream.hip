@@ -33,7 +33,8 @@ namespace {
 constexpr int HS_TQ = 96;                       // queries per panel (MFMA columns = lanes, 3 tiles of 32)
 constexpr int HS_NT = 3, HS_MT = 2;
 constexpr int HS_WROWS = 64;                    // candidate rows per wave
-constexpr int HS_WLIST = 384;                   // uncertain pairs buffered per wave (int2 entries)
+constexpr int HS_WLIST = 384;                   // uncertain pairs buffered per wave (int2 entries) ...
+constexpr int HS_SUBLIST = HS_WLIST / 3;        // ... as one sub-list per 32-query sub-tile of the panel
 constexpr int HS_PF = 3, HS_RING = 4;           // candidate fragments: units in flight / ring slots
 #ifndef HS_SCALAR_SUB
 #define HS_SCALAR_SUB 1                         /* epilogue: w = v - a_lo as four v_sub_f32 instead of two v_pk_add_f32 (-3 %) */
@@ -117,19 +118,31 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     int cnt[HS_NT] = {0, 0, 0};
     float alo[HS_NT], ahi[HS_NT];
     int qid[HS_NT], tru[HS_NT];                                     // query id / its true candidate (local index; -1: none)
-    int nlist = 0;                                                  // entries in this wave's LDS list (wave-uniform)
+    // This wave's LDS list: one sub-list per 32-query sub-tile of the panel (wave-uniform fill counts).  Flushed into the
+    // global list -- or, with p.region_count, into the REGION of (panel, sub-tile): the exact recheck then takes a region
+    // at a time with the sub-tile's 32 query rows resident in LDS (kge_lp_split_recheck_regions: half the row fetches).
+    int nl[HS_NT] = {0, 0, 0};
 
-    auto flush_list = [&]() __attribute__((always_inline)) {
-        if (nlist > 0) {
+    auto flush_sub = [&](int nt, int qp) __attribute__((always_inline)) {
+        if (nl[nt] > 0) {
+            int32_t *ctr = p.list_count;
+            int2 *dst = reinterpret_cast<int2 *>(p.list);
+            unsigned lim = (unsigned)p.cap;
+            if (p.region_count) {
+                const int reg = qp * HS_NT + nt;
+                ctr = p.region_count + reg;
+                dst += (int64_t)reg * p.region_cap;
+                lim = (unsigned)p.region_cap;
+            }
             int base = 0;
-            if (lane == 0) base = atomicAdd(p.list_count, nlist);
+            if (lane == 0) base = atomicAdd(ctr, nl[nt]);
             base = __builtin_amdgcn_readfirstlane(base);
-            for (int i = lane; i < nlist; i += 64) {
+            for (int i = lane; i < nl[nt]; i += 64) {
                 const int pos = base + i;
-                if ((unsigned)pos < (unsigned)p.cap) reinterpret_cast<int2 *>(p.list)[pos] = wlist[i];
+                if ((unsigned)pos < lim) dst[pos] = wlist[nt * HS_SUBLIST + i];
                 else *p.overflow = 1.0f;
             }
-            nlist = 0;
+            nl[nt] = 0;
         }
     };
     auto load_panel = [&](int64_t q0) __attribute__((always_inline)) {
@@ -184,6 +197,27 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
 #pragma unroll
         for (int mt = 0; mt < HS_MT; ++mt)
             dst[mt] = *reinterpret_cast<const f16x8 *>(tp + mt * gstride + (u << 10) + lane16);
+    };
+
+    // the one global list: the three sub-lists behind ONE atomic (a returning same-address atomic per sub-list tripled the
+    // waves' stalls: 0.50 -> 0.55 ms per evaluate, profiles/r05/region_recheck_ab.txt)
+    auto flush_all = [&]() __attribute__((always_inline)) {
+        const int total = nl[0] + nl[1] + nl[2];
+        if (total > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(p.list_count, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int nt = 0; nt < HS_NT; ++nt) {
+                for (int i = lane; i < nl[nt]; i += 64) {
+                    const int pos = base + i;
+                    if ((unsigned)pos < (unsigned)p.cap) reinterpret_cast<int2 *>(p.list)[pos] = wlist[nt * HS_SUBLIST + i];
+                    else *p.overflow = 1.0f;
+                }
+                base += nl[nt];
+                nl[nt] = 0;
+            }
+        }
     };
 
     f32x16 zero16;
@@ -364,10 +398,10 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                                     const bool unc = bq[qq][e] <= hwb && cand != tru[nt];
                                     const unsigned long long m = __ballot(unc);
                                     if (m) {
-                                        const int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                        if (unc && pos < HS_WLIST) wlist[pos] = make_int2(qid[nt], cand);
-                                        nlist += __popcll(m);
+                                        const int pos = nl[nt] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                        if (unc && pos < HS_SUBLIST) wlist[nt * HS_SUBLIST + pos] = make_int2(qid[nt], cand);
+                                        nl[nt] += __popcll(m);
                                     }
                                 }
                             }
@@ -387,11 +421,20 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         }
         // the list buffer: a tile that outran it raises the overflow flag (the caller redoes the count on the next level down);
         // flushed while >= 2/3 of it is free for the next tile (a density of 4 % of the tile's pairs: UNC_CAP's)
-        if (nlist > HS_WLIST) {
-            if (lane == 0) *p.overflow = 1.0f;
-            nlist = HS_WLIST;
+#pragma unroll
+        for (int nt = 0; nt < HS_NT; ++nt) {
+            if (nl[nt] > HS_SUBLIST) {
+                if (lane == 0) *p.overflow = 1.0f;
+                nl[nt] = HS_SUBLIST;
+            }
         }
-        if (nlist >= HS_WLIST / 3) flush_list();
+        if (p.region_count) {
+#pragma unroll
+            for (int nt = 0; nt < HS_NT; ++nt)
+                if (nl[nt] >= HS_SUBLIST / 3 || switching) flush_sub(nt, qp_cur);   // (a region belongs to ONE panel)
+        } else if (max(max(nl[0], nl[1]), nl[2]) >= HS_SUBLIST / 3) {
+            flush_all();
+        }
 
         // ---- query panel change (block-uniform): the only block-wide synchronisation of the sweep
         if (switching) {
@@ -405,7 +448,12 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         qp_cur = qp_next; ct_cur = ct_next; tp_cur = tp_next; act_cur = act_next;
     }
     flush_counts();
-    flush_list();
+    if (p.region_count) {
+#pragma unroll
+        for (int nt = 0; nt < HS_NT; ++nt) flush_sub(nt, qp_cur);
+    } else {
+        flush_all();
+    }
 }
 
 template <int NW, int UNITS, int PM, int PROBE = 0>

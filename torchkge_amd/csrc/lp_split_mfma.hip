@@ -2034,6 +2034,122 @@ __global__ __launch_bounds__(64, 2) void split_recheck_kernel(const kge_lp_desc 
     }
 }
 
+// ---- exact re-scoring REGION BY REGION (r05) -------------------------------------------------------------------------
+// The free-running sweep can leave its uncertain pairs in regions of the list, one per (query panel, 32-query sub-tile)
+// (kge_split_args.region_count).  A block takes a region: the sub-tile's 32 query rows go to LDS ONCE (fp32, row stride an
+// odd number of 16-byte pieces: conflict-free b128 reads at per-lane rows), then every pair costs the candidate row
+// alone -- staged cooperatively like lp_staged_segment's -- instead of both rows: the recheck is bound by the L2's row
+// bandwidth (8.8 TB/s of 1.6 KB per pair at cfg2), so half the bytes is most of half the time.  Same chains (lp_chain_dot
+// on 32-column chunks, segment after segment), same epilogue: same bits as lp_pair_score.  Rows must be float4-readable
+// (kge_lp_vec4).
+__device__ __forceinline__ float recheck_e_segment(const float *__restrict__ T, int64_t ldt, int K, int ci,
+                                                   const float *__restrict__ qrow, float *es, float acc)
+{
+    const int lane = threadIdx.x & 63;
+    // Full 32-column chunks, TWO of them in flight (register sets e / f): the kernel is bound by the loads a CU keeps in
+    // flight, and with the query rows resident a pair has half the bytes of lp_staged_segment's to fetch.
+    const int nfull = K / KGE_PS_KC;
+    float4 e0, e1, e2, e3, e4, e5, e6, e7, f0, f1, f2, f3, f4, f5, f6, f7;
+#define KGE_RR_FETCH(IT, S, KK)                                                                               \
+    {                                                                                                         \
+        const int idx_ = lane + 64 * IT, rr_ = idx_ >> 3, pc_ = idx_ & 7;                                     \
+        const int rc_ = __shfl(ci, rr_, 64);                                                                  \
+        S##IT = *reinterpret_cast<const float4 *>(T + (int64_t)rc_ * ldt + (KK) + pc_ * 4);                   \
+    }
+#define KGE_RR_STORE(IT, S)                                                                                   \
+    {                                                                                                         \
+        const int idx_ = lane + 64 * IT, rr_ = idx_ >> 3, pc_ = idx_ & 7;                                     \
+        *reinterpret_cast<float4 *>(es + rr_ * KGE_PS_LD + pc_ * 4) = S##IT;                                  \
+    }
+#define KGE_RR_ALL(M, ...) M(0, ##__VA_ARGS__) M(1, ##__VA_ARGS__) M(2, ##__VA_ARGS__) M(3, ##__VA_ARGS__) \
+                           M(4, ##__VA_ARGS__) M(5, ##__VA_ARGS__) M(6, ##__VA_ARGS__) M(7, ##__VA_ARGS__)
+#define KGE_RR_CHAIN(KK)                                                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                                    \
+    acc = lp_chain_dot(qrow + (KK), es + lane * KGE_PS_LD, KGE_PS_KC, acc);                                   \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (nfull >= 1) { KGE_RR_ALL(KGE_RR_FETCH, e, 0) }
+    if (nfull >= 2) { KGE_RR_ALL(KGE_RR_FETCH, f, KGE_PS_KC) }
+    int c = 0;
+    for (; c + 2 <= nfull; c += 2) {
+        KGE_RR_ALL(KGE_RR_STORE, e)
+        if (c + 2 < nfull) { KGE_RR_ALL(KGE_RR_FETCH, e, (c + 2) * KGE_PS_KC) }
+        KGE_RR_CHAIN(c * KGE_PS_KC)
+        KGE_RR_ALL(KGE_RR_STORE, f)
+        if (c + 3 < nfull) { KGE_RR_ALL(KGE_RR_FETCH, f, (c + 3) * KGE_PS_KC) }
+        KGE_RR_CHAIN((c + 1) * KGE_PS_KC)
+    }
+    if (c < nfull) {        // an odd number of full chunks: the last one sits in set e
+        KGE_RR_ALL(KGE_RR_STORE, e)
+        KGE_RR_CHAIN(c * KGE_PS_KC)
+    }
+#undef KGE_RR_CHAIN
+#undef KGE_RR_ALL
+#undef KGE_RR_STORE
+#undef KGE_RR_FETCH
+    for (int k0 = nfull * KGE_PS_KC; k0 < K; k0 += KGE_PS_KC) {      // the last, partial chunk (K % 4 == 0)
+        const int kc = min(KGE_PS_KC, K - k0);
+        const int pieces = kc >> 2;
+        for (int idx = lane; idx < 64 * pieces; idx += 64) {
+            const int rr = idx / pieces, pc = idx - rr * pieces;
+            const int rc = __shfl(ci, rr, 64);
+            *reinterpret_cast<float4 *>(es + rr * KGE_PS_LD + pc * 4) =
+                *reinterpret_cast<const float4 *>(T + (int64_t)rc * ldt + k0 + pc * 4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        acc = lp_chain_dot(qrow + k0, es + lane * KGE_PS_LD, kc, acc);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    return acc;
+}
+
+constexpr int RR_ROWS = 32, RR_PANEL = 96;      // queries per region / per panel of the free-running sweep (lp_hi_stream.hip)
+
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void split_recheck_regions_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
+                                                                        const int32_t *__restrict__ list, int32_t region_cap,
+                                                                        const int32_t *__restrict__ region_count, int n_regions,
+                                                                        int ldq, int32_t *raw_count, float *list_stat,
+                                                                        int32_t *list_count)
+{
+    extern __shared__ __attribute__((aligned(16))) float rr_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float *qrows = rr_smem;
+    float *es = rr_smem + RR_ROWS * ldq + wv * 64 * KGE_PS_LD;
+    const int np0 = d.K0 >> 2, npieces = np0 + (d.K1 >> 2);
+    int n_block = 0;
+    for (int reg = blockIdx.x; reg < n_regions; reg += gridDim.x) {
+        const int n = (int)min((unsigned)region_count[reg], (unsigned)region_cap);   // (past the capacity: overflow flagged by the sweep)
+        if (n == 0) continue;                   // (block-uniform)
+        n_block += n;
+        const int64_t q0 = (int64_t)(reg / 3) * RR_PANEL + (reg % 3) * RR_ROWS;
+        __syncthreads();                        // the previous region's readers are done
+        for (int idx = tid; idx < RR_ROWS * npieces; idx += 64 * NWV) {
+            const int rr = idx / npieces, pc = idx - rr * npieces;
+            const int64_t q = min(q0 + rr, d.B - 1);
+            const float4 v = pc < np0 ? *reinterpret_cast<const float4 *>(d.A0 + q * d.lda0 + pc * 4)
+                                      : *reinterpret_cast<const float4 *>(d.A1 + q * d.lda1 + (pc - np0) * 4);
+            *reinterpret_cast<float4 *>(qrows + rr * ldq + pc * 4) = v;
+        }
+        __syncthreads();
+        const int2 *ent = reinterpret_cast<const int2 *>(list) + (int64_t)reg * region_cap;
+        for (int c0 = wv * 64; c0 < n; c0 += NWV * 64) {
+            const int pi = c0 + lane;
+            const bool valid = pi < n;
+            const int2 e = ent[valid ? pi : c0];       // idle lanes shadow the group's first pair
+            const int qi = e.x, ci = e.y;
+            const float *qrow = qrows + (int)(qi - q0) * ldq;
+            float acc = recheck_e_segment(d.T0, d.ldt0, d.K0, ci, qrow, es, 0.0f);
+            if (d.K1 > 0) acc = recheck_e_segment(d.T1, d.ldt1, d.K1, ci, qrow + d.K0, es, acc);
+            const float sc = lp_epilogue_any(d, acc, qi, ci);
+            if (valid && !(sc >= s_true[qi])) atomicSub(&raw_count[qi], 1);
+        }
+    }
+    if (tid == 0 && n_block > 0) {              // pairs re-scored per evaluation (level policy) / the list's length
+        if (list_stat) atomicAdd(list_stat, (float)n_block);
+        if (list_count) atomicAdd(list_count, n_block);
+    }
+}
+
 template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
@@ -2354,6 +2470,14 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
         h.X = p.X; h.ldx = p.ldx; h.r_idx = p.r_idx; h.yc = p.yc;
         h.raw_count = raw_count; h.list = list; h.cap = cap; h.list_count = list_count; h.overflow = overflow;
         h.col_q = a->col_q;
+        h.region_count = nullptr; h.region_cap = 0;
+        if (a->region_count) {      // the list cut into regions (kge_lp_split_recheck_regions takes them)
+            if (a->col_q || !kge_lp_split_regions_supported(d)) return KGE_EINVAL;
+            const int n_regions = kge_lp_split_regions(d->B);
+            h.region_count = a->region_count;
+            h.region_cap = cap / n_regions;
+            if (h.region_cap <= 0) return KGE_EINVAL;
+        }
         h.true_idx = a->true_idx; h.c_base = d->c_base;
         const int pm = d->mode == KGE_LP_L2_PROJH ? 1 : (d->mode == KGE_LP_L2_PROJD ? 2 : 0);
         return kge_hi_stream_launch(h, pm, slots, s);
@@ -2420,6 +2544,66 @@ extern "C" int kge_lp_split_recheck(const kge_lp_desc *d, const float *s_true, c
     else
         hipLaunchKernelGGL(split_recheck_kernel<false>, dim3(grid), dim3(64), 0, kge_s(stream), *d, s_true, list,
                            cap, list_count, raw_count, list_stat);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
+/* regions of the list of n queries' sweep: 3 per panel of 96 queries (kge_split_args.region_count) */
+extern "C" int kge_lp_split_regions(int64_t B)
+{
+    return (int)(kge_lp_split_rows_padded(B, 1) / RR_PANEL) * 3;
+}
+
+/* 1 if kge_lp_split_count / kge_lp_split_recheck_regions take a list cut into regions for this problem */
+extern "C" int kge_lp_split_regions_supported(const kge_lp_desc *d)
+{
+    if (kge_lp_desc_check(d) || !KGE_LP_IS_MFMA(d->mode) || !kge_lp_vec4(*d)) return 0;
+    const int K = d->K0 + d->K1;
+    const int ldq = K + (((K >> 2) & 1) ? 0 : 4);
+    // (measured r05, profiles/r05/region_recheck_ab.txt: at K = 200 the region's 26 KB of query rows leave six wavefronts per
+    // CU and the recheck goes 75 -> 68 us; at K = 400 they are 52 KB, four wavefronts per CU remain and it gets SLOWER
+    // (363 -> 396 us) -- the kernel is bound by the loads it keeps in flight, not by their bytes: regions up to 36 KB)
+    return RR_ROWS * ldq * 4 <= kge_env_int("KGE_REGION_MAX_BYTES", 36 * 1024) ? 1 : 0;
+}
+
+extern "C" int kge_lp_split_recheck_regions(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
+                                            const int32_t *region_count, int32_t *raw_count, float *list_stat,
+                                            int32_t *list_count, kge_stream_t stream)
+{
+    int rc = kge_lp_desc_check(d);
+    if (rc) return rc;
+    if (d->B == 0 || d->N == 0) return 0;
+    if (!s_true || !list || cap <= 0 || !region_count || !raw_count) return KGE_EINVAL;
+    if (!kge_lp_split_regions_supported(d)) return KGE_EINVAL;
+    const int n_regions = kge_lp_split_regions(d->B);
+    const int32_t region_cap = cap / n_regions;
+    if (region_cap <= 0) return KGE_EINVAL;
+    const int K = d->K0 + d->K1;
+    const int ldq = K + (((K >> 2) & 1) ? 0 : 4);       // floats: a multiple of 4, an odd number of 16-byte pieces
+    const int nwv = kge_env_int("KGE_RECHECK_REGION_WAVES", 2);
+    const int smem = (RR_ROWS * ldq + (nwv == 4 ? 4 : 2) * 64 * KGE_PS_LD) * 4;
+    const int want = split_num_cus() * 6;
+    const int grid = n_regions < want ? n_regions : want;
+    static int attr2 = 0, attr4 = 0;
+    if (nwv == 4) {
+        auto k = split_recheck_regions_kernel<4>;
+        if (smem > attr4) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr4 = smem;
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, kge_s(stream), *d, s_true, list, region_cap, region_count, n_regions,
+                           ldq, raw_count, list_stat, list_count);
+    } else {
+        auto k = split_recheck_regions_kernel<2>;
+        if (smem > attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr2 = smem;
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(128), smem, kge_s(stream), *d, s_true, list, region_cap, region_count, n_regions,
+                           ldq, raw_count, list_stat, list_count);
+    }
     KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -402,7 +402,7 @@ class Model(Module):
               'list_stat': g[6:7], 'es_frag': frag}
         pre = _hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if len(rel) > 1 else None, h_idx, t_idx, r_idx,
                                          sp['enmax'], nm1, sp['de2max'], g[0:1], sp['overflow'], zero_counts=True,
-                                         dn_bmax=dnb)
+                                         dn_bmax=dnb, regions=bool(frag))
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
         prob.split = sp
