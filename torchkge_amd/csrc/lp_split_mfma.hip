@@ -2046,47 +2046,37 @@ __device__ __forceinline__ float recheck_e_segment(const float *__restrict__ T, 
                                                    const float *__restrict__ qrow, float *es, float acc)
 {
     const int lane = threadIdx.x & 63;
-    // Full 32-column chunks, TWO of them in flight (register sets e / f): the kernel is bound by the loads a CU keeps in
-    // flight, and with the query rows resident a pair has half the bytes of lp_staged_segment's to fetch.
-    const int nfull = K / KGE_PS_KC;
-    float4 e0, e1, e2, e3, e4, e5, e6, e7, f0, f1, f2, f3, f4, f5, f6, f7;
-#define KGE_RR_FETCH(IT, S, KK)                                                                               \
+    // (ONE 32-column chunk in flight per wavefront, as lp_staged_segment: with two -- 175 VGPRs -- the kernel took 83 us
+    // instead of 68, profiles/r05/region_recheck_ab.txt)
+    int k0 = 0;
+    if (K >= KGE_PS_KC) {
+        float4 e0, e1, e2, e3, e4, e5, e6, e7;
+#define KGE_RR_FETCH(IT, KK)                                                                                  \
     {                                                                                                         \
         const int idx_ = lane + 64 * IT, rr_ = idx_ >> 3, pc_ = idx_ & 7;                                     \
         const int rc_ = __shfl(ci, rr_, 64);                                                                  \
-        S##IT = *reinterpret_cast<const float4 *>(T + (int64_t)rc_ * ldt + (KK) + pc_ * 4);                   \
+        e##IT = *reinterpret_cast<const float4 *>(T + (int64_t)rc_ * ldt + (KK) + pc_ * 4);                   \
     }
-#define KGE_RR_STORE(IT, S)                                                                                   \
+#define KGE_RR_STORE(IT)                                                                                      \
     {                                                                                                         \
         const int idx_ = lane + 64 * IT, rr_ = idx_ >> 3, pc_ = idx_ & 7;                                     \
-        *reinterpret_cast<float4 *>(es + rr_ * KGE_PS_LD + pc_ * 4) = S##IT;                                  \
+        *reinterpret_cast<float4 *>(es + rr_ * KGE_PS_LD + pc_ * 4) = e##IT;                                  \
     }
 #define KGE_RR_ALL(M, ...) M(0, ##__VA_ARGS__) M(1, ##__VA_ARGS__) M(2, ##__VA_ARGS__) M(3, ##__VA_ARGS__) \
                            M(4, ##__VA_ARGS__) M(5, ##__VA_ARGS__) M(6, ##__VA_ARGS__) M(7, ##__VA_ARGS__)
-#define KGE_RR_CHAIN(KK)                                                                                      \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                                    \
-    acc = lp_chain_dot(qrow + (KK), es + lane * KGE_PS_LD, KGE_PS_KC, acc);                                   \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (nfull >= 1) { KGE_RR_ALL(KGE_RR_FETCH, e, 0) }
-    if (nfull >= 2) { KGE_RR_ALL(KGE_RR_FETCH, f, KGE_PS_KC) }
-    int c = 0;
-    for (; c + 2 <= nfull; c += 2) {
-        KGE_RR_ALL(KGE_RR_STORE, e)
-        if (c + 2 < nfull) { KGE_RR_ALL(KGE_RR_FETCH, e, (c + 2) * KGE_PS_KC) }
-        KGE_RR_CHAIN(c * KGE_PS_KC)
-        KGE_RR_ALL(KGE_RR_STORE, f)
-        if (c + 3 < nfull) { KGE_RR_ALL(KGE_RR_FETCH, f, (c + 3) * KGE_PS_KC) }
-        KGE_RR_CHAIN((c + 1) * KGE_PS_KC)
-    }
-    if (c < nfull) {        // an odd number of full chunks: the last one sits in set e
-        KGE_RR_ALL(KGE_RR_STORE, e)
-        KGE_RR_CHAIN(c * KGE_PS_KC)
-    }
-#undef KGE_RR_CHAIN
+        KGE_RR_ALL(KGE_RR_FETCH, 0)
+        for (; k0 + KGE_PS_KC <= K; k0 += KGE_PS_KC) {
+            KGE_RR_ALL(KGE_RR_STORE)
+            if (k0 + 2 * KGE_PS_KC <= K) { KGE_RR_ALL(KGE_RR_FETCH, k0 + KGE_PS_KC) }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            acc = lp_chain_dot(qrow + k0, es + lane * KGE_PS_LD, KGE_PS_KC, acc);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
 #undef KGE_RR_ALL
 #undef KGE_RR_STORE
 #undef KGE_RR_FETCH
-    for (int k0 = nfull * KGE_PS_KC; k0 < K; k0 += KGE_PS_KC) {      // the last, partial chunk (K % 4 == 0)
+    }
+    for (; k0 < K; k0 += KGE_PS_KC) {      // the last, partial chunk (K % 4 == 0)
         const int kc = min(KGE_PS_KC, K - k0);
         const int pieces = kc >> 2;
         for (int idx = lane; idx < 64 * pieces; idx += 64) {
