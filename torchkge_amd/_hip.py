@@ -600,6 +600,9 @@ def table_prep_l2(E, emax_io, de2max_io, deferred_max=False, K=None):
 # the uncertain-pair list of the free-running sweep cut into regions of 32 queries, re-scored with the region's query rows
 # resident in LDS (kge_lp_split_recheck_regions); KGE_REGION_RECHECK=0: the one global list
 REGION_RECHECK = os.environ.get('KGE_REGION_RECHECK', '1') == '1'
+# ... for the projection models too (TransH / TransD, ~5 listed pairs per query: a region's fixed cost -- 26 KB of query rows
+# for ~170 pairs -- outweighs the rows it saves: 0.64 -> 0.66 ms, profiles/r05/region_recheck_ab.txt; off)
+REGION_RECHECK_PROJ = os.environ.get('KGE_REGION_RECHECK_PROJ', '0') == '1'
 
 
 def _counts_and_regions(Bq, dev, regions):
@@ -846,6 +849,7 @@ class LpProblem(object):
         self.pre = None         # outputs of the fused query pipeline (true scores, split queries, thresholds)
         self.cols = None        # filter_index.ColumnPlan of a both-sides batch: split count over distinct query rows
         self.pre_q = None       # (Qh, q_dn2): the queries' planar hi operand, already built (projection models, level 1)
+        self.region_count = None    # zeroed region counters of the sweep's uncertain-pair list (wants_regions)
         self.split_true = None  # (s_true tensor, true ids): the thresholds are the exact scores of these pairs (evaluator)
 
     def scores(self, out=None):
@@ -936,6 +940,20 @@ class LpProblem(object):
                    'kge_lp_count_ge')
         return raw
 
+    def wants_regions(self):
+        """Region counters the caller may zero for this problem's sweep (set them as ``self.region_count``): the
+        free-running sweep without a fused query pipeline (TransH / TransD) -- 0 when the regions do not apply."""
+        sp = self.split
+        if (not REGION_RECHECK or not REGION_RECHECK_PROJ or sp is None or self.pre is not None or self.pre_q is None or not sp.get('es_frag')
+                or int(sp.get('level', 0)) != 1 or self.B == 0 or self.N == 0):
+            return 0
+        if self.cols is not None and self.cols.n_multi_p == 0:
+            return 0        # (single-query columns keep their column -> query map; grouped ones fall back to per query)
+        lib = load_library()
+        if not int(lib.kge_lp_split_regions_supported(ctypes.byref(self.desc))):
+            return 0
+        return int(lib.kge_lp_split_regions(self.B))
+
     def split_prepare(self):
         """Per-batch operands of the f16-split prefilter: the split query matrix and
         the scratch buffers (thresholds, uncertain-pair list, its counter)."""
@@ -982,6 +1000,8 @@ class LpProblem(object):
         elif level == 1 and getattr(self, 'pre_q', None) is not None and self.cols is None:
             Qs, dn2 = self.pre_q        # (the projection models' query preparation wrote the hi operand in its own launch)
             extra = {'cols': None, 'q_dn2': dn2}
+            if getattr(self, 'region_count', None) is not None and self.split.get('es_frag'):
+                extra['region_count'] = self.region_count
         elif level == 1:                # L2 on the one-product level (non-fused query path)
             cols = self.cols
             Qs, dn2 = hi_rows(A0, K=K, is_query=True, want_dn2=True, row_index=None if cols is None else cols.rep)
@@ -1042,11 +1062,11 @@ class LpProblem(object):
         if rcnt is not None and not int(lib.kge_lp_split_regions_supported(ctypes.byref(self.desc))):
             rcnt = prep['region_count'] = None
         if rcnt is not None:
-            if self.pre.get('regions_used'):        # a second sweep on the same operands: the counters start from zero again
+            if getattr(self, '_regions_used', False):   # a second sweep on the same operands: the counters start from zero again
                 rcnt.zero_()
                 if a.thr_ready:
                     prep['n_list'].zero_()
-            self.pre['regions_used'] = True
+            self._regions_used = True
             a.region_count = _p(rcnt)
         if a.es_frag:
             assert a.level == 1 and (cols is None or cols.n_multi_p == 0), 'the free-running sweep takes no grouped columns'

@@ -145,7 +145,12 @@ class HipRankEngine(object):
         if pre_counts is not None and pad == 0 and tuple(pre_counts.shape) == (3, prob.B):
             out = pre_counts        # zeroed by the fused query pipeline's launch: no fill node
         else:
-            out = torch.zeros(3, prob.B + pad, dtype=torch.int32, device=s_true.device)
+            # (+ the region counters of the sweep's uncertain-pair list where they apply -- TransH / TransD: the same fill)
+            nreg = prob.wants_regions() if (pad == 0 and hasattr(prob, 'wants_regions')) else 0
+            buf = torch.zeros(3 * (prob.B + pad) + nreg, dtype=torch.int32, device=s_true.device)
+            out = buf[:3 * (prob.B + pad)].view(3, prob.B + pad)
+            if nreg:
+                prob.region_count = buf[3 * (prob.B + pad):]
         # (only beside the split-prefilter count kernel -- one persistent workgroup per CU that leaves 30 KB of LDS and a
         # fifth of the registers free; the fp32 tile kernel runs TWO workgroups per CU and loses one of them to a
         # co-resident kernel's LDS: measured 2.44 -> 3.37 ms per evaluate with --no-split)
@@ -293,6 +298,8 @@ _STATES = weakref.WeakKeyDictionary()       # model -> {(id(kg), options): _Eval
 SHARE_STATE = os.environ.get('KGE_SHARE_EVAL_STATE', '1') != '0'
 # the filter correction of the second stream beside the exact recheck (1) instead of beside the count sweep (0)
 FILTER_BESIDE_RECHECK = os.environ.get('KGE_FILTER_BESIDE_RECHECK', '0') == '1'
+# region recheck (one-product level): from this many re-scored pairs per query on the three-product level
+REGION_MIN_LEVEL0 = float(os.environ.get('KGE_REGION_MIN_LEVEL0', '1.2'))
 
 
 def _shared_state(model, kg, cfg):
@@ -896,6 +903,14 @@ class LinkPredictionEvaluator(object):
             level_now = self._level if (guard is not None and both and level_ok) else 0
             if hasattr(self.model, '_split_level'):
                 object.__setattr__(self.model, '_split_level', level_now)
+            # the sweep's uncertain pairs in regions of 32 queries (kge_lp_split_recheck_regions) pay when a region holds
+            # enough of them to amortise its query rows: ~5 x the three-product level's count on the one-product level
+            # -> from REGION_MIN_LEVEL0 re-scored pairs per query there (TransE cfg2: 1.8 -> 9.5 per query: 0.50 -> 0.48 ms;
+            # TransH at 5 per query: 0.64 -> 0.66)
+            regions_now = bool(level_now == 1 and not kdist.multi(world) and self._level0_seen is not None
+                               and self._level0_seen >= REGION_MIN_LEVEL0)
+            if hasattr(self.model, '_split_level'):
+                object.__setattr__(self.model, '_lp_regions', regions_now)
             multi = kdist.multi(world)
             segmented = multi and sharded and both
             one_graph = segmented and self.graph_collectives and kdist.backend_name(self.group) == 'nccl'
@@ -913,7 +928,7 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, one_graph, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                       level_now, getattr(self.model, 'split_level', None), self.overlap_filter,
+                       level_now, regions_now, getattr(self.model, 'split_level', None), self.overlap_filter,
                        tuple(p_.data_ptr() for p_ in params), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))

@@ -326,6 +326,7 @@ class Model(Module):
     # pairs the last evaluation re-scored (LinkPredictionEvaluator._level); 0 / 1 force a level.
     split_level = 'auto'
     _split_level = 0        # what the running evaluation uses (set by the evaluator)
+    _lp_regions = False     # ... and whether the sweep's uncertain pairs go to regions of 32 queries (region recheck)
 
     # the one-product level on the FREE-RUNNING count kernel (lp_hi_stream.hip: fragment-major candidate table, resident
     # query panel, no block-wide barriers) wherever it handles the GEMM's width; it sweeps per query (no query columns)
@@ -402,7 +403,7 @@ class Model(Module):
               'list_stat': g[6:7], 'es_frag': frag}
         pre = _hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if len(rel) > 1 else None, h_idx, t_idx, r_idx,
                                          sp['enmax'], nm1, sp['de2max'], g[0:1], sp['overflow'], zero_counts=True,
-                                         dn_bmax=dnb, regions=bool(frag))
+                                         dn_bmax=dnb, regions=bool(frag) and bool(getattr(self, '_lp_regions', False)))
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
         prob.split = sp

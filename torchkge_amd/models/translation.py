@@ -158,7 +158,7 @@ class TransEModel(TranslationModel):
                 Eh, de2 = self._cache.get('eh%d_' % frag + key, [E], lambda: _hip.hi_table(E, aug=en, frag=frag))
             tp_bmax = prep[2] if prep is not None else None
             pre = _hip.lp_query_pipeline(sd, Eq, tabs[1], h_idx, t_idx, r_idx, enq(), g[1:2], g[0:1], cols=cols, level=1,
-                                         de2max=de2, tp_bmax=tp_bmax, zero_counts=True, regions=bool(frag))
+                                         de2max=de2, tp_bmax=tp_bmax, zero_counts=True, regions=bool(frag) and bool(getattr(self, '_lp_regions', False)))
             split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'overflow': g[2:3], 'level': 1, 'de2max': de2,
                      'list_stat': g[6:7], 'es_frag': frag}
         else:
