@@ -538,7 +538,8 @@ typedef struct kge_split_args {
      * by the power of two that fits ||q_i||, not the batch maximum); qn0 then holds the total squared norm per query, qn1 /
      * qmax0 / qmax1 are not read.  Matters only when the thresholds are recomputed (thr_ready = 0). */
     int32_t q_scale_per_query;
-    /* es_frag = 1, col_q = NULL, optional (r05): kge_lp_split_regions(B) int32, ZEROED -- the sweep then leaves its uncertain pairs
+    /* es_frag = 1, col_q = NULL, optional (r05): kge_lp_split_regions(B) int32, ZEROED by the caller when thr_ready = 1 (the
+     * threshold kernel zeroes them with *list_count otherwise) -- the sweep then leaves its uncertain pairs
      * in REGIONS of `list` (cap / regions entries each), one per 32 consecutive queries, counts here; *list_count is not
      * touched.  Follow with kge_lp_split_recheck_regions (which re-scores a region with its 32 query rows resident in LDS:
      * half the row fetches of kge_lp_split_recheck).  Only when kge_lp_split_regions_supported(d). */

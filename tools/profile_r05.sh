@@ -28,6 +28,7 @@ tl transe_fb15k237
 tl complex_wn18rr --workload complex_wn18rr
 tl distmult_fb15k --workload distmult_fb15k
 tl transh_fb15k237 --workload transh_fb15k237
+tl transd_fb15k237 --workload transd_fb15k237
 # kernel stats of the timed loop alone
 tr eval --steps 20 --warmup 5
 tr complex_wn18rr --steps 10 --warmup 3 --workload complex_wn18rr

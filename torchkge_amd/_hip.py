@@ -1062,10 +1062,11 @@ class LpProblem(object):
         if rcnt is not None and not int(lib.kge_lp_split_regions_supported(ctypes.byref(self.desc))):
             rcnt = prep['region_count'] = None
         if rcnt is not None:
-            if getattr(self, '_regions_used', False):   # a second sweep on the same operands: the counters start from zero again
+            # a second sweep on the same operands: the counters start from zero again (zeroed by the threshold kernel when it
+            # runs -- thr_ready = 0 -- like *list_count; by two fills otherwise)
+            if getattr(self, '_regions_used', False) and a.thr_ready:
                 rcnt.zero_()
-                if a.thr_ready:
-                    prep['n_list'].zero_()
+                prep['n_list'].zero_()
             self._regions_used = True
             a.region_count = _p(rcnt)
         if a.es_frag:

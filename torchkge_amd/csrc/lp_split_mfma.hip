@@ -684,6 +684,8 @@ struct SplitThrParams {
     const float *tp_bmax;           // optional [2][tp_blocks]: block maxima left by kge_lp_table_prep_l2 (emax0, de2max): folded
     int tp_blocks;                  // into the two scalars by every block on its way in, stored by block 0
     float *emax_out, *de2max_out;
+    int32_t *zero_i32;              // optional: zero_n int32 zeroed by this launch (the region counters of the sweep's list)
+    int zero_n;
     int q_scale_per_query;          // DOT, level 1: the query operand of row i is scaled by split_scale(||q_i||^2), its own norm
                                     // (kge_lp_dot_query_pipeline), not by the batch maximum's; qn0 then holds the total
 };
@@ -789,6 +791,7 @@ __global__ void split_thr_kernel(const SplitThrParams p)
         em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
         if (p.level == 1) de2m = *p.de2max;
     }
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p.zero_n; j += gridDim.x * blockDim.x) p.zero_i32[j] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *p.list_count = 0;
         // non-finite norms (diverged embeddings): f16 operands would hold inf / NaN and the
@@ -2391,6 +2394,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     t.s_true = s_true;
     t.qmax0 = a->qmax0; t.qmax1 = (d->K1 > 0 && !pq) ? a->qmax1 : nullptr;
     t.q_scale_per_query = pq ? 1 : 0;
+    // (thresholds recomputed = another sweep on these operands: the list's region counters start from zero like *list_count)
+    t.zero_i32 = a->region_count; t.zero_n = a->region_count ? kge_lp_split_regions(d->B) : 0;
     t.emax0 = a->emax0; t.emax1 = (d->mode == KGE_LP_DOT && d->K1 > 0) ? a->emax1 : nullptr;
     t.B = d->B; t.Bp = Bp; t.K = K; t.units = units;
     t.eps_scale = a->eps_scale;
