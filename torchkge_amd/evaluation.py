@@ -128,6 +128,7 @@ class HipRankEngine(object):
         seg_lo, seg_hi, true_idx, targets = self.lookup_both(index_t, index_h, h, t, r)
         plan = FilterPlan(seg_lo, seg_hi, true_idx, targets)
         plan.cols = None
+        plan.r_both = torch.cat([r, r]).contiguous() if (r.is_cuda and r.dtype == torch.int64) else None
         if model is not None and getattr(model, 'lp_dedupe_queries', False) and h.shape[0] > 0 and DEDUPE_QUERIES:
             plan.cols = ColumnPlan(h, t, r, model.n_ent, model.n_rel, _hip.split_group_sets(), _hip.split_query_rows_padded,
                                    relation_major=(model.lp_dedupe_queries == 'relation-major'))
@@ -562,7 +563,15 @@ class LinkPredictionEvaluator(object):
             not (hasattr(self.model, '_level1_stream') and self.model._level1_stream())
         if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and (lvl1_cols or not lvl1):
             xkw['cols'] = plan.cols     # (entity shards too: the columns are a property of the queries, not of the candidates)
-        prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
+        # (the relation id per query of a both-sides batch -- [r | r] -- precomputed with the plan: no concatenation kernel per batch)
+        hint = getattr(plan, 'r_both', None) if plan is not None else None
+        if hint is not None and hasattr(self.model, '_lp_r_both'):
+            object.__setattr__(self.model, '_lp_r_both', hint)
+        try:
+            prob = eng.problem(self.model, h, t, r, 'both', lo, hi, **xkw)
+        finally:
+            if hint is not None and hasattr(self.model, '_lp_r_both'):
+                object.__setattr__(self.model, '_lp_r_both', None)
         if by_scores:
             return self._exchange_score_tiles(prob, h.shape[0], true_idx, seg_lo, seg_hi, targets, out, off)
         s_true = None
@@ -767,7 +776,15 @@ class LinkPredictionEvaluator(object):
     def evaluate(self, b_size, verbose=True):
         """Rank the true head and tail of every fact of ``kg`` among all
         entities, raw and filtered (evaluation.py:263-308)."""
-        params = list(self.model.parameters())       # (walked once per evaluate(): device, capture key)
+        # (the tensors whose addresses the capture key holds: the model's own table list where it has one -- a walk over
+        # Module.parameters() costs three times as much host time, and the GPU idles while the host prepares the replay)
+        tables_of = getattr(self.model, '_tables', None)
+        try:
+            params = list(tables_of()) if callable(tables_of) else None
+        except NotImplementedError:         # (a user model on the generic path: interfaces.Model._tables is abstract)
+            params = None
+        if not params:
+            params = list(self.model.parameters())
         device = params[0].device
         self._dev = device
         self.engine.check_device(device)

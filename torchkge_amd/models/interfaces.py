@@ -327,6 +327,7 @@ class Model(Module):
     split_level = 'auto'
     _split_level = 0        # what the running evaluation uses (set by the evaluator)
     _lp_regions = False     # ... and whether the sweep's uncertain pairs go to regions of 32 queries (region recheck)
+    _lp_r_both = None       # ... and, around one lp_problem('both') call, the batch's [r | r] vector (FilterPlan.r_both)
 
     # the one-product level on the FREE-RUNNING count kernel (lp_hi_stream.hip: fragment-major candidate table, resident
     # query panel, no block-wide barriers) wherever it handles the GEMM's width; it sweeps per query (no query columns)

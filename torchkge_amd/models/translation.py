@@ -174,9 +174,12 @@ class TransEModel(TranslationModel):
         return prob
 
 
-def _both_r(r_idx, sd):
-    """Relation id per query: the 2B queries of a both-sides batch are the B facts twice."""
+def _both_r(r_idx, sd, hint=None):
+    """Relation id per query: the 2B queries of a both-sides batch are the B facts twice (``hint``: that vector, precomputed by
+    the evaluator with the batch's FilterPlan)."""
     r_idx = _hip.i64c(r_idx)
+    if sd == _hip.SIDE_BOTH and hint is not None and hint.shape[0] == 2 * r_idx.shape[0] and hint.device == r_idx.device:
+        return hint
     return torch.cat([r_idx, r_idx]) if sd == _hip.SIDE_BOTH else r_idx
 
 
@@ -299,7 +302,7 @@ class TransHModel(TranslationModel):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         tabs = [x.data for x in self._tables()]
         sd = _hip.side_code(side)
-        r_both = _both_r(r_idx, sd)
+        r_both = _both_r(r_idx, sd, getattr(self, '_lp_r_both', None))
         if self._proj_fast_ok() and h_idx.shape[0] > 0:
             W = _hip.f32c(self.norm_vect.weight.data)
             prob = self._proj_fast_problem(sd, h_idx, t_idx, r_idx, r_both, ent_lo, ent_hi, exchange, qtabs,
@@ -436,7 +439,7 @@ class TransDModel(TranslationModel):
     def lp_problem(self, h_idx, t_idx, r_idx, side, ent_lo=0, ent_hi=None, exchange=None, qtabs=None, cols=None):
         ent_lo, ent_hi = _ent_range(self, ent_lo, ent_hi)
         sd = _hip.side_code(side)
-        r_both = _both_r(r_idx, sd)
+        r_both = _both_r(r_idx, sd, getattr(self, '_lp_r_both', None))
         if self._proj_fast_ok() and h_idx.shape[0] > 0:
             Rp = _hip.f32c(self.rel_proj_vect.weight.data)
             prob = self._proj_fast_problem(sd, h_idx, t_idx, r_idx, r_both, ent_lo, ent_hi, exchange, qtabs,
