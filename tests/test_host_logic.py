@@ -515,3 +515,28 @@ def test_names_the_engine_leaves_out_behave_like_absent_attributes():
     with pytest.raises(ImportError):
         from torchkge_amd import RelationInference  # noqa: F401
     assert not hasattr(tk, 'no_such_name')
+
+
+def test_relation_ids_of_a_both_sides_batch_take_the_plans_vector_only_when_it_fits():
+    """translation._both_r: the [r | r] vector the evaluator precomputes with a batch's FilterPlan is used as it is -- and
+    only for a both-sides batch of exactly that size on the same device; anything else concatenates as before."""
+    from torchkge_amd.models.translation import _both_r
+    r = torch.tensor([3, 1, 2], dtype=torch.int64)
+    hint = torch.cat([r, r])
+    assert _both_r(r, _hip.SIDE_BOTH, hint) is hint
+    assert torch.equal(_both_r(r, _hip.SIDE_BOTH, None), hint)
+    assert torch.equal(_both_r(r, _hip.SIDE_BOTH, torch.cat([r, r, r])), hint)      # a stale vector of another batch size
+    assert _both_r(r, _hip.SIDE_TAIL, hint).shape[0] == 3
+
+
+def test_region_helpers_of_the_c_abi():
+    """kge_lp_split_regions: three regions (32 queries each) per panel of 96 padded query rows; kge_lp_dot_table_prep_blocks:
+    the sizes of the two scratch arrays of the DOT candidate preparation (host-only helpers: no GPU needed)."""
+    lib = _hip.load_library()
+    for B in (1, 96, 97, 192, 193, 40932):
+        Bp = int(lib.kge_lp_split_rows_padded(B, 1))
+        assert Bp % 96 == 0 and int(lib.kge_lp_split_regions(B)) == Bp // 96 * 3
+    for rows in (1, 63, 64, 65, 14951, 4594485):
+        a, b = int(lib.kge_lp_dot_table_prep_blocks(rows, 0)), int(lib.kge_lp_dot_table_prep_blocks(rows, 1))
+        assert 1 <= a <= 2048 and a == min((rows + 63) // 64, 2048)
+        assert 1 <= b <= 4096 and b == min(int(lib.kge_lp_split_rows_padded(rows, 0)) // 16, 4096)
