@@ -540,3 +540,25 @@ def test_region_helpers_of_the_c_abi():
         a, b = int(lib.kge_lp_dot_table_prep_blocks(rows, 0)), int(lib.kge_lp_dot_table_prep_blocks(rows, 1))
         assert 1 <= a <= 2048 and a == min((rows + 63) // 64, 2048)
         assert 1 <= b <= 4096 and b == min(int(lib.kge_lp_split_rows_padded(rows, 0)) // 16, 4096)
+
+
+def test_training_criteria_equal_the_stock_torch_ones():
+    """utils/losses.py writes the three criteria out as elementwise formulas: the same values as the torch.nn criteria with
+    reduction='sum' that the reference wraps (utils/losses.py:19-112), and the same gradients."""
+    from torchkge_amd.utils import MarginLoss, LogisticLoss, BinaryCrossEntropyLoss
+    g = torch.Generator().manual_seed(3)
+    pos0, neg0 = 3 * torch.randn(257, generator=g), 3 * torch.randn(257, generator=g)
+    ones = torch.ones(257)
+    stock = {
+        'margin': lambda p, n: torch.nn.MarginRankingLoss(margin=0.5, reduction='sum')(p, n, target=ones),
+        'logistic': lambda p, n: torch.nn.SoftMarginLoss(reduction='sum')(p, ones) + torch.nn.SoftMarginLoss(reduction='sum')(n, -ones),
+        'bce': lambda p, n: torch.nn.BCELoss(reduction='sum')(torch.sigmoid(torch.cat([p, n])), torch.cat([ones, 0 * ones])),
+    }
+    ours = {'margin': MarginLoss(0.5), 'logistic': LogisticLoss(), 'bce': BinaryCrossEntropyLoss()}
+    for name in stock:
+        pa, na = pos0.clone().requires_grad_(True), neg0.clone().requires_grad_(True)
+        pb, nb = pos0.clone().requires_grad_(True), neg0.clone().requires_grad_(True)
+        la, lb = ours[name](pa, na), stock[name](pb, nb)
+        assert torch.allclose(la, lb, rtol=1e-6, atol=0), name
+        la.backward(); lb.backward()
+        assert torch.allclose(pa.grad, pb.grad, rtol=1e-5, atol=1e-7) and torch.allclose(na.grad, nb.grad, rtol=1e-5, atol=1e-7), name
