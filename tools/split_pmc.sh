@@ -15,7 +15,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 try:
     for r in csv.DictReader(open(sys.argv[1])):
         k=r['Kernel_Name'][:48]
-        if 'split_count' in k:
+        if 'split_count' in k or 'lp_hi_stream' in k:
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 except Exception as e:
     print('ERR',e)
