@@ -703,6 +703,8 @@ def main():
         ev.evaluate(args.batch, verbose=False)
     sync()
     elapsed = time.perf_counter() - t0
+    # (read HERE: the legs that follow -- the other exchange, the weak mode -- run evaluations of their own on this model)
+    level_timed, rescored_timed = int(getattr(model, '_split_level', 0)), getattr(ev, 'last_rescored_per_query', None)
     if multi:
         tt = torch.tensor([elapsed], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1363,8 +1365,8 @@ def main():
                        'collectives_in_graph': bool(getattr(ev, 'graph_collectives', False)) and multi and shard == 'entities',
                        'scored_triples_per_step': total_units},
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
-            'split_prefilter': {'level_of_the_timed_evaluations': int(getattr(model, '_split_level', 0)),
-                                'rescored_pairs_per_query': getattr(ev, 'last_rescored_per_query', None),
+            'split_prefilter': {'level_of_the_timed_evaluations': level_timed,
+                                'rescored_pairs_per_query': rescored_timed,
                                 'policy': 'level 1 (one MFMA product per k16 unit, 8x wider band) when the previous evaluation '
                                           're-scored <= %.0f pairs per query on three products; back to three products above %.0f'
                                           % (tk.evaluation.LEVEL1_ENTER, tk.evaluation.LEVEL1_LEAVE)},
