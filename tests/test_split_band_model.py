@@ -221,3 +221,82 @@ def test_one_product_band_is_certified_under_the_measured_accumulation_model(kin
         uncertain = ~(sure_yes | sure_no)
         assert uncertain[np.arange(B), t].all() or kind == 'cancel'
         assert uncertain.mean() < (0.5 if kind in ('ties', 'near', 'cancel') else 0.2)
+
+
+# ---- DOT mode on the one-product level with PER-QUERY operand scales (r05: kge_lp_dot_query_pipeline, split_thr_dot_hi) ------
+def _split_scale(norm2):
+    """split_scale of lp_split_mfma.hip: the power of two that puts a row of squared norm `norm2` just inside f16 range."""
+    m = np.sqrt(np.asarray(norm2, dtype=np.float64))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        e = np.floor(np.log2(16384.0 / m)) - 1.0
+    e = np.clip(np.where(m > 0, e, 0.0), -100.0, 100.0)
+    return np.where(m > 0, np.ldexp(1.0, e.astype(np.int64)), 1.0)
+
+
+def _thresholds_dot_hi(qn, st, em, K, units, dq2, de2m, s_q, s_e, eps_scale, c_acc=F(1.25)):
+    """split_thr_dot_hi (fp32 arithmetic as in the kernel): query i's thresholds carry ITS scale s_q[i] times the table's s_e."""
+    qn, st, dq2 = qn.astype(F), st.astype(F), dq2.astype(F)
+    enrm, qnrm = np.sqrt(F(em)) * F(1.000001), np.sqrt(qn) * F(1.000001)
+    sqk = np.sqrt(F(K))
+    eps_abs = F(1.4901161e-8) * sqk * (np.sqrt(qn) * enrm + np.sqrt(F(em)) * qnrm) + F(1e-30)
+    acc_err = c_acc * F(16.0) * TWO24 * (F(units) * (qnrm * enrm))
+    chain_err = F(1.01) * F(K) * TWO24 * (qnrm * enrm)
+    dqn, den = np.sqrt(dq2) * F(1.0001), np.sqrt(F(de2m)) * F(1.0001)
+    resid = (dqn * enrm + (qnrm + dqn) * den) * F(1.0005)
+    eps_dot = (acc_err + chain_err + resid + eps_abs) * F(eps_scale)
+    hw = eps_dot + TWO22 * np.abs(st)
+    out_scale = (s_q * s_e).astype(F)
+    return ((st - hw) * out_scale).astype(F), ((st + hw) * out_scale).astype(F)
+
+
+@pytest.mark.parametrize('kind', ['plain', 'ties', 'near', 'range'])
+@pytest.mark.parametrize('K', [200, 48, 400])
+def test_dot_one_product_band_with_per_query_scales_is_certified(kind, K):
+    """DistMult / ComplEx on level 1 as kge_lp_dot_query_pipeline prepares it: every QUERY row scaled by the power of two
+    that fits its own norm (rows spread over four decades here -- a batch-wide scale would push the small rows into f16's
+    subnormals), the candidate table by the one that fits its largest row; acc >= a_hi => the exact fp32 chain score
+    counts, acc < a_lo => it does not; the guard column keeps a padding candidate (-65504 against the guard) below every
+    threshold."""
+    lib = oracle_clib()
+    rng = np.random.default_rng(77 * K + ['plain', 'ties', 'near', 'range'].index(kind))
+    B, N = 12, 300
+    Q, E, t = _case(kind, B, N, K, rng)
+    Q = (Q * (10.0 ** rng.uniform(-2, 2, size=(B, 1)))).astype(F)           # query rows of very different magnitude
+    E = (E * (10.0 ** rng.uniform(-0.5, 0.5, size=(N, 1)))).astype(F)
+    if kind in ('ties', 'near'):        # keep the duplicates / near-duplicates of the true entities what they were
+        _, E0, _ = _case(kind, B, N, K, np.random.default_rng(77 * K + ['plain', 'ties', 'near', 'range'].index(kind)))
+        E = (E0 * F(1.7)).astype(F)
+    Q, E = np.ascontiguousarray(Q), np.ascontiguousarray(E)
+    i64 = ctypes.c_int64
+    exact = np.empty((B, N), F)
+    lib.orc_lp_gemm_chain(fptr(Q), i64(K), fptr(E), i64(K), i64(K), None, i64(0), None, i64(0), i64(0),
+                          i64(B), i64(N), ctypes.c_int(0), None, None, fptr(exact))
+    st = exact[np.arange(B), t]
+    qn = (Q.astype(np.float64) ** 2).sum(axis=1).astype(F)          # (a bound in this mode: any summation order)
+    en = (E.astype(np.float64) ** 2).sum(axis=1).astype(F)
+    em = F(en.max())
+    s_q, s_e = _split_scale(qn), float(_split_scale(em))
+    units = (K + 2 + 15) // 16
+    Kp = units * 16
+    Qa, Ea = np.zeros((B, Kp), np.float64), np.zeros((N + 1, Kp), np.float64)
+    Qa[:, :K] = (Q.astype(np.float64) * s_q[:, None]).astype(F)      # (a power-of-two factor: the product is exact)
+    Ea[:N, :K] = (E.astype(np.float64) * s_e).astype(F)
+    qh, eh = Qa.astype(np.float16).astype(np.float64), Ea.astype(np.float16).astype(np.float64)
+    assert np.isfinite(qh).all() and np.isfinite(eh).all()
+    dq2 = (((Qa - qh)[:, :K] ** 2).sum(axis=1) / s_q ** 2 * 1.0001).astype(F)
+    de2m = float((((Ea - eh)[:N, :K] ** 2).sum(axis=1) / s_e ** 2 * 1.0001).max())
+    # the guard column: queries max(0.25 * ||q|| * (1 + 1/256) * s_q, 1), real candidates 0, the padding candidate -65504
+    qr = np.sqrt(qn.astype(np.float64))
+    qh[:, K] = np.maximum(0.25 * (qr + qr * 0.00390625) * s_q, 1.0).astype(F).astype(np.float16).astype(np.float64)
+    eh[N, K] = -65504.0
+    acc = _hi_accumulate(qh, eh, units)
+    counts_exact = exact >= st[:, None]
+    for eps_scale in ((1.0, 0.5) if K >= 200 else (1.0,)):
+        lo, hi = _thresholds_dot_hi(qn, st, em, K, units, dq2, de2m, s_q, s_e, eps_scale)
+        sure_yes, sure_no = acc[:, :N] >= hi[:, None], acc[:, :N] < lo[:, None]
+        assert not (sure_yes & ~counts_exact).any(), (kind, K, eps_scale)
+        assert not (sure_no & counts_exact).any(), (kind, K, eps_scale)
+        assert (acc[:, N] < lo).all(), 'the padding candidate must stay below every threshold'
+        uncertain = ~(sure_yes | sure_no)
+        assert uncertain[np.arange(B), t].all()
+        assert uncertain.mean() < 0.5
