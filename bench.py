@@ -125,6 +125,9 @@ def parse():
                     help='skip the two rocprofv3 --pmc child passes that measure the dominant kernel\'s HBM-side bytes')
     ap.add_argument('--no-full-parity', action='store_true',
                     help='skip the full-test-split comparison against the GPU-resident reference algorithm')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='only prove the N-rank launch: rendezvous on 127.0.0.1, one all-reduce over the ranks, rank 0 prints '
+                         'a JSON line -- no GPU is touched (CPU test of the self-launch path, --backend gloo)')
     return ap.parse_args()
 
 
@@ -534,6 +537,22 @@ def _measure_traffic(args, kernel_sym, extra_out=None):
     return int((2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
 
 
+def _self_launch(n):
+    """Re-run this command line under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node n`` on 127.0.0.1
+    with a free port; stdout / stderr pass through (rank 0 prints the JSON line).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC (RCCL / tensor sharing across processes)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     if args.only_timed:
@@ -543,7 +562,24 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+            # plain `python bench.py --gpus N`: launch the N ranks ourselves (what the driver's torch.distributed.run line
+            # does), one per GPU over RCCL -- or, with --backend gloo, N ranks sharing GPU 0 (logic dry run)
+            raise SystemExit(_self_launch(args.gpus))
+    if args.launch_check:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world > 1:
+            dist.init_process_group('gloo')
+            tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(tt)
+            dist.barrier()
+            got = float(tt.item())
+            dist.destroy_process_group()
+        else:
+            got = 1.0
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'n_gpus': args.gpus, 'world_size': world, 'backend': 'gloo',
+                              'sum_of_rank_plus_one': got, 'expected': world * (world + 1) / 2.0}), flush=True)
+        return
     dev_index = local_rank % max(torch.cuda.device_count(), 1)   # (>1 rank per GPU only in --backend gloo dry runs)
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)

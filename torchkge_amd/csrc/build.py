@@ -14,7 +14,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['score_triples.hip', 'lp_prep.hip', 'lp_gemm_mfma.hip', 'lp_split_mfma.hip', 'lp_hi_stream.hip', 'lp_direct.hip',
+SOURCES = ['score_triples.hip', 'lp_prep.hip', 'lp_gemm_mfma.hip', 'lp_split_mfma.hip', 'lp_hi_stream.hip', 'lp_hi_chunk.hip', 'lp_direct.hip',
            'lp_l1_sad.hip', 'rank_filter.hip', 'corrupt.hip', 'key_sort.hip', 'index_build.hip']
 HEADERS = ['kge_common.h', os.path.join('..', '..', 'include', 'kge_hip.h')]
 LIB = os.path.join(HERE, 'libkge_hip.so')
@@ -31,7 +31,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 # to run (tools/dbg_pm.py, profiles/r05/pm_epilogue_slp_bisect.txt: same source, -fno-slp-vectorize: 0 mismatches in every
 # run; the prefetch placement and an explicit vmcnt(0) do not matter).  Not root-caused; packed f32 ops are an anti-lever
 # beside MFMAs anyway (MI355X_MICROARCH.md), so the file is built without the SLP vectoriser.
-EXTRA_FLAGS = {'lp_direct.hip': ['-fno-slp-vectorize'], 'lp_hi_stream.hip': ['-fno-slp-vectorize']}
+EXTRA_FLAGS = {'lp_direct.hip': ['-fno-slp-vectorize'], 'lp_hi_stream.hip': ['-fno-slp-vectorize'],
+               'lp_hi_chunk.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

@@ -326,3 +326,19 @@ struct kge_hi_stream_params {
 };
 int kge_hi_stream_max_units(void);
 int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_t s);
+// ... and its chunked-panel form for rows too long for a resident panel (lp_hi_chunk.hip; PM = 0, one global list)
+int kge_hi_chunk_supported(int units);
+int kge_hi_chunk_launch(kge_hi_stream_params p, int num_cus, hipStream_t s);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remember what was set per device
+// (`cache`: 16 zero-initialised ints owned by the launch site), not once per process.
+static inline int kge_ensure_dyn_smem(const void *func, int smem, int *cache)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    if (dev >= 0 && __atomic_load_n(&cache[dev], __ATOMIC_RELAXED) >= smem) return 0;
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0) __atomic_store_n(&cache[dev], smem, __ATOMIC_RELAXED);   // (racing first calls both set the attribute: idempotent)
+    return 0;
+}

@@ -564,13 +564,8 @@ int launch_pk(DirectParams &p, hipStream_t s)
     p.col_chunks = (p.col_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
     const int grid = p.row_panels * p.col_chunks;
     auto k = lp_direct_pk_kernel<AXPY, COUNT, TM, GS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static int attr_dev[16];    // per instantiation, per device
+    if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), SMEM_BYTES, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), SMEM_BYTES, s, p);
     KGE_CHECK_LAUNCH();
     return 0;
@@ -595,13 +590,8 @@ int launch(DirectParams &p, hipStream_t s)
     const int grid = p.row_panels * p.col_chunks;
 
     auto k = lp_direct_kernel<VEC4, L1, AXPY, COUNT, TM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static int attr_dev[16];    // per instantiation, per device
+    if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), SMEM_BYTES, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), SMEM_BYTES, s, p);
     KGE_CHECK_LAUNCH();
     return 0;

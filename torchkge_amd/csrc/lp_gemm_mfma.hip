@@ -405,13 +405,8 @@ template <bool VEC4, bool COUNT, int MODE, int NWM, int NWN>
 int launch(const GemmParams &p, int grid, hipStream_t s)
 {
     auto k = lp_gemm_kernel<VEC4, COUNT, MODE, NWM, NWN>;
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static int attr_dev[16];    // per instantiation, per device
+    if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), SMEM_BYTES, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NWM * NWN), SMEM_BYTES, s, p);
     KGE_CHECK_LAUNCH();
     return 0;

@@ -460,12 +460,8 @@ template <int NW, int UNITS, int PM, int PROBE = 0>
 int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 {
     auto k = lp_hi_stream_kernel<NW, UNITS, PM, PROBE>;
-    static int attr_smem = 0;   // per instantiation
-    if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_smem = smem;
-    }
+    static int attr_dev[16];    // per instantiation, per device
+    if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, p);
     KGE_CHECK_LAUNCH();
     return 0;

@@ -2147,13 +2147,8 @@ template <int NWAVES, bool DBG, int PM, int GS = 0, int LV = 0>
 int launch_split(const SplitParams &p, int grid, hipStream_t s)
 {
     auto k = lp_split_count_kernel<NWAVES, DBG, PM, GS, LV>;
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static int attr_dev[16];    // per instantiation, per device
+    if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), SMEM_BYTES, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NWAVES), SMEM_BYTES, s, p);
     KGE_CHECK_LAUNCH();
     return 0;
@@ -2303,7 +2298,8 @@ extern "C" int kge_lp_dot_table_prep(const float *X0, int64_t ld0, int K0, const
 /* 1 if kge_lp_split_count takes a fragment-major candidate table (es_frag = 1) for K columns on the one-product level */
 extern "C" int kge_lp_hi_stream_supported(int K)
 {
-    return (K + 2 + 15) / 16 <= kge_hi_stream_max_units() ? 1 : 0;
+    const int units = (K + 2 + 15) / 16;
+    return (units <= kge_hi_stream_max_units() || kge_hi_chunk_supported(units)) ? 1 : 0;
 }
 
 /* Candidate-table preparation of the L2 one-product sweep in one pass: en[row] = ||X[row]||^2 by kge_row_sqnorm's
@@ -2333,12 +2329,9 @@ extern "C" int kge_lp_table_prep_l2(const float *X, int64_t ld, int64_t rows, in
     const int smem = (16 * lds_ld + 16 * 17 + 16) * 4;
     const int64_t blocks = p.rows_p / 16;
     auto k = table_prep_l2_kernel;
-    static int attr_smem = 0;
-    if (smem > 48 * 1024 && smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_smem = smem;
-    }
+    static int attr_dev[16];
+    if (smem > 48 * 1024)
+        if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), smem, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
@@ -2451,7 +2444,8 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     const int slots = split_num_cus();
     if (a->es_frag) {
         // the free-running one-product kernel (lp_hi_stream.hip): fragment-major candidate table, resident query panel
-        if (!lv1 || a->members || a->n_multi_p > 0 || units > kge_hi_stream_max_units()) return KGE_EINVAL;
+        const bool chunked = units > kge_hi_stream_max_units();     // long rows: the panel streamed in chunks (lp_hi_chunk.hip)
+        if (!lv1 || a->members || a->n_multi_p > 0 || (chunked && !kge_hi_chunk_supported(units))) return KGE_EINVAL;
         kge_hi_stream_params h;
         h.Ef = reinterpret_cast<const char *>(Es);
         h.Qh = reinterpret_cast<const char *>(Qs);
@@ -2475,6 +2469,10 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
         }
         h.true_idx = a->true_idx; h.c_base = d->c_base;
         const int pm = d->mode == KGE_LP_L2_PROJH ? 1 : (d->mode == KGE_LP_L2_PROJD ? 2 : 0);
+        if (chunked) {
+            if (pm != 0 || h.region_count) return KGE_EUNSUPPORTED;
+            return kge_hi_chunk_launch(h, slots, s);
+        }
         return kge_hi_stream_launch(h, pm, slots, s);
     }
     if (a->col_q || a->members) {
@@ -2579,23 +2577,15 @@ extern "C" int kge_lp_split_recheck_regions(const kge_lp_desc *d, const float *s
     const int smem = (RR_ROWS * ldq + (nwv == 4 ? 4 : 2) * 64 * KGE_PS_LD) * 4;
     const int want = split_num_cus() * 6;
     const int grid = n_regions < want ? n_regions : want;
-    static int attr2 = 0, attr4 = 0;
+    static int attr2[16], attr4[16];     // per device
     if (nwv == 4) {
         auto k = split_recheck_regions_kernel<4>;
-        if (smem > attr4) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            if (e != hipSuccess) return (int)e;
-            attr4 = smem;
-        }
+        if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr4)) return e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, kge_s(stream), *d, s_true, list, region_cap, region_count, n_regions,
                            ldq, raw_count, list_stat, list_count);
     } else {
         auto k = split_recheck_regions_kernel<2>;
-        if (smem > attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            if (e != hipSuccess) return (int)e;
-            attr2 = smem;
-        }
+        if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr2)) return e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(128), smem, kge_s(stream), *d, s_true, list, region_cap, region_count, n_regions,
                            ldq, raw_count, list_stat, list_count);
     }
