@@ -115,9 +115,10 @@ def parse():
                     help="model weights: 'trained' = a few hundred engine training steps before the timed region; "
                          "'unit' = uniform(-0.5, 0.5) tables (scores of unit scale like a fitted model's; what the "
                          "Wikidata5M-size workload uses instead of 'trained': dense Adam state would triple 18.8 GB)")
-    ap.add_argument('--parity-sample', type=int, default=64,
+    ap.add_argument('--parity-sample', type=int, default=512,
                     help='workloads too large for the full-split comparison (cfg5): this many test facts through the '
-                         'reference algorithm on ATen GPU ops at b_size 2 (SURVEY 8d)')
+                         'reference algorithm on ATen GPU ops at b_size 2 (SURVEY 8d says <= 64; r06: 512, which on the Zipf graph '
+                         'includes the hub keys -- filter lists of 10^5 entities)')
     ap.add_argument('--train-steps', type=int, default=None)
     ap.add_argument('--only-timed', action='store_true',
                     help='profiling aid: nothing but the warm-up and the timed loop (no roofline / f32 / cpu / parity legs)')
@@ -161,6 +162,10 @@ def make_triples(orc, shape, n_ent, n_rel, seed, kg_kind='zipf'):
 
 
 TRAIN_DEFAULTS = {'steps': 500, 'batch': 32768, 'lr': 1e-2, 'margin': 0.5}
+# cfg5 (ComplEx d = 512 on 4.59 M entities, 20.6 M facts): the same training step at a batch of 2 M facts -- a dense Adam step
+# costs the same whatever the batch (18.8 GB of tables + gradients + two moments = 75 GB of the 288), so the ~30 epochs a
+# fitted score distribution takes are ~300 steps instead of 19,000
+TRAIN_DEFAULTS_BIG = {'steps': 300, 'batch': 1 << 21, 'lr': 1e-2, 'margin': 0.5}
 
 
 def train_like(model, kg, steps=None, batch=None, lr=None, margin=None, seed=0):
@@ -170,7 +175,7 @@ def train_like(model, kg, steps=None, batch=None, lr=None, margin=None, seed=0):
     no held-out structure, so the test facts are trained on too: what is wanted is the score
     DISTRIBUTION of a fitted model (small true ranks, clustered embeddings, dense near-ties)."""
     import torchkge_amd as tk
-    cfg = dict(TRAIN_DEFAULTS)
+    cfg = dict(TRAIN_DEFAULTS_BIG if model.n_ent > 2000000 else TRAIN_DEFAULTS)
     for k, v in (('steps', steps), ('batch', batch), ('lr', lr), ('margin', margin)):
         if v is not None:
             cfg[k] = v
@@ -196,7 +201,11 @@ def train_like(model, kg, steps=None, batch=None, lr=None, margin=None, seed=0):
         if (s + 1) % per_epoch == 0:
             model.normalize_parameters()
     model.normalize_parameters()
+    for prm in model.parameters():
+        prm.grad = None
+    del opt
     torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()        # (cfg5: 56 GB of gradients and Adam moments go back before the evaluation allocates)
     return model
 
 
@@ -229,7 +238,7 @@ def build_workload(name, device, weights='trained', kg_kind='zipf', n_ent_mult=1
         t0 = time.perf_counter()
         train_like(model, kg, **(train_cfg or {}))
         info['train_s'] = round(time.perf_counter() - t0, 2)
-        info['train'] = dict(TRAIN_DEFAULTS, **(train_cfg or {}))
+        info['train'] = dict(TRAIN_DEFAULTS_BIG if n_ent > 2000000 else TRAIN_DEFAULTS, **(train_cfg or {}))
         if tables is not None:
             tables = [x.detach().cpu().clone() for x in model._tables()]
     return model, tables, kg, kg_test, info
@@ -615,8 +624,8 @@ def main():
     # exchange partial results over RCCL -- per-GPU work is fixed as N grows.
     ent_weak = multi and args.scaling == 'weak' and args.shard == 'entities'
     weights = args.weights
-    if shape == 'wikidata5m' and weights == 'trained':
-        weights = 'unit'        # cfg5: 18.8 GB tables (dense Adam state would triple that): unit-scale uniform tables
+    # (cfg5 trains like the others since r06: 18.8 GB of tables + gradients + Adam moments = 75 GB of the 288 GB;
+    #  --weights unit keeps r03-r05's untrained unit-scale tables)
     train_cfg = {'steps': args.train_steps} if args.train_steps is not None else None
     # N > 1: only rank 0 trains (atomics make training run-to-run different); its tables are broadcast below
     model, tables, kg, kg_test, info = build_workload(args.workload, device, kg_kind=args.kg,
@@ -1003,12 +1012,21 @@ def main():
                  'accumulate; band from the measured f16 residuals)') if level == 1 else \
                 'lp_split_count_kernel (f16 hi/lo split, v_mfma_f32_32x32x16_f16, fp32 accumulate)'
             ksym = 'lp_hi_stream_kernel' if (level == 1 and stream) else 'lp_split_count_kernel'
+            chunked = level == 1 and stream and (K + 2 + 15) // 16 > 32
+            if chunked:     # long rows (r06): the query panel streamed through LDS in chunks, lp_hi_chunk.hip
+                ksym = 'lp_hi_chunk_kernel'
+                kname = ('lp_hi_chunk_kernel (one-product level, r06: ONE v_mfma_f32_32x32x16_f16 product per k16 unit on f16 hi '
+                         'operands, fp32 accumulate; candidate fragments straight from the fragment-major table into a register '
+                         'ring, the 128-query panel streamed through a two-slot LDS ring in chunks of 13 units, one block-wide '
+                         'barrier per chunk; band from the measured f16 residuals)')
             peak, bound = PEAK_F16_TFLOPS, 'mfma'
             # what the matrix cores EXECUTE: the sweep runs over the batch's COLUMNS (distinct query rows, padded to the
             # 192-column panel) x the candidates padded to the 256-row tile, three f16 products per k16 unit -- not over
             # (query, candidate) pairs (r03 multiplied by pairs and over-stated executed_frac: 0.51 where PMC says 0.39)
             mfma_cols = (cols.n_single_p + cols.n_multi_p) if cols is not None else (B + 191) // 192 * 192
             mfma_pairs = mfma_cols * ((n_ent + 255) // 256 * 256)
+            if chunked:
+                mfma_pairs = ((B + 127) // 128 * 128) * ((n_ent + 511) // 512 * 512)
             if level == 1 and stream:       # units are exact there (no padding of K to 64): ceil((K + 2) / 16) per pair
                 exec_flops = 2 * 16 * ((K + 2 + 15) // 16)
             extra = {'peak_is': 'dense f16 MFMA (the unit the kernel runs on)',
@@ -1403,9 +1421,11 @@ def main():
             'filtered_hits_at_10': hit10[1], 'filtered_mrr': mrr[1],
             'split_prefilter': {'level_of_the_timed_evaluations': level_timed,
                                 'rescored_pairs_per_query': rescored_timed,
-                                'policy': 'level 1 (one MFMA product per k16 unit, 8x wider band) when the previous evaluation '
-                                          're-scored <= %.0f pairs per query on three products; back to three products above %.0f'
-                                          % (tk.evaluation.LEVEL1_ENTER, tk.evaluation.LEVEL1_LEAVE)},
+                                'policy': 'level 1 (one MFMA product per k16 unit, wider band) when the previous evaluation '
+                                          're-scored <= %.0f pairs per query on three products; back to three products above %.0f '
+                                          '(cfg2\'s 4 / 30 scaled by N / 14,541: both the sweep saved and the exact chains paid scale '
+                                          'with the row width, their ratio with the candidates per query)'
+                                          % tk.evaluation.level1_thresholds(n_ent_full)},
             'workload_detail': {'kg': args.kg, 'weights': weights, 'train': info.get('train'), 'train_s': info.get('train_s'),
                                 'filter_lists': flt_stats},
             'roofline': roof, 'cpu_baseline': cpu, 'parity_full_split': parity, 'secondary': sec,

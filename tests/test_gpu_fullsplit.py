@@ -94,17 +94,20 @@ def test_full_test_split_vs_gpu_resident_reference(hip, workload, weights):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('kind,d', [('transe', 128), ('distmult', 128)])
-def test_large_entity_set_trained_like_vs_gpu_resident_reference(hip, kind, d):
+@pytest.mark.parametrize('kind,d,n_ent,n_facts', [('transe', 128, 1000000, 3000000), ('distmult', 128, 1000000, 3000000),
+                                                  ('complex', 512, 200000, 1000000)])
+def test_large_entity_set_trained_like_vs_gpu_resident_reference(hip, kind, d, n_ent, n_facts):
     """N = 1,000,000 entities, TRAINED-like tables (a few hundred steps of the engine's own training path on a 3 M-fact Zipf
     graph with hub keys): at this N a 2e-5 score window around a random threshold holds tens of candidates, so tie-interval
     containment only says something when the true entities sit in the sparse upper tail -- which a fitted model's do.
     The steady-state path (one-product level, hipGraph replay) against the reference algorithm on ATen GPU ops for 512 of
-    the 2,048 test facts (oracle.lp_evaluate with its (b, N, d) temporaries at b = 8), split == fp32 on all of them."""
+    the 2,048 test facts (oracle.lp_evaluate with its (b, N, d) temporaries at b = 8), split == fp32 on all of them.
+    r06: ComplEx d = 512 (K = 1024, BASELINE cfg5's row width: the one-product level runs on the CHUNKED-panel kernel
+    lp_hi_chunk.hip) on 200,000 entities, trained-like."""
     import bench
     import torchkge_amd as tk
     dev = torch.device('cuda', 0)
-    n_ent, n_rel, n_facts, n_test = 1000000, 64, 3000000, 2048
+    n_rel, n_test = 64, 2048
     tables = orc.init_tables(kind, n_ent, n_rel, d, seed=3)
     model = bench.make_model(kind, 2, tables, n_ent, n_rel).to(dev)
     hubs = ((5000, 'head'), (2500, 'tail'), (1200, 'head'), (600, 'tail'))
@@ -150,6 +153,17 @@ def test_large_entity_set_trained_like_vs_gpu_resident_reference(hip, kind, d):
     assert par['abs_diff_filt_hits10'] < 1e-5 + par['filtered_ranks_across_the_hits10_boundary'] * 0.5 / 512, par
     assert par['median_filt_rank_ref'] < 0.05 * n_ent, 'the trained-like model should rank its facts high'
     assert par['filter_list_entries_of_the_sample'] > 5000
+    if kind == 'complex':
+        # whatever the policy chose: the same ranks with the one-product level (long rows: the chunked-panel kernel) forced
+        assert hip.hi_stream_ok(2 * d) and (2 * d + 2 + 15) // 16 > 32
+        model.split_level = 1
+        ev1 = tk.LinkPredictionEvaluator(model, kg_test, share_state=False)
+        for _ in range(2):
+            ev1.evaluate(b_size=32768, verbose=False)
+            assert model._use_level1()
+            for a, b in zip(split, _ranks(ev1)):
+                assert torch.equal(a, b)
+        model.split_level = 'auto'
     model.split_filter = False
     ev2 = tk.LinkPredictionEvaluator(model, kg_test)
     ev2.evaluate(b_size=32768, verbose=False)

@@ -1574,6 +1574,63 @@ def test_split_one_product_level_dot_mode(hip, B, N, K, K1, scale, frag):
         hip.SPLIT_EPS_SCALE = 1.0
 
 
+@pytest.mark.parametrize('nt', [3, 4])
+@pytest.mark.parametrize('mode,B,N,K,K1,scale', [('l2', 1500, 6000, 1024, 0, 1.0), ('l2', 700, 3000, 512, 0, 1.0),
+                                               ('l2', 130, 70001, 1024, 0, 1.0), ('dot', 500, 4000, 512, 512, 1.0),
+                                               ('dot', 300, 2000, 256, 256, 30.0), ('dot', 1100, 2500, 512, 0, 1e-2),
+                                               ('dot', 64, 513, 1024, 0, 1.0)])
+def test_split_one_product_level_long_rows_chunked_panel(hip, monkeypatch, mode, B, N, K, K1, scale, nt):
+    """Rows too long for a resident query panel (33 / 65 k16 units: K = 512 / 1024, ComplEx d = 512 of BASELINE cfg5) take the
+    CHUNKED-panel kernel (lp_hi_chunk.hip, r06: the panel streamed through a two-slot LDS ring, 96 or 128 queries per panel):
+    counts after the exact recheck == the fp32 kernel's, thresholds in the DENSE part of the score distribution (random true
+    entities: every tile lists pairs), batch sizes that leave partial panels, a candidate count that leaves a partial tile."""
+    monkeypatch.setenv('KGE_HC_NT', str(nt))
+    assert hip.hi_stream_ok(K + K1)
+    g = torch.Generator().manual_seed(B * 13 + K + nt)
+    guard = torch.zeros(8, device='cuda')
+    if mode == 'l2':
+        E = torch.nn.functional.normalize(torch.randn(N, K, generator=g), dim=1)
+        R = torch.randn(7, K, generator=g) * (0.6 / K ** 0.5)
+        h = torch.randint(0, N, (B,), generator=g); r = torch.randint(0, 7, (B,), generator=g)
+        dE, dq = E.cuda(), (E[h] + R[r]).cuda().contiguous()
+        en = hip.row_sqnorm(dE, max_io=guard[1:2]); qn = hip.row_sqnorm(dq, max_io=guard[0:1])
+        prob = hip.LpProblem(hip.LP_L2_EXPAND, dq, dE, qn=qn, en=en)
+        Eh, de2 = hip.hi_table(dE, aug=en, frag=True)
+        split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'overflow': guard[2:3], 'level': 1, 'de2max': de2,
+                 'list_stat': guard[6:7], 'es_frag': True}
+    else:
+        T0 = (torch.randn(N, K, generator=g) * scale).cuda()
+        T1 = (torch.randn(N, K1, generator=g) * scale).cuda() if K1 else None
+        A0 = (torch.randn(B, K, generator=g) * scale).cuda()
+        A1 = (torch.randn(B, K1, generator=g) * scale).cuda() if K1 else None
+        A0[0] = 0.0
+        if A1 is not None:
+            A1[0] = 0.0
+        prob = hip.LpProblem(hip.LP_DOT, A0, T0, A1=A1, T1=T1)
+        hip.row_sqnorm(T0, max_io=guard[1:2])
+        nm1 = None
+        if T1 is not None:
+            hip.row_sqnorm(T1, max_io=guard[5:6])
+            nm1 = guard[5:6]
+        Eh, de2 = hip.hi_table(T0, X1=T1, dot=True, nmax0=guard[1:2], nmax1=nm1, frag=True)
+        split = {'Es': Eh, 'e2pref': None, 'enmax': guard[1:2], 'enmax1': nm1, 'overflow': guard[2:3], 'level': 1,
+                 'de2max': de2, 'list_stat': guard[6:7], 'es_frag': True}
+    t = torch.randint(0, N, (B,), generator=g).cuda()
+    st = prob.pair_scores(t)
+    exact = prob.count_ge(st)
+    prob.split = split
+    try:
+        for eps in (1.0, 0.5):
+            hip.SPLIT_EPS_SCALE = eps
+            guard[6] = 0
+            got = prob.count_ge(st)
+            assert torch.equal(got, exact), (eps, int((got != exact).sum()))
+            assert int(prob.last_split[0].item()) >= B
+    finally:
+        hip.SPLIT_EPS_SCALE = 1.0
+    assert float(guard[2]) == 0.0
+
+
 @pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex', 'transh', 'transd'])
 def test_evaluator_level_policy_and_identical_ranks(hip, kind):
     """LinkPredictionEvaluator with the one-product level forced on (model.split_level = 1), forced off (0) and on

@@ -68,6 +68,20 @@ LEVEL1_ENTER, LEVEL1_LEAVE = 4.0, 30.0
 # (measured: the one-product sweep re-scores ~5.8x the pairs of the three-product one -- entering at <= 4 predicts <= 23 --;
 #  an evaluator that had to LEAVE level 1 does not try again until the three-product count has halved: no flip-flopping
 #  between two captured graphs on a model that sits at the boundary)
+# Both numbers are cfg2's (N = 14,541 candidates).  What level 1 saves per query is two thirds of a three-product sweep over
+# the N candidates, what it costs is one exact chain per extra pair -- both proportional to the row width, so the break-even
+# number of extra pairs per query scales with N alone: 24 at N = 14,541, i.e. N / 600.  r06: at cfg5's shape (N = 4.59 M,
+# K = 1024) the sweep goes 270 -> 84 ms for 10,266 queries (profiles/r06/hi_chunk_first_timing.txt), 18 us per query or
+# thousands of exact pair scores: a fitted model there re-scores hundreds of pairs per query on three products and still
+# belongs on level 1.
+LEVEL1_CANDIDATES_REF = 14541.0
+
+
+def level1_thresholds(n_cand):
+    """(enter, leave): re-scored pairs per query on the three-product level up to which the next evaluation runs on the
+    one-product level / on the one-product level above which it goes back, for `n_cand` candidates per query."""
+    scale = max(1.0, float(n_cand) / LEVEL1_CANDIDATES_REF)
+    return LEVEL1_ENTER * scale, LEVEL1_LEAVE * scale
 
 
 class HipRankEngine(object):
@@ -288,7 +302,7 @@ class _EvalState(object):
         self._aux_stream = None
         self._n_evaluations = 0
         self._level = 0         # level of the split prefilter the next evaluation runs (see LEVEL1_ENTER)
-        self._level1_max = LEVEL1_ENTER     # three-product re-scored pairs per query below which level 1 is (re-)entered
+        self._level1_max = None             # cap on the three-product re-scored pairs per query at which level 1 is RE-entered (None: no cap)
         self._level0_seen = None            # ... the last such count observed on level 0
         self._mem_fit = None
         self._graph_failed = False
@@ -918,6 +932,8 @@ class LinkPredictionEvaluator(object):
             level_ok = (not kdist.multi(world)) or (sharded and both and not by_scores and
                                                    getattr(self.engine, 'flag_columns', False))
             level_now = self._level if (guard is not None and both and level_ok) else 0
+            # (the WHOLE candidate range: entity shards sum their re-scored pairs over the ranks -- same number, same decision)
+            lvl_enter, lvl_leave = level1_thresholds(self.model.n_ent)
             if hasattr(self.model, '_split_level'):
                 object.__setattr__(self.model, '_split_level', level_now)
             # the sweep's uncertain pairs in regions of 32 queries (kge_lp_split_recheck_regions) pay when a region holds
@@ -1081,7 +1097,7 @@ class LinkPredictionEvaluator(object):
                     # (... and do not come back before the three-product count has halved -- as when LEAVING level 1: an
                     # evaluator whose level-0 count sits below LEVEL1_ENTER would otherwise enter, overflow and redo on
                     # every other evaluation)
-                    self._level1_max = 0.5 * (self._level0_seen if self._level0_seen is not None else LEVEL1_ENTER)
+                    self._level1_max = 0.5 * (self._level0_seen if self._level0_seen is not None else lvl_enter)
                     object.__setattr__(self.model, '_split_level', 0)
                     redo = check_again = True
                 elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
@@ -1093,9 +1109,10 @@ class LinkPredictionEvaluator(object):
                     self.last_rescored_per_query = per_q
                     if level_now == 0 and rescored > 0:
                         self._level0_seen = per_q
-                        if per_q <= min(LEVEL1_ENTER, self._level1_max) and getattr(self.model, 'split_level', 0) == 'auto':
+                        cap_ = lvl_enter if self._level1_max is None else min(lvl_enter, self._level1_max)
+                        if per_q <= cap_ and getattr(self.model, 'split_level', 0) == 'auto':
                             self._level = 1
-                    elif level_now == 1 and per_q > LEVEL1_LEAVE:
+                    elif level_now == 1 and per_q > lvl_leave:
                         self._level = 0
                         if self._level0_seen is not None:       # do not come back before the model has changed a lot
                             self._level1_max = 0.5 * self._level0_seen
