@@ -562,3 +562,79 @@ def test_training_criteria_equal_the_stock_torch_ones():
         assert torch.allclose(la, lb, rtol=1e-6, atol=0), name
         la.backward(); lb.backward()
         assert torch.allclose(pa.grad, pb.grad, rtol=1e-5, atol=1e-7) and torch.allclose(na.grad, nb.grad, rtol=1e-5, atol=1e-7), name
+
+
+def test_mfma_kernels_hold_no_lane_crossing_packed_f32_operand():
+    """r05 / r06: hipcc's SLP vectoriser packs scalar f32 arithmetic of the count kernels' epilogues into v_pk_*_f32 and, when
+    the scalars it wants to splat sit in one register pair, selects them with op_sel -- and the form in which the LOW result
+    lane reads the HIGH dword of a VGPR pair (op_sel:[.,1,.]) misreads ~once per 1e3 wave-instructions inside the free-running
+    kernel, where another wave's MFMAs co-execute (tools/probe/slp_bisect.sh, profiles/r06/slp_bisect.txt).  The three MFMA
+    count kernels are therefore built without the vectoriser; this compiles each of them to gfx950 assembly with the build's
+    own flags and checks that NO packed f32 instruction carries an op_sel:[...] with a set bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    from torchkge_amd.csrc import build as hb
+    hipcc = hb._hipcc()
+    files = [f for f, fl in hb.EXTRA_FLAGS.items() if '-DKGE_BUILD_NO_SLP=1' in fl]
+    assert set(files) >= {'lp_hi_stream.hip', 'lp_hi_chunk.hip', 'lp_split_mfma.hip'}
+
+    def isa(src):
+        cmd = [hipcc] + hb.FLAGS + hb.EXTRA_FLAGS[src] + ['-S', '--cuda-device-only', os.path.join(hb.HERE, src), '-o', '-']
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return src, r.stdout
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        for src, text in ex.map(isa, files):
+            assert 'v_mfma_f32_32x32x16_f16' in text, src
+            bad = [l.strip() for l in text.split('\n')
+                   if re.search(r'\bv_pk_(fma|mul|add)_f32\b', l) and re.search(r'op_sel:\[[01,]*1[01,]*\]', l)]
+            assert not bad, (src, bad[:4])
+    # ... and without the build's flag the sources refuse to compile at all
+    r = subprocess.run([hipcc] + hb.FLAGS + ['-fsyntax-only', '--cuda-device-only', os.path.join(hb.HERE, 'lp_hi_chunk.hip')],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and 'KGE_BUILD_NO_SLP' in r.stderr
+
+
+def test_evaluator_state_cache_is_bounded_weak_and_clearable():
+    """What evaluators learn about (model, kg, options) is shared at module level (evaluation._EvalState): at most
+    MAX_STATES_PER_MODEL states per model (least recently used first out), none once the model is gone, and
+    clear_eval_state(model) drops them -- ADVICE r05: the cache used to grow without bound and its graph-segment closures
+    kept the model alive through the evaluator."""
+    import gc
+    import weakref
+    from torchkge_amd import evaluation as evm
+    m = tk.TransEModel(8, 20, 3, 'L2')
+    kgs = []
+    for i in range(evm.MAX_STATES_PER_MODEL + 3):
+        h = torch.randint(0, 20, (30,)); t = torch.randint(0, 20, (30,)); r = torch.randint(0, 3, (30,))
+        kgs.append(tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={j: j for j in range(20)},
+                                     rel2ix={j: j for j in range(3)}))
+    evs = [tk.LinkPredictionEvaluator(m, kg) for kg in kgs]
+    assert len(evm._STATES[m]) == evm.MAX_STATES_PER_MODEL
+    assert tk.LinkPredictionEvaluator(m, kgs[-1])._st is evs[-1]._st          # same (model, kg, options): shared
+    assert tk.LinkPredictionEvaluator(m, kgs[0])._st is not evs[0]._st        # the evicted one: a fresh state
+    assert tk.LinkPredictionEvaluator(m, kgs[-1], share_state=False)._st is not evs[-1]._st
+    # the closures recorded for graph replays hold the STATE, never the evaluator (which holds the model)
+    call = evs[-1]._timed(lambda: None)
+    assert all(c.cell_contents is not evs[-1] for c in (call.__closure__ or ()))
+    tk.clear_eval_state(m)
+    assert m not in evm._STATES
+    ev = tk.LinkPredictionEvaluator(m, kgs[1])
+    assert m in evm._STATES
+    ref = weakref.ref(m)
+    del m, ev, evs, call
+    gc.collect()
+    assert ref() is None and len(evm._STATES) == 0 or all(k is not None for k in evm._STATES.keys())
+    assert ref() is None
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun re-executes itself under torch.distributed.run (one rank per GPU; here the
+    launch check only: rendezvous on 127.0.0.1 over gloo, one all-reduce, rank 0 prints ONE JSON line, no GPU touched)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--launch-check'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['launch_check'] and d['n_gpus'] == 2 and d['world_size'] == 2 and d['sum_of_rank_plus_one'] == 3.0

@@ -7,7 +7,7 @@ from .exceptions import NotYetEvaluatedError, NotProvidedError
 from .utils import MarginLoss, LogisticLoss
 from .utils import l1_dissimilarity, l2_dissimilarity
 from .data_structures import KnowledgeGraph, SmallKG
-from .evaluation import LinkPredictionEvaluator, RelationPredictionEvaluator
+from .evaluation import LinkPredictionEvaluator, RelationPredictionEvaluator, clear_eval_state
 from .inference import EntityInference
 from .models import TransEModel, TransHModel, TransDModel, DistMultModel, ComplExModel
 from .sampling import BernoulliNegativeSampler, UniformNegativeSampler

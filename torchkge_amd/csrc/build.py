@@ -26,13 +26,22 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 # per-file extras.  lp_direct.hip: the SLP vectoriser turns the L1 inner loop (sub, then add |.|) into v_pk_add_f32
 # pairs -- which issue at HALF rate on gfx950 (tools/probe/valu_rate_probe.hip: 34 T vs 63 T lane-ops/s) and have no
 # abs modifier, so every element pays an extra v_and: 3 issue slots per element instead of 2.
-# lp_hi_stream.hip: with SLP on, the projection (TransH / TransD) epilogue of the free-running count kernel becomes
-# v_pk_fma_f32 / v_pk_mul_f32 chains -- and ~1 in 3e6 pairs then gets a grossly wrong projection term, differently from run
-# to run (tools/dbg_pm.py, profiles/r05/pm_epilogue_slp_bisect.txt: same source, -fno-slp-vectorize: 0 mismatches in every
-# run; the prefetch placement and an explicit vmcnt(0) do not matter).  Not root-caused; packed f32 ops are an anti-lever
-# beside MFMAs anyway (MI355X_MICROARCH.md), so the file is built without the SLP vectoriser.
-EXTRA_FLAGS = {'lp_direct.hip': ['-fno-slp-vectorize'], 'lp_hi_stream.hip': ['-fno-slp-vectorize'],
-               'lp_hi_chunk.hip': ['-fno-slp-vectorize']}
+# The MFMA count kernels (lp_hi_stream.hip, lp_hi_chunk.hip, lp_split_mfma.hip): NO SLP-packed f32 arithmetic.  r05 found
+# ~1 pair in 3e6 of the TransH / TransD epilogue of the free-running kernel miscounted, differently from launch to launch;
+# r06 bisected it at INSTRUCTION level (tools/probe/asm_patch_build.py + slp_bisect.sh, profiles/r06/slp_bisect.txt): the only
+# instructions that matter are  v_pk_fma_f32 D, A, B, C op_sel:[0,1,0]  -- the LOW result lane taking the HIGH dword of a
+# VGPR-pair source.  Rewriting just those (12 per kernel) as two v_fma_f32, as the plain packed form on materialised pairs, or
+# recomputing only their low lane removes every mismatch; the same instructions in two register copies, behind 1000 cycles
+# of s_nop, or with only src2's op_sel_hi:[.,.,0] (high lane from the low dword) do not / are fine.  In isolation the
+# instruction is correct (tools/probe/pk_opsel_probe.hip: 0 wrong of 1e10 beside MFMA / VALU / VMEM traffic) -- it misreads
+# only inside the kernel, where the partner wave's MFMAs co-execute with this wave's epilogue: not a missing wait state
+# (more nops -> MORE errors), not a source race.  The vectoriser emits that form whenever two scalars it wants to splat sit
+# in one register pair; without it no packed f32 instruction of these files selects a high dword for the low lane
+# (tests/test_host_logic.py::test_mfma_kernels_hold_no_lane_crossing_packed_f32_operand checks the built ISA).  The sources
+# refuse to compile without the flag (KGE_BUILD_NO_SLP).
+_NO_SLP = ['-fno-slp-vectorize', '-DKGE_BUILD_NO_SLP=1']
+EXTRA_FLAGS = {'lp_direct.hip': ['-fno-slp-vectorize'], 'lp_hi_stream.hip': _NO_SLP, 'lp_hi_chunk.hip': _NO_SLP,
+               'lp_split_mfma.hip': _NO_SLP}
 
 
 def _hipcc():

@@ -22,6 +22,9 @@
 //
 // Epilogue, uncertain-pair lists, work order: lp_hi_stream.hip's (PM = 0, one global list).
 #include "kge_common.h"
+#ifndef KGE_BUILD_NO_SLP
+#error "build with -fno-slp-vectorize -DKGE_BUILD_NO_SLP=1 (torchkge_amd/csrc/build.py): SLP-packed v_pk_fma_f32 with a lane-crossing op_sel misreads beside co-executing MFMAs (profiles/r06/slp_bisect.txt)"
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

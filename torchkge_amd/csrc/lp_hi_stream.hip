@@ -23,6 +23,9 @@
 // Wave tile 64 candidates x 96 queries (2 x 3 MFMA tiles, 96 accumulator VGPRs) as before; a workgroup is NW waves x 64
 // rows of ONE panel: NW = 4 (256 threads, TWO workgroups per CU, panel <= 22 units) or NW = 8 (512 threads, one per CU).
 #include "kge_common.h"
+#ifndef KGE_BUILD_NO_SLP
+#error "build with -fno-slp-vectorize -DKGE_BUILD_NO_SLP=1 (torchkge_amd/csrc/build.py): SLP-packed v_pk_fma_f32 with a lane-crossing op_sel misreads beside co-executing MFMAs (profiles/r06/slp_bisect.txt)"
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -57,6 +57,9 @@
 // make thresholds and counters per-lane constants, so the epilogue is two
 // compares and an add-with-carry per element.
 #include "kge_common.h"
+#ifndef KGE_BUILD_NO_SLP
+#error "build with -fno-slp-vectorize -DKGE_BUILD_NO_SLP=1 (torchkge_amd/csrc/build.py): SLP-packed v_pk_fma_f32 with a lane-crossing op_sel misreads beside co-executing MFMAs (profiles/r06/slp_bisect.txt)"
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

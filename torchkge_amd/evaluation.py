@@ -292,7 +292,7 @@ class _EvalState(object):
 
     SHARED = ('_plans', '_plan_stamp', '_plan_refs', '_plan_gen', '_perm', '_qmap', '_graph', '_graph_static', '_graph_key',
               '_graph_src', '_graph_seen', '_graph_cache', '_aux_stream', '_n_evaluations', '_level', '_level1_max',
-              '_level0_seen', '_mem_fit', '_graph_failed')
+              '_level0_seen', '_mem_fit', '_graph_failed', '_ctimes')
 
     def __init__(self):
         self._plans = self._plan_stamp = self._plan_refs = self._perm = self._qmap = None
@@ -306,7 +306,9 @@ class _EvalState(object):
         self._level0_seen = None            # ... the last such count observed on level 0
         self._mem_fit = None
         self._graph_failed = False
+        self._ctimes = None     # collective_timing(): (start, end) event pairs of the data-path collectives
         self.kg_ref = None
+        self.group_ref = None   # the process group of the options key (held so that its id() cannot be reused while this state lives)
 
 
 _STATES = weakref.WeakKeyDictionary()       # model -> {(id(kg), options): _EvalState}
@@ -317,22 +319,51 @@ FILTER_BESIDE_RECHECK = os.environ.get('KGE_FILTER_BESIDE_RECHECK', '0') == '1'
 REGION_MIN_LEVEL0 = float(os.environ.get('KGE_REGION_MIN_LEVEL0', '1.2'))
 
 
-def _shared_state(model, kg, cfg):
-    """The _EvalState of (model, kg, cfg) -- created on first use; None when the pair cannot be weakly referenced."""
+# states kept per model: the least recently used one goes when a new (kg, options) pair would exceed it -- its captured
+# hipGraphs, their memory pools, static fact / output buffers and plans are released then (at evaluator CONSTRUCTION: no
+# capture of this thread is running).  Evaluators that still hold such a state keep working on it privately.
+MAX_STATES_PER_MODEL = int(os.environ.get('KGE_EVAL_STATES_PER_MODEL', 4))
+
+
+def _shared_state(model, kg, cfg, group=None):
+    """The _EvalState of (model, kg, cfg) -- created on first use; None when the pair cannot be weakly referenced.
+    ``group``: the process group whose id() is part of `cfg` -- held by the state, so that the id cannot be handed to
+    another group object while the state lives."""
+    import collections
     try:
-        per_model = _STATES.setdefault(model, {})
+        per_model = _STATES.get(model)
+        if per_model is None:
+            per_model = _STATES[model] = collections.OrderedDict()
         key = (id(kg), cfg)
         st = per_model.get(key)
-        if st is not None and st.kg_ref() is kg:
+        if st is not None and st.kg_ref() is kg and st.group_ref is group:
+            per_model.move_to_end(key)
             return st
         for k in [k for k, v in per_model.items() if v.kg_ref() is None]:    # graphs that are gone (id() may be reused)
             del per_model[k]
         st = _EvalState()
         st.kg_ref = weakref.ref(kg)
+        st.group_ref = group
         per_model[key] = st
+        while len(per_model) > max(1, MAX_STATES_PER_MODEL):
+            per_model.popitem(last=False)
         return st
     except TypeError:
         return None
+
+
+def clear_eval_state(model=None):
+    """Forget what evaluators have learned -- plans, split level, captured hipGraphs and their memory pools -- about
+    `model` (None: about every model).  The state is shared by all LinkPredictionEvaluator objects built on the same
+    (model, knowledge graph, options): a NEW evaluator inherits the level policy's state, the captured graphs and a
+    failed-capture flag from its predecessors (``share_state=False`` or KGE_SHARE_EVAL_STATE=0 opt out).  Call this to
+    release the device memory those graphs hold while the model stays alive, or to start from a clean slate after the
+    tables were replaced by something unrelated.  Not while an evaluate() of the model is being captured."""
+    if model is None:
+        for m in list(_STATES.keys()):
+            _STATES.pop(m, None)
+    else:
+        _STATES.pop(model, None)
 
 
 class LinkPredictionEvaluator(object):
@@ -396,7 +427,6 @@ class LinkPredictionEvaluator(object):
         self._cut = None        # set while evaluate() is being captured as graph segments (see _GraphSegments)
         # per-batch FilterPlans (filter segments, true ids, grouping): a function of the test facts and the filter
         # index only, kept across evaluate() calls; _plan_stamp tells when they went stale
-        self._ctimes = None     # collective_timing(): (start, end) event pairs of the data-path collectives
         self._fl, self._fl_done = None, False
         # row-sharded models: the distinct entities of the test facts and the facts re-indexed into that list
         # (static like the plans); their rows are exchanged ONCE per evaluate() (query_exchange='evaluate') instead
@@ -420,7 +450,7 @@ class LinkPredictionEvaluator(object):
         if share and engine is None:
             cfg = (fused, shard, exchange, id(group) if group is not None else None, graph, overlap, both_sides,
                    query_exchange, coalesce, self.graph_collectives, self.overlap_filter)
-            st = _shared_state(model, knowledge_graph, cfg)
+            st = _shared_state(model, knowledge_graph, cfg, group)
         self._st = st if st is not None else _EvalState()
         if self._st._graph_failed:
             self.graph = False
@@ -603,7 +633,7 @@ class LinkPredictionEvaluator(object):
         if s_true is None:
             s_true = eng.true_scores(prob, true_idx)
             if sharded:
-                self._collective(lambda s_=s_true: kdist.all_reduce_sum(s_, self.group))
+                self._collective(lambda s_=s_true, g_=self.group: kdist.all_reduce_sum(s_, g_))
         n2 = s_true.shape[0]
         # entity shards, last batch: the two guard decisions ride the counts exchange as 0 / 1 columns (a SUM > 0
         # means "some rank says so"; max ||q||^2 is the same on every rank, so "max_q + max_e_p > limit on some
@@ -622,7 +652,7 @@ class LinkPredictionEvaluator(object):
             counts[0, n2 + 1:n2 + 2] = (guard[2:3] > 0).to(torch.int32)
             counts[0, n2 + 2:n2 + 3] = guard[6:7].to(torch.int32)      # pairs this shard re-scored (level policy: their SUM)
         if sharded:     # (the recorded call runs again at every graph replay: bind the tensor, not the name)
-            self._collective(lambda c_=counts: kdist.all_reduce_sum(c_, self.group))
+            self._collective(lambda c_=counts, g_=self.group: kdist.all_reduce_sum(c_, g_))
         if ride:
             self._shard_flags = counts[0, n2:n2 + 3]
         fkw = {}
@@ -662,7 +692,7 @@ class LinkPredictionEvaluator(object):
             # (a world of one -- forced collectives -- exchanges nothing: the rank kernel reads the own block from `loc`;
             # a property of the process group, so it is the same when this call is recorded into graph segments)
             in_place = world == 1
-            self._collective(lambda a_=loc, b_=recv: kdist.all_to_all_rows(a_, b_, self.group))
+            self._collective(lambda a_=loc, b_=recv, g_=self.group: kdist.all_to_all_rows(a_, b_, g_))
             my0 = q0 + rank * m
             rows = min(m, q1 - my0)
             if rows > 0:
@@ -676,8 +706,8 @@ class LinkPredictionEvaluator(object):
         hands the (2B, K) rows to every rank (x + 0 is exact)."""
         if not sharded:
             return {}
-        kw = {'exchange': lambda tensors: self._collective(
-            lambda: [kdist.all_reduce_sum(x, self.group) for x in tensors])}
+        kw = {'exchange': lambda tensors, g_=self.group: self._collective(
+            lambda: [kdist.all_reduce_sum(x, g_) for x in tensors])}
         if self._qb is not None:
             kw['qctx'] = self._qb
         return kw
@@ -685,16 +715,20 @@ class LinkPredictionEvaluator(object):
     def _timed(self, fn):
         """`fn` bracketed by two events on the current stream while collective timing is on (decided when the call
         RUNS: the calls recorded into graph segments at capture time are timed at replay too)."""
+        st = self._st       # (NOT the evaluator: recorded calls live in the shared state of (model, kg) and are replayed by later
+        # evaluator objects -- a closure over `self` would keep the first evaluator, and through it the model that keys the
+        # weak dictionary of states, alive for ever)
+
         def call(*a):
             # (timing-enabled events must not be recorded into a stream capture: with the collectives captured inside
             # the graph -- graph_collectives -- the capture call runs untimed, and replays contain no Python calls)
-            if self._ctimes is None or torch.cuda.is_current_stream_capturing():
+            if st._ctimes is None or torch.cuda.is_current_stream_capturing():
                 return fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a)
             e1.record()
-            self._ctimes.append((e0, e1))
+            st._ctimes.append((e0, e1))
             return out
         return call
 
@@ -873,11 +907,13 @@ class LinkPredictionEvaluator(object):
             def run(heads, tails, rels, out, fl):
                 with session, torch.no_grad():
                     self._guard_zeroed = False
-                    if guard is not None and self.model._expand_ok is None:
+                    if guard is not None:
                         # (clean when the previous evaluation's last finalize zeroed it -- Model._lp_guard_clean; replays
                         # of a graph captured without this fill check the flag in front of the replay)
-                        if not getattr(self.model, '_lp_guard_clean', False):
+                        if self.model._expand_ok is None and not getattr(self.model, '_lp_guard_clean', False):
                             guard.zero_()
+                        # whatever this run does, it dirties the vector: a redo that raises or ends without a zeroing
+                        # finalize must not leave the flag standing over stale overflow / re-scored counts
                         object.__setattr__(self.model, '_lp_guard_clean', False)
                     n_batches = get_n_batches(n_local, b_size)
                     if by_scores:       # every rank writes only the columns of the queries it ranks
@@ -888,8 +924,8 @@ class LinkPredictionEvaluator(object):
                     if use_qmap:    # row-sharded tables: replicas of the rows of the query entities, once per evaluate()
                         gather = None
                         if getattr(self.engine, 'uses_plans', False):
-                            gather = lambda blk: self._collective_value(
-                                lambda out_: kdist.all_gather_blocks(blk, out_, self.group),
+                            gather = lambda blk, g_=self.group: self._collective_value(
+                                lambda out_: kdist.all_gather_blocks(blk, out_, g_),
                                 (blk.shape[0] * world_n, blk.shape[1]), blk)
                         qt = self.model.lp_query_tables(self._qmap, self._xkw(True)['exchange'], gather)
                     for i in tqdm(range(n_batches), total=n_batches, unit='batch', disable=(not verbose),
@@ -908,7 +944,7 @@ class LinkPredictionEvaluator(object):
                         out[1, sl], out[3, sl] = self._rank_side(h, t, r, 'tail', index_t, lo, hi, sharded)
                         out[0, sl], out[2, sl] = self._rank_side(h, t, r, 'head', index_h, lo, hi, sharded)
                     if by_scores:       # ... and one SUM completes the (4, n) rank matrix on every rank
-                        self._collective(lambda o_=out: kdist.all_reduce_sum(o_, self.group))
+                        self._collective(lambda o_=out, g_=self.group: kdist.all_reduce_sum(o_, g_))
                     if guard is not None and self._shard_flags is not None:
                         # entity shards: the flags came back summed over the ranks with the last batch's counts
                         fl[0:1].copy_(torch.where(self._shard_flags[0:1] > 0, float('inf'), 0.0))
