@@ -392,8 +392,22 @@ def strong_scaling_model(n_test, n_ent, d, measured_ms_1gpu=None):
             u_bytes = 0.83 * n_ent * d * 4.0
             coll = (P - 1) / P * u_bytes / 120e9 * 1e3 + 2 * 0.025
         out[str(P)] = round(fixed + per_p / P + coll, 4)
+    # the OTHER partition of the same job (shard='queries'): tables replicated, the 2 x n_test queries split across the ranks,
+    # ONE all-gather of the (4, n) int64 ranks at the end.  Every rank still prepares the whole candidate table (not / P); the
+    # query pipeline, sweep, recheck and filter correction shrink with the queries.
+    tprep = 0.010 * (n_ent / 14541.0) * (d / 200.0)
+    per_p_q = 0.040 * qscale + 0.290 * scale + 0.070 * scale + 0.035 * qscale
+    out_q = {}
+    for P in (1, 2, 4, 8):
+        coll = 0.0 if P == 1 else (P - 1) / P * 4 * n_test * 8 / 76.8e9 * 1e3 + 0.025
+        out_q[str(P)] = round(0.078 + tprep + per_p_q / P + coll, 4)
     res = {'modelled_ms_per_evaluate': out,
            'modelled_speedup_vs_1gpu': {k: round(out['1'] / v, 2) for k, v in out.items()},
+           'query_partition': {'modelled_ms_per_evaluate': out_q,
+                               'modelled_speedup_vs_1gpu': {k: round(out_q['1'] / v, 2) for k, v in out_q.items()},
+                               'what': "shard='queries': replicated tables, 2B/P queries per GPU, one all-gather of the ranks; "
+                                       'the better partition while the tables fit one GPU (cfg2: 11.6 MB) -- entity shards are '
+                                       'what north_star names and what cfg5 needs'},
            'phases_ms_at_P1': {'fixed': round(fixed, 4), 'shrinks_as_1_over_P': round(per_p, 4)},
            'note': 'a MODEL (single-GPU phase times of profiles/r05 scaled by work; collectives from link arithmetic), not a '
                    'measurement: no multi-GPU node was available to any round'}
@@ -688,10 +702,14 @@ def main():
     if multi and not replicas:
         shard = 'entities' if args.shard == 'entities' else 'queries'
     table_bytes_full = model.entity_table_bytes()
+    model_rep = None
     if shard == 'entities' and args.tables == 'sharded':
         # ROW-SHARDED entity tables: this rank keeps rows [lo, hi) of every entity-indexed table;
         # relation tables stay replicated; query rows are built by the owner rank and summed over the ranks
         from torchkge_amd import distributed as kd
+        if table_bytes_full <= (1 << 30) and not args.materialize:
+            import copy as _copy0
+            model_rep = _copy0.deepcopy(model)      # (a replica: the query partition of the same job, measured beside the headline)
         kd.shard_model_(model)
         torch.cuda.empty_cache()
     # (N > 1: graph=None = 'auto' -- first call eager, second captures, and a capture that fails on real multi-GPU
@@ -849,6 +867,23 @@ def main():
                    'collective_time': collective_ms(ev_o, ob, exchange=ox) if device.type == 'cuda' else None}
         del ev_o
 
+    # ... the same job under the OTHER partition: test facts split across the ranks, tables replicated, no data-path collective
+    # (one all-gather of the ranks at the end) -- both partitions on the line, each with its scaling model
+    query_part = None
+    if model_rep is not None and multi:
+        ev_q = tk.LinkPredictionEvaluator(model_rep, kg_test, shard='queries', graph=graph_arg, both_sides=not args.no_both)
+        for _ in range(4):      # eager, level switch + capture, replays
+            ev_q.evaluate(args.batch, verbose=False)
+        n_q = max(2, args.steps // 2)
+        el_q = timed_steps(ev_q, args.batch, n_q)
+        same_q = all(torch.equal(a, b) for a, b in zip(
+            [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails],
+            [ev_q.rank_true_heads, ev_q.rank_true_tails, ev_q.filt_rank_true_heads, ev_q.filt_rank_true_tails]))
+        query_part = {'partition': "shard='queries' (replicated tables, 2B/P queries per rank, one all-gather of the ranks)",
+                      'steps': n_q, 'ms_per_step': round(el_q / n_q * 1e3, 4), 'value': round(n_test * 2 * n_ent * n_q / el_q, 1),
+                      'split_level': int(getattr(model_rep, '_split_level', 0)),
+                      'ranks_identical_to_headline_run': bool(same_q)}
+        del ev_q
     # ... and, beside a strong-scaling run, the WEAK mode: the entity table grown to N dataset-sized shards (Xavier
     # weights), every rank scoring its own shard for all test facts, counts exchange -- per-GPU work fixed as N grows
     weak_mode = None
@@ -1459,7 +1494,11 @@ def main():
                 'layout': ('row-sharded: N/P rows per GPU, relation tables replicated' if (shard == 'entities' and args.tables == 'sharded')
                            else 'replicated'),
                 'bytes_full': table_bytes_full, 'bytes_this_rank': model.entity_table_bytes()},
-            'collective_time': headline_coll, 'other_exchange': other_x, 'weak_mode': weak_mode, 'cfg4_mode': cfg4_mode,
+            'collective_time': headline_coll, 'other_exchange': other_x, 'query_partition': query_part, 'weak_mode': weak_mode,
+            'cfg4_mode': cfg4_mode,
+            'collectives_fallback': None if not multi else
+            'KGE_EAGER_COLLECTIVES=1 runs every kernel and every RCCL call of a sharded evaluate() as ordinary eager launches (no '
+            'graph segments, no captured collectives): the escape hatch if segment replay misbehaves on a multi-GPU node',
             'f32_mfma_only': None if f32_only_ms is None else {
                 'ms_per_step': round(f32_only_ms, 4), 'value': round(total_units / f32_only_ms * 1e3, 1),
                 'ranks_identical_to_headline_run': True},

@@ -30,6 +30,10 @@ def main():
     ap.add_argument('--score-facts', type=int, default=0, help='facts of the score-exchange run (0: the whole split)')
     ap.add_argument('--batch', type=int, default=32768)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--weights', default=None, help="default: 'unit' at Wikidata5M size, else 'xavier'; 'trained' (r06) = the "
+                    "bench's trained-like tables -- rank 0 trains (or reads KGE_BENCH_TABLE_CACHE), the others read its cache")
+    ap.add_argument('--evals', type=int, default=2, help='evaluations of the counts exchange before the timed one (>= 3 lets the '
+                                                          'level policy reach the one-product level and its captured segments)')
     args = ap.parse_args()
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     torch.cuda.set_device(0)
@@ -41,8 +45,16 @@ def main():
     from torchkge_amd import evaluation as ev_mod
 
     kind, shape, d, p = bench.WORKLOADS[args.workload]
-    weights = 'unit' if shape == 'wikidata5m' else 'xavier'
-    model, tables, kg, kg_test, info = bench.build_workload(args.workload, dev, weights=weights)
+    weights = args.weights or ('unit' if shape == 'wikidata5m' else 'xavier')
+    if weights == 'trained':        # one rank trains, the others read what it cached (same tables on every rank)
+        os.environ.setdefault('KGE_BENCH_TABLE_CACHE', '/tmp/kge_cache')
+        if rank == 0:
+            model, tables, kg, kg_test, info = bench.build_workload(args.workload, dev, weights=weights)
+        dist.barrier()
+        if rank != 0:
+            model, tables, kg, kg_test, info = bench.build_workload(args.workload, dev, weights=weights)
+    else:
+        model, tables, kg, kg_test, info = bench.build_workload(args.workload, dev, weights=weights)
     for x in ('head_idx', 'tail_idx', 'relations'):
         setattr(kg_test, x, getattr(kg_test, x).to(dev))
     n_test, n_ent = kg_test.n_facts, info['n_ent']
@@ -75,9 +87,10 @@ def main():
            'rows_this_rank': [lo, hi], 'single_gpu_ms_per_evaluate': None if t_single is None else round(t_single, 3)}
     ok = True
 
-    def run(exchange, kgx, n_facts, graph):
+    def run(exchange, kgx, n_facts, graph, evals=1):
         evx = tk.LinkPredictionEvaluator(model, kgx, shard='entities', exchange=exchange, graph=graph)
-        evx.evaluate(args.batch, verbose=False)
+        for _ in range(max(1, evals)):
+            evx.evaluate(args.batch, verbose=False)
         sync()
         t0 = time.perf_counter()
         evx.evaluate(args.batch, verbose=False)
@@ -87,9 +100,10 @@ def main():
         diff = int((got != want[:, :n_facts]).sum())
         return {'exchange': exchange, 'facts': n_facts, 'ranks_compared': int(got.numel()),
                 'ranks_differing_from_unsharded': diff, 'ms_per_evaluate_two_gloo_ranks_one_gpu': round(ms, 2),
-                'hip_graph_segments': bool(graph)}
+                'hip_graph_segments': bool(graph), 'split_level': int(getattr(model, '_split_level', 0)),
+                'rescored_pairs_per_query': evx.last_rescored_per_query, 'evaluations_before_the_timed_one': max(1, evals)}
 
-    res['counts'] = run('counts', kg_test, n_test, graph=None)
+    res['counts'] = run('counts', kg_test, n_test, graph=None, evals=args.evals)
     ok = ok and res['counts']['ranks_differing_from_unsharded'] == 0
     ns = n_test if args.score_facts <= 0 else min(n_test, args.score_facts)
     sub = kg_test

@@ -419,7 +419,11 @@ int kge_hi_chunk_launch(kge_hi_stream_params p, int num_cus, hipStream_t s)
         grid -= grid % 8;
         const int nbx = grid / 8;
         while (p.qg < 64 && nbx % (p.qg * 2) == 0) p.qg *= 2;
-        const int cap_qg = kge_env_int("KGE_HS_QG", 64);
+        // panels interleaved under one candidate sweep: 8, not "as many as divide the blocks of an XCD" -- a block re-reads ITS
+        // panel (TQ x 2 KB) once per candidate tile, and an XCD's 4 MiB L2 cannot hold 32 of them beside the tiles: measured at
+        // cfg5's shape (profiles/r06/hi_chunk_work_order_sweep.txt, L2-miss bytes per launch / ms): 32 panels 224 GB / 83.9,
+        // 16: 173 / 83.7, 8: 139 / 84.7, 4: 215 / 93.4.  (Model: G panels x 278 KB + 32/G tiles x 1.1 MB per 32 items.)
+        const int cap_qg = kge_env_int("KGE_HS_QG", 8);
         while (p.qg > cap_qg && p.qg > 1) p.qg /= 2;
     }
     if (p.units == 65) {

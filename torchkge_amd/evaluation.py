@@ -965,8 +965,10 @@ class LinkPredictionEvaluator(object):
             # level of the split prefilter for THIS evaluation (single GPU, fused): decided by the previous one
             # (entity shards exchanging counts: the re-scored pair count rides the counts all-reduce like the guard flags, so
             # every rank takes the same decision -- r05; other multi-rank forms stay on the three-product level)
-            level_ok = (not kdist.multi(world)) or (sharded and both and not by_scores and
-                                                   getattr(self.engine, 'flag_columns', False))
+            # (r06: query shards too -- their ranks meet only in the final all-gather, the re-scored pair counts are summed over
+            # the ranks beside the guard flags so that every rank takes the same decision and captures the same graphs)
+            level_ok = (not kdist.multi(world)) or self.shard == 'queries' or (sharded and both and not by_scores and
+                                                                                getattr(self.engine, 'flag_columns', False))
             level_now = self._level if (guard is not None and both and level_ok) else 0
             # (the WHOLE candidate range: entity shards sum their re-scored pairs over the ranks -- same number, same decision)
             lvl_enter, lvl_leave = level1_thresholds(self.model.n_ent)
@@ -1108,6 +1110,7 @@ class LinkPredictionEvaluator(object):
                     flat, out, fl = st['out']
 
             res = None
+            n_pol = None
             for attempt in (0, 1):
                 if guard is None:
                     break
@@ -1118,6 +1121,11 @@ class LinkPredictionEvaluator(object):
                     kdist.all_reduce_max(flags, self.group)     # every rank must take the same branch
                     worst, overflow = flags.tolist()
                     rescored = 0.0
+                    if self.shard == 'queries' and level_ok:
+                        resc = fl[2:3].clone()
+                        kdist.all_reduce_sum(resc, self.group)
+                        rescored = float(resc.item())
+                        n_pol = kg.n_facts          # (the sum covers every rank's facts)
                 else:   # one device-to-host transfer for the ranks and the flags (16 bytes = two int64)
                     packed = _to_host(flat)
                     worst, overflow, rescored, _ = packed[-2:].view(torch.float32).tolist()
@@ -1139,9 +1147,9 @@ class LinkPredictionEvaluator(object):
                 elif overflow > 0:      # more near-ties than the split prefilter's list holds: exact fp32 counts
                     self.model._split_ok = False
                     redo = True
-                elif n_local > 0 and (not kdist.multi(world) or (level_ok and self._shard_flags is not None)):
+                elif n_local > 0 and (not kdist.multi(world) or (level_ok and (self._shard_flags is not None or n_pol is not None))):
                     # level policy for the NEXT evaluation, from the pairs this one re-scored (flags[2])
-                    per_q = rescored / (2.0 * n_local)
+                    per_q = rescored / (2.0 * (n_pol if n_pol is not None else n_local))
                     self.last_rescored_per_query = per_q
                     if level_now == 0 and rescored > 0:
                         self._level0_seen = per_q
