@@ -1306,6 +1306,35 @@ def test_evaluator_dedupes_query_rows_and_keeps_the_ranks(hip, monkeypatch, kind
         assert any(pl.cols is not None and pl.cols.n_multi > 0 for pl in ev._plans.values())
 
 
+def test_evaluator_level1_query_columns_on_the_free_running_kernel(hip):
+    """r06: the free-running one-product kernel sweeping query COLUMNS (lp_hi_stream_kernel<.., GS = 4>: one matrix sweep per
+    distinct query row, the grouped columns' members compared pass by pass from LDS thresholds) -- an opt-in
+    (Model.lp_stream_columns / lp_dedupe_level1: measured slower than the per-query sweep at cfg2) whose ranks must equal the
+    per-query sweep's, eager and as hipGraph replays, on a graph with hub keys."""
+    import torchkge_amd as tk
+    n_ent, n_rel, d = 3001, 9, 64
+    tables = orc.init_tables('transe', n_ent, n_rel, d, seed=6)
+    m = build_model('transe', 2, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 30000, 3, hubs=((900, 'head'), (400, 'tail')))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(27000, 3000))
+    names = ['rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails']
+    m.split_level = 1
+    m.lp_stream_columns, m.lp_dedupe_level1 = False, False
+    ref = tk.LinkPredictionEvaluator(m, kg_test, graph=False, share_state=False)
+    ref.evaluate(b_size=1024, verbose=False)
+    m.lp_stream_columns, m.lp_dedupe_level1 = True, True
+    assert m._level1_stream() and m._level1_stream_columns()
+    for graph in (False, True):
+        ev = tk.LinkPredictionEvaluator(m, kg_test, graph=graph, share_state=False)
+        for _ in range(3):
+            ev.evaluate(b_size=1024, verbose=False)
+            for nm in names:
+                assert torch.equal(getattr(ev, nm), getattr(ref, nm)), (graph, nm)
+        assert any(pl.cols is not None and pl.cols.n_multi > 0 for pl in ev._plans.values())
+
+
 def test_filter_lookup_both_equals_two_lookups(hip):
     """kge_filter_lookup_both = kge_filter_lookup on the tail index and on the head index
     (head segments shifted by the tail index's target count), plus the concatenated true ids."""

@@ -563,6 +563,12 @@ def hi_stream_ok(K):
     return HI_STREAM and int(load_library().kge_lp_hi_stream_supported(int(K))) == 1
 
 
+def hi_stream_groups_ok(mode, K):
+    """Does the free-running sweep take GROUPED query columns (ColumnPlan.members) for this problem?  r06: the plain-threshold
+    modes (KGE_LP_DOT / KGE_LP_L2_EXPAND) on rows short enough for the resident panel (<= 32 k16 units)."""
+    return mode in (LP_DOT, LP_L2_EXPAND) and (int(K) + 2 + 15) // 16 <= 32
+
+
 def hi_table(X, K=None, aug=None, X1=None, K1=None, dot=False, nmax0=None, nmax1=None, frag=False):
     """Candidate operand of the one-product level: (Eh, de2max) -- the hi table (planar, or fragment-major for the
     free-running sweep) and the device scalar max_c ||e_c - hi(e_c)||^2 of its error band."""
@@ -962,8 +968,11 @@ class LpProblem(object):
         A0, A1 = self.keep[0], self.keep[2]
         extra = {}
         level = int(self.split.get('level', 0))
-        if self.split.get('es_frag') and self.pre is None and self.cols is not None and self.cols.n_multi_p > 0:
-            self.cols = None        # the free-running sweep takes no grouped columns: per query (always valid)
+        if self.split.get('es_frag') and self.pre is None and self.cols is not None and self.cols.n_multi_p > 0 \
+                and not hi_stream_groups_ok(int(self.desc.mode), K + int(self.desc.K1)):
+            # grouped columns on the free-running sweep (r06): plain thresholds, resident panel only -- the projection
+            # epilogues and the chunked-panel kernel of long rows sweep per query (always valid)
+            self.cols = None
         want_ss = self.split.get('e2pref') is not None and level == 0    # prefix-norm magnitude bound of the error band
         if self.pre is not None:
             assert int(self.pre.get('level', 0)) == level
@@ -1070,7 +1079,9 @@ class LpProblem(object):
             self._regions_used = True
             a.region_count = _p(rcnt)
         if a.es_frag:
-            assert a.level == 1 and (cols is None or cols.n_multi_p == 0), 'the free-running sweep takes no grouped columns'
+            assert a.level == 1 and (cols is None or cols.n_multi_p == 0 or
+                                     hi_stream_groups_ok(int(self.desc.mode), int(self.desc.K0) + int(self.desc.K1))), \
+                'grouped columns on the free-running sweep: plain-threshold modes on resident panels only'
             # s_true IS the exact score of (query, split_true entity): the sweep need not list that pair
             st_true = getattr(self, 'split_true', None)
             if st_true is not None and st_true[0] is s_true:

@@ -315,6 +315,7 @@ struct kge_hi_stream_params {
     int32_t *list_count;
     float *overflow;
     const int32_t *col_q;       // optional: column -> query id (< 0: padding)
+    const int32_t *members;     // grouped launch (r06): [q_rows][sets] query ids (< 0: unused) -- Qh row = one column of up to `sets` queries
     int32_t *region_count;      // optional [q_panels * 3], zeroed: the list is cut into REGIONS of region_cap entries, one per
     int32_t region_cap;         // (panel, 32-query sub-tile); entries land in their query's region, list_count is not touched
     const int64_t *true_idx;    // optional: GLOBAL id of the entity whose exact score is the query's threshold s_true ...

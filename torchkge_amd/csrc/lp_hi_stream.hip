@@ -49,9 +49,13 @@ constexpr int HS_PF = 3, HS_RING = 4;           // candidate fragments: units in
 // PROBE (timing probes, wrong results; env KGE_HS_PROBE, instantiated for <4, 13, 0> only): 1 no compare epilogue, 2 every
 // wave streams the table's first rows (cache-hot candidates), 4 no query-fragment reads in the K sweep, 8 no candidate loads
 // in the K sweep, 16 no MFMAs; 32 / 64 / 96: VALID results, epilogue variants (scalar subtracts / test per 8 elements / both)
-template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM, int PROBE = 0>
+// GS > 0 (r06; PM = 0 only): the panel's 96 rows are GROUPED columns -- one query row shared by up to GS queries of the same key
+// (p.members[column * GS + s], < 0: unused), which differ only in their thresholds: the matrix sweep runs once per column,
+// the compare epilogue once per member (thresholds, per-member counters and the sub-tiles' pass counts live in LDS).
+template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM, int PROBE = 0, int GS = 0>
 __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_stream_params p)
 {
+    static_assert(GS == 0 || PM == 0, "grouped columns: plain thresholds only");
     constexpr int NTHREADS = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int units = UNITS ? UNITS : p.units;
@@ -62,6 +66,10 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     int2 *wlist = reinterpret_cast<int2 *>(smem + p.panel_bytes) + wid * HS_WLIST;
     float4 *pthr = reinterpret_cast<float4 *>(smem + p.panel_bytes + NW * HS_WLIST * 8);     // PM: per query of the panel
     int *prow = reinterpret_cast<int *>(pthr + HS_TQ);
+    // GS: per (column, member) (a_lo, a_hi, query id, its true candidate) and the member's count of this panel's sweep
+    [[maybe_unused]] float4 *mthr = pthr;
+    [[maybe_unused]] int *mcnt = reinterpret_cast<int *>(mthr + HS_TQ * (GS > 0 ? GS : 1));
+    [[maybe_unused]] int npass[HS_NT] = {0, 0, 0};                                   // GS: compare passes of a sub-tile = its fullest column's members
 
     // work order: as lp_split_count_kernel -- QG panels interleaved under a sweep of the candidate tiles, XCD x owns an
     // eighth of the item list, its blocks take stride-nbx positions (nbx a multiple of QG: a block keeps its panel)
@@ -148,6 +156,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
             nl[nt] = 0;
         }
     };
+    [[maybe_unused]] bool first_panel = true;
     auto load_panel = [&](int64_t q0) __attribute__((always_inline)) {
         // rows of the planar query operand -> LDS rows of stride RS
         const int cpr = 2 * units;                                  // 16-byte chunks per row
@@ -163,6 +172,44 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                 pthr[tid] = q >= 0 ? p.thr4[q] : make_float4(INFINITY, INFINITY, 0.f, 0.f);
                 prow[tid] = (int)p.r_idx[min(max(q, (int64_t)0), p.B - 1)];
             }
+        }
+        if constexpr (GS > 0) {
+            // (called between two block barriers: thread idx owns entry idx of mthr / mcnt -- the previous panel's counts
+            // leave through it before the entry is rewritten)
+            for (int idx = tid; idx < HS_TQ * GS; idx += NTHREADS) {
+                if (!first_panel) {
+                    const int c = mcnt[idx], oq = __float_as_int(mthr[idx].z);
+                    if (c != 0 && oq >= 0) atomicAdd(&p.raw_count[oq], c);
+                }
+                const int64_t col = q0 + idx / GS;
+                int64_t q = col < p.q_rows ? (int64_t)p.members[col * GS + (idx % GS)] : -1;
+                if (q >= p.B) q = -1;
+                float2 t = make_float2(INFINITY, INFINITY);
+                int tr = -1;
+                if (q >= 0) {
+                    t = p.thr[q];
+                    if (p.true_idx) tr = (int)(p.true_idx[q] - p.c_base);
+                }
+                mthr[idx] = make_float4(t.x, t.y, __int_as_float((int)q), __int_as_float(tr));
+                mcnt[idx] = 0;
+            }
+#pragma unroll
+            for (int nt = 0; nt < HS_NT; ++nt) {    // members of this lane's column -> the sub-tile's maximum (wave-uniform)
+                const int64_t col = q0 + nt * 32 + l31;
+                int m = 0;
+                if (col < p.q_rows) {
+#pragma unroll
+                    for (int s = 0; s < GS; ++s) {
+                        const int q = p.members[col * GS + s];
+                        m += (q >= 0 && q < p.B) ? 1 : 0;
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+                npass[nt] = __builtin_amdgcn_readfirstlane(m);
+            }
+            first_panel = false;
+            return;
         }
 #pragma unroll
         for (int nt = 0; nt < HS_NT; ++nt) {
@@ -181,6 +228,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         }
     };
     auto flush_counts = [&]() __attribute__((always_inline)) {
+        if constexpr (GS > 0) return;       // (grouped columns count in LDS: mcnt, flushed by load_panel / at the end)
 #pragma unroll
         for (int nt = 0; nt < HS_NT; ++nt) {
             const int v = cnt[nt] + __shfl_xor(cnt[nt], 32, 64);
@@ -315,6 +363,70 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
             if (u < units) load_A(A[u], tp_next, u);
         if (!switching) load_B(Bf[0], 0);
 
+        // ---- grouped columns: the same compare once per MEMBER of the column (thresholds from LDS, runtime pass count)
+        if constexpr (GS > 0) {
+            if (act_cur) {
+                const int64_t c0 = (int64_t)ct_cur * (NW * HS_WROWS) + wid * HS_WROWS;
+                int cl_base = 4 * half;
+                asm volatile("" : "+v"(cl_base));
+#pragma unroll
+                for (int nt = 0; nt < HS_NT; ++nt) {
+                    for (int s = 0; s < npass[nt]; ++s) {
+                        const float4 t4 = mthr[(nt * 32 + l31) * GS + s];
+                        const float lo_n = t4.x;
+                        const int qid_s = __float_as_int(t4.z), tru_s = __float_as_int(t4.w);
+                        const float hwf = t4.y - lo_n;
+                        const unsigned hwb = hwf >= 0.f ? __float_as_uint(hwf) : 0u;
+                        unsigned smask = 0u;
+#pragma unroll
+                        for (int mt = 0; mt < HS_MT; ++mt) {
+#pragma unroll
+                            for (int gh = 0; gh < 2; ++gh) {
+                                unsigned bq[2][4];
+#pragma unroll
+                                for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const unsigned b = __float_as_uint(acc[mt][nt][(2 * gh + qq) * 4 + e] - lo_n);
+                                        smask = __builtin_amdgcn_alignbit(smask, b, 31);
+                                        bq[qq][e] = b;
+                                    }
+                                }
+                                const unsigned mq = min(min(min(bq[0][0], bq[0][1]), min(bq[0][2], bq[0][3])),
+                                                        min(min(bq[1][0], bq[1][1]), min(bq[1][2], bq[1][3])));
+                                if (__ballot(mq <= hwb)) {
+#pragma unroll
+                                    for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            const int cand = (int)c0 + cl_base + mt * 32 + e + 8 * (2 * gh + qq);
+                                            const bool unc = bq[qq][e] <= hwb && cand != tru_s;
+                                            const unsigned long long m = __ballot(unc);
+                                            if (m) {
+                                                const int pos = nl[nt] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                                if (unc && pos < HS_SUBLIST) wlist[nt * HS_SUBLIST + pos] = make_int2(qid_s, cand);
+                                                nl[nt] += __popcll(m);
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        const int c = 32 - __popc(smask);
+                        if (c != 0 && qid_s >= 0) atomicAdd(&mcnt[(nt * 32 + l31) * GS + s], c);
+                        // (a sub-list that fills up inside the member loop leaves at once: up to GS passes append to it per tile)
+                        if (nl[nt] >= HS_SUBLIST / 2) {
+                            if (nl[nt] > HS_SUBLIST) {
+                                if (lane == 0) *p.overflow = 1.0f;
+                                nl[nt] = HS_SUBLIST;
+                            }
+                            flush_all();
+                        }
+                    }
+                }
+            }
+        } else
         // ---- compare epilogue (as lp_split_count_kernel: w = v - a_lo, sign bits -> popcount, band test on the bits)
         if (act_cur && !(PROBE & 1)) {
             const int64_t c0 = (int64_t)ct_cur * (NW * HS_WROWS) + wid * HS_WROWS;
@@ -451,6 +563,13 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         qp_cur = qp_next; ct_cur = ct_next; tp_cur = tp_next; act_cur = act_next;
     }
     flush_counts();
+    if constexpr (GS > 0) {
+        __syncthreads();        // every wave's LDS counts of the last panel are in
+        for (int idx = tid; idx < HS_TQ * GS; idx += NTHREADS) {
+            const int c = mcnt[idx], oq = __float_as_int(mthr[idx].z);
+            if (c != 0 && oq >= 0) atomicAdd(&p.raw_count[oq], c);
+        }
+    }
     if (p.region_count) {
 #pragma unroll
         for (int nt = 0; nt < HS_NT; ++nt) flush_sub(nt, qp_cur);
@@ -459,10 +578,12 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     }
 }
 
-template <int NW, int UNITS, int PM, int PROBE = 0>
+constexpr int HS_GS = 4;        // queries per grouped column (= kge_lp_split_group_sets(), the layout of kge_split_args.members)
+
+template <int NW, int UNITS, int PM, int PROBE = 0, int GS = 0>
 int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 {
-    auto k = lp_hi_stream_kernel<NW, UNITS, PM, PROBE>;
+    auto k = lp_hi_stream_kernel<NW, UNITS, PM, PROBE, GS>;
     static int attr_dev[16];    // per instantiation, per device
     if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, p);
@@ -473,7 +594,7 @@ int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 template <int NW, int PM>
 int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 {
-    if (NW == 4 && PM == 0 && p.units == 13) {
+    if (NW == 4 && PM == 0 && p.units == 13 && !p.members) {
         switch (kge_env_int("KGE_HS_PROBE", 0)) {
         case 1: return hs_launch<4, 13, 0, 1>(p, grid, smem, s);
         case 2: return hs_launch<4, 13, 0, 2>(p, grid, smem, s);
@@ -489,6 +610,14 @@ int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, hipStre
         default: break;
         }
     }
+    if (p.members) {            // grouped columns (PM = 0, checked by the caller)
+        if constexpr (PM == 0) {
+            if (p.units == 13) return hs_launch<NW, 13, 0, 0, HS_GS>(p, grid, smem, s);
+            if (p.units == 26) return hs_launch<NW, 26, 0, 0, HS_GS>(p, grid, smem, s);
+            return hs_launch<NW, 0, 0, 0, HS_GS>(p, grid, smem, s);
+        }
+        return KGE_EUNSUPPORTED;
+    }
     if (p.units == 13) return hs_launch<NW, 13, PM>(p, grid, smem, s);
     if (p.units == 26) return hs_launch<NW, 26, PM>(p, grid, smem, s);
     return hs_launch<NW, 0, PM>(p, grid, smem, s);
@@ -502,10 +631,11 @@ int kge_hi_stream_max_units(void) { return 32; }
 int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_t s)
 {
     if (p.units <= 0 || p.units > 32 || p.rows_p % 64 != 0 || p.rows_p < 64) return KGE_EINVAL;
+    if (p.members && (pm != 0 || p.col_q || p.region_count)) return KGE_EINVAL;
     const int RS = p.units * 32 + 16;
     p.panel_bytes = (HS_TQ * RS + 15) / 16 * 16;
     // two 4-wave workgroups per CU while two panels (+ lists) fit the LDS; else one 8-wave workgroup
-    const int extra = HS_TQ * 20;
+    const int extra = p.members ? HS_TQ * HS_GS * 20 : HS_TQ * 20;
     const int smem4 = p.panel_bytes + 4 * HS_WLIST * 8 + extra, smem8 = p.panel_bytes + 8 * HS_WLIST * 8 + extra;
     int nw = 2 * smem4 <= 160 * 1024 - 2048 ? 4 : 8;
     const int force = kge_env_int("KGE_HS_WAVES", 0);

@@ -2448,7 +2448,11 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     if (a->es_frag) {
         // the free-running one-product kernel (lp_hi_stream.hip): fragment-major candidate table, resident query panel
         const bool chunked = units > kge_hi_stream_max_units();     // long rows: the panel streamed in chunks (lp_hi_chunk.hip)
-        if (!lv1 || a->members || a->n_multi_p > 0 || (chunked && !kge_hi_chunk_supported(units))) return KGE_EINVAL;
+        const bool grouped = a->members && a->n_multi_p > 0;         // r06: + a second launch over the grouped columns
+        if (!lv1 || (chunked && !kge_hi_chunk_supported(units))) return KGE_EINVAL;
+        if ((a->members != nullptr) != (a->n_multi_p > 0) || (grouped && (chunked || proj || a->region_count || !a->col_q)))
+            return KGE_EINVAL;
+        if (grouped && (a->n_multi_p % TQ || GSETS != 4)) return KGE_EINVAL;
         kge_hi_stream_params h;
         h.Ef = reinterpret_cast<const char *>(Es);
         h.Qh = reinterpret_cast<const char *>(Qs);
@@ -2462,6 +2466,7 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
         h.X = p.X; h.ldx = p.ldx; h.r_idx = p.r_idx; h.yc = p.yc;
         h.raw_count = raw_count; h.list = list; h.cap = cap; h.list_count = list_count; h.overflow = overflow;
         h.col_q = a->col_q;
+        h.members = nullptr;
         h.region_count = nullptr; h.region_cap = 0;
         if (a->region_count) {      // the list cut into regions (kge_lp_split_recheck_regions takes them)
             if (a->col_q || !kge_lp_split_regions_supported(d)) return KGE_EINVAL;
@@ -2476,7 +2481,17 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
             if (pm != 0 || h.region_count) return KGE_EUNSUPPORTED;
             return kge_hi_chunk_launch(h, slots, s);
         }
-        return kge_hi_stream_launch(h, pm, slots, s);
+        if (!grouped) return kge_hi_stream_launch(h, pm, slots, s);
+        // columns: the single-query ones (col_q), then the grouped ones (members) -- two launches over the same candidate table
+        if (a->n_single_p > 0) {
+            rc = kge_hi_stream_launch(h, pm, slots, s);
+            if (rc) return rc;
+        }
+        h.Qh = reinterpret_cast<const char *>(Qs) + a->n_single_p * (int64_t)p.row_bytes;
+        h.q_rows = a->n_multi_p;
+        h.col_q = nullptr;
+        h.members = a->members;
+        return kge_hi_stream_launch(h, 0, slots, s);
     }
     if (a->col_q || a->members) {
         // Columns instead of queries: Qs holds n_single_p rows that carry one query each (col_q), then n_multi_p rows

@@ -602,9 +602,11 @@ class LinkPredictionEvaluator(object):
         lvl1 = hasattr(self.model, '_use_level1') and self.model._use_level1()      # (the policy's choice, or a forced level)
         # (one-product level: the matrix work a shared row saves is a third of what it was, the grouped columns' multi-pass
         # epilogue costs what it always did -- models say whether columns still pay there: lp_dedupe_level1)
-        # (... and the free-running one-product kernel sweeps per query: no columns there)
+        # (... the free-running one-product kernel takes columns since r06 where the model's count has plain thresholds and
+        # its rows fit the resident panel: Model._level1_stream_columns)
         lvl1_cols = DEDUPE_LEVEL1 and getattr(self.model, 'lp_dedupe_level1', True) and \
-            not (hasattr(self.model, '_level1_stream') and self.model._level1_stream())
+            (not (hasattr(self.model, '_level1_stream') and self.model._level1_stream()) or
+             (hasattr(self.model, '_level1_stream_columns') and self.model._level1_stream_columns()))
         if plan is not None and getattr(plan, 'cols', None) is not None and not by_scores and (lvl1_cols or not lvl1):
             xkw['cols'] = plan.cols     # (entity shards too: the columns are a property of the queries, not of the candidates)
         # (the relation id per query of a both-sides batch -- [r | r] -- precomputed with the plan: no concatenation kernel per batch)

@@ -340,6 +340,14 @@ class Model(Module):
     def _level1_stream(self):
         return bool(self.lp_hi_stream) and _hip.hi_stream_ok(self._lp_width())
 
+    # ... which CAN sweep query COLUMNS (one matrix sweep per distinct query row, the members' thresholds compared in the
+    # epilogue: lp_hi_stream_kernel<.., GS = 4>, r06) for the plain-threshold counts -- TransE-L2, DistMult, ComplEx -- on rows
+    # that fit its resident panel.  Off by default: measured slower than the per-query sweep at cfg2 (TransEModel.lp_dedupe_level1)
+    lp_stream_columns = os.environ.get('KGE_STREAM_COLUMNS', '0') == '1'
+
+    def _level1_stream_columns(self):
+        return bool(self.lp_stream_columns) and (self._lp_width() + 2 + 15) // 16 <= 32
+
     def _use_level1(self):
         lv = self.split_level
         want = self._split_level == 1 if lv == 'auto' else int(lv) == 1

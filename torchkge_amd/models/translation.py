@@ -8,6 +8,8 @@ translation.py:260-284 / :629-652): one scalar per (entity, relation) [TransH:
 a = E.W^T] or per entity [TransD: s = Ep.E] is enough, and the rank-1
 correction is applied inside the all-candidates kernel.
 """
+import os
+
 import torch
 
 from .. import _hip
@@ -58,8 +60,12 @@ class TransEModel(TranslationModel):
     # per DISTINCT query row of the batch and the count kernel sweeps columns instead of queries
     lp_dedupe_queries = True
     # ... but not on the one-product level of the split prefilter: at d = 200 a shared row saves 4 MFMA groups per tile,
-    # less than the grouped columns' multi-pass epilogue costs (evaluation.DEDUPE_LEVEL1: 0.632 vs 0.648 ms per evaluate)
-    lp_dedupe_level1 = False
+    # less than the grouped columns' multi-pass epilogue costs (r04 kernel: 0.632 vs 0.648 ms per evaluate).  r06 taught the
+    # free-running kernel grouped columns (lp_hi_stream_kernel<.., GS = 4>) and measured again, same box, alternating: per
+    # query 0.487-0.491 ms, columns 0.532-0.544 (profiles/r06/dedupe_level1_stream_ab.txt: the single-query launch 187 us +
+    # the grouped one 104 us -- 57 panels, 6 items per workgroup, 2.85 compare passes per column -- against 283 us for the
+    # per-query sweep; -24 % MFMAs do not pay on a kernel whose matrix pipe is 42 % busy).  KGE_TRANSE_DEDUPE_L1=1 turns it on.
+    lp_dedupe_level1 = os.environ.get('KGE_TRANSE_DEDUPE_L1', '0') == '1'
     # the count sweep is enqueued in front of the second stream's filter correction (evaluation.COUNT_FIRST: -3 % here)
     lp_count_first = True
 
@@ -132,7 +138,7 @@ class TransEModel(TranslationModel):
         key = '%d_%d' % (c_base, E.shape[0])
         Eq = E if qrep is None else qrep            # where the query pipeline reads e_src / e_true
         lvl1 = self._use_level1()
-        frag = lvl1 and self._level1_stream() and (cols is None or cols.n_multi_p == 0)
+        frag = lvl1 and self._level1_stream()       # (r06: grouped columns run on the free-running kernel too)
         prep = None
         if frag:
             # the candidate side of the free-running sweep in ONE launch: ||e||^2 (the reference chain), the fragment-major
@@ -201,6 +207,7 @@ class TransHModel(TranslationModel):
     # the count kernel's epilogue gathers X[r_i, c]: queries processed in relation order share those rows
     lp_sort_queries_by_relation = True
     lp_dedupe_queries = 'relation-major'   # ColumnPlan with the columns in relation order (same reason)
+    lp_stream_columns = False              # (the free-running kernel's projection epilogue sweeps per query)
 
     def _tables(self):
         return [self.ent_emb.weight, self.rel_emb.weight, self.norm_vect.weight]
@@ -329,6 +336,7 @@ class TransDModel(TranslationModel):
     _ENT_POS = (0, 2)
     lp_sort_queries_by_relation = True     # (as TransH: the epilogue gathers G[r_i, c])
     lp_dedupe_queries = 'relation-major'
+    lp_stream_columns = False
 
     def __init__(self, ent_emb_dim, rel_emb_dim, n_entities, n_relations):
         super().__init__(n_entities, n_relations, 'L2')
