@@ -169,7 +169,12 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         if (PM) {
             if (tid < HS_TQ) {
                 const int64_t q = p.col_q ? (int64_t)p.col_q[q0 + tid] : q0 + tid;
-                pthr[tid] = q >= 0 ? p.thr4[q] : make_float4(INFINITY, INFINITY, 0.f, 0.f);
+                // (p_i, z_i) pre-multiplied by -2^23, the accumulators' scale (exact): the epilogue's projection term is then two
+                // FMAs per element, v + x (x z' + p'), instead of fma, mul, fma (r06; one rounding fewer than before -- inside the
+                // band's 9 x 2^-22 allowance for this term either way)
+                float4 t4 = q >= 0 ? p.thr4[q] : make_float4(INFINITY, INFINITY, 0.f, 0.f);
+                t4.z *= -8388608.0f; t4.w *= -8388608.0f;
+                pthr[tid] = t4;
                 prow[tid] = (int)p.r_idx[min(max(q, (int64_t)0), p.B - 1)];
             }
         }
@@ -466,14 +471,12 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                             vq[e] = acc[mt][nt][g4 * 4 + e];
                             if (PM) {
                                 const float xe = e == 0 ? x4[g4].x : (e == 1 ? x4[g4].y : (e == 2 ? x4[g4].z : x4[g4].w));
-                                float corr;
                                 if (PM == 1) {
-                                    corr = xe * fmaf(xe, z_n, p_n);
+                                    vq[e] = fmaf(xe, fmaf(xe, z_n, p_n), vq[e]);
                                 } else {
                                     const float ye = e == 0 ? y4[g4].x : (e == 1 ? y4[g4].y : (e == 2 ? y4[g4].z : y4[g4].w));
-                                    corr = ye * fmaf(ye, z_n, fmaf(2.0f, xe, p_n));
+                                    vq[e] = fmaf(ye, fmaf(ye, z_n, fmaf(-16777216.0f, xe, p_n)), vq[e]);
                                 }
-                                vq[e] = fmaf(corr, -8388608.0f, vq[e]);
                             }
                         }
                         unsigned b0, b1, b2, b3;
