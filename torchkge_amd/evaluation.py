@@ -972,6 +972,11 @@ class LinkPredictionEvaluator(object):
             level_ok = (not kdist.multi(world)) or self.shard == 'queries' or (sharded and both and not by_scores and
                                                                                 getattr(self.engine, 'flag_columns', False))
             level_now = self._level if (guard is not None and both and level_ok) else 0
+            forced_level = getattr(self.model, 'split_level', 'auto')
+            if forced_level != 'auto' and guard is not None and both:
+                # (a forced level is what Model._use_level1 runs whatever the policy's state says: the capture key, the region
+                # decision and Model._split_level name THAT level -- r06: a fresh shared state used to report 0 here)
+                level_now = 1 if (int(forced_level) == 1 and self.model._use_level1()) else 0
             # (the WHOLE candidate range: entity shards sum their re-scored pairs over the ranks -- same number, same decision)
             lvl_enter, lvl_leave = level1_thresholds(self.model.n_ent)
             if hasattr(self.model, '_split_level'):
