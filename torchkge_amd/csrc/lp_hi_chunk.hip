@@ -391,7 +391,7 @@ int hc_launch(const kge_hi_stream_params &p, int grid, hipStream_t s)
 } // namespace
 
 // k16 units the chunked kernel is instantiated for (beyond kge_hi_stream_max_units())
-int kge_hi_chunk_supported(int units) { return units == 65 || units == 33; }
+int kge_hi_chunk_supported(int units) { return units == 65 || units == 33 || units == 26; }
 
 int kge_hi_chunk_query_rows(int units)
 {
@@ -429,6 +429,10 @@ int kge_hi_chunk_launch(kge_hi_stream_params p, int num_cus, hipStream_t s)
     if (p.units == 65) {
         if (nt == 3) return hc_launch<8, 3, 65, 13, 6, 2>(p, grid, s);
         return hc_launch<8, 4, 65, 13, 4, 1>(p, grid, s);
+    }
+    if (p.units == 26) {        // (K = 400: an experiment against the resident-panel kernel, KGE_HC_FORCE=1)
+        if (nt == 3) return hc_launch<8, 3, 26, 13, 6, 2>(p, grid, s);
+        return hc_launch<8, 4, 26, 13, 4, 1>(p, grid, s);
     }
     if (nt == 3) return hc_launch<8, 3, 33, 11, 6, 2>(p, grid, s);
     return hc_launch<8, 4, 33, 11, 4, 1>(p, grid, s);

@@ -2447,7 +2447,10 @@ extern "C" int kge_lp_split_count(const kge_lp_desc *d, const kge_split_args *a,
     const int slots = split_num_cus();
     if (a->es_frag) {
         // the free-running one-product kernel (lp_hi_stream.hip): fragment-major candidate table, resident query panel
-        const bool chunked = units > kge_hi_stream_max_units();     // long rows: the panel streamed in chunks (lp_hi_chunk.hip)
+        // long rows: the panel streamed in chunks (lp_hi_chunk.hip); KGE_HC_FORCE=1: also where the resident panel would fit (A/B)
+        const bool chunked = units > kge_hi_stream_max_units() ||
+                             (kge_env_int("KGE_HC_FORCE", 0) && kge_hi_chunk_supported(units) && !a->members && !a->region_count &&
+                              d->mode < KGE_LP_L2_PROJH);
         const bool grouped = a->members && a->n_multi_p > 0;         // r06: + a second launch over the grouped columns
         if (!lv1 || (chunked && !kge_hi_chunk_supported(units))) return KGE_EINVAL;
         if ((a->members != nullptr) != (a->n_multi_p > 0) || (grouped && (chunked || proj || a->region_count || !a->col_q)))
