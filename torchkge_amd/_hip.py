@@ -605,6 +605,20 @@ def table_prep_l2(E, emax_io, de2max_io, deferred_max=False, K=None):
 
 # the uncertain-pair list of the free-running sweep cut into regions of 32 queries, re-scored with the region's query rows
 # resident in LDS (kge_lp_split_recheck_regions); KGE_REGION_RECHECK=0: the one global list
+# the count sweep of a fused-query-side batch as TWO launches over the halves of the queries, the first half's region recheck on
+# a side stream beside the second half's sweep (LpProblem._count_ge_split_halves)
+SWEEP_HALVES = os.environ.get('KGE_SWEEP_HALVES', '0') == '1'
+_HALVES_STREAMS = {}
+
+
+def _halves_stream(device):
+    key = str(device)
+    s = _HALVES_STREAMS.get(key)
+    if s is None:
+        s = _HALVES_STREAMS[key] = torch.cuda.Stream(device)
+    return s
+
+
 REGION_RECHECK = os.environ.get('KGE_REGION_RECHECK', '1') == '1'
 # ... for the projection models too (TransH / TransD, ~5 listed pairs per query: a region's fixed cost -- 26 KB of query rows
 # for ~170 pairs -- outweighs the rows it saves: 0.64 -> 0.66 ms, profiles/r05/region_recheck_ab.txt; off)
@@ -1146,11 +1160,74 @@ class LpProblem(object):
         ``between``: called after the sweep is enqueued and before the recheck (the evaluator forks its filter correction
         there: beside the recheck instead of beside the sweep)."""
         prep = self.split_prepare()
+        if self._sweep_in_halves(prep, s_true):
+            return self._count_ge_split_halves(prep, s_true, raw, between)
         self.split_count(prep, s_true, raw)
         if between is not None:
             between()
         self.split_recheck(prep, s_true, raw)
         self.last_split = (prep['n_list'], prep)     # kept alive until the launches have run; tests read n_list
+        return raw
+
+    # ---- the sweep in two halves, the first half's exact recheck beside the second half's sweep (r06) -------------------------
+    def _sweep_in_halves(self, prep, s_true):
+        """Applies where the sweep's uncertain pairs go to REGIONS (free-running kernel, fused query side with ready thresholds,
+        K <= 256): a region belongs to 32 consecutive queries, so the queries [0, H) and [H, B) are two independent problems
+        on the same operands -- same kernels, pointers advanced -- and the recheck of the first need not wait for the second."""
+        if not SWEEP_HALVES or prep.get('region_count') is None or not self.split.get('es_frag') or prep.get('cols') is not None:
+            return False
+        if prep.get('s_true_pre') is not s_true or prep.get('thr_used') or self.desc.K1 or int(self.desc.mode) not in (LP_L2_EXPAND, LP_DOT):
+            return False
+        return self.B >= 8 * 192 and s_true.is_cuda
+
+    def _count_ge_split_halves(self, prep, s_true, raw, between=None):
+        lib = load_library()
+        if not int(lib.kge_lp_split_regions_supported(ctypes.byref(self.desc))):
+            prep['region_count'] = None
+            self.split_count(prep, s_true, raw)
+            if between is not None:
+                between()
+            self.split_recheck(prep, s_true, raw)
+            self.last_split = (prep['n_list'], prep)
+            return raw
+        import copy as _copy
+        Bp = int(lib.kge_lp_split_rows_padded(self.B, 1))
+        H = (Bp // 2) // 192 * 192                      # whole 192-row padding units: the halves pad like the whole
+        K = int(self.desc.K0) + int(self.desc.K1)
+        row_bytes = int(lib.kge_lp_hi_units(K)) * 32
+        cap_h = int(prep['cap']) // 2
+        st_true = getattr(self, 'split_true', None)
+        halves = []
+        for q0, q1, li in ((0, H, 0), (H, self.B, 1)):
+            sp = _copy.copy(self)
+            d = LpDesc.from_buffer_copy(self.desc)
+            d.B = q1 - q0
+            d.A0 = self.desc.A0 + 4 * q0 * self.desc.lda0
+            if self.desc.qn:
+                d.qn = self.desc.qn + 4 * q0
+            sp.desc, sp.B = d, q1 - q0
+            s_sub = s_true[q0:q1]
+            sp.split_true = (s_sub, st_true[1][q0:q1]) if (st_true is not None and st_true[0] is s_true) else None
+            sp._regions_used = False
+            pp = {'Qs': prep['Qs'][q0 * row_bytes:], 'thr': prep['thr'][2 * q0:], 'cap': cap_h,
+                  'list': prep['list'][2 * cap_h * li:2 * cap_h * (li + 1)], 'n_list': prep['n_list'], 'cols': None,
+                  's_true_pre': s_sub, 'region_count': prep['region_count'][(q0 // 32):], 'q_dn2': prep.get('q_dn2'),
+                  'q_dn2_per_query': prep.get('q_dn2_per_query')}
+            halves.append((sp, pp, s_sub, raw[q0:q1]))
+        main = torch.cuda.current_stream(self.device)
+        side = _halves_stream(self.device)
+        (p0, pp0, s0, r0), (p1, pp1, s1, r1) = halves
+        p0.split_count(pp0, s0, r0)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            p0.split_recheck(pp0, s0, r0)
+        p1.split_count(pp1, s1, r1)
+        if between is not None:
+            between()
+        p1.split_recheck(pp1, s1, r1)
+        main.wait_stream(side)
+        prep['thr_used'] = True
+        self.last_split = (prep['n_list'], (prep, pp0, pp1))
         return raw
 
     def filter_sub(self, s_true, true_idx, seg_lo, seg_hi, targets, sub=None, found=None, grouped=False, plan=None):
