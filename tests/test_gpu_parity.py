@@ -1335,6 +1335,72 @@ def test_evaluator_level1_query_columns_on_the_free_running_kernel(hip):
         assert any(pl.cols is not None and pl.cols.n_multi > 0 for pl in ev._plans.values())
 
 
+def test_steady_state_fast_replay_follows_every_change(hip, monkeypatch):
+    """r06: steady-state evaluate() calls replay the captured hipGraph without the full prologue (LinkPredictionEvaluator.
+    _fast_sig / _evaluate_fast).  The shortcut must be invisible: same ranks as the full path, and every change that keys
+    the capture -- table VALUES written in place (same addresses: the replay re-reads them), tables REPLACED (new
+    addresses), facts edited in place (version bump), another b_size, a switched-off prefilter -- shows in the ranks exactly
+    as it does for a fresh evaluator."""
+    import torchkge_amd as tk
+    import torchkge_amd.evaluation as evm
+    n_ent, n_rel, d = 2000, 7, 64
+    tables = orc.init_tables('transe', n_ent, n_rel, d, seed=9)
+    m = build_model('transe', 2, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 12000, 5, hubs=((300, 'head'),))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(11000, 1000))
+    for x in ('head_idx', 'tail_idx', 'relations'):
+        setattr(kg_test, x, getattr(kg_test, x).cuda())
+    names = ['rank_true_heads', 'rank_true_tails', 'filt_rank_true_heads', 'filt_rank_true_tails']
+
+    def fresh(b=512):
+        monkeypatch.setattr(evm, 'FAST_REPLAY', False)
+        e = tk.LinkPredictionEvaluator(m, kg_test, graph=False, share_state=False)
+        e.evaluate(b_size=b, verbose=False)
+        monkeypatch.setattr(evm, 'FAST_REPLAY', True)
+        return [getattr(e, nm).clone() for nm in names]
+
+    def same(e, want, what):
+        for nm, w in zip(names, want):
+            assert torch.equal(getattr(e, nm), w), what
+
+    ev = tk.LinkPredictionEvaluator(m, kg_test, share_state=False)
+    want = fresh()
+    for i in range(5):
+        ev.evaluate(b_size=512, verbose=False)
+        same(ev, want, 'steady state %d' % i)
+    assert ev._st._fast is not None, 'the fast path is armed after plain replays'
+    n_before = ev._n_evaluations
+    ev.evaluate(b_size=512, verbose=False)
+    assert ev._st._fast is not None and ev._n_evaluations == n_before + 1
+    # table values change IN PLACE (an optimiser step): same addresses, the replay reads the new values
+    with torch.no_grad():
+        m.ent_emb.weight.mul_(0.9).add_(0.01 * torch.randn_like(m.ent_emb.weight))
+        m.normalize_parameters()
+    want2 = fresh()
+    assert any(not torch.equal(a, b) for a, b in zip(want, want2))
+    ev.evaluate(b_size=512, verbose=False)
+    same(ev, want2, 'values written in place')
+    # tables REPLACED (new storage): the capture key changes -> full path, new capture
+    m.ent_emb.weight.data = m.ent_emb.weight.data.clone()
+    ev.evaluate(b_size=512, verbose=False)
+    same(ev, want2, 'tables replaced')
+    # facts edited in place
+    kg_test.tail_idx[0:10] = (kg_test.tail_idx[0:10] + 1) % n_ent
+    want3 = fresh()
+    for _ in range(3):
+        ev.evaluate(b_size=512, verbose=False)
+        same(ev, want3, 'facts edited in place')
+    # another b_size, then the prefilter switched off: both key the capture
+    ev.evaluate(b_size=300, verbose=False)
+    same(ev, want3, 'b_size')
+    m.split_filter = False
+    ev.evaluate(b_size=300, verbose=False)
+    same(ev, want3, 'split_filter off')
+    m.split_filter = True
+
+
 def test_filter_lookup_both_equals_two_lookups(hip):
     """kge_filter_lookup_both = kge_filter_lookup on the tail index and on the head index
     (head segments shifted by the tail index's target count), plus the concatenated true ids."""

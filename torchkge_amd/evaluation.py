@@ -292,7 +292,7 @@ class _EvalState(object):
 
     SHARED = ('_plans', '_plan_stamp', '_plan_refs', '_plan_gen', '_perm', '_qmap', '_graph', '_graph_static', '_graph_key',
               '_graph_src', '_graph_seen', '_graph_cache', '_aux_stream', '_n_evaluations', '_level', '_level1_max',
-              '_level0_seen', '_mem_fit', '_graph_failed', '_ctimes')
+              '_level0_seen', '_mem_fit', '_graph_failed', '_ctimes', '_fast')
 
     def __init__(self):
         self._plans = self._plan_stamp = self._plan_refs = self._perm = self._qmap = None
@@ -307,6 +307,7 @@ class _EvalState(object):
         self._mem_fit = None
         self._graph_failed = False
         self._ctimes = None     # collective_timing(): (start, end) event pairs of the data-path collectives
+        self._fast = None       # (signature, replay info) of the last steady-state graph replay: LinkPredictionEvaluator._fast_sig
         self.kg_ref = None
         self.group_ref = None   # the process group of the options key (held so that its id() cannot be reused while this state lives)
 
@@ -315,6 +316,8 @@ _STATES = weakref.WeakKeyDictionary()       # model -> {(id(kg), options): _Eval
 SHARE_STATE = os.environ.get('KGE_SHARE_EVAL_STATE', '1') != '0'
 # the filter correction of the second stream beside the exact recheck (1) instead of beside the count sweep (0)
 FILTER_BESIDE_RECHECK = os.environ.get('KGE_FILTER_BESIDE_RECHECK', '0') == '1'
+# steady-state evaluate() calls skip the full prologue (LinkPredictionEvaluator._fast_sig / _evaluate_fast, r06)
+FAST_REPLAY = os.environ.get('KGE_FAST_REPLAY', '1') != '0'
 # region recheck (one-product level): from this many re-scored pairs per query on the three-product level
 REGION_MIN_LEVEL0 = float(os.environ.get('KGE_REGION_MIN_LEVEL0', '1.2'))
 
@@ -826,6 +829,18 @@ class LinkPredictionEvaluator(object):
     def evaluate(self, b_size, verbose=True):
         """Rank the true head and tail of every fact of ``kg`` among all
         entities, raw and filtered (evaluation.py:263-308)."""
+        # STEADY STATE (r06): the previous evaluation of this (model, kg, options) was a plain single-GPU graph replay and
+        # nothing that keys the capture has changed -- same b_size, same fact tensors (identity + version), same table
+        # addresses, same kernel-choice switches, same split level: replay at once.  The GPU idles while the host prepares a
+        # replay (~65 us of a 0.49 ms step at cfg2: profiles/r05/timeline_transe_fb15k237.txt); the full prologue below --
+        # plan stamps, capture key, filter indices, guard / session bookkeeping -- is ~35 us of that.  Anything unusual
+        # (a guard flag up, a list overflow, every 32nd evaluation's memory check) goes through the full path.
+        user_b_size = b_size
+        fast = self._st._fast if FAST_REPLAY else None
+        if fast is not None:
+            if self._n_evaluations % 32 != 0 and fast[0] == self._fast_sig(user_b_size) and self._evaluate_fast(fast[1]):
+                return
+            self._st._fast = None
         # (the tensors whose addresses the capture key holds: the model's own table list where it has one -- a walk over
         # Module.parameters() costs three times as much host time, and the GPU idles while the host prepares the replay)
         tables_of = getattr(self.model, '_tables', None)
@@ -1118,6 +1133,7 @@ class LinkPredictionEvaluator(object):
 
             res = None
             n_pol = None
+            any_redo = False
             for attempt in (0, 1):
                 if guard is None:
                     break
@@ -1169,6 +1185,7 @@ class LinkPredictionEvaluator(object):
                             self._level1_max = 0.5 * self._level0_seen
                 if not redo:
                     break
+                any_redo = True
                 res = None
                 flat, out, fl = alloc_out()
                 run(*facts(), out, fl)
@@ -1186,6 +1203,66 @@ class LinkPredictionEvaluator(object):
         self.filt_rank_true_heads, self.filt_rank_true_tails = res[2], res[3]
         self.evaluated = True
         self._n_evaluations += 1
+        # the next call may replay at once if THIS one was an undisturbed single-GPU replay of the current capture
+        self._st._fast = None
+        if (FAST_REPLAY and use_graph and key is not None and self._graph_key == key and not kdist.multi(world)
+                and guard is not None and not any_redo and isinstance(self._graph, torch.cuda.CUDAGraph)
+                and (forced_level != 'auto' or self._level == level_now) and self._fast_sig(user_b_size) is not None):
+            gst = self._graph_static
+            self._st._fast = (self._fast_sig(user_b_size),
+                              {'graph': self._graph, 'static': gst, 'guard': guard, 'n_local': n_local, 'level': level_now,
+                               'needs_clean_guard': bool(gst.get('needs_clean_guard')), 'zeroes_guard': bool(gst.get('zeroes_guard'))})
+
+    def _fast_sig(self, b_size):
+        """What must be unchanged for the last captured graph to be replayed without the full prologue (cheap to compute:
+        identities, versions, addresses)."""
+        kg, m, st = self.kg, self.model, self._st
+        h, t, r = kg.head_idx, kg.tail_idx, kg.relations
+        try:
+            tabs = m._tables()
+        except Exception:
+            return None
+        return (b_size, id(kg), id(h), h._version, id(t), t._version, id(r), r._version, kg.n_facts,
+                tuple(p.data_ptr() for p in tabs), getattr(m, 'l2_mode', None), getattr(m, 'split_filter', None),
+                getattr(m, 'split_level', None), st._level, st._level1_max, self.graph, id(getattr(m, '_lp_guard', None)),
+                id(st._graph), st._plan_gen, id(getattr(kg, '_lazy', None)), self.coalesce, st._mem_fit)
+
+    def _evaluate_fast(self, info):
+        """One steady-state evaluation: guard hygiene, graph replay, ONE device-to-host copy (ranks + flags), the level
+        policy.  False: something needs the full path (nothing has been changed that it would not redo)."""
+        m = self.model
+        guard, n_local = info['guard'], info['n_local']
+        if info['needs_clean_guard']:
+            if not getattr(m, '_lp_guard_clean', False):
+                guard.zero_()
+            object.__setattr__(m, '_lp_guard_clean', False)
+        info['graph'].replay()
+        if info['zeroes_guard']:
+            object.__setattr__(m, '_lp_guard_clean', True)
+        packed = _to_host(info['static']['out'][0])
+        worst, overflow, rescored, _ = packed[-2:].view(torch.float32).tolist()
+        if not worst <= m.L2_EXPAND_LIMIT or overflow > 0:
+            return False        # (norm guard / list overflow: the full path replays, sees the same flags and redoes)
+        level_now = info['level']
+        if n_local > 0:
+            lvl_enter, lvl_leave = level1_thresholds(m.n_ent)
+            per_q = rescored / (2.0 * n_local)
+            self.last_rescored_per_query = per_q
+            if level_now == 0 and rescored > 0:
+                self._level0_seen = per_q
+                cap_ = lvl_enter if self._level1_max is None else min(lvl_enter, self._level1_max)
+                if per_q <= cap_ and getattr(m, 'split_level', 0) == 'auto':
+                    self._level = 1
+            elif level_now == 1 and per_q > lvl_leave:
+                self._level = 0
+                if self._level0_seen is not None:
+                    self._level1_max = 0.5 * self._level0_seen
+        res = packed[:-2].view(4, n_local)
+        self.rank_true_heads, self.rank_true_tails = res[0], res[1]
+        self.filt_rank_true_heads, self.filt_rank_true_tails = res[2], res[3]
+        self.evaluated = True
+        self._n_evaluations += 1
+        return True
 
     # -- metrics (evaluation.py:310-425) --------------------------------------
     def _check(self):
