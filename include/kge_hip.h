@@ -523,8 +523,13 @@ typedef struct kge_split_args {
      * unit) holding chunk (row % 32) + 32 * (k / 8 % 2): the A operand of v_mfma_f32_32x32x16_f16 in lane order.  The
      * count kernel then keeps a 96-query panel resident in LDS, every wavefront reads the fragments of ITS 64 candidate
      * rows straight from global memory into registers and runs without block-wide barriers (lp_hi_stream.hip); same
-     * thresholds, same counts, same list.  Qs stays the planar operand.  Columns: col_q only (members must be NULL).
-     * K must satisfy kge_lp_hi_stream_supported(K). */
+     * thresholds, same counts, same list.  Qs stays the planar operand.  K must satisfy kge_lp_hi_stream_supported(K).
+     * ABI 29 (r06): (1) rows of 33 / 65 k16 units (K = 497..512, 1009..1024 -- ComplEx d = 512) run on the CHUNKED-panel form of
+     * the same kernel (lp_hi_chunk.hip: the query panel streamed through a two-slot LDS ring in chunks of 11 / 13 units,
+     * 128-query panels; KGE_LP_DOT / KGE_LP_L2_EXPAND, one global list); (2) columns: col_q, and -- for the plain-threshold
+     * modes on rows of <= 32 units -- GROUPED columns too (members / n_multi_p: a second launch whose epilogue compares a
+     * column's accumulators with the thresholds of each member; not together with region_count).  The projection modes and
+     * the chunked form sweep single-query columns only (members must be NULL: KGE_EINVAL otherwise). */
     int32_t es_frag;
     /* es_frag = 1, optional: true_idx[i] = GLOBAL id of the entity whose exact score IS s_true[i] (the evaluator's true
      * entity).  That pair is counted and can never be taken back by the recheck, so the sweep does not list it. */

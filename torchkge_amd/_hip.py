@@ -147,7 +147,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 28        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 29        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():

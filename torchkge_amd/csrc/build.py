@@ -9,6 +9,7 @@ the GPU box with the gpurun snapshot.  -ffp-contract=off is part of the
 numerical contract (see kge_common.h): fused multiply-adds are explicit fmaf().
 """
 import os
+import shutil
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -58,6 +59,35 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def rocm_roots():
+    """ROCm installation prefixes to look under: $ROCM_PATH / $ROCM_HOME first, then hipcc's own prefix, then /opt/rocm."""
+    roots = [os.environ.get(k) for k in ('ROCM_PATH', 'ROCM_HOME')]
+    hipcc = shutil.which('hipcc')
+    if hipcc:
+        roots.append(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))))
+    roots.append('/opt/rocm')
+    out = []
+    for r in roots:
+        if r and r not in out:
+            out.append(r)
+    return out
+
+
+def rccl_install():
+    """(include dir, library dir) of the RCCL to link libkge_hip_coll.so against, or None when there is none.
+
+    ONE definition for build() here and __graft_entry__.build(): the header AND the linker name `librccl.so` (what `-lrccl`
+    resolves; a bare librccl.so.1 run-time library cannot be linked against) under the same prefix."""
+    for root in rocm_roots():
+        for inc in (os.path.join(root, 'include'),):
+            if not (os.path.exists(os.path.join(inc, 'rccl', 'rccl.h')) or os.path.exists(os.path.join(inc, 'rccl.h'))):
+                continue
+            for libdir in (os.path.join(root, 'lib'), os.path.join(root, 'lib64')):
+                if os.path.exists(os.path.join(libdir, 'librccl.so')):
+                    return inc, libdir
+    return None
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libkge_hip.so.  Returns the path."""
     bdir = os.path.join(HERE, '_build')
@@ -94,21 +124,20 @@ def build(force=False, verbose=False):
     cs = os.path.join(HERE, COLL_SRC)
     if force or _stale(COLL_LIB, [cs, os.path.join(HERE, '..', '..', 'include', 'kge_hip_coll.h')] + hdrs):
         # (-lrccl resolves to whichever librccl.so.1 the process has loaded first -- torch's own when the host is Python)
-        # Optional: a box without the RCCL headers / library still gets the single-GPU core (libkge_hip.so); the sharded
-        # path through the C-ABI (torchkge_amd/_hip_coll.py) then fails loudly when it is first used.
-        # Optional ONLY where RCCL itself is missing: a box without its header / library still gets the single-GPU core
-        # (libkge_hip.so) and the sharded path through the C-ABI fails loudly on first use.  Where RCCL is installed a
-        # compile error in collectives.hip is an error (it used to be downgraded to a warning).
-        have_rccl = any(os.path.exists(os.path.join(d, 'rccl', 'rccl.h')) or os.path.exists(os.path.join(d, 'rccl.h'))
-                        for d in ('/opt/rocm/include',)) and \
-            any(os.path.exists(os.path.join('/opt/rocm/lib', n)) for n in ('librccl.so', 'librccl.so.1'))
-        if have_rccl:
-            run([hipcc] + FLAGS + ['-shared', '-o', COLL_LIB, cs, '-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib'])
+        # Optional ONLY where RCCL itself is missing (rccl_install() is None): such a box still gets the single-GPU core
+        # (libkge_hip.so) and the sharded path through the C-ABI (torchkge_amd/_hip_coll.py) fails loudly on first use.
+        # Where RCCL is installed a compile error in collectives.hip is an error (run() raises) -- "missing" and "does
+        # not compile" are never the same outcome.
+        rccl = rccl_install()
+        if rccl is not None:
+            inc, libdir = rccl
+            run([hipcc] + FLAGS + ['-I' + inc, '-shared', '-o', COLL_LIB, cs, '-L' + libdir, '-lrccl', '-Wl,-rpath,' + libdir])
         else:
             import warnings
             if os.path.exists(COLL_LIB):
                 os.remove(COLL_LIB)
-            warnings.warn('torchkge_amd: libkge_hip_coll.so not built: RCCL header / library not found under /opt/rocm')
+            warnings.warn('torchkge_amd: libkge_hip_coll.so not built: rccl.h + librccl.so not found under %s'
+                          % ', '.join(rocm_roots()))
     return LIB
 
 
