@@ -1978,12 +1978,13 @@ def test_dot_query_side_in_one_launch_equals_the_separate_kernels(hip, kind, B, 
     g2 = torch.zeros(8, device='cuda')
     Eh2, dnb, _ws = hip.dot_table_prep(T0, T1, g2[1:2], g2[5:6] if cplx else None, frag)
     assert torch.equal(Eh2, Eh) and float(g2[1]) == float(guard[1]) and float(g2[5]) == float(guard[5])
-    assert float(dnb.max()) == float(de2)
+    # (the fragment-major table comes from the coalesced kernel, r06: the same exact residuals summed in another order)
+    assert float(dnb.max()) == pytest.approx(float(de2), rel=1e-5)
     split = {'Es': Eh2, 'e2pref': None, 'enmax': g2[1:2], 'enmax1': g2[5:6] if cplx else None, 'overflow': guard[2:3], 'level': 1,
              'de2max': g2[7:8], 'list_stat': guard[6:7], 'es_frag': frag}
     pre = hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if cplx else None, h, t, r, g2[1:2], g2[5:6] if cplx else None,
                                     g2[7:8], guard[0:1], guard[2:3], zero_counts=True, dn_bmax=dnb)
-    assert float(g2[7]) == float(de2)
+    assert float(g2[7]) == float(dnb.max())
     assert torch.equal(pre['Q'], Q0) and (not cplx or torch.equal(pre['Q1'], Q1))
     true = torch.cat([t, h]) if side == 'both' else (t if side == 'tail' else h)
     ref = hip.LpProblem(hip.LP_DOT, Q0, T0, A1=Q1 if cplx else None, T1=T1)

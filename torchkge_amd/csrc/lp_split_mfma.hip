@@ -370,6 +370,127 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
     }
 }
 
+// ---- the same table for DOT candidates, FRAGMENT-MAJOR, with coalesced traffic on both sides (r06) -----------------------
+// hi_rows_kernel reads 64 bytes per lane (a wave's float4 load touches 16 B of 64 different 64-byte pieces) and writes a
+// fragment block 64 bytes at a time: at ComplEx d = 512 on 4.59 M entities it moves 28.8 GB in 8.9 ms (3.2 TB/s), the
+// address pipes being the limit, not HBM.  Here a block takes a 32-row group and walks the row in spans of 256 columns:
+// a wave reads 1 KiB of ONE row per instruction (lane l: columns 4 l .. 4 l + 3), converts, and leaves the f16 values in
+// an LDS tile laid out like the output -- [unit][k-half][row][16 B], a 16-byte pad per k-half block: the 16 lanes of a
+// write pass hit 16 different 8-byte bank pairs -- from which every wave then copies whole 1-KiB fragment blocks to the
+// table, one coalesced store per block.  Two LDS tiles, ONE barrier per span, the next span's loads in flight across it.
+// Same hi values as hi_rows_kernel (aug_mode 4: guard column K = 0 for real rows, -65504 for padding rows); the residual
+// sums are the same exact differences in another order (a bound input: any order, see the 1.0001 below).
+// Needs float4-readable rows (K0, K1, ld % 4 == 0, 16-byte aligned bases).
+constexpr int HF_HST = 512 + 16, HF_UST = 2 * HF_HST;     // LDS strides of a k-half block / a unit
+
+__global__ __launch_bounds__(256) void hi_rows_frag_kernel(const HiRowsParams p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char tile[2][16 * HF_UST];
+    __shared__ unsigned bmax[4];
+    float scale, nmax;
+    {       // the block maxima of dot_table_norm_max_kernel -> the two scalars (as hi_rows_kernel)
+        __shared__ unsigned red[8];
+        unsigned m0 = 0u, m1 = 0u;
+        for (int j = threadIdx.x; j < p.nm_blocks; j += 256) {
+            m0 = max(m0, __float_as_uint(p.nm_bmax[j]));
+            m1 = max(m1, __float_as_uint(p.nm_bmax[p.nm_blocks + j]));
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 = max(m0, (unsigned)__shfl_xor((int)m0, off, 64));
+            m1 = max(m1, (unsigned)__shfl_xor((int)m1, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m0; red[4 + (threadIdx.x >> 6)] = m1; }
+        __syncthreads();
+        m0 = max(max(red[0], red[1]), max(red[2], red[3]));
+        m1 = max(max(red[4], red[5]), max(red[6], red[7]));
+        const float n0 = __uint_as_float(max(m0, __float_as_uint(*p.nmax0)));
+        const float n1 = p.nmax1 ? __uint_as_float(max(m1, __float_as_uint(*p.nmax1))) : 0.f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *const_cast<float *>(p.nmax0) = n0;
+            if (p.nmax1) *const_cast<float *>(p.nmax1) = n1;
+        }
+        nmax = n0 + n1;
+        scale = split_scale(nmax);
+    }
+    const float inv2 = 1.0f / (scale * scale);
+    const int K = p.K0 + p.K1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nspan = (p.units_p + 15) >> 4;
+    const int64_t ngroups = p.rows_p >> 5;
+    const int wo = (lane >> 2) * HF_UST + ((lane >> 1) & 1) * HF_HST + (lane & 1) * 8;     // this lane's 8 bytes of a tile row
+    const int ro = (lane >> 5) * HF_HST + (lane & 31) * 16;                                 // this lane's chunk of a fragment block
+    float4 v[8];
+    float dn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dn[j] = 0.f;
+    float dmax = 0.f;
+    auto load = [&](int64_t g, int s) {
+        const int col = s * 256 + 4 * lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = g * 32 + wv * 8 + j;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.rows && col < K)
+                v[j] = col < p.K0 ? *reinterpret_cast<const float4 *>(p.X0 + row * p.ld0 + col)
+                                  : *reinterpret_cast<const float4 *>(p.X1 + row * p.ld1 + (col - p.K0));
+        }
+    };
+    int64_t g = blockIdx.x;
+    int s = 0, it = 0;
+    bool have = g < ngroups;
+    if (have) load(g, s);
+    while (have) {                      // (block-uniform)
+        unsigned char *tl = tile[it & 1];
+        const int col = s * 256 + 4 * lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool real = g * 32 + wv * 8 + j < p.rows;
+            const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            _Float16 h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = xs[e] * scale;
+                h[e] = (_Float16)x;                         // round to nearest even
+                if (real && col < K) {                      // (K % 4 == 0: a float4 is data or padding as a whole)
+                    const float d = x - (float)h[e];        // exact in fp32
+                    dn[j] = fmaf(d, d, dn[j]);
+                }
+            }
+            if (col == K && !real) h[0] = (_Float16)(-65504.f);      // the guard column of a padding candidate: can never count
+            union { _Float16 hh[4]; uint2 u; } pk;
+            pk.hh[0] = h[0]; pk.hh[1] = h[1]; pk.hh[2] = h[2]; pk.hh[3] = h[3];
+            *reinterpret_cast<uint2 *>(tl + wo + (wv * 8 + j) * 16) = pk.u;
+        }
+        int64_t g2 = g;
+        int s2 = s + 1;
+        if (s2 == nspan) { s2 = 0; g2 += gridDim.x; }
+        const bool have2 = g2 < ngroups;
+        if (have2) load(g2, s2);
+        __syncthreads();                // the tile is complete; the other tile's readers of two spans ago are long past
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+            const int ul = wv * 4 + uu, u = s * 16 + ul;
+            if (u < p.units_p)
+                p.out[((g * p.units_p + u) << 6) + lane] = *reinterpret_cast<const uint4 *>(tl + ul * HF_UST + ro);
+        }
+        if (s == nspan - 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = dn[j];
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+                a *= inv2 * 1.0001f;    // (fp32 summation error: K * 2^-24 relative)
+                if (g * 32 + wv * 8 + j < p.rows) dmax = fmaxf(dmax, a);
+                dn[j] = 0.f;
+            }
+        }
+        g = g2; s = s2; have = have2; ++it;
+    }
+    unsigned m = __float_as_uint(dmax);
+    if (lane == 0) bmax[wv] = m;        // (uniform over the wave after the reductions)
+    __syncthreads();
+    if (threadIdx.x == 0) p.dn_bmax[blockIdx.x] = __uint_as_float(max(max(bmax[0], bmax[1]), max(bmax[2], bmax[3])));
+}
+
 // Squared-norm maxima of the rows of one or two tables ([Re | Im] segments of a DOT candidate table) in ONE sweep, any
 // summation order (they fix the operand scale and bound the error band; no score contains them): row_sqnorm_any_kernel
 // for both segments without the per-row outputs, the blocks' maxima as plain stores (bmax[2][gridDim.x]) -- the consumer
@@ -2293,7 +2414,14 @@ extern "C" int kge_lp_dot_table_prep(const float *X0, int64_t ld0, int K0, const
     p.dn2 = nullptr; p.dn2max = nullptr; p.row_index = nullptr;
     p.frag = frag ? 1 : 0;
     p.nm_bmax = ws; p.nm_blocks = nb; p.dn_bmax = dn_block_max;
-    hipLaunchKernelGGL(hi_rows_kernel, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
+    // fragment-major tables of float4-readable rows: the coalesced kernel (KGE_HIROWS_OLD=1: the general one, for A/B runs)
+    static const int old_only = getenv("KGE_HIROWS_OLD") ? atoi(getenv("KGE_HIROWS_OLD")) : 0;
+    const bool vec = K0 % 4 == 0 && K1 % 4 == 0 && ld0 % 4 == 0 && ((size_t)X0 & 15) == 0 &&
+                     (K1 == 0 || (ld1 % 4 == 0 && ((size_t)X1 & 15) == 0));
+    if (frag && vec && !old_only)
+        hipLaunchKernelGGL(hi_rows_frag_kernel, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
+    else
+        hipLaunchKernelGGL(hi_rows_kernel, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     return 0;
 }
