@@ -318,6 +318,8 @@ SHARE_STATE = os.environ.get('KGE_SHARE_EVAL_STATE', '1') != '0'
 FILTER_BESIDE_RECHECK = os.environ.get('KGE_FILTER_BESIDE_RECHECK', '0') == '1'
 # steady-state evaluate() calls skip the full prologue (LinkPredictionEvaluator._fast_sig / _evaluate_fast, r06)
 FAST_REPLAY = os.environ.get('KGE_FAST_REPLAY', '1') != '0'
+# TransH / TransD: candidate-side preparation of an evaluation on the second stream, beside the query side (r06)
+PREP_SIDE_STREAM = os.environ.get('KGE_PREP_SIDE_STREAM', '1') != '0'
 # region recheck (one-product level): from this many re-scored pairs per query on the three-product level
 REGION_MIN_LEVEL0 = float(os.environ.get('KGE_REGION_MIN_LEVEL0', '1.2'))
 
@@ -889,6 +891,10 @@ class LinkPredictionEvaluator(object):
             if was_clean and guard is not None and guard is same_guard:
                 object.__setattr__(self.model, '_lp_guard_clean', True)     # (zeroed by the last evaluation's finalize launch)
         session = self.model.lp_session() if hasattr(self.model, 'lp_session') else _NullCtx()
+        # (TransH / TransD: the candidate-side preparation runs on the second stream beside the query side's launches --
+        # Model._proj_fast_problem; KGE_PREP_SIDE_STREAM=0 keeps one stream)
+        if self._use_aux and PREP_SIDE_STREAM and not self._generic_model:
+            object.__setattr__(self.model, '_lp_side_stream', self._aux_stream)
 
         try:
             overlap = (self.overlap and self.fused and not sharded and not self._generic_model and
@@ -1193,6 +1199,7 @@ class LinkPredictionEvaluator(object):
                     break
         finally:
             self._qb = None
+            object.__setattr__(self.model, '_lp_side_stream', None)
             if guard is not None:      # never leave the model in guarded mode (exceptions included)
                 self.model.lp_guard_end()
         if self.shard == 'queries' and kdist.multi(world):

@@ -589,27 +589,52 @@ class TranslationModel(Model):
             return None
         lvl1 = self._use_level1()
         frag = lvl1 and self._level1_stream()
+        key = '%d_%d' % (ent_lo, table.shape[0])
+
+        def cand_side():
+            """norms + fragment-major hi table + residual maximum, X = W.E^T (TransD: G, sigma): per evaluation, cached"""
+            prep_ = None
+            if frag:
+                prep_ = self._cache.get('tp_' + key, [table],
+                                        lambda: _hip.table_prep_l2(table, g[1:2], g[7:8], deferred_max=True, K=K0))
+            if prep_ is not None:
+                en_ = self._cache.get('en_' + key, [table], lambda: prep_[0])
+            else:
+                en_ = self._cache.get('en_' + key, [table], lambda: _hip.row_sqnorm(table, K=K0, max_io=g[1:2]))
+            XT_, yc_ = build_side(table, ent_lo, K0)
+            if yc_ is not None:
+                self._cache.get('ymax_' + key, [yc_], lambda: _hip.absmax(yc_, g[4:5]))
+            return prep_, en_, XT_, yc_
+
+        # (r06) the candidate side -- three to five launches that read tables only -- on the evaluator's second stream
+        # beside the query side's two (LinkPredictionEvaluator hands the stream over for the session: fork / join by
+        # events, two parallel branches of the captured graph).  They write different guard scalars.
+        side = getattr(self, '_lp_side_stream', None) if table.is_cuda else None
+        if side is not None:
+            main = torch.cuda.current_stream(table.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cand = cand_side()
         # (one-product level on unsharded tables / replicas: the query rows' planar hi operand rides the same launch)
         hi_too = frag and (self._row_shard is None or qtabs is not None)
         out = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, **({'want_hi': True} if hi_too else {}))
         Q0 = out[0]
         st = _hip.proj_query_stats(Q0, Wt, r_both, scale, z_add, qmax_io=g[0:1])
+        if side is not None:
+            main.wait_stream(side)
+            for x in cand[0] or ():
+                if torch.is_tensor(x):
+                    x.record_stream(main)       # allocated on the side stream, consumed on this one
+            for x in cand[1:]:
+                if torch.is_tensor(x):
+                    x.record_stream(main)
         if st is None:
             return None
         qn, pz = st
-        key = '%d_%d' % (ent_lo, table.shape[0])
-        prep = None
-        if frag:
-            prep = self._cache.get('tp_' + key, [table], lambda: _hip.table_prep_l2(table, g[1:2], g[7:8], deferred_max=True, K=K0))
-        if prep is not None:
-            en = self._cache.get('en_' + key, [table], lambda: prep[0])
-        else:
-            en = self._cache.get('en_' + key, [table], lambda: _hip.row_sqnorm(table, K=K0, max_io=g[1:2]))
-        XT, yc = build_side(table, ent_lo, K0)
+        prep, en, XT, yc = cand if side is not None else cand_side()
         prob = _hip.LpProblem(mode, Q0, table, qn=qn, en=en, Wq=pz, scal=XT, r_idx=r_both, yc=yc, c_base=ent_lo, K0=K0)
         split = {'enmax': g[1:2], 'overflow': g[2:3], 'xabsmax': None, 'yabsmax': None, 'list_stat': g[6:7]}
         if yc is not None:
-            self._cache.get('ymax_' + key, [yc], lambda: _hip.absmax(yc, g[4:5]))
             split['yabsmax'] = g[4:5]
         if lvl1:
             if prep is not None:
