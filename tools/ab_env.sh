@@ -1,7 +1,7 @@
-#!/bin/bash
-# same-box A/B of an environment switch:  bash tools/ab_env.sh VAR [rounds] [bench args]   (VAR=0 vs VAR=1, alternating)
-V=$1; R=${2:-3}; shift 2
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for r in $(seq 1 $R); do for x in 0 1; do
-  echo "$V=$x $(env $V=$x python bench.py --only-timed --steps 40 --warmup 5 "$@" 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*')"
+# A/B of environment switches on one box: bash tools/ab_env.sh "<workload args>" VAR=a VAR=b ...   (alternating, 3 rounds)
+W="$1"; shift
+export KGE_BENCH_TABLE_CACHE=/tmp/kge_cache
+python bench.py --only-timed --steps 50 --warmup 5 $W > /dev/null 2>&1
+for rep in 1 2 3; do for kv in "$@"; do
+  echo "$kv: $(env $kv python bench.py --only-timed --steps 300 --warmup 30 $W 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])')"
 done; done
