@@ -631,7 +631,15 @@ int kge_lp_dot_query_pipeline(int side, const float *E0, const float *E1, const 
                               int64_t zero_n,
                               const float *dn_block_max /* optional: kge_lp_dot_table_prep's residual block maxima; the kernel
                                                            folds them into *de2max (written through the const pointer) */,
-                              int dn_blocks, kge_stream_t stream);
+                              int dn_blocks,
+                              const float *nm_block_max /* optional (ABI 30): kge_lp_dot_table_prep_fused's squared-norm block
+                                                           maxima [2][nm_blocks]; folded into *emax0 / *emax1 */,
+                              int nm_blocks,
+                              float *prev_nmax /* optional (ABI 30), 2 device floats: receives the folded maxima for the NEXT
+                                                  kge_lp_dot_table_prep_fused; with nm_block_max they are read first -- the
+                                                  maxima the table was scaled by -- and *overflow = 2 (not the list's 1: run the
+                                                  same path again) if the new ones ask for another power-of-two scale */,
+                              kge_stream_t stream);
 /* Candidate side of a DistMult / ComplEx problem on the one-product level in TWO launches (r05) -- what two
  * kge_row_sqnorm_any_order passes, a zero-fill and kge_lp_hi_rows[_frag](aug_mode 4) do in four, with the table read twice
  * instead of three times and no same-address atomics: (1) the squared-norm maxima of [X0 | X1] per block, (2) the hi table
@@ -643,6 +651,16 @@ int kge_lp_dot_table_prep_blocks(int64_t rows, int which);
 int kge_lp_dot_table_prep(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows, int frag,
                           float *norm2max0_io, float *norm2max1_io, void *out, float *dn_block_max, float *ws,
                           kge_stream_t stream);
+/* The same in ONE launch and ONE pass over the table (ABI 30; fragment-major output only): the scale is the one the maxima
+ * of a PREVIOUS evaluation ask for (prev_nmax, 2 device floats kept by kge_lp_dot_query_pipeline) -- any power of two under
+ * which nothing overflows is valid, the error band is built from the residuals measured in this pass -- and this pass's
+ * squared-norm maxima come out per block (nm_block_max[2][kge_lp_dot_table_prep_blocks(rows, 1)]) for the query pipeline
+ * to fold and to check against the scale that was used.  A table that has outgrown its scale sets the pipeline's
+ * *overflow to 2 (the caller runs the same two calls again: prev_nmax holds the new maxima by then).
+ * KGE_EINVAL unless rows are float4-readable (K0, K1, ld0, ld1 % 4 == 0, 16-byte aligned bases). */
+int kge_lp_dot_table_prep_fused(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1, int64_t rows,
+                                const float *prev_nmax, void *out, float *dn_block_max, float *nm_block_max,
+                                kge_stream_t stream);
 /* TransE-L2 query side of one batch in ONE launch -- what kge_lp_prep, kge_row_sqnorm (queries),
  * kge_lp_pair_scores (true scores), kge_lp_split_rows (queries) and the threshold kernel of
  * kge_lp_split_count do separately, with bit-identical outputs: Q (B,d), qn (B), s_true (B), Qs, thr

@@ -1739,6 +1739,117 @@ def test_split_one_product_level_long_rows_chunked_panel(hip, monkeypatch, mode,
         hip.SPLIT_EPS_SCALE = 1.0
 
 
+@pytest.mark.parametrize('kind,d,n_ent', [('distmult', 64, 1500), ('complex', 40, 777), ('complex', 512, 300), ('distmult', 400, 2049)])
+def test_dot_candidate_table_in_one_pass(hip, kind, d, n_ent):
+    """r06: kge_lp_dot_table_prep_fused -- the fragment-major hi table of a DOT candidate table in ONE pass, scaled by the
+    squared-norm maxima a previous evaluation left: the same table bit for bit as the two-launch preparation when those
+    maxima still hold, the same residual bound, this pass's norm maxima per block; the query pipeline folds them, stores
+    them for the next call and raises the overflow flag when the table has left the binade its scale was chosen for."""
+    cplx = kind == 'complex'
+    tables = orc.init_tables(kind, n_ent, 7, d, seed=3)
+    m = build_model(kind, 2, tables, n_ent, 7)
+    tabs = [hip.f32c(x.data) for x in m._tables()]
+    T0, T1 = tabs[0], (tabs[1] if cplx else None)
+    rel = tabs[2:] if cplx else tabs[1:]
+    with torch.no_grad():
+        T0[::5] *= 2.5
+    g = torch.zeros(8, device='cuda')
+    nm1 = g[5:6] if cplx else None
+    Eh, dnb, _ws = hip.dot_table_prep(T0, T1, g[1:2], nm1, True)
+    prev = torch.stack([g[1], g[5]]).contiguous()
+    g2 = torch.zeros(8, device='cuda')
+    Eh2, dnb2, nmb = hip.dot_table_prep(T0, T1, g2[1:2], g2[5:6] if cplx else None, True, prev_nmax=prev)
+    assert torch.equal(Eh2, Eh)
+    assert float(dnb2.max()) == pytest.approx(float(dnb.max()), rel=1e-5)
+    nb = nmb.shape[0] // 2
+    n0, n1 = float(nmb[:nb].max()), float(nmb[nb:].max())
+    assert n0 == pytest.approx(float(g[1]), rel=2e-4) and n0 >= float((T0.double() ** 2).sum(1).max()) * (1 - 1e-6)
+    if cplx:
+        assert n1 == pytest.approx(float(g[5]), rel=2e-4) and n1 >= float((T1.double() ** 2).sum(1).max()) * (1 - 1e-6)
+    else:
+        assert n1 == 0.0
+    B = 300
+    gen = torch.Generator().manual_seed(d)
+    h = torch.randint(0, n_ent, (B,), generator=gen).cuda(); t = torch.randint(0, n_ent, (B,), generator=gen).cuda()
+    r = torch.randint(0, 7, (B,), generator=gen).cuda()
+
+    def pipe(gv, prev_):
+        return hip.lp_dot_query_pipeline(hip.SIDE_BOTH, T0, T1, rel[0], rel[1] if cplx else None, h, t, r, gv[1:2],
+                                         gv[5:6] if cplx else None, gv[7:8], gv[0:1], gv[2:3], zero_counts=True, dn_bmax=dnb2,
+                                         nm_bmax=nmb, prev_nmax=prev_)
+    pre = pipe(g2, prev)
+    assert float(g2[2]) == 0.0 and float(g2[1]) == n0 and float(g2[5]) == n1      # folded, no flag, stored for the next call
+    assert float(prev[0]) == n0 and float(prev[1]) == n1
+    # counts through the sweep on the one-pass operands == exact counts
+    true = torch.cat([t, h])
+    ref = hip.LpProblem(hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
+    st = ref.pair_scores(true)
+    exact = ref.count_ge(st)
+    prob = hip.LpProblem(hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
+    pre['true_idx'] = true
+    prob.split = {'Es': Eh2, 'e2pref': None, 'enmax': g2[1:2], 'enmax1': g2[5:6] if cplx else None, 'overflow': g2[2:3], 'level': 1,
+                  'de2max': g2[7:8], 'list_stat': g2[6:7], 'es_frag': True}
+    prob.pre = pre
+    got = prob.count_ge(prob.pair_scores(true))
+    assert float(g2[2]) == 0.0 and torch.equal(got, exact)
+    # a table scaled under maxima of ANOTHER binade (norms 16 x smaller / larger then): the pipeline says so and leaves the
+    # true maxima for the next call
+    for f in (1.0 / 16, 16.0):
+        stale = torch.tensor([n0 * f, n1 * f], device='cuda')
+        g3 = torch.zeros(8, device='cuda')
+        _E, dnb3, nmb3 = hip.dot_table_prep(T0, T1, g3[1:2], g3[5:6] if cplx else None, True, prev_nmax=stale)
+        hip.lp_dot_query_pipeline(hip.SIDE_BOTH, T0, T1, rel[0], rel[1] if cplx else None, h, t, r, g3[1:2],
+                                  g3[5:6] if cplx else None, g3[7:8], g3[0:1], g3[2:3], zero_counts=True, dn_bmax=dnb3,
+                                  nm_bmax=nmb3, prev_nmax=stale)
+        assert float(g3[2]) == 2.0 and float(stale[0]) == n0 and float(stale[1]) == n1
+
+
+@pytest.mark.parametrize('kind', ['distmult', 'complex'])
+def test_evaluator_one_pass_table_follows_growing_tables(hip, kind):
+    """The evaluator on the one-product level takes the DOT candidate table's scale from the previous evaluation's maxima
+    (one pass over the table): ranks stay those of the exact fp32 counts while the tables change between evaluations --
+    slowly (same binade: no redo) and by a factor of 4 (the scale is stale: that evaluation is redone, the next one is
+    back on one pass) -- as hipGraph replays."""
+    import torchkge_amd as tk
+    n_ent, n_rel, d = 3000, 9, 64
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=7)
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 20000, 5, hubs=((900, 'head'),))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(18500, 1500))
+
+    def ranks(ev):
+        return [ev.rank_true_heads.clone(), ev.rank_true_tails.clone(), ev.filt_rank_true_heads.clone(),
+                ev.filt_rank_true_tails.clone()]
+
+    def exact():
+        m.split_filter = False
+        try:
+            e = tk.LinkPredictionEvaluator(m, kg_test, graph=False, share_state=False)
+            e.evaluate(512, verbose=False)
+            return ranks(e)
+        finally:
+            m.split_filter = True
+    m.split_level = 1
+    ev = tk.LinkPredictionEvaluator(m, kg_test)
+    ev._level = 1
+    ent_tabs = [m.ent_emb] if kind == 'distmult' else [m.re_ent_emb, m.im_ent_emb]
+    redone = []
+    for step, f in enumerate((1.0, 1.0, 1.01, 1.02, 4.0, 1.0, 1.03, 0.2, 1.0)):
+        with torch.no_grad():
+            for e_ in ent_tabs:
+                e_.weight.data.mul_(f)
+        ev.evaluate(512, verbose=False)
+        for a, b in zip(exact(), ranks(ev)):
+            assert torch.equal(a, b), 'step %d (tables x %g)' % (step, f)
+        redone.append(bool(getattr(ev, '_last_redo', False)))
+    assert m.__dict__['_lp_dot_prev'][1] is not None
+    # (which evaluations had to be redone is the evaluator's business; the scale changes by 16 and 25 must have been noticed)
+    if hasattr(ev, '_last_redo'):
+        assert redone[4] and redone[7] and not redone[2] and not redone[3] and not redone[6]
+
+
 @pytest.mark.parametrize('kind', ['transe', 'distmult', 'complex', 'transh', 'transd'])
 def test_evaluator_level_policy_and_identical_ranks(hip, kind):
     """LinkPredictionEvaluator with the one-product level forced on (model.split_level = 1), forced off (0) and on

@@ -114,8 +114,9 @@ _SIGNATURES = {
     'kge_lp_query_pipeline': [_int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, ctypes.c_float, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _i64, _vp],
     'kge_lp_dot_query_pipeline': [_int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, ctypes.c_float,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int, _vp],
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int, _vp, _int, _vp, _vp],
     'kge_lp_dot_table_prep': [_vp, _i64, _int, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp],
+    'kge_lp_dot_table_prep_fused': [_vp, _i64, _int, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp],
     'kge_mfma_f16_selftest': [],
     'kge_lp_filter_sub': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'kge_lp_filter_sub_grouped': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -147,7 +148,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 29        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 30        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -672,10 +673,21 @@ def lp_query_pipeline(side, E, R, h, t, r, en, emax, qmax_io, e2pref=None, cols=
     return out
 
 
-def dot_table_prep(X0, X1, nmax0_io, nmax1_io, frag):
-    """Candidate side of a DOT problem on the one-product level in two launches (kge_lp_dot_table_prep): (Eh, dn_block_max) --
-    the hi table (fragment-major when ``frag``) and its residual maxima per block, to be folded by lp_dot_query_pipeline;
-    the squared-norm maxima of the table's segment(s) end up in nmax0_io / nmax1_io."""
+def dot_table_prep_fusable(X0, X1):
+    """kge_lp_dot_table_prep_fused takes these tables (float4-readable rows)."""
+    ok = X0.shape[1] % 4 == 0 and X0.stride(0) % 4 == 0 and X0.data_ptr() % 16 == 0
+    if X1 is not None:
+        ok = ok and X1.shape[1] % 4 == 0 and X1.stride(0) % 4 == 0 and X1.data_ptr() % 16 == 0
+    return ok
+
+
+def dot_table_prep(X0, X1, nmax0_io, nmax1_io, frag, prev_nmax=None):
+    """Candidate side of a DOT problem on the one-product level in two launches (kge_lp_dot_table_prep): (Eh, dn_block_max, ws)
+    -- the hi table (fragment-major when ``frag``) and its residual maxima per block, to be folded by lp_dot_query_pipeline;
+    the squared-norm maxima of the table's segment(s) end up in nmax0_io / nmax1_io.
+    ``prev_nmax`` (2 device floats, r06): ONE launch, one pass (kge_lp_dot_table_prep_fused) -- the scale of the maxima a
+    previous evaluation left there; ws then holds THIS pass's squared-norm block maxima: hand it to
+    lp_dot_query_pipeline(nm_bmax=ws, prev_nmax=prev_nmax), which folds them into nmax0_io / nmax1_io."""
     lib = load_library()
     require_cuda(X0, X1, nmax0_io, nmax1_io)
     X0 = f32c(X0)
@@ -687,6 +699,15 @@ def dot_table_prep(X0, X1, nmax0_io, nmax1_io, frag):
     units_p = int(lib.kge_lp_hi_units(K0 + K1))
     rows_p = int(lib.kge_lp_split_rows_padded(rows, 0))
     out = torch.empty(rows_p * units_p * 32, dtype=torch.uint8, device=X0.device)
+    if prev_nmax is not None:
+        assert frag, 'the one-pass table preparation writes the fragment-major table'
+        nb = int(lib.kge_lp_dot_table_prep_blocks(rows, 1))
+        nmb = torch.empty(2 * nb, dtype=torch.float32, device=X0.device)
+        dnb = torch.empty(nb, dtype=torch.float32, device=X0.device)
+        with _on(X0.device):
+            _check(lib.kge_lp_dot_table_prep_fused(_p(X0), X0.stride(0), K0, _p(X1), ld1, K1, rows, _p(prev_nmax), _p(out),
+                                                   _p(dnb), _p(nmb), _stream()), 'kge_lp_dot_table_prep_fused')
+        return out, dnb, nmb
     ws = torch.empty(2 * int(lib.kge_lp_dot_table_prep_blocks(rows, 0)), dtype=torch.float32, device=X0.device)
     dnb = torch.empty(int(lib.kge_lp_dot_table_prep_blocks(rows, 1)), dtype=torch.float32, device=X0.device)
     with _on(X0.device):
@@ -696,7 +717,7 @@ def dot_table_prep(X0, X1, nmax0_io, nmax1_io, frag):
 
 
 def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, qmax_io, overflow, zero_counts=False,
-                          dn_bmax=None, regions=False):
+                          dn_bmax=None, regions=False, nm_bmax=None, prev_nmax=None):
     """DistMult (E1 = R1 = None) / ComplEx query side of one batch on the one-product level in one launch
     (kge_lp_dot_query_pipeline): dict with Q (and Q1), qn, s_true, Qs (planar hi operand, PER-QUERY scales), thr, q_dn2,
     n_list, counts -- Q / Q1 / s_true bit-identical to lp_prep + pair_scores."""
@@ -726,7 +747,8 @@ def lp_dot_query_pipeline(side, E0, E1, R0, R1, h, t, r, emax0, emax1, de2max, q
                                              _p(out['Q']), _p(out['Q1']), _p(out['qn']), _p(out['s_true']), _p(out['Qs']),
                                              _p(out['thr']), _p(out['q_dn2']), _p(out['n_list']), _p(overflow),
                                              _p(out.get('counts')), zero_n, _p(dn_bmax),
-                                             0 if dn_bmax is None else dn_bmax.shape[0], _stream()),
+                                             0 if dn_bmax is None else dn_bmax.shape[0], _p(nm_bmax),
+                                             0 if nm_bmax is None else nm_bmax.shape[0] // 2, _p(prev_nmax), _stream()),
                'kge_lp_dot_query_pipeline')
     return out
 

@@ -242,6 +242,9 @@ struct HiRowsParams {
     const float *nm_bmax;     // optional [2][nm_blocks]: per-block squared-norm maxima of the two segments (dot_table_norm_max_kernel)
     int nm_blocks;            //   -- every block folds them into *nmax0 / *nmax1 on its way in, block 0 stores the two scalars
     float *dn_bmax;           // optional [gridDim.x]: the blocks' residual maxima as plain stores INSTEAD of the dn2max atomic
+    const float *prev_nmax;   // hi_rows_frag_kernel<true> (r06, ONE pass over the table): the two squared-norm maxima a PREVIOUS
+    float *nm_out;            //   evaluation measured fix the scale; this pass's maxima per block go to nm_out[2][gridDim.x] and
+                              //   the consumer (dot_query_pipeline_kernel) raises the overflow flag if they ask for another scale
     int frag;                 // 1: FRAGMENT-MAJOR output [rows_p / 32][units_p][64][16 B] -- chunk (row % 32) + 32 * k-half of
                               // the 1-KiB block of (32-row group, unit): the A operand of v_mfma_f32_32x32x16_f16 in lane
                               // order, one coalesced global_load_dwordx4 per block (lp_hi_stream.hip)
@@ -383,12 +386,20 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const HiRowsParams p)
 // Needs float4-readable rows (K0, K1, ld % 4 == 0, 16-byte aligned bases).
 constexpr int HF_HST = 512 + 16, HF_UST = 2 * HF_HST;     // LDS strides of a k-half block / a unit
 
+// FUSED (r06): no norm pass in front -- the scale comes from the maxima of the PREVIOUS evaluation (p.prev_nmax; any power
+// of two under which nothing overflows is a valid scale: the band is built from residuals measured HERE), the rows'
+// squared norms are summed on the way (a bound input: any order) and their maxima left per block in p.nm_out for the
+// query pipeline, which checks that they still ask for the scale that was used.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void hi_rows_frag_kernel(const HiRowsParams p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char tile[2][16 * HF_UST];
-    __shared__ unsigned bmax[4];
+    __shared__ unsigned bmax[4], nbmax[8];
     float scale, nmax;
-    {       // the block maxima of dot_table_norm_max_kernel -> the two scalars (as hi_rows_kernel)
+    if (FUSED) {
+        nmax = p.prev_nmax[0] + p.prev_nmax[1];
+        scale = split_scale(nmax);
+    } else {       // the block maxima of dot_table_norm_max_kernel -> the two scalars (as hi_rows_kernel)
         __shared__ unsigned red[8];
         unsigned m0 = 0u, m1 = 0u;
         for (int j = threadIdx.x; j < p.nm_blocks; j += 256) {
@@ -420,10 +431,10 @@ __global__ __launch_bounds__(256) void hi_rows_frag_kernel(const HiRowsParams p)
     const int wo = (lane >> 2) * HF_UST + ((lane >> 1) & 1) * HF_HST + (lane & 1) * 8;     // this lane's 8 bytes of a tile row
     const int ro = (lane >> 5) * HF_HST + (lane & 31) * 16;                                 // this lane's chunk of a fragment block
     float4 v[8];
-    float dn[8];
+    float dn[8], nn0[8], nn1[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dn[j] = 0.f;
-    float dmax = 0.f;
+    for (int j = 0; j < 8; ++j) dn[j] = nn0[j] = nn1[j] = 0.f;
+    float dmax = 0.f, n0max = 0.f, n1max = 0.f;
     auto load = [&](int64_t g, int s) {
         const int col = s * 256 + 4 * lane;
 #pragma unroll
@@ -446,6 +457,10 @@ __global__ __launch_bounds__(256) void hi_rows_frag_kernel(const HiRowsParams p)
         for (int j = 0; j < 8; ++j) {
             const bool real = g * 32 + wv * 8 + j < p.rows;
             const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            if (FUSED) {        // (padding lanes hold zeros)
+                const float ss = fmaf(xs[0], xs[0], fmaf(xs[1], xs[1], fmaf(xs[2], xs[2], xs[3] * xs[3])));
+                if (col < p.K0) nn0[j] += ss; else nn1[j] += ss;
+            }
             _Float16 h[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -481,14 +496,27 @@ __global__ __launch_bounds__(256) void hi_rows_frag_kernel(const HiRowsParams p)
                 a *= inv2 * 1.0001f;    // (fp32 summation error: K * 2^-24 relative)
                 if (g * 32 + wv * 8 + j < p.rows) dmax = fmaxf(dmax, a);
                 dn[j] = 0.f;
+                if (FUSED) {
+                    float b0 = nn0[j], b1 = nn1[j];
+                    for (int off = 32; off > 0; off >>= 1) { b0 += __shfl_xor(b0, off, 64); b1 += __shfl_xor(b1, off, 64); }
+                    n0max = fmaxf(n0max, b0 * 1.0001f);     // (summation order: K * 2^-24 relative)
+                    n1max = fmaxf(n1max, b1 * 1.0001f);
+                    nn0[j] = nn1[j] = 0.f;
+                }
             }
         }
         g = g2; s = s2; have = have2; ++it;
     }
     unsigned m = __float_as_uint(dmax);
-    if (lane == 0) bmax[wv] = m;        // (uniform over the wave after the reductions)
+    if (lane == 0) { bmax[wv] = m; nbmax[wv] = __float_as_uint(n0max); nbmax[4 + wv] = __float_as_uint(n1max); }   // (wave-uniform)
     __syncthreads();
-    if (threadIdx.x == 0) p.dn_bmax[blockIdx.x] = __uint_as_float(max(max(bmax[0], bmax[1]), max(bmax[2], bmax[3])));
+    if (threadIdx.x == 0) {
+        p.dn_bmax[blockIdx.x] = __uint_as_float(max(max(bmax[0], bmax[1]), max(bmax[2], bmax[3])));
+        if (FUSED) {
+            p.nm_out[blockIdx.x] = __uint_as_float(max(max(nbmax[0], nbmax[1]), max(nbmax[2], nbmax[3])));
+            p.nm_out[gridDim.x + blockIdx.x] = __uint_as_float(max(max(nbmax[4], nbmax[5]), max(nbmax[6], nbmax[7])));
+        }
+    }
 }
 
 // Squared-norm maxima of the rows of one or two tables ([Re | Im] segments of a DOT candidate table) in ONE sweep, any
@@ -1281,6 +1309,10 @@ struct DotPipeParams {
     int64_t zero_n;
     const float *dn_bmax;           // optional [dn_blocks]: block maxima of the candidate table's residuals (kge_lp_dot_table_prep):
     int dn_blocks;                  // folded into *de2max by every block on its way in, stored by block 0
+    const float *nm_bmax;           // optional [2][nm_blocks]: squared-norm maxima per block of kge_lp_dot_table_prep_fused -- folded
+    int nm_blocks;                  // into *emax0 / *emax1 the same way
+    float *prev_nmax;               // optional [2]: the maxima the NEXT one-pass table preparation takes its scale from (stored by
+                                    // block 0); with nm_bmax: the ones THIS table was scaled by -- another scale: *overflow = 1
 };
 
 // thresholds of one DOT query on the one-product level, operand scales s_q (its own) and s_e
@@ -1313,7 +1345,42 @@ __global__ __launch_bounds__(256) void dot_query_pipeline_kernel(const DotPipePa
     const int d = p.d, nseg = CPLX ? 2 : 1, K = nseg * d, kpad = p.units_p * 16;
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.list_count = 0;
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < p.zero_n; j += (int64_t)gridDim.x * 256) p.zero_i32[j] = 0;
-    const float em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
+    float em;
+    if (p.nm_bmax) {        // (as query_pipeline_kernel: block maxima -> the scalars, folded into what they hold)
+        __shared__ unsigned nred[8];
+        unsigned m0 = 0u, m1 = 0u;
+        for (int j = threadIdx.x; j < p.nm_blocks; j += 256) {
+            m0 = max(m0, __float_as_uint(p.nm_bmax[j]));
+            m1 = max(m1, __float_as_uint(p.nm_bmax[p.nm_blocks + j]));
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 = max(m0, (unsigned)__shfl_xor((int)m0, off, 64));
+            m1 = max(m1, (unsigned)__shfl_xor((int)m1, off, 64));
+        }
+        if (lane == 0) { nred[wv] = m0; nred[4 + wv] = m1; }
+        __syncthreads();
+        m0 = max(max(nred[0], nred[1]), max(nred[2], nred[3]));
+        m1 = max(max(nred[4], nred[5]), max(nred[6], nred[7]));
+        const float n0 = __uint_as_float(max(m0, __float_as_uint(*p.emax0)));
+        const float n1 = p.emax1 ? __uint_as_float(max(m1, __float_as_uint(*p.emax1))) : 0.f;
+        em = n0 + n1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *const_cast<float *>(p.emax0) = n0;
+            if (p.emax1) *const_cast<float *>(p.emax1) = n1;
+            if (p.prev_nmax) {
+                // the table was converted under split_scale(prev): thresholds and table agree only under the same scale
+                // (2: not the list -- the caller runs the same path again, now under the maxima stored below)
+                if (split_scale(p.prev_nmax[0] + p.prev_nmax[1]) != split_scale(em)) *p.overflow = 2.0f;
+                p.prev_nmax[0] = n0; p.prev_nmax[1] = n1;
+            }
+        }
+    } else {
+        em = *p.emax0 + (p.emax1 ? *p.emax1 : 0.f);
+        if (p.prev_nmax && blockIdx.x == 0 && threadIdx.x == 0) {
+            p.prev_nmax[0] = *p.emax0;
+            p.prev_nmax[1] = p.emax1 ? *p.emax1 : 0.f;
+        }
+    }
     float de2m;
     if (p.dn_bmax) {
         __shared__ unsigned red[4];
@@ -2352,7 +2419,7 @@ static int hi_rows_impl(const float *X0, int64_t ld0, int K0, const float *X1, i
     p.out = reinterpret_cast<uint4 *>(out);
     p.dn2 = dn2; p.dn2max = dn2max; p.row_index = row_index;
     p.frag = frag;
-    p.nm_bmax = nullptr; p.nm_blocks = 0; p.dn_bmax = nullptr;
+    p.nm_bmax = nullptr; p.nm_blocks = 0; p.dn_bmax = nullptr; p.prev_nmax = nullptr; p.nm_out = nullptr;
     const int64_t blocks = p.rows_p / 16;
     if (blocks == 0) return 0;
     // every block ends with ONE same-address atomic (dn2max), and those serialise at ~20-30 ns each (measured r05 on the
@@ -2413,13 +2480,13 @@ extern "C" int kge_lp_dot_table_prep(const float *X0, int64_t ld0, int K0, const
     p.out = reinterpret_cast<uint4 *>(out);
     p.dn2 = nullptr; p.dn2max = nullptr; p.row_index = nullptr;
     p.frag = frag ? 1 : 0;
-    p.nm_bmax = ws; p.nm_blocks = nb; p.dn_bmax = dn_block_max;
+    p.nm_bmax = ws; p.nm_blocks = nb; p.dn_bmax = dn_block_max; p.prev_nmax = nullptr; p.nm_out = nullptr;
     // fragment-major tables of float4-readable rows: the coalesced kernel (KGE_HIROWS_OLD=1: the general one, for A/B runs)
     static const int old_only = getenv("KGE_HIROWS_OLD") ? atoi(getenv("KGE_HIROWS_OLD")) : 0;
     const bool vec = K0 % 4 == 0 && K1 % 4 == 0 && ld0 % 4 == 0 && ((size_t)X0 & 15) == 0 &&
                      (K1 == 0 || (ld1 % 4 == 0 && ((size_t)X1 & 15) == 0));
     if (frag && vec && !old_only)
-        hipLaunchKernelGGL(hi_rows_frag_kernel, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
+        hipLaunchKernelGGL(hi_rows_frag_kernel<false>, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
     else
         hipLaunchKernelGGL(hi_rows_kernel, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
@@ -2801,6 +2868,38 @@ extern "C" int kge_mfma_f16_selftest(void)
     return 1;
 }
 
+/* The same candidate side in ONE launch and ONE pass over the table (r06): the operand scale is the one the squared-norm
+ * maxima of a PREVIOUS evaluation ask for (prev_nmax[2], device; kge_lp_dot_query_pipeline keeps them), the fragment-major
+ * hi table, its residual maxima per block (dn_block_max) and THIS pass's squared-norm maxima per block
+ * (nm_block_max[2][kge_lp_dot_table_prep_blocks(rows, 1)]) come out; hand both arrays and prev_nmax to
+ * kge_lp_dot_query_pipeline, which folds them, raises *overflow when the table has outgrown (or fallen below) the scale
+ * that was used -- the caller redoes that evaluation on another path -- and stores the new maxima for the next call.
+ * KGE_EINVAL unless the rows are float4-readable (K0, K1, ld % 4 == 0, 16-byte aligned): then kge_lp_dot_table_prep. */
+extern "C" int kge_lp_dot_table_prep_fused(const float *X0, int64_t ld0, int K0, const float *X1, int64_t ld1, int K1,
+                                           int64_t rows, const float *prev_nmax, void *out, float *dn_block_max,
+                                           float *nm_block_max, kge_stream_t stream)
+{
+    if (rows <= 0 || K0 <= 0 || K1 < 0 || ld0 < K0 || (K1 > 0 && ld1 < K1)) return KGE_EINVAL;
+    if (!X0 || (K1 > 0 && !X1) || !prev_nmax || !out || !dn_block_max || !nm_block_max) return KGE_EINVAL;
+    const bool vec = K0 % 4 == 0 && K1 % 4 == 0 && ld0 % 4 == 0 && ((size_t)X0 & 15) == 0 &&
+                     (K1 == 0 || (ld1 % 4 == 0 && ((size_t)X1 & 15) == 0));
+    if (!vec) return KGE_EINVAL;
+    HiRowsParams p;
+    p.X0 = X0; p.X1 = K1 > 0 ? X1 : nullptr; p.ld0 = ld0; p.ld1 = ld1; p.K0 = K0; p.K1 = K1;
+    p.rows = rows;
+    p.rows_p = kge_lp_split_rows_padded(rows, 0);
+    p.aug_mode = 4; p.aug = nullptr; p.aug_mul = 0.f;
+    p.nmax0 = nullptr; p.nmax1 = nullptr;
+    p.units_p = kge_lp_hi_units(K0 + K1);
+    p.out = reinterpret_cast<uint4 *>(out);
+    p.dn2 = nullptr; p.dn2max = nullptr; p.row_index = nullptr;
+    p.frag = 1;
+    p.nm_bmax = nullptr; p.nm_blocks = 0; p.dn_bmax = dn_block_max; p.prev_nmax = prev_nmax; p.nm_out = nm_block_max;
+    hipLaunchKernelGGL(hi_rows_frag_kernel<true>, dim3(kge_lp_dot_table_prep_blocks(rows, 1)), dim3(256), 0, kge_s(stream), p);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 /* TransE-L2 query side of one batch in ONE launch (what kge_lp_prep + kge_row_sqnorm + kge_lp_pair_scores
  * (true scores) + kge_lp_split_rows(queries) + the threshold kernel of kge_lp_split_count do separately),
  * bit-identical outputs.  Q (B,d), qn (B), s_true (B), Qs (split operand), thr (2*Bp floats), *list_count = 0.
@@ -2814,9 +2913,10 @@ extern "C" int kge_lp_dot_query_pipeline(int side, const float *E0, const float 
                                          int accum_model, float eps_scale, float *Q0, float *Q1, float *qn, float *s_true,
                                          void *Qh, float *thr, float *q_dn2, int32_t *list_count, float *overflow,
                                          int32_t *zero_i32, int64_t zero_n, const float *dn_block_max, int dn_blocks,
-                                         kge_stream_t stream)
+                                         const float *nm_block_max, int nm_blocks, float *prev_nmax, kge_stream_t stream)
 {
     if (dn_block_max && dn_blocks <= 0) return KGE_EINVAL;
+    if (nm_block_max && nm_blocks <= 0) return KGE_EINVAL;
     const bool both = side == KGE_SIDE_BOTH, cplx = E1 != nullptr;
     if ((side != KGE_SIDE_TAIL && side != KGE_SIDE_HEAD && !both) || d <= 0 || d > 4096 || B < 0) return KGE_EINVAL;
     if (B == 0) return 0;
@@ -2842,6 +2942,7 @@ extern "C" int kge_lp_dot_query_pipeline(int side, const float *E0, const float 
     p.list_count = list_count; p.overflow = overflow;
     p.zero_i32 = zero_i32; p.zero_n = zero_n;
     p.dn_bmax = dn_block_max; p.dn_blocks = dn_blocks;
+    p.nm_bmax = nm_block_max; p.nm_blocks = nm_blocks; p.prev_nmax = prev_nmax;
     // queries per wavefront: 16 -- or 4 for a small batch (the kernel is a latency chain per group: fewer than two groups of
     // 16 per SIMD leave most of the chip idle while ~400 wavefronts walk 10 chunks each)
     const int qpw = kge_env_int("KGE_DQPIPE_QPW", p.Bp / 16 < 2048 ? 4 : 16);

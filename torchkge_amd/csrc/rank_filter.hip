@@ -1210,5 +1210,5 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 29; }
+extern "C" int kge_abi_version(void) { return 30; }
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -1166,6 +1166,11 @@ class LinkPredictionEvaluator(object):
                 if not worst <= self.model.L2_EXPAND_LIMIT:
                     self.model._expand_ok = False
                     redo = True
+                elif overflow == 2.0 and attempt == 0:
+                    # (r06) not the list: a DOT candidate table converted in one pass under the scale of the PREVIOUS
+                    # evaluation's norm maxima has left that binade (Model._dot_fused_problem).  The query pipeline has stored
+                    # the new maxima: the same path again -- a replay of the same graph -- is consistent now
+                    redo = check_again = True
                 elif overflow > 0 and level_now == 1 and attempt == 0 and getattr(self.model, 'split_level', 0) == 'auto':
                     # the one-product level's wider band overflowed the list: this evaluation again on the three-product
                     # sweep (whose own flags are then checked like a first run's)
@@ -1213,6 +1218,8 @@ class LinkPredictionEvaluator(object):
         self.filt_rank_true_heads, self.filt_rank_true_tails = res[2], res[3]
         self.evaluated = True
         self._n_evaluations += 1
+        # (this evaluation ran twice: guard flag, list overflow, stale table scale)
+        self.__dict__['_last_redo'] = any_redo or self.__dict__.pop('_fast_flagged', False)
         # the next call may replay at once if THIS one was an undisturbed single-GPU replay of the current capture
         self._st._fast = None
         if (FAST_REPLAY and use_graph and key is not None and self._graph_key == key and not kdist.multi(world)
@@ -1253,7 +1260,10 @@ class LinkPredictionEvaluator(object):
         # (the four flag floats straight from the pinned buffer: slicing + view + tolist cost 4 us of GPU idle time per call)
         worst, overflow, rescored, _ = _FLAGS4.unpack(ctypes.string_at(packed.data_ptr() + 8 * (packed.numel() - 2), 16))
         if not worst <= m.L2_EXPAND_LIMIT or overflow > 0:
-            return False        # (norm guard / list overflow: the full path replays, sees the same flags and redoes)
+            # (norm guard / list overflow: the full path replays, sees the same flags and redoes; a stale table scale -- flag
+            # value 2 -- is gone in that replay: the query pipeline has stored the new maxima)
+            self.__dict__['_fast_flagged'] = True
+            return False
         level_now = info['level']
         if n_local > 0:
             lvl_enter, lvl_leave = level1_thresholds(m.n_ent)
@@ -1272,6 +1282,7 @@ class LinkPredictionEvaluator(object):
         # here cost 5 us between two replays)
         self.__dict__['_rank_rows'] = packed.as_strided((4, n_local), (n_local, 1))
         self.__dict__['_rank_set'] = {}
+        self.__dict__['_last_redo'] = False
         self.evaluated = True
         self._n_evaluations += 1
         return True

@@ -133,6 +133,8 @@ def _table_of(cand):
 
 # the DOT models' query side of a batch in one launch (kge_lp_dot_query_pipeline); KGE_DOT_FUSED=0: the separate kernels
 DOT_FUSED = os.environ.get('KGE_DOT_FUSED', '1') == '1'
+# ... and their candidate table in one pass from the second evaluation on (kge_lp_dot_table_prep_fused); KGE_DOT_PREP_ONE_PASS=0: two
+DOT_PREP_ONE_PASS = os.environ.get('KGE_DOT_PREP_ONE_PASS', '1') != '0'
 
 
 class Model(Module):
@@ -406,13 +408,25 @@ class Model(Module):
         # them into guard[1] / guard[5] and leave their residual maxima per block -- folded into guard[7] by every query
         # pipeline launch on its way in (kge_lp_dot_table_prep; the guard vector is zeroed per evaluation)
         srcs = [T0] + ([T1] if T1 is not None else [])
-        Eh, dnb, _ws = self._cache.get('dtp%d_0_%d' % (frag, T0.shape[0]), srcs,
-                                       lambda: _hip.dot_table_prep(T0, T1, g[1:2], nm1, frag))
+        # r06: from the second evaluation on ONE launch and one pass -- the scale of the maxima the previous evaluation's
+        # query pipeline left in `prev`; the pipeline folds this pass's maxima, and a table that has outgrown its scale
+        # raises the overflow flag (that evaluation is redone on three products; the next one finds the new maxima)
+        prev = self.__dict__.get('_lp_dot_prev')
+        if prev is None or prev[0].device != T0.device:
+            prev = [torch.zeros(2, dtype=torch.float32, device=T0.device), None]
+            object.__setattr__(self, '_lp_dot_prev', prev)
+        sig = (T0.data_ptr(), None if T1 is None else T1.data_ptr(), tuple(T0.shape))
+        one_pass = bool(DOT_PREP_ONE_PASS and frag and prev[1] == sig and _hip.dot_table_prep_fusable(T0, T1))
+        ckey = 'dtp%d%d_0_%d' % (frag, one_pass, T0.shape[0])
+        Eh, dnb, ws = self._cache.get(ckey, srcs, lambda: _hip.dot_table_prep(T0, T1, g[1:2], nm1, frag,
+                                                                              prev_nmax=prev[0] if one_pass else None))
+        prev[1] = sig       # (the pipeline below stores this evaluation's maxima there)
         sp = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'level': 1, 'de2max': g[7:8],
               'list_stat': g[6:7], 'es_frag': frag}
         pre = _hip.lp_dot_query_pipeline(sd, T0, T1, rel[0], rel[1] if len(rel) > 1 else None, h_idx, t_idx, r_idx,
                                          sp['enmax'], nm1, sp['de2max'], g[0:1], sp['overflow'], zero_counts=True,
-                                         dn_bmax=dnb, regions=bool(frag) and bool(getattr(self, '_lp_regions', False)))
+                                         dn_bmax=dnb, regions=bool(frag) and bool(getattr(self, '_lp_regions', False)),
+                                         nm_bmax=ws if one_pass else None, prev_nmax=prev[0])
         pre['true_idx'] = t_idx if sd == _hip.SIDE_TAIL else (h_idx if sd == _hip.SIDE_HEAD else None)
         prob = _hip.LpProblem(_hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
         prob.split = sp
