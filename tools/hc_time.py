@@ -61,7 +61,7 @@ tables = {}
 
 
 def split_for(variant):
-    if variant in ('hc3', 'hc4', 'lv1'):
+    if variant in ('hc3', 'hc4', 'lv1', 'hs', 'hs3', 'hs4'):
         frag = variant != 'lv1'
         key = 'hi%d' % frag
         if key not in tables:
@@ -76,8 +76,13 @@ def split_for(variant):
 
 
 for variant in VARIANTS:
+    os.environ.pop('KGE_HC_FORCE', None)    # 'hs': the resident-panel free-running kernel (rows <= 32 units)
+    os.environ.pop('KGE_HS_NT', None)
+    if variant in ('hs3', 'hs4'):           # ... with 96- / 128-query panels
+        os.environ['KGE_HS_NT'] = variant[2]
     if variant in ('hc3', 'hc4'):
         os.environ['KGE_HC_NT'] = variant[2]
+        os.environ['KGE_HC_FORCE'] = '1'
     guard[2] = 0
     prob.split = split_for(variant)
     prep = prob.split_prepare()

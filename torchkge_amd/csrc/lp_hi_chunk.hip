@@ -22,6 +22,7 @@
 //
 // Epilogue, uncertain-pair lists, work order: lp_hi_stream.hip's (PM = 0, one global list).
 #include "kge_common.h"
+#include <type_traits>
 #ifndef KGE_BUILD_NO_SLP
 #error "build with -fno-slp-vectorize -DKGE_BUILD_NO_SLP=1 (torchkge_amd/csrc/build.py): SLP-packed v_pk_fma_f32 with a lane-crossing op_sel misreads beside co-executing MFMAs (profiles/r06/slp_bisect.txt)"
 #endif
@@ -222,6 +223,10 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_chunk_kernel(const kge_hi_st
 
         // ---- the K sweep of one wave tile, fully unrolled: per unit NT x 2 MFMAs, NT ds_read_b128 (queries of the next
         // unit), 2 global loads (candidates RING - 1 units ahead), at most one staging load and one staging store
+        // RESTAGE = false (rows of ONE chunk only, NCH == 1: the panel is RESIDENT in its slot): the next item sweeps the same
+        // panel -- no staging, no barrier, no slot change; the waves of the block run free across items as in lp_hi_stream.hip
+        auto sweep = [&](auto rs_tag) __attribute__((always_inline)) {
+        constexpr bool RESTAGE = decltype(rs_tag)::value;
 #pragma unroll
         for (int g = 0; g < UNITS; ++g) {
             const int c = g / CU, uc = g - c * CU;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_chunk_kernel(const kge_hi_st
             const bool last_in_chunk = uc == cuc - 1;
             const int cn = c + 1 < NCH ? c + 1 : 0;                 // the chunk being staged
             const int cucn = cn == NCH - 1 ? CUL : CU;
-            if (last_in_chunk) {
+            if (last_in_chunk && RESTAGE) {
                 // slot cur ^ 1 is complete (every thread's stores), slot cur has been read for the last time (the fragments
                 // of this unit were fetched one unit ago): hand over
                 __syncthreads();
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_chunk_kernel(const kge_hi_st
                 st_nxt = (2 * st_lane + BUFB) - st_nxt;
             }
             const bool has_B = g + 1 < UNITS, has_A = g + PF < UNITS;
-            const bool st_w = !last_in_chunk && uc >= 2 && uc - 2 < S, st_r = !last_in_chunk && uc < S;
+            const bool st_w = RESTAGE && !last_in_chunk && uc >= 2 && uc - 2 < S, st_r = RESTAGE && !last_in_chunk && uc < S;
             const int un = last_in_chunk ? 0 : uc + 1;              // unit g + 1 inside ITS chunk (slot `cur` after the hand-over)
             if (BDB == 2) {
                 if (has_B) load_B(Bf[(g + 1) & 1], un);
@@ -293,6 +298,9 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_chunk_kernel(const kge_hi_st
                 }
             }
         }
+        };
+        if (NCH > 1 || qp_next != qp_cur) sweep(std::true_type{});
+        else sweep(std::false_type{});
 
         // ---- the next item: its first candidate fragments fly under this tile's epilogue; its chunk 0 sits in slot cur
         bool act_next;
@@ -391,7 +399,7 @@ int hc_launch(const kge_hi_stream_params &p, int grid, hipStream_t s)
 } // namespace
 
 // k16 units the chunked kernel is instantiated for (beyond kge_hi_stream_max_units())
-int kge_hi_chunk_supported(int units) { return units == 65 || units == 33 || units == 26; }
+int kge_hi_chunk_supported(int units) { return units == 65 || units == 33 || units == 26 || units == 13; }
 
 int kge_hi_chunk_query_rows(int units)
 {
@@ -429,6 +437,11 @@ int kge_hi_chunk_launch(kge_hi_stream_params p, int num_cus, hipStream_t s)
     if (p.units == 65) {
         if (nt == 3) return hc_launch<8, 3, 65, 13, 6, 2>(p, grid, s);
         return hc_launch<8, 4, 65, 13, 4, 1>(p, grid, s);
+    }
+    if (p.units == 13) {        // (K <= 206: ONE chunk = a RESIDENT 96 / 128-query panel; an experiment against lp_hi_stream.hip's
+                                //  two workgroups of four waves per CU, KGE_HC_FORCE=1)
+        if (nt == 3) return hc_launch<8, 3, 13, 13, 6, 2>(p, grid, s);
+        return hc_launch<8, 4, 13, 13, 4, 1>(p, grid, s);
     }
     if (p.units == 26) {        // (K = 400: an experiment against the resident-panel kernel, KGE_HC_FORCE=1)
         if (nt == 3) return hc_launch<8, 3, 26, 13, 6, 2>(p, grid, s);

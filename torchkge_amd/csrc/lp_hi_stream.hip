@@ -52,10 +52,14 @@ constexpr int HS_PF = 3, HS_RING = 4;           // candidate fragments: units in
 // GS > 0 (r06; PM = 0 only): the panel's 96 rows are GROUPED columns -- one query row shared by up to GS queries of the same key
 // (p.members[column * GS + s], < 0: unused), which differ only in their thresholds: the matrix sweep runs once per column,
 // the compare epilogue once per member (thresholds, per-member counters and the sub-tiles' pass counts live in LDS).
-template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM, int PROBE = 0, int GS = 0>
+// NT (r06): 32-query sub-tiles per panel -- 3 (96 queries, 96 accumulator VGPRs) or 4 (128 queries, 128 accumulators: every
+// candidate fragment feeds four MFMAs instead of three; PM = 0, GS = 0 only)
+template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM, int PROBE = 0, int GS = 0, int NT = 3>
 __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_stream_params p)
 {
     static_assert(GS == 0 || PM == 0, "grouped columns: plain thresholds only");
+    static_assert(NT == 3 || (NT == 4 && PM == 0 && GS == 0), "128-query panels: plain thresholds, one query per column");
+    constexpr int TQn = 32 * NT, SUBn = HS_WLIST / NT;
     constexpr int NTHREADS = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int units = UNITS ? UNITS : p.units;
@@ -65,11 +69,11 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     char *panel = smem;
     int2 *wlist = reinterpret_cast<int2 *>(smem + p.panel_bytes) + wid * HS_WLIST;
     float4 *pthr = reinterpret_cast<float4 *>(smem + p.panel_bytes + NW * HS_WLIST * 8);     // PM: per query of the panel
-    int *prow = reinterpret_cast<int *>(pthr + HS_TQ);
+    int *prow = reinterpret_cast<int *>(pthr + TQn);
     // GS: per (column, member) (a_lo, a_hi, query id, its true candidate) and the member's count of this panel's sweep
     [[maybe_unused]] float4 *mthr = pthr;
-    [[maybe_unused]] int *mcnt = reinterpret_cast<int *>(mthr + HS_TQ * (GS > 0 ? GS : 1));
-    [[maybe_unused]] int npass[HS_NT] = {0, 0, 0};                                   // GS: compare passes of a sub-tile = its fullest column's members
+    [[maybe_unused]] int *mcnt = reinterpret_cast<int *>(mthr + TQn * (GS > 0 ? GS : 1));
+    [[maybe_unused]] int npass[NT] = {};                                   // GS: compare passes of a sub-tile = its fullest column's members
 
     // work order: as lp_split_count_kernel -- QG panels interleaved under a sweep of the candidate tiles, XCD x owns an
     // eighth of the item list, its blocks take stride-nbx positions (nbx a multiple of QG: a block keeps its panel)
@@ -124,15 +128,15 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     };
     const unsigned lane16 = lane * 16;
 
-    f32x16 acc[HS_MT][HS_NT];
-    f16x8 A[HS_RING][HS_MT], Bf[2][HS_NT];
-    int cnt[HS_NT] = {0, 0, 0};
-    float alo[HS_NT], ahi[HS_NT];
-    int qid[HS_NT], tru[HS_NT];                                     // query id / its true candidate (local index; -1: none)
+    f32x16 acc[HS_MT][NT];
+    f16x8 A[HS_RING][HS_MT], Bf[2][NT];
+    int cnt[NT] = {};
+    float alo[NT], ahi[NT];
+    int qid[NT], tru[NT];                                     // query id / its true candidate (local index; -1: none)
     // This wave's LDS list: one sub-list per 32-query sub-tile of the panel (wave-uniform fill counts).  Flushed into the
     // global list -- or, with p.region_count, into the REGION of (panel, sub-tile): the exact recheck then takes a region
     // at a time with the sub-tile's 32 query rows resident in LDS (kge_lp_split_recheck_regions: half the row fetches).
-    int nl[HS_NT] = {0, 0, 0};
+    int nl[NT] = {};
 
     auto flush_sub = [&](int nt, int qp) __attribute__((always_inline)) {
         if (nl[nt] > 0) {
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
             int2 *dst = reinterpret_cast<int2 *>(p.list);
             unsigned lim = (unsigned)p.cap;
             if (p.region_count) {
-                const int reg = qp * HS_NT + nt;
+                const int reg = qp * NT + nt;
                 ctr = p.region_count + reg;
                 dst += (int64_t)reg * p.region_cap;
                 lim = (unsigned)p.region_cap;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
             base = __builtin_amdgcn_readfirstlane(base);
             for (int i = lane; i < nl[nt]; i += 64) {
                 const int pos = base + i;
-                if ((unsigned)pos < lim) dst[pos] = wlist[nt * HS_SUBLIST + i];
+                if ((unsigned)pos < lim) dst[pos] = wlist[nt * SUBn + i];
                 else *p.overflow = 1.0f;
             }
             nl[nt] = 0;
@@ -160,14 +164,15 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     auto load_panel = [&](int64_t q0) __attribute__((always_inline)) {
         // rows of the planar query operand -> LDS rows of stride RS
         const int cpr = 2 * units;                                  // 16-byte chunks per row
-        const int total = HS_TQ * cpr;
+        const int total = TQn * cpr;
         for (int n = tid; n < total; n += NTHREADS) {
             const int row = n / cpr, c = n - row * cpr;
-            const uint4 v = *reinterpret_cast<const uint4 *>(p.Qh + (q0 + row) * p.q_row_bytes + c * 16);
+            // (a 128-query panel may reach past the operand's rows, padded to 96s: its last row again -- thresholds +inf)
+            const uint4 v = *reinterpret_cast<const uint4 *>(p.Qh + min(q0 + row, p.q_rows - 1) * p.q_row_bytes + c * 16);
             *reinterpret_cast<uint4 *>(panel + row * RS + c * 16) = v;
         }
         if (PM) {
-            if (tid < HS_TQ) {
+            if (tid < TQn) {
                 const int64_t q = p.col_q ? (int64_t)p.col_q[q0 + tid] : q0 + tid;
                 // (p_i, z_i) pre-multiplied by -2^23, the accumulators' scale (exact): the epilogue's projection term is then two
                 // FMAs per element, v + x (x z' + p'), instead of fma, mul, fma (r06; one rounding fewer than before -- inside the
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         if constexpr (GS > 0) {
             // (called between two block barriers: thread idx owns entry idx of mthr / mcnt -- the previous panel's counts
             // leave through it before the entry is rewritten)
-            for (int idx = tid; idx < HS_TQ * GS; idx += NTHREADS) {
+            for (int idx = tid; idx < TQn * GS; idx += NTHREADS) {
                 if (!first_panel) {
                     const int c = mcnt[idx], oq = __float_as_int(mthr[idx].z);
                     if (c != 0 && oq >= 0) atomicAdd(&p.raw_count[oq], c);
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                 mcnt[idx] = 0;
             }
 #pragma unroll
-            for (int nt = 0; nt < HS_NT; ++nt) {    // members of this lane's column -> the sub-tile's maximum (wave-uniform)
+            for (int nt = 0; nt < NT; ++nt) {    // members of this lane's column -> the sub-tile's maximum (wave-uniform)
                 const int64_t col = q0 + nt * 32 + l31;
                 int m = 0;
                 if (col < p.q_rows) {
@@ -217,9 +222,10 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
             return;
         }
 #pragma unroll
-        for (int nt = 0; nt < HS_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             const int64_t col = q0 + nt * 32 + l31;
-            int64_t q = p.col_q ? (int64_t)p.col_q[col] : col;
+            int64_t q = -1;
+            if (col < p.q_rows) q = p.col_q ? (int64_t)p.col_q[col] : col;
             if (q >= p.B) q = -1;
             float2 t = make_float2(INFINITY, INFINITY);
             if (q >= 0) {
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     auto flush_counts = [&]() __attribute__((always_inline)) {
         if constexpr (GS > 0) return;       // (grouped columns count in LDS: mcnt, flushed by load_panel / at the end)
 #pragma unroll
-        for (int nt = 0; nt < HS_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             const int v = cnt[nt] + __shfl_xor(cnt[nt], 32, 64);
             if (half == 0 && v != 0 && qid[nt] >= 0) atomicAdd(&p.raw_count[qid[nt]], v);
             cnt[nt] = 0;
@@ -244,9 +250,9 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
 
     // fragment addresses inside the panel: row nt * 32 + l31, unit u, k-half `half`
     const unsigned b_lane = (unsigned)(l31 * RS + half * 16);
-    auto load_B = [&](f16x8 (&dst)[HS_NT], int u) __attribute__((always_inline)) {
+    auto load_B = [&](f16x8 (&dst)[NT], int u) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nt = 0; nt < HS_NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
             dst[nt] = *reinterpret_cast<const f16x8 *>(panel + b_lane + nt * 32 * RS + u * 32);
     };
     auto load_A = [&](f16x8 (&dst)[HS_MT], const char *tp, int u) __attribute__((always_inline)) {
@@ -258,16 +264,18 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     // the one global list: the three sub-lists behind ONE atomic (a returning same-address atomic per sub-list tripled the
     // waves' stalls: 0.50 -> 0.55 ms per evaluate, profiles/r05/region_recheck_ab.txt)
     auto flush_all = [&]() __attribute__((always_inline)) {
-        const int total = nl[0] + nl[1] + nl[2];
+        int total = 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) total += nl[nt];
         if (total > 0) {
             int base = 0;
             if (lane == 0) base = atomicAdd(p.list_count, total);
             base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-            for (int nt = 0; nt < HS_NT; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 for (int i = lane; i < nl[nt]; i += 64) {
                     const int pos = base + i;
-                    if ((unsigned)pos < (unsigned)p.cap) reinterpret_cast<int2 *>(p.list)[pos] = wlist[nt * HS_SUBLIST + i];
+                    if ((unsigned)pos < (unsigned)p.cap) reinterpret_cast<int2 *>(p.list)[pos] = wlist[nt * SUBn + i];
                     else *p.overflow = 1.0f;
                 }
                 base += nl[nt];
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
 
     int qp_cur, ct_cur;
     item_qp_ct(0, qp_cur, ct_cur);
-    int64_t cur_q0 = (int64_t)qp_cur * HS_TQ;
+    int64_t cur_q0 = (int64_t)qp_cur * TQn;
     load_panel(cur_q0);
     bool act_cur;
     const char *tp_cur = tile_ptr(ct_cur, act_cur);
@@ -305,40 +313,40 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
 #pragma unroll
                         for (int mt = 0; mt < HS_MT; ++mt)
 #pragma unroll
-                            for (int nt = 0; nt < HS_NT; ++nt) acc[mt][nt] = zero16;
+                            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16;
                     }
                     // (keep the loads alive)
 #pragma unroll
                     for (int mt = 0; mt < HS_MT; ++mt) acc[mt][0][0] += (float)A[u % HS_RING][mt][0];
 #pragma unroll
-                    for (int nt = 0; nt < HS_NT; ++nt) acc[0][nt][1] += (float)Bf[u & 1][nt][0];
+                    for (int nt = 0; nt < NT; ++nt) acc[0][nt][1] += (float)Bf[u & 1][nt][0];
                     continue;
                 }
 #pragma unroll
                 for (int mt = 0; mt < HS_MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < HS_NT; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[u % HS_RING][mt], Bf[u & 1][nt],
                                                                             u == 0 ? zero16 : acc[mt][nt], 0, 0, 0);
-                // interleave: one load behind each of the first five MFMAs of the unit
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                // interleave: one load behind each of the first NT + 2 MFMAs of the unit (NT query fragments, 2 candidate loads)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+                for (int i = 0; i < NT - 2; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         } else {
             // any number of units: a runtime loop over groups of four (the ring's period), guards on the tail
 #pragma unroll
             for (int mt = 0; mt < HS_MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < HS_NT; ++nt) acc[mt][nt] = zero16;
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16;
             for (int u0 = 0; u0 < units; u0 += HS_RING) {
 #pragma unroll
                 for (int j = 0; j < HS_RING; ++j) {
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
 #pragma unroll
                         for (int mt = 0; mt < HS_MT; ++mt)
 #pragma unroll
-                            for (int nt = 0; nt < HS_NT; ++nt)
+                            for (int nt = 0; nt < NT; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[j][mt], Bf[j & 1][nt], acc[mt][nt], 0, 0, 0);
                     }
                 }
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                 int cl_base = 4 * half;
                 asm volatile("" : "+v"(cl_base));
 #pragma unroll
-                for (int nt = 0; nt < HS_NT; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     for (int s = 0; s < npass[nt]; ++s) {
                         const float4 t4 = mthr[(nt * 32 + l31) * GS + s];
                         const float lo_n = t4.x;
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                                             if (m) {
                                                 const int pos = nl[nt] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                                if (unc && pos < HS_SUBLIST) wlist[nt * HS_SUBLIST + pos] = make_int2(qid_s, cand);
+                                                if (unc && pos < SUBn) wlist[nt * SUBn + pos] = make_int2(qid_s, cand);
                                                 nl[nt] += __popcll(m);
                                             }
                                         }
@@ -421,10 +429,10 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                         const int c = 32 - __popc(smask);
                         if (c != 0 && qid_s >= 0) atomicAdd(&mcnt[(nt * 32 + l31) * GS + s], c);
                         // (a sub-list that fills up inside the member loop leaves at once: up to GS passes append to it per tile)
-                        if (nl[nt] >= HS_SUBLIST / 2) {
-                            if (nl[nt] > HS_SUBLIST) {
+                        if (nl[nt] >= SUBn / 2) {
+                            if (nl[nt] > SUBn) {
                                 if (lane == 0) *p.overflow = 1.0f;
-                                nl[nt] = HS_SUBLIST;
+                                nl[nt] = SUBn;
                             }
                             flush_all();
                         }
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
             int cl_base = 4 * half;
             asm volatile("" : "+v"(cl_base));
 #pragma unroll
-            for (int nt = 0; nt < HS_NT; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 float lo_n = alo[nt], hi_n = ahi[nt], p_n = 0.f, z_n = 0.f;
                 const float *xrow = nullptr;
                 if (PM) {
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
                                     if (m) {
                                         const int pos = nl[nt] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                                                            __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                        if (unc && pos < HS_SUBLIST) wlist[nt * HS_SUBLIST + pos] = make_int2(qid[nt], cand);
+                                        if (unc && pos < SUBn) wlist[nt * SUBn + pos] = make_int2(qid[nt], cand);
                                         nl[nt] += __popcll(m);
                                     }
                                 }
@@ -535,30 +543,33 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
 #pragma unroll
             for (int mt = 0; mt < HS_MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < HS_NT; ++nt) cnt[nt] += __float_as_int(acc[mt][nt][5]) & 1;
+                for (int nt = 0; nt < NT; ++nt) cnt[nt] += __float_as_int(acc[mt][nt][5]) & 1;
         }
         // the list buffer: a tile that outran it raises the overflow flag (the caller redoes the count on the next level down);
         // flushed while >= 2/3 of it is free for the next tile (a density of 4 % of the tile's pairs: UNC_CAP's)
 #pragma unroll
-        for (int nt = 0; nt < HS_NT; ++nt) {
-            if (nl[nt] > HS_SUBLIST) {
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nl[nt] > SUBn) {
                 if (lane == 0) *p.overflow = 1.0f;
-                nl[nt] = HS_SUBLIST;
+                nl[nt] = SUBn;
             }
         }
         if (p.region_count) {
 #pragma unroll
-            for (int nt = 0; nt < HS_NT; ++nt)
-                if (nl[nt] >= HS_SUBLIST / 3 || switching) flush_sub(nt, qp_cur);   // (a region belongs to ONE panel)
-        } else if (max(max(nl[0], nl[1]), nl[2]) >= HS_SUBLIST / 3) {
-            flush_all();
+            for (int nt = 0; nt < NT; ++nt)
+                if (nl[nt] >= SUBn / 3 || switching) flush_sub(nt, qp_cur);   // (a region belongs to ONE panel)
+        } else {
+            int nl_max = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) nl_max = max(nl_max, nl[nt]);
+            if (nl_max >= SUBn / 3) flush_all();
         }
 
         // ---- query panel change (block-uniform): the only block-wide synchronisation of the sweep
         if (switching) {
             flush_counts();
             __syncthreads();                    // every wave is done reading the old panel
-            cur_q0 = (int64_t)qp_next * HS_TQ;
+            cur_q0 = (int64_t)qp_next * TQn;
             load_panel(cur_q0);
             __syncthreads();
             load_B(Bf[0], 0);
@@ -568,25 +579,26 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
     flush_counts();
     if constexpr (GS > 0) {
         __syncthreads();        // every wave's LDS counts of the last panel are in
-        for (int idx = tid; idx < HS_TQ * GS; idx += NTHREADS) {
+        for (int idx = tid; idx < TQn * GS; idx += NTHREADS) {
             const int c = mcnt[idx], oq = __float_as_int(mthr[idx].z);
             if (c != 0 && oq >= 0) atomicAdd(&p.raw_count[oq], c);
         }
     }
     if (p.region_count) {
 #pragma unroll
-        for (int nt = 0; nt < HS_NT; ++nt) flush_sub(nt, qp_cur);
+        for (int nt = 0; nt < NT; ++nt) flush_sub(nt, qp_cur);
     } else {
         flush_all();
     }
 }
 
+constexpr int HS_NT_DEFAULT = 4;
 constexpr int HS_GS = 4;        // queries per grouped column (= kge_lp_split_group_sets(), the layout of kge_split_args.members)
 
-template <int NW, int UNITS, int PM, int PROBE = 0, int GS = 0>
+template <int NW, int UNITS, int PM, int PROBE = 0, int GS = 0, int NT = 3>
 int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 {
-    auto k = lp_hi_stream_kernel<NW, UNITS, PM, PROBE, GS>;
+    auto k = lp_hi_stream_kernel<NW, UNITS, PM, PROBE, GS, NT>;
     static int attr_dev[16];    // per instantiation, per device
     if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr_dev)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, p);
@@ -595,8 +607,15 @@ int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 }
 
 template <int NW, int PM>
-int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
+int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, int nt, hipStream_t s)
 {
+    if (nt == 4) {              // 128-query panels (kge_hi_stream_launch: PM = 0, one query per column, 13 / 26 units)
+        if constexpr (PM == 0) {
+            if (p.units == 13) return hs_launch<NW, 13, 0, 0, 0, 4>(p, grid, smem, s);
+            if (p.units == 26) return hs_launch<NW, 26, 0, 0, 0, 4>(p, grid, smem, s);
+        }
+        return KGE_EUNSUPPORTED;
+    }
     if (NW == 4 && PM == 0 && p.units == 13 && !p.members) {
         switch (kge_env_int("KGE_HS_PROBE", 0)) {
         case 1: return hs_launch<4, 13, 0, 1>(p, grid, smem, s);
@@ -636,9 +655,14 @@ int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_
     if (p.units <= 0 || p.units > 32 || p.rows_p % 64 != 0 || p.rows_p < 64) return KGE_EINVAL;
     if (p.members && (pm != 0 || p.col_q || p.region_count)) return KGE_EINVAL;
     const int RS = p.units * 32 + 16;
-    p.panel_bytes = (HS_TQ * RS + 15) / 16 * 16;
+    // (r06) 128-query panels where they are instantiated: every candidate fragment feeds four MFMAs instead of three
+    // (KGE_HS_NT=3: the 96-query panels of r05)
+    const int nt = (pm == 0 && !p.members && (p.units == 13 || p.units == 26) && kge_env_int("KGE_HS_NT", HS_NT_DEFAULT) == 4 &&
+                    kge_env_int("KGE_HS_PROBE", 0) == 0) ? 4 : 3;
+    const int tq = 32 * nt;
+    p.panel_bytes = (tq * RS + 15) / 16 * 16;
     // two 4-wave workgroups per CU while two panels (+ lists) fit the LDS; else one 8-wave workgroup
-    const int extra = p.members ? HS_TQ * HS_GS * 20 : HS_TQ * 20;
+    const int extra = p.members ? HS_TQ * HS_GS * 20 : tq * 20;
     const int smem4 = p.panel_bytes + 4 * HS_WLIST * 8 + extra, smem8 = p.panel_bytes + 8 * HS_WLIST * 8 + extra;
     int nw = 2 * smem4 <= 160 * 1024 - 2048 ? 4 : 8;
     const int force = kge_env_int("KGE_HS_WAVES", 0);
@@ -646,7 +670,7 @@ int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_
     if (force == 8) nw = 8;
     if (nw == 8 && smem8 > 160 * 1024) return KGE_EUNSUPPORTED;
     const int tile_rows = nw * HS_WROWS;
-    p.q_panels = (int)((p.q_rows + HS_TQ - 1) / HS_TQ);
+    p.q_panels = (int)((p.q_rows + tq - 1) / tq);
     p.c_tiles = (int)((p.rows_p + tile_rows - 1) / tile_rows);
     p.n_items = (int64_t)p.q_panels * p.c_tiles;
     if (p.n_items == 0) return 0;
@@ -665,11 +689,11 @@ int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_
     }
     const int smem = nw == 4 ? smem4 : smem8;
     if (nw == 4) {
-        if (pm == 1) return hs_dispatch_units<4, 1>(p, grid, smem, s);
-        if (pm == 2) return hs_dispatch_units<4, 2>(p, grid, smem, s);
-        return hs_dispatch_units<4, 0>(p, grid, smem, s);
+        if (pm == 1) return hs_dispatch_units<4, 1>(p, grid, smem, nt, s);
+        if (pm == 2) return hs_dispatch_units<4, 2>(p, grid, smem, nt, s);
+        return hs_dispatch_units<4, 0>(p, grid, smem, nt, s);
     }
-    if (pm == 1) return hs_dispatch_units<8, 1>(p, grid, smem, s);
-    if (pm == 2) return hs_dispatch_units<8, 2>(p, grid, smem, s);
-    return hs_dispatch_units<8, 0>(p, grid, smem, s);
+    if (pm == 1) return hs_dispatch_units<8, 1>(p, grid, smem, nt, s);
+    if (pm == 2) return hs_dispatch_units<8, 2>(p, grid, smem, nt, s);
+    return hs_dispatch_units<8, 0>(p, grid, smem, nt, s);
 }
