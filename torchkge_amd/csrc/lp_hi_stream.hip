@@ -58,7 +58,7 @@ template <int NW, int UNITS /* 0: runtime (<= 32) */, int PM, int PROBE = 0, int
 __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_stream_params p)
 {
     static_assert(GS == 0 || PM == 0, "grouped columns: plain thresholds only");
-    static_assert(NT == 3 || (NT == 4 && PM == 0 && GS == 0), "128-query panels: plain thresholds, one query per column");
+    static_assert(NT == 3 || (NT == 4 && GS == 0), "128-query panels: one query per column");
     constexpr int TQn = 32 * NT, SUBn = HS_WLIST / NT;
     constexpr int NTHREADS = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(64 * NW, 2) void lp_hi_stream_kernel(const kge_hi_s
         }
         if (PM) {
             if (tid < TQn) {
-                const int64_t q = p.col_q ? (int64_t)p.col_q[q0 + tid] : q0 + tid;
+                int64_t q = -1;
+                if (q0 + tid < p.q_rows) q = p.col_q ? (int64_t)p.col_q[q0 + tid] : q0 + tid;
                 // (p_i, z_i) pre-multiplied by -2^23, the accumulators' scale (exact): the epilogue's projection term is then two
                 // FMAs per element, v + x (x z' + p'), instead of fma, mul, fma (r06; one rounding fewer than before -- inside the
                 // band's 9 x 2^-22 allowance for this term either way)
@@ -609,10 +610,11 @@ int hs_launch(const kge_hi_stream_params &p, int grid, int smem, hipStream_t s)
 template <int NW, int PM>
 int hs_dispatch_units(const kge_hi_stream_params &p, int grid, int smem, int nt, hipStream_t s)
 {
-    if (nt == 4) {              // 128-query panels (kge_hi_stream_launch: PM = 0, one query per column, 13 / 26 units)
+    if (nt == 4) {              // 128-query panels (kge_hi_stream_launch: PM = 0, one query per column)
+        if (p.units == 13) return hs_launch<NW, 13, PM, 0, 0, 4>(p, grid, smem, s);
         if constexpr (PM == 0) {
-            if (p.units == 13) return hs_launch<NW, 13, 0, 0, 0, 4>(p, grid, smem, s);
             if (p.units == 26) return hs_launch<NW, 26, 0, 0, 0, 4>(p, grid, smem, s);
+            return hs_launch<NW, 0, 0, 0, 0, 4>(p, grid, smem, s);
         }
         return KGE_EUNSUPPORTED;
     }
@@ -655,10 +657,11 @@ int kge_hi_stream_launch(kge_hi_stream_params p, int pm, int num_cus, hipStream_
     if (p.units <= 0 || p.units > 32 || p.rows_p % 64 != 0 || p.rows_p < 64) return KGE_EINVAL;
     if (p.members && (pm != 0 || p.col_q || p.region_count)) return KGE_EINVAL;
     const int RS = p.units * 32 + 16;
-    // (r06) 128-query panels where they are instantiated: every candidate fragment feeds four MFMAs instead of three
+    // (r06) 128-query panels for plain thresholds, one query per column: every candidate fragment feeds four MFMAs instead of three
     // (KGE_HS_NT=3: the 96-query panels of r05)
-    const int nt = (pm == 0 && !p.members && (p.units == 13 || p.units == 26) && kge_env_int("KGE_HS_NT", HS_NT_DEFAULT) == 4 &&
-                    kge_env_int("KGE_HS_PROBE", 0) == 0) ? 4 : 3;
+    const int nt = ((pm == 0 || (p.units == 13 && kge_env_int("KGE_HS_NT_PM", 0))) && !p.members &&
+                    kge_env_int("KGE_HS_NT", HS_NT_DEFAULT) == 4 && kge_env_int("KGE_HS_PROBE", 0) == 0 &&
+                    128 * RS + 8 * HS_WLIST * 8 + 128 * 20 <= 160 * 1024) ? 4 : 3;
     const int tq = 32 * nt;
     p.panel_bytes = (tq * RS + 15) / 16 * 16;
     // two 4-wave workgroups per CU while two panels (+ lists) fit the LDS; else one 8-wave workgroup
