@@ -1060,7 +1060,7 @@ def main():
             alg_flops, exec_flops = 2 * K, (1 if level == 1 else 3) * 2 * k16
             stream = bool(prob.split.get('es_frag'))    # r05: the free-running one-product kernel (lp_hi_stream.hip)
             kname = ('lp_hi_stream_kernel (one-product level, r05: ONE v_mfma_f32_32x32x16_f16 product per k16 unit on f16 hi '
-                     'operands, fp32 accumulate; resident 96-query panel in LDS, candidate fragments straight from the '
+                     'operands, fp32 accumulate; resident 128-query panel in LDS (r06; projection epilogues: 96), candidate fragments straight from the '
                      'fragment-major table into registers, no block-wide barriers in the tile loop; band from the measured f16 '
                      'residuals)') if (level == 1 and stream) else \
                 ('lp_split_count_kernel, LV = 1 (f16 hi operands, ONE v_mfma_f32_32x32x16_f16 product per k16 unit, fp32 '
