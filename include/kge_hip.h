@@ -337,7 +337,15 @@ int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t
                            behind the ranks by the same launch) */,
                            int zero_guard /* with flags: the 8 guard floats are zeroed after they were read -- the next
                            evaluation finds them clean and needs no fill of its own */,
+                           int64_t *const *out_indirect /* optional (ABI 31): the result matrix of THIS launch is *out_indirect,
+                           read on the device when the launch runs -- a replayed hipGraph writes where the host pointed it
+                           before the replay; `out` is then ignored and the flags go behind the four rows (out + 4 ld).
+                           Meant for PINNED HOST memory (kge_host_device_pointer): the ranks reach the host without a copy
+                           of their own */,
                            kge_stream_t stream);
+/* *dev = the device-visible address of pinned host memory (hipHostMalloc / hipHostRegister; torch's pinned tensors);
+ * KGE_EINVAL when it is not mapped into the device's address space. */
+int kge_host_device_pointer(void *host, void **dev);
 
 /* generic: every query has its own candidate matrix cand[i] (N,K) at
  * cand + i*stride_b (stride_b = 0: shared), rows at stride_n.

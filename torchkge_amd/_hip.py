@@ -123,7 +123,8 @@ _SIGNATURES = {
     'kge_lp_filter_sub_planned': [ctypes.POINTER(LpDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                                   _vp, _vp],
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
-    'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp],
+    'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp],
+    'kge_host_device_pointer': [_vp, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
     'kge_get_rank': [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     'kge_filter_lookup': [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -148,7 +149,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 30        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 31        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -1298,9 +1299,11 @@ def rank_finalize(raw, sub, found):
     return rank, filt
 
 
-def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=None, zero_guard=False):
+def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=None, zero_guard=False, indirect=None):
     """kge_rank_finalize_both: the ranks of a 2B-query batch into the (4, n) int64 result matrix
-    `out` (rows: head raw, tail raw, head filtered, tail filtered) at columns off .. off + B - 1."""
+    `out` (rows: head raw, tail raw, head filtered, tail filtered) at columns off .. off + B - 1.
+    ``indirect`` (r06): address of a device-visible int64 holding the address of the result matrix of THIS launch (pinned host
+    memory: host_device_pointer) -- `out` then only gives the shape, the flags go behind the four rows."""
     lib = load_library()
     require_cuda(raw, out)
     B = raw.shape[0] // 2
@@ -1309,9 +1312,19 @@ def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=No
     with _on(raw.device):
         _check(lib.kge_rank_finalize_both(_p(raw), _p(sub), _p(found), B, _p(out), out.stride(0), off, _p(pos),
                                           _p(guard if flags is not None else None), _p(flags),
-                                          1 if (zero_guard and flags is not None) else 0, _stream()),
+                                          1 if (zero_guard and flags is not None) else 0,
+                                          ctypes.c_void_p(int(indirect)) if indirect else None, _stream()),
                'kge_rank_finalize_both')
     return out
+
+
+def host_device_pointer(t):
+    """Device-visible address of a PINNED host tensor (kge_host_device_pointer); None when it is not mapped."""
+    lib = load_library()
+    dev = ctypes.c_void_p()
+    if lib.kge_host_device_pointer(ctypes.c_void_p(t.data_ptr()), ctypes.byref(dev)) != 0 or not dev.value:
+        return None
+    return int(dev.value)
 
 
 def lp_scores_batched(mode, q, cand):

@@ -581,8 +581,16 @@ __global__ void rank_finalize_kernel(const int32_t *__restrict__ raw, const int3
 __global__ void rank_finalize_both_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ sub,
                                           const int32_t *__restrict__ found, int64_t B, int64_t *out, int64_t ld,
                                           int64_t off, const int64_t *__restrict__ pos,
-                                          float *__restrict__ guard, float *flags, int zero_guard)
+                                          float *__restrict__ guard, float *flags, int zero_guard,
+                                          int64_t *const *out_indirect)
 {
+    // (r06) out_indirect: the result matrix of THIS launch is *out_indirect -- a device-visible pointer the host stores there
+    // before the launch (a hipGraph replays the launch with the pointer of the day): pinned host memory, so that the ranks
+    // need no copy of their own; the flags then sit behind the four rows, as in the evaluator's packed buffer
+    if (out_indirect) {
+        out = *out_indirect;
+        if (flags) flags = reinterpret_cast<float *>(out + 4 * ld);
+    }
     // the evaluation's two guard decisions ride the last finalize (instead of an add + a copy node of their own):
     // flags[0] = max ||q||^2 + max ||e||^2 (norm-expansion guard), flags[1] = overflow of the uncertain-pair list
     if (flags && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1142,13 +1150,13 @@ extern "C" int kge_rank_finalize(const int32_t *raw, const int32_t *sub, const i
 
 extern "C" int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t *found, int64_t B,
                                       int64_t *out, int64_t ld, int64_t off, const int64_t *pos, float *guard,
-                                      float *flags, int zero_guard, kge_stream_t stream)
+                                      float *flags, int zero_guard, int64_t *const *out_indirect, kge_stream_t stream)
 {
     if (B < 0 || off < 0 || ld < off + B) return KGE_EINVAL;
     if (B == 0) return 0;
-    if (!raw || !sub || !found || !out || (flags && !guard)) return KGE_EINVAL;
+    if (!raw || !sub || !found || (!out && !out_indirect) || (flags && !guard)) return KGE_EINVAL;
     hipLaunchKernelGGL(rank_finalize_both_kernel, dim3(grid1d(2 * B, 256)), dim3(256), 0, kge_s(stream), raw, sub,
-                       found, B, out, ld, off, pos, guard, flags, (flags && zero_guard) ? 1 : 0);
+                       found, B, out, ld, off, pos, guard, flags, (flags && zero_guard) ? 1 : 0, out_indirect);
     KGE_CHECK_LAUNCH();
     return 0;
 }
@@ -1210,5 +1218,16 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 30; }
+extern "C" int kge_abi_version(void) { return 31; }
+
+/* *dev = the device-visible address of pinned (hipHostMalloc / hipHostRegister) host memory -- what a kernel may be handed as
+ * kge_rank_finalize_both's *out_indirect.  KGE_EINVAL when the memory is not mapped into the device's address space. */
+extern "C" int kge_host_device_pointer(void *host, void **dev)
+{
+    if (!host || !dev) return KGE_EINVAL;
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess || !d) { (void)hipGetLastError(); return KGE_EINVAL; }
+    *dev = d;
+    return 0;
+}
 extern "C" const char *kge_build_arch(void) { return "gfx950"; }

@@ -205,11 +205,14 @@ class HipRankEngine(object):
     writes_flags = True     # finalize_both(guard=, flags=): the guard decisions are written by the same launch
 
     @staticmethod
-    def finalize_both(counts, out, off, pos=None, guard=None, flags=None, zero_guard=False):
+    def finalize_both(counts, out, off, pos=None, guard=None, flags=None, zero_guard=False, indirect=None):
         """Ranks of a 2B-query batch into the (4, n) result matrix at columns off..off+B-1 (or pos[off..]);
         ``flags`` (2 floats behind the ranks): [max ||q||^2 + max ||e||^2, list overflow] from the guard vector;
-        ``zero_guard``: the launch leaves the guard vector zeroed for the next evaluation."""
-        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off, pos, guard, flags, zero_guard)
+        ``zero_guard``: the launch leaves the guard vector zeroed for the next evaluation;
+        ``indirect``: the launch writes to the matrix whose address it finds THERE (pinned host memory, r06)."""
+        _hip.rank_finalize_both(counts[0], counts[1], counts[2], out, off, pos, guard, flags, zero_guard, indirect)
+
+    writes_host = True      # finalize_both(indirect=) exists
 
     zeroes_guard = True     # finalize_both(zero_guard=True) exists
 
@@ -323,6 +326,8 @@ FAST_REPLAY = os.environ.get('KGE_FAST_REPLAY', '1') != '0'
 _FLAGS4 = struct.Struct('4f')
 # TransH / TransD: candidate-side preparation of an evaluation on the second stream, beside the query side (r06)
 PREP_SIDE_STREAM = os.environ.get('KGE_PREP_SIDE_STREAM', '1') != '0'
+# single-GPU both-sides evaluation: ranks + flags written by the finalize launches straight into pinned host memory (r06)
+DIRECT_HOST_RANKS = os.environ.get('KGE_DIRECT_HOST_RANKS', '1') != '0'
 # region recheck (one-product level): from this many re-scored pairs per query on the three-product level
 REGION_MIN_LEVEL0 = float(os.environ.get('KGE_REGION_MIN_LEVEL0', '1.2'))
 
@@ -672,6 +677,8 @@ class LinkPredictionEvaluator(object):
             if getattr(eng, 'zeroes_guard', False):         # ... and leaves the guard vector zeroed for the next evaluation
                 fkw['zero_guard'] = True
                 self._guard_zeroed = True
+        if self.__dict__.get('_direct_ptr') and not sharded:
+            fkw['indirect'] = self.__dict__['_direct_ptr']      # ranks (and flags) straight into pinned host memory
         if self._perm is not None:
             eng.finalize_both(counts[:, :n2] if ride else counts, out, off, self._perm, **fkw)
         else:
@@ -1023,6 +1030,19 @@ class LinkPredictionEvaluator(object):
                 # escape hatch for a multi-GPU box (no code change): no graph segments, no captured collectives --
                 # every kernel and every RCCL call of a sharded evaluate() is an ordinary eager launch
                 use_graph = one_graph = False
+            # (r06) single GPU, both-sides batches: the finalize launches write ranks and flags straight into a pinned host
+            # buffer (its address reaches them through a mailbox the host fills before every run / replay): no rank copy
+            host_buf = None
+            self.__dict__['_direct_ptr'] = None
+            # (not where the facts are processed in another order -- TransH / TransD sort them by relation: scattered 8-byte
+            # stores across PCIe cost more than the copy they save, 0.60 -> 0.66 ms)
+            if (DIRECT_HOST_RANKS and not multi and both and guard is not None and n_local > 0 and not by_scores and not overlap
+                    and self._perm is None and device.type == 'cuda' and getattr(self.engine, 'writes_host', False)
+                    and getattr(self.engine, 'writes_flags', False)):
+                host_buf = self._arm_host_out(n_local)
+                if host_buf is not None:
+                    self.__dict__['_direct_ptr'] = self._st.__dict__['_mailbox'][1]
+            direct_now = host_buf is not None
             key = None
             if use_graph:
                 # capture is keyed on everything that fixes shapes and ADDRESSES (tables, filter index); table
@@ -1030,7 +1050,7 @@ class LinkPredictionEvaluator(object):
                 # are baked into it).
                 key = (b_size, n_local, str(device), self.fused, overlap, both, segmented, one_graph, lo, hi, f_lo, f_hi,
                        getattr(self.model, 'l2_mode', None), getattr(self.model, 'split_filter', None),   # kernel choice is baked in
-                       level_now, regions_now, getattr(self.model, 'split_level', None), self.overlap_filter,
+                       level_now, regions_now, getattr(self.model, 'split_level', None), self.overlap_filter, direct_now,
                        tuple(p_.data_ptr() for p_ in params), self._plan_gen, use_qmap,
                        tuple((x.data_ptr(), x.shape[0]) for ix in (index_h, index_t)
                              for x in (ix.keys, ix.offsets, ix.targets)))
@@ -1159,7 +1179,11 @@ class LinkPredictionEvaluator(object):
                         rescored = float(resc.item())
                         n_pol = kg.n_facts          # (the sum covers every rank's facts)
                 else:   # one device-to-host transfer for the ranks and the flags (16 bytes = two int64)
-                    packed = _to_host(flat)
+                    if host_buf is not None:    # ... which the last finalize launch has made itself
+                        torch.cuda.current_stream(device).synchronize()
+                        packed = host_buf
+                    else:
+                        packed = _to_host(flat)
                     worst, overflow, rescored, _ = packed[-2:].view(torch.float32).tolist()
                     res = packed[:-2].view(4, n_local)
                 redo = check_again = False
@@ -1207,11 +1231,15 @@ class LinkPredictionEvaluator(object):
                     break
         finally:
             self._qb = None
+            self.__dict__['_direct_ptr'] = None
             object.__setattr__(self.model, '_lp_side_stream', None)
             if guard is not None:      # never leave the model in guarded mode (exceptions included)
                 self.model.lp_guard_end()
         if self.shard == 'queries' and kdist.multi(world):
             out = kdist.all_gather_facts(out, kg.n_facts, self.group)
+        if res is None and host_buf is not None:     # (a redone evaluation: its finalize launches wrote there too)
+            torch.cuda.current_stream(device).synchronize()
+            res = host_buf[:-2].view(4, n_local)
         if res is None:
             res = _to_host(out)
         self.rank_true_heads, self.rank_true_tails = res[0], res[1]
@@ -1228,7 +1256,8 @@ class LinkPredictionEvaluator(object):
             gst = self._graph_static
             self._st._fast = (self._fast_sig(user_b_size),
                               {'graph': self._graph, 'static': gst, 'guard': guard, 'n_local': n_local, 'level': level_now,
-                               'needs_clean_guard': bool(gst.get('needs_clean_guard')), 'zeroes_guard': bool(gst.get('zeroes_guard'))})
+                               'needs_clean_guard': bool(gst.get('needs_clean_guard')), 'zeroes_guard': bool(gst.get('zeroes_guard')),
+                               'direct': direct_now})
 
     def _fast_sig(self, b_size):
         """What must be unchanged for the last captured graph to be replayed without the full prologue (cheap to compute:
@@ -1244,6 +1273,24 @@ class LinkPredictionEvaluator(object):
                 getattr(m, 'split_level', None), st._level, st._level1_max, self.graph, id(getattr(m, '_lp_guard', None)),
                 id(st._graph), st._plan_gen, id(getattr(kg, '_lazy', None)), self.coalesce, st._mem_fit)
 
+    def _arm_host_out(self, n_local):
+        """Direct host results (r06): a fresh pinned (4 n + 2) int64 buffer whose device-visible address goes into the
+        state's mailbox -- the finalize launches of the coming run / replay write there.  None: not available."""
+        st = self._st
+        mb = st.__dict__.get('_mailbox')
+        if mb is None:
+            box = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+            dev = _hip.host_device_pointer(box)
+            mb = st.__dict__['_mailbox'] = (box, dev, ctypes.c_int64.from_address(box.data_ptr()))
+        if mb[1] is None:
+            return None
+        host = torch.empty(4 * n_local + 2, dtype=torch.int64, pin_memory=True)
+        dev = _hip.host_device_pointer(host)
+        if dev is None:
+            return None
+        mb[2].value = dev
+        return host
+
     def _evaluate_fast(self, info):
         """One steady-state evaluation: guard hygiene, graph replay, ONE device-to-host copy (ranks + flags), the level
         policy.  False: something needs the full path (nothing has been changed that it would not redo)."""
@@ -1253,10 +1300,19 @@ class LinkPredictionEvaluator(object):
             if not getattr(m, '_lp_guard_clean', False):
                 guard.zero_()
             object.__setattr__(m, '_lp_guard_clean', False)
+        host = None
+        if info.get('direct'):
+            host = self._arm_host_out(n_local)
+            if host is None:
+                return False
         info['graph'].replay()
         if info['zeroes_guard']:
             object.__setattr__(m, '_lp_guard_clean', True)
-        packed = _to_host(info['static']['out'][0])
+        if host is not None:        # the last finalize of the graph wrote ranks and flags there
+            torch.cuda.current_stream(info['static']['out'][0].device).synchronize()
+            packed = host
+        else:
+            packed = _to_host(info['static']['out'][0])
         # (the four flag floats straight from the pinned buffer: slicing + view + tolist cost 4 us of GPU idle time per call)
         worst, overflow, rescored, _ = _FLAGS4.unpack(ctypes.string_at(packed.data_ptr() + 8 * (packed.numel() - 2), 16))
         if not worst <= m.L2_EXPAND_LIMIT or overflow > 0:
