@@ -346,6 +346,10 @@ int kge_rank_finalize_both(const int32_t *raw, const int32_t *sub, const int32_t
 /* *dev = the device-visible address of pinned host memory (hipHostMalloc / hipHostRegister; torch's pinned tensors);
  * KGE_EINVAL when it is not mapped into the device's address space. */
 int kge_host_device_pointer(void *host, void **dev);
+/* dst[0 .. n) = src[0 .. n), dst = *dst_indirect read on the device when the launch runs: the packed (4 n + 2) int64 result of
+ * an evaluation whose finalize launches scatter (pos != NULL) leaves for pinned host memory in one coalesced pass inside the
+ * captured graph. */
+int kge_copy_i64_indirect(const int64_t *src, int64_t n, int64_t *const *dst_indirect, kge_stream_t stream);
 
 /* generic: every query has its own candidate matrix cand[i] (N,K) at
  * cand + i*stride_b (stride_b = 0: shared), rows at stride_n.

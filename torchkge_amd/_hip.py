@@ -125,6 +125,7 @@ _SIGNATURES = {
     'kge_rank_finalize': [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     'kge_rank_finalize_both': [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp],
     'kge_host_device_pointer': [_vp, _vp],
+    'kge_copy_i64_indirect': [_vp, _i64, _vp, _vp],
     'kge_lp_scores_batched': [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
     'kge_get_rank': [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     'kge_filter_lookup': [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -1316,6 +1317,14 @@ def rank_finalize_both(raw, sub, found, out, off, pos=None, guard=None, flags=No
                                           ctypes.c_void_p(int(indirect)) if indirect else None, _stream()),
                'kge_rank_finalize_both')
     return out
+
+
+def copy_i64_indirect(src, n, indirect):
+    """kge_copy_i64_indirect: n int64 from the device tensor ``src`` to the buffer whose address the device finds at ``indirect``."""
+    lib = load_library()
+    require_cuda(src)
+    with _on(src.device):
+        _check(lib.kge_copy_i64_indirect(_p(src), int(n), ctypes.c_void_p(int(indirect)), _stream()), 'kge_copy_i64_indirect')
 
 
 def host_device_pointer(t):

@@ -1220,6 +1220,24 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
 
 extern "C" int kge_abi_version(void) { return 31; }
 
+__global__ __launch_bounds__(256) void copy_i64_indirect_kernel(const int64_t *__restrict__ src, int64_t n, int64_t *const *dst_ind)
+{
+    int64_t *dst = *dst_ind;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+/* dst[0 .. n) = src[0 .. n) with dst = *dst_indirect read on the device when the launch runs (see kge_rank_finalize_both's
+ * out_indirect): the packed result of an evaluation whose finalize launches had to scatter (facts processed in another
+ * order) leaves for pinned host memory as ONE coalesced pass at the end of the captured graph instead of a copy of its own. */
+extern "C" int kge_copy_i64_indirect(const int64_t *src, int64_t n, int64_t *const *dst_indirect, kge_stream_t stream)
+{
+    if (n < 0 || (n > 0 && (!src || !dst_indirect))) return KGE_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(copy_i64_indirect_kernel, dim3(grid1d(n, 256)), dim3(256), 0, kge_s(stream), src, n, dst_indirect);
+    KGE_CHECK_LAUNCH();
+    return 0;
+}
+
 /* *dev = the device-visible address of pinned (hipHostMalloc / hipHostRegister) host memory -- what a kernel may be handed as
  * kge_rank_finalize_both's *out_indirect.  KGE_EINVAL when the memory is not mapped into the device's address space. */
 extern "C" int kge_host_device_pointer(void *host, void **dev)

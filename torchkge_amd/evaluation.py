@@ -677,10 +677,15 @@ class LinkPredictionEvaluator(object):
             if getattr(eng, 'zeroes_guard', False):         # ... and leaves the guard vector zeroed for the next evaluation
                 fkw['zero_guard'] = True
                 self._guard_zeroed = True
-        if self.__dict__.get('_direct_ptr') and not sharded:
-            fkw['indirect'] = self.__dict__['_direct_ptr']      # ranks (and flags) straight into pinned host memory
+        direct = self.__dict__.get('_direct_ptr') if not sharded else None
+        if direct and self._perm is None:
+            fkw['indirect'] = direct            # ranks (and flags) straight into pinned host memory
         if self._perm is not None:
             eng.finalize_both(counts[:, :n2] if ride else counts, out, off, self._perm, **fkw)
+            if direct and last:
+                # facts processed in another order (sorted by relation): the finalize launches scatter into the device matrix;
+                # the packed result (ranks + flags, `out` is its head) then leaves in ONE coalesced pass of the same graph
+                _hip.copy_i64_indirect(out, 4 * out.shape[1] + 2, direct)
         else:
             eng.finalize_both(counts[:, :n2] if ride else counts, out, off, **fkw)
 
@@ -1034,10 +1039,11 @@ class LinkPredictionEvaluator(object):
             # buffer (its address reaches them through a mailbox the host fills before every run / replay): no rank copy
             host_buf = None
             self.__dict__['_direct_ptr'] = None
-            # (not where the facts are processed in another order -- TransH / TransD sort them by relation: scattered 8-byte
-            # stores across PCIe cost more than the copy they save, 0.60 -> 0.66 ms)
+            # (where the facts are processed in another order -- TransH / TransD sort them by relation -- the finalize launches
+            # keep scattering on the device, scattered 8-byte stores across PCIe cost 0.60 -> 0.66 ms, and one coalesced pass
+            # at the end of the graph carries the packed result over: _rank_batch_both)
             if (DIRECT_HOST_RANKS and not multi and both and guard is not None and n_local > 0 and not by_scores and not overlap
-                    and self._perm is None and device.type == 'cuda' and getattr(self.engine, 'writes_host', False)
+                    and device.type == 'cuda' and getattr(self.engine, 'writes_host', False)
                     and getattr(self.engine, 'writes_flags', False)):
                 host_buf = self._arm_host_out(n_local)
                 if host_buf is not None:
