@@ -1804,6 +1804,51 @@ def test_dot_candidate_table_in_one_pass(hip, kind, d, n_ent):
         assert float(g3[2]) == 2.0 and float(stale[0]) == n0 and float(stale[1]) == n1
 
 
+@pytest.mark.parametrize('kind', ['transe', 'transh', 'complex'])
+def test_ranks_written_straight_to_pinned_host_memory(hip, kind, monkeypatch):
+    """r06: the finalize launches of a single-GPU both-sides evaluation write ranks and flags into a pinned host buffer whose
+    address they read from a mailbox (kge_rank_finalize_both out_indirect; TransH: the packed result by one coalesced pass,
+    kge_copy_i64_indirect) -- same ranks as through the device-to-host copy, eager and as graph replays, and every call hands
+    out its OWN buffer: the tensors of an earlier call survive later calls on changed tables."""
+    import torchkge_amd as tk
+    import torchkge_amd.evaluation as evm
+    n_ent, n_rel, d = 2500, 7, 64
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=9)
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    h, t, r = orc.synthetic_triples_zipf(n_ent, n_rel, 16000, 3, hubs=((700, 'tail'),))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={i: i for i in range(n_ent)},
+                           rel2ix={i: i for i in range(n_rel)})
+    _, kg_test = kg.split_kg(sizes=(14800, 1200))
+
+    def ranks(ev):
+        return [ev.rank_true_heads, ev.rank_true_tails, ev.filt_rank_true_heads, ev.filt_rank_true_tails]
+    monkeypatch.setattr(evm, 'DIRECT_HOST_RANKS', False)
+    ev0 = tk.LinkPredictionEvaluator(m, kg_test, graph=False, share_state=False)
+    ev0.evaluate(256, verbose=False)
+    want = [x.clone() for x in ranks(ev0)]
+    monkeypatch.setattr(evm, 'DIRECT_HOST_RANKS', True)
+    assert hip.host_device_pointer(torch.zeros(4, dtype=torch.int64, pin_memory=True)) is not None
+    for graph in (False, None):
+        ev = tk.LinkPredictionEvaluator(m, kg_test, graph=graph, share_state=False)
+        kept = []
+        for _ in range(4):
+            ev.evaluate(256, verbose=False)
+            got = ranks(ev)
+            assert all(x.is_pinned() for x in got) and all(torch.equal(a, b) for a, b in zip(want, got))
+            kept.append(got)
+        assert ev._st.__dict__.get('_mailbox') is not None and ev._st.__dict__['_mailbox'][1] is not None
+        assert len({x[0].data_ptr() for x in kept}) == len(kept)        # a fresh buffer per call
+        # other tables: new ranks in a new buffer, the old tensors untouched
+        ent = m.ent_emb if kind != 'complex' else m.re_ent_emb
+        with torch.no_grad():
+            ent.weight.data[::3] *= -1.0
+        ev.evaluate(256, verbose=False)
+        assert not all(torch.equal(a, b) for a, b in zip(want, ranks(ev)))
+        assert all(torch.equal(a, b) for got in kept for a, b in zip(want, got))
+        with torch.no_grad():
+            ent.weight.data[::3] *= -1.0
+
+
 @pytest.mark.parametrize('kind', ['distmult', 'complex'])
 def test_evaluator_one_pass_table_follows_growing_tables(hip, kind):
     """The evaluator on the one-product level takes the DOT candidate table's scale from the previous evaluation's maxima

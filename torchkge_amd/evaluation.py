@@ -1284,13 +1284,17 @@ class LinkPredictionEvaluator(object):
         state's mailbox -- the finalize launches of the coming run / replay write there.  None: not available."""
         st = self._st
         mb = st.__dict__.get('_mailbox')
-        if mb is None:
-            box = torch.zeros(1, dtype=torch.int64, pin_memory=True)
-            dev = _hip.host_device_pointer(box)
-            mb = st.__dict__['_mailbox'] = (box, dev, ctypes.c_int64.from_address(box.data_ptr()))
-        if mb[1] is None:
+        try:
+            if mb is None:
+                box = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+                dev = _hip.host_device_pointer(box)
+                mb = st.__dict__['_mailbox'] = (box, dev, ctypes.c_int64.from_address(box.data_ptr()))
+            if mb[1] is None:
+                return None
+            host = torch.empty(4 * n_local + 2, dtype=torch.int64, pin_memory=True)
+        except RuntimeError:        # (no pinned memory to be had: the copy path needs none of this)
+            st.__dict__['_mailbox'] = (None, None, None)
             return None
-        host = torch.empty(4 * n_local + 2, dtype=torch.int64, pin_memory=True)
         dev = _hip.host_device_pointer(host)
         if dev is None:
             return None
