@@ -1739,6 +1739,52 @@ def test_split_one_product_level_long_rows_chunked_panel(hip, monkeypatch, mode,
         hip.SPLIT_EPS_SCALE = 1.0
 
 
+@pytest.mark.parametrize('kind,d', [('complex', 200), ('distmult', 400), ('complex', 136), ('distmult', 200)])
+@pytest.mark.parametrize('seg_bytes', [None, 8192])
+def test_region_recheck_of_long_rows_in_segments(hip, kind, d, seg_bytes, monkeypatch):
+    """r06: kge_lp_split_recheck_regions for rows longer than one LDS segment (DistMult / ComplEx d = 400: K = 400 / 2 x 200;
+    KGE_REGION_MAX_BYTES=8192: segments of 32 columns, every shape in several pieces and ComplEx's [Re | Im] boundary inside
+    one) -- the chains of a batch of pairs rest in registers between segments: same counts and as many listed pairs as the
+    global list + kge_lp_split_recheck, equal to the exact fp32 counts."""
+    if seg_bytes is not None:
+        monkeypatch.setenv('KGE_REGION_MAX_BYTES', str(seg_bytes))
+    cplx = kind == 'complex'
+    n_ent, n_rel, B = 1800, 6, 900
+    tables = orc.init_tables(kind, n_ent, n_rel, d, seed=13)
+    m = build_model(kind, 2, tables, n_ent, n_rel)
+    tabs = [hip.f32c(x.data) for x in m._tables()]
+    T0, T1 = tabs[0], (tabs[1] if cplx else None)
+    rel = tabs[2:] if cplx else tabs[1:]
+    gen = torch.Generator().manual_seed(d)
+    h = torch.randint(0, n_ent, (B,), generator=gen).cuda(); t = torch.randint(0, n_ent, (B,), generator=gen).cuda()
+    h[: B // 2] = h[0]          # a hub: a region with many pairs (several batches of the segmented recheck)
+    r = torch.randint(0, n_rel, (B,), generator=gen).cuda()
+    true = torch.cat([t, h])
+    got, listed = {}, {}
+    for regions in (False, True):
+        g = torch.zeros(8, device='cuda')
+        nm1 = g[5:6] if cplx else None
+        Eh, dnb, _ws = hip.dot_table_prep(T0, T1, g[1:2], nm1, True)
+        pre = hip.lp_dot_query_pipeline(hip.SIDE_BOTH, T0, T1, rel[0], rel[1] if cplx else None, h, t, r, g[1:2], nm1, g[7:8],
+                                        g[0:1], g[2:3], zero_counts=True, dn_bmax=dnb, regions=regions)
+        assert (pre.get('region_count') is not None) == regions
+        pre['true_idx'] = true
+        prob = hip.LpProblem(hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
+        prob.split = {'Es': Eh, 'e2pref': None, 'enmax': g[1:2], 'enmax1': nm1, 'overflow': g[2:3], 'level': 1, 'de2max': g[7:8],
+                      'list_stat': g[6:7], 'es_frag': True}
+        prob.pre = pre
+        st = prob.pair_scores(true)
+        got[regions] = prob.count_ge(st).clone()
+        assert float(g[2]) == 0.0
+        listed[regions] = (int(prob.last_split[0]), float(g[6]))
+        if regions:
+            assert int(pre['region_count'].sum()) == listed[True][0]
+            ref = hip.LpProblem(hip.LP_DOT, pre['Q'], T0, A1=pre['Q1'], T1=T1)
+            assert torch.equal(got[True], ref.count_ge(st))
+    assert torch.equal(got[False], got[True])
+    assert listed[False] == listed[True] and listed[True][0] > 0
+
+
 @pytest.mark.parametrize('kind,d,n_ent', [('distmult', 64, 1500), ('complex', 40, 777), ('complex', 512, 300), ('distmult', 400, 2049)])
 def test_dot_candidate_table_in_one_pass(hip, kind, d, n_ent):
     """r06: kge_lp_dot_table_prep_fused -- the fragment-major hi table of a DOT candidate table in ONE pass, scaled by the
@@ -2166,7 +2212,7 @@ def test_dot_query_side_in_one_launch_equals_the_separate_kernels(hip, kind, B, 
     assert torch.equal(got2, ref.count_ge(st2))
 
 
-@pytest.mark.parametrize('B,N,d', [(50, 300, 64), (700, 2100, 200), (1500, 900, 104)])
+@pytest.mark.parametrize('B,N,d', [(50, 300, 64), (700, 2100, 200), (1500, 900, 104), (700, 2100, 400), (300, 1200, 500), (2000, 700, 288)])
 @pytest.mark.parametrize('waves', [2, 4])
 def test_region_recheck_equals_the_global_list(hip, B, N, d, waves, monkeypatch):
     """r05: the free-running sweep leaves its uncertain pairs in REGIONS of the list (one per 32 consecutive queries,

@@ -2288,44 +2288,95 @@ __device__ __forceinline__ float recheck_e_segment(const float *__restrict__ T, 
 
 constexpr int RR_ROWS = 32, RR_PANEL = 96;      // queries per region / per panel of the free-running sweep (lp_hi_stream.hip)
 
+// Rows longer than one LDS segment (r06; K > 256 or so -- DistMult / ComplEx d = 400: the recheck was 20 % of cfg4's step, all
+// of it row fetches): the region's query rows pass through LDS in SEGMENTS of seg_cols logical columns of [A0 | A1] while the
+// chains of up to RR_G pair groups per wave (a batch of NWV * 64 * RR_G pairs: a whole region, typically) rest in registers
+// between segments -- the sequential chain is cut, not reordered: same bits.  One segment (K <= seg_cols) is r05's form.
+constexpr int RR_G = 4;
+
 template <int NWV>
 __global__ __launch_bounds__(64 * NWV) void split_recheck_regions_kernel(const kge_lp_desc d, const float *__restrict__ s_true,
                                                                         const int32_t *__restrict__ list, int32_t region_cap,
                                                                         const int32_t *__restrict__ region_count, int n_regions,
-                                                                        int ldq, int32_t *raw_count, float *list_stat,
+                                                                        int ldq, int seg_cols, int32_t *raw_count, float *list_stat,
                                                                         int32_t *list_count)
 {
     extern __shared__ __attribute__((aligned(16))) float rr_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float *qrows = rr_smem;
     float *es = rr_smem + RR_ROWS * ldq + wv * 64 * KGE_PS_LD;
-    const int np0 = d.K0 >> 2, npieces = np0 + (d.K1 >> 2);
+    const int K = d.K0 + d.K1;
     int n_block = 0;
+    // logical columns [c0, c1) of the region's 32 query rows -> LDS (row stride ldq)
+    auto stage = [&](int64_t q0, int c0, int c1) {
+        const int np = (c1 - c0) >> 2;
+        for (int idx = tid; idx < RR_ROWS * np; idx += 64 * NWV) {
+            const int rr = idx / np, pc = idx - rr * np;
+            const int64_t q = min(q0 + rr, d.B - 1);
+            const int col = c0 + pc * 4;        // (K0 % 4 == 0: a piece lies in one segment of the operand)
+            const float4 v = col < d.K0 ? *reinterpret_cast<const float4 *>(d.A0 + q * d.lda0 + col)
+                                        : *reinterpret_cast<const float4 *>(d.A1 + q * d.lda1 + (col - d.K0));
+            *reinterpret_cast<float4 *>(qrows + rr * ldq + pc * 4) = v;
+        }
+    };
+    // the chain of one pair over the staged columns [c0, c1): operand segment 0, then 1
+    auto chain = [&](float acc, int ci, const float *qrow, int c0, int c1) -> float {
+        if (c0 < d.K0) acc = recheck_e_segment(d.T0 + c0, d.ldt0, min(c1, d.K0) - c0, ci, qrow, es, acc);
+        if (c1 > d.K0 && d.K1 > 0) {
+            const int s0 = max(c0, d.K0);
+            acc = recheck_e_segment(d.T1 + (s0 - d.K0), d.ldt1, c1 - s0, ci, qrow + (s0 - c0), es, acc);
+        }
+        return acc;
+    };
     for (int reg = blockIdx.x; reg < n_regions; reg += gridDim.x) {
         const int n = (int)min((unsigned)region_count[reg], (unsigned)region_cap);   // (past the capacity: overflow flagged by the sweep)
         if (n == 0) continue;                   // (block-uniform)
         n_block += n;
         const int64_t q0 = (int64_t)(reg / 3) * RR_PANEL + (reg % 3) * RR_ROWS;
-        __syncthreads();                        // the previous region's readers are done
-        for (int idx = tid; idx < RR_ROWS * npieces; idx += 64 * NWV) {
-            const int rr = idx / npieces, pc = idx - rr * npieces;
-            const int64_t q = min(q0 + rr, d.B - 1);
-            const float4 v = pc < np0 ? *reinterpret_cast<const float4 *>(d.A0 + q * d.lda0 + pc * 4)
-                                      : *reinterpret_cast<const float4 *>(d.A1 + q * d.lda1 + (pc - np0) * 4);
-            *reinterpret_cast<float4 *>(qrows + rr * ldq + pc * 4) = v;
-        }
-        __syncthreads();
         const int2 *ent = reinterpret_cast<const int2 *>(list) + (int64_t)reg * region_cap;
-        for (int c0 = wv * 64; c0 < n; c0 += NWV * 64) {
-            const int pi = c0 + lane;
-            const bool valid = pi < n;
-            const int2 e = ent[valid ? pi : c0];       // idle lanes shadow the group's first pair
-            const int qi = e.x, ci = e.y;
-            const float *qrow = qrows + (int)(qi - q0) * ldq;
-            float acc = recheck_e_segment(d.T0, d.ldt0, d.K0, ci, qrow, es, 0.0f);
-            if (d.K1 > 0) acc = recheck_e_segment(d.T1, d.ldt1, d.K1, ci, qrow + d.K0, es, acc);
-            const float sc = lp_epilogue_any(d, acc, qi, ci);
-            if (valid && !(sc >= s_true[qi])) atomicSub(&raw_count[qi], 1);
+        if (K <= seg_cols) {
+            __syncthreads();                    // the previous region's readers are done
+            stage(q0, 0, K);
+            __syncthreads();
+            for (int c0 = wv * 64; c0 < n; c0 += NWV * 64) {
+                const int pi = c0 + lane;
+                const bool valid = pi < n;
+                const int2 e = ent[valid ? pi : c0];       // idle lanes shadow the group's first pair
+                const int qi = e.x, ci = e.y;
+                const float acc = chain(0.0f, ci, qrows + (int)(qi - q0) * ldq, 0, K);
+                const float sc = lp_epilogue_any(d, acc, qi, ci);
+                if (valid && !(sc >= s_true[qi])) atomicSub(&raw_count[qi], 1);
+            }
+            continue;
+        }
+        for (int b0 = 0; b0 < n; b0 += NWV * 64 * RR_G) {       // (block-uniform trip counts: barriers inside)
+            float acc[RR_G];
+            int qi[RR_G], ci[RR_G];
+#pragma unroll
+            for (int g = 0; g < RR_G; ++g) {
+                const int c0 = b0 + (g * NWV + wv) * 64;
+                const int pi = c0 + lane;
+                const int2 e = ent[min(pi < n ? pi : c0, n - 1)];   // idle lanes shadow the group's first pair (idle groups: the last pair)
+                qi[g] = e.x; ci[g] = e.y; acc[g] = 0.0f;
+            }
+            for (int c0 = 0; c0 < K; c0 += seg_cols) {
+                const int c1 = min(K, c0 + seg_cols);
+                __syncthreads();                // the previous segment's / region's readers are done
+                stage(q0, c0, c1);
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < RR_G; ++g)
+                    if (b0 + (g * NWV + wv) * 64 < n)       // (wave-uniform)
+                        acc[g] = chain(acc[g], ci[g], qrows + (int)(qi[g] - q0) * ldq, c0, c1);
+            }
+#pragma unroll
+            for (int g = 0; g < RR_G; ++g) {
+                const int pi = b0 + (g * NWV + wv) * 64 + lane;
+                if (pi < n) {
+                    const float sc = lp_epilogue_any(d, acc[g], qi[g], ci[g]);
+                    if (!(sc >= s_true[qi[g]])) atomicSub(&raw_count[qi[g]], 1);
+                }
+            }
         }
     }
     if (tid == 0 && n_block > 0) {              // pairs re-scored per evaluation (level policy) / the list's length
@@ -2763,16 +2814,33 @@ extern "C" int kge_lp_split_regions(int64_t B)
     return (int)(kge_lp_split_rows_padded(B, 1) / RR_PANEL) * 3;
 }
 
+// LDS segment of the region recheck: logical columns of the query rows resident at a time (a multiple of 32, the chunk of the
+// candidate-row staging), from the byte budget of the 32 rows (KGE_REGION_MAX_BYTES, default 36 KiB: at K = 200 the region's
+// 26 KB of query rows leave six wavefronts per CU; measured r05 -- profiles/r05/region_recheck_ab.txt -- a WHOLE 52 KB row
+// block at K = 400 left four and was slower than no regions; r06 passes longer rows through in segments instead)
+static int region_seg_cols(int K)
+{
+    const int max_ld = kge_env_int("KGE_REGION_MAX_BYTES", 36 * 1024) / (RR_ROWS * 4);
+    const int ld_full = K + (((K >> 2) & 1) ? 0 : 4);
+    if (ld_full <= max_ld) return K;
+    // longer rows: SMALLER segments than the budget of a whole row block -- more wavefronts per CU is what the kernel lives on
+    // (cfg4, DistMult d = 400, same box: no regions 2.107 ms per evaluate, 36 KiB segments 2.083, 20 KiB 2.031, 12 KiB 2.036;
+    // profiles/r06/region_segments_ab.txt)
+    const int seg_ld = min(max_ld, kge_env_int("KGE_REGION_SEG_BYTES", 20 * 1024) / (RR_ROWS * 4));
+    int seg = ((seg_ld - 4) / 32) * 32;
+    return seg < 32 ? 32 : seg;
+}
+
 /* 1 if kge_lp_split_count / kge_lp_split_recheck_regions take a list cut into regions for this problem */
 extern "C" int kge_lp_split_regions_supported(const kge_lp_desc *d)
 {
     if (kge_lp_desc_check(d) || !KGE_LP_IS_MFMA(d->mode) || !kge_lp_vec4(*d)) return 0;
     const int K = d->K0 + d->K1;
-    const int ldq = K + (((K >> 2) & 1) ? 0 : 4);
-    // (measured r05, profiles/r05/region_recheck_ab.txt: at K = 200 the region's 26 KB of query rows leave six wavefronts per
-    // CU and the recheck goes 75 -> 68 us; at K = 400 they are 52 KB, four wavefronts per CU remain and it gets SLOWER
-    // (363 -> 396 us) -- the kernel is bound by the loads it keeps in flight, not by their bytes: regions up to 36 KB)
-    return RR_ROWS * ldq * 4 <= kge_env_int("KGE_REGION_MAX_BYTES", 36 * 1024) ? 1 : 0;
+    // (rows of the free-running kernel's range: the chunked-panel kernel of longer rows keeps one global list; segments of the
+    // operand must not cut a 16-byte piece: K0 % 4 == 0 is part of kge_lp_vec4)
+    if ((K + 2 + 15) / 16 > 32) return 0;
+    if (region_seg_cols(K) < K && kge_env_int("KGE_REGION_SEGMENTS", 1) == 0) return 0;
+    return 1;
 }
 
 extern "C" int kge_lp_split_recheck_regions(const kge_lp_desc *d, const float *s_true, const int32_t *list, int32_t cap,
@@ -2788,7 +2856,8 @@ extern "C" int kge_lp_split_recheck_regions(const kge_lp_desc *d, const float *s
     const int32_t region_cap = cap / n_regions;
     if (region_cap <= 0) return KGE_EINVAL;
     const int K = d->K0 + d->K1;
-    const int ldq = K + (((K >> 2) & 1) ? 0 : 4);       // floats: a multiple of 4, an odd number of 16-byte pieces
+    const int seg = region_seg_cols(K);
+    const int ldq = seg + (((seg >> 2) & 1) ? 0 : 4);   // floats: a multiple of 4, an odd number of 16-byte pieces
     const int nwv = kge_env_int("KGE_RECHECK_REGION_WAVES", 2);
     const int smem = (RR_ROWS * ldq + (nwv == 4 ? 4 : 2) * 64 * KGE_PS_LD) * 4;
     const int want = split_num_cus() * 6;
@@ -2798,12 +2867,12 @@ extern "C" int kge_lp_split_recheck_regions(const kge_lp_desc *d, const float *s
         auto k = split_recheck_regions_kernel<4>;
         if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr4)) return e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, kge_s(stream), *d, s_true, list, region_cap, region_count, n_regions,
-                           ldq, raw_count, list_stat, list_count);
+                           ldq, seg, raw_count, list_stat, list_count);
     } else {
         auto k = split_recheck_regions_kernel<2>;
         if (int e = kge_ensure_dyn_smem(reinterpret_cast<const void *>(k), smem, attr2)) return e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(128), smem, kge_s(stream), *d, s_true, list, region_cap, region_count, n_regions,
-                           ldq, raw_count, list_stat, list_count);
+                           ldq, seg, raw_count, list_stat, list_count);
     }
     KGE_CHECK_LAUNCH();
     return 0;

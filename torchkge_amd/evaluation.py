@@ -296,7 +296,7 @@ class _EvalState(object):
     graph its predecessor captured instead of paying first-call prices again."""
 
     SHARED = ('_plans', '_plan_stamp', '_plan_refs', '_plan_gen', '_perm', '_qmap', '_graph', '_graph_static', '_graph_key',
-              '_graph_src', '_graph_seen', '_graph_cache', '_aux_stream', '_n_evaluations', '_level', '_level1_max',
+              '_graph_src', '_graph_seen', '_graph_cache', '_aux_stream', '_n_evaluations', '_level', '_level1_max', '_level1_seen',
               '_level0_seen', '_mem_fit', '_graph_failed', '_ctimes', '_fast')
 
     def __init__(self):
@@ -309,6 +309,7 @@ class _EvalState(object):
         self._level = 0         # level of the split prefilter the next evaluation runs (see LEVEL1_ENTER)
         self._level1_max = None             # cap on the three-product re-scored pairs per query at which level 1 is RE-entered (None: no cap)
         self._level0_seen = None            # ... the last such count observed on level 0
+        self._level1_seen = None            # re-scored pairs per query last observed on level 1 (the region decision's input)
         self._mem_fit = None
         self._graph_failed = False
         self._ctimes = None     # collective_timing(): (start, end) event pairs of the data-path collectives
@@ -330,6 +331,9 @@ PREP_SIDE_STREAM = os.environ.get('KGE_PREP_SIDE_STREAM', '1') != '0'
 DIRECT_HOST_RANKS = os.environ.get('KGE_DIRECT_HOST_RANKS', '1') != '0'
 # region recheck (one-product level): from this many re-scored pairs per query on the three-product level
 REGION_MIN_LEVEL0 = float(os.environ.get('KGE_REGION_MIN_LEVEL0', '1.2'))
+# ... and, once an evaluation on the one-product level has been seen, from this many re-scored pairs per query THERE (r06: rows
+# longer than one LDS segment -- DistMult / ComplEx d = 400 -- gain 3.6 % at 9.6 pairs per query and lose 1-3 % at 2.0)
+REGION_MIN_LEVEL1 = float(os.environ.get('KGE_REGION_MIN_LEVEL1', '5.0'))
 
 
 # states kept per model: the least recently used one goes when a new (kg, options) pair would exceed it -- its captured
@@ -1021,8 +1025,7 @@ class LinkPredictionEvaluator(object):
             # enough of them to amortise its query rows: ~5 x the three-product level's count on the one-product level
             # -> from REGION_MIN_LEVEL0 re-scored pairs per query there (TransE cfg2: 1.8 -> 9.5 per query: 0.50 -> 0.48 ms;
             # TransH at 5 per query: 0.64 -> 0.66)
-            regions_now = bool(level_now == 1 and not kdist.multi(world) and self._level0_seen is not None
-                               and self._level0_seen >= REGION_MIN_LEVEL0)
+            regions_now = self._regions_for(level_now, kdist.multi(world))
             if hasattr(self.model, '_split_level'):
                 object.__setattr__(self.model, '_lp_regions', regions_now)
             multi = kdist.multi(world)
@@ -1227,6 +1230,8 @@ class LinkPredictionEvaluator(object):
                         self._level = 0
                         if self._level0_seen is not None:       # do not come back before the model has changed a lot
                             self._level1_max = 0.5 * self._level0_seen
+                    if level_now == 1 and rescored > 0:
+                        self._level1_seen = per_q
                 if not redo:
                     break
                 any_redo = True
@@ -1258,12 +1263,13 @@ class LinkPredictionEvaluator(object):
         self._st._fast = None
         if (FAST_REPLAY and use_graph and key is not None and self._graph_key == key and not kdist.multi(world)
                 and guard is not None and not any_redo and isinstance(self._graph, torch.cuda.CUDAGraph)
-                and (forced_level != 'auto' or self._level == level_now) and self._fast_sig(user_b_size) is not None):
+                and (forced_level != 'auto' or self._level == level_now) and self._regions_for(level_now, False) == regions_now
+                and self._fast_sig(user_b_size) is not None):
             gst = self._graph_static
             self._st._fast = (self._fast_sig(user_b_size),
                               {'graph': self._graph, 'static': gst, 'guard': guard, 'n_local': n_local, 'level': level_now,
                                'needs_clean_guard': bool(gst.get('needs_clean_guard')), 'zeroes_guard': bool(gst.get('zeroes_guard')),
-                               'direct': direct_now})
+                               'direct': direct_now, 'regions': regions_now})
 
     def _fast_sig(self, b_size):
         """What must be unchanged for the last captured graph to be replayed without the full prologue (cheap to compute:
@@ -1278,6 +1284,14 @@ class LinkPredictionEvaluator(object):
                 tuple(p.data_ptr() for p in tabs), getattr(m, 'l2_mode', None), getattr(m, 'split_filter', None),
                 getattr(m, 'split_level', None), st._level, st._level1_max, self.graph, id(getattr(m, '_lp_guard', None)),
                 id(st._graph), st._plan_gen, id(getattr(kg, '_lazy', None)), self.coalesce, st._mem_fit)
+
+    def _regions_for(self, level, multi):
+        """The sweep's uncertain pairs in regions of 32 queries?  From REGION_MIN_LEVEL0 re-scored pairs per query seen on the
+        three-product level -- and, once the one-product level has been measured, from REGION_MIN_LEVEL1 there."""
+        r = bool(level == 1 and not multi and self._level0_seen is not None and self._level0_seen >= REGION_MIN_LEVEL0)
+        if r and self._level1_seen is not None and self._level1_seen < REGION_MIN_LEVEL1:
+            r = False       # (too few pairs to amortise a region's query rows)
+        return r
 
     def _arm_host_out(self, n_local):
         """Direct host results (r06): a fresh pinned (4 n + 2) int64 buffer whose device-visible address goes into the
@@ -1344,6 +1358,10 @@ class LinkPredictionEvaluator(object):
                 self._level = 0
                 if self._level0_seen is not None:
                     self._level1_max = 0.5 * self._level0_seen
+            if level_now == 1 and rescored > 0:
+                self._level1_seen = per_q
+                if self._regions_for(1, False) != info.get('regions'):
+                    self._st._fast = None       # (the next call decides about the regions again: full path, another capture)
         # (the four rank vectors are rows of this host tensor, handed out on access -- _rank_row: four view objects built
         # here cost 5 us between two replays)
         self.__dict__['_rank_rows'] = packed.as_strided((4, n_local), (n_local, 1))
