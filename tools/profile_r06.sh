@@ -21,8 +21,8 @@ b transe_fb15k237 --steps 20 --warmup 3
 b transe_fb15k237_three_products --steps 20 --warmup 3 --split-level 0 $T --no-secondary
 b complex_wn18rr --steps 10 --warmup 3 --workload complex_wn18rr $T
 b distmult_fb15k --steps 5 --warmup 2 --workload distmult_fb15k $T
-b transh_fb15k237 --steps 5 --warmup 2 --workload transh_fb15k237 $T
-b transd_fb15k237 --steps 5 --warmup 2 --workload transd_fb15k237 $T
+b transh_fb15k237 --steps 20 --warmup 3 --workload transh_fb15k237 $T
+b transd_fb15k237 --steps 20 --warmup 3 --workload transd_fb15k237 $T
 b complex_wikidata5m --workload complex_wikidata5m --no-secondary --steps 5 --warmup 2 --batch 8192
 # one steady-state evaluate() dispatch by dispatch
 tl transe_fb15k237
