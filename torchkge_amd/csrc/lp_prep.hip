@@ -41,6 +41,7 @@ struct PrepParams {
     int hi_units_p;
     int64_t Bp;
     float *q_dn2;
+    int inflight;           // TransH / TransD rows of <= 256 columns: all loads of a query at once (KGE_PREP_INFLIGHT=0: the loops)
 };
 
 __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
@@ -133,10 +134,39 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
         }
         case KGE_TRANSH: {
             const float *e = p.t0 + ei * de, *r = p.t1 + ri * dr, *w = p.t2 + ri * dr;
+            float *wq = p.Wq ? p.Wq + i * dr : nullptr;
+            if (dr <= 256 && p.inflight) {
+                // (r06) rows of up to 256 columns: ALL loads of the query in flight at once -- the kernel is a chain of load
+                // latencies per query (dot -> reduction -> second pass: 49-59 us for 40.9 k queries); same operations in
+                // the same order as the loops below: same bits
+                float ev[4], wv[4], rv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    const bool in = k < dr;
+                    ev[j] = in ? e[k] : 0.f; wv[j] = in ? w[k] : 0.f; rv[j] = in ? r[k] : 0.f;
+                }
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (lane + 64 * j < dr) a = fmaf(ev[j], wv[j], a);
+                a = wave_sum(a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < dr) {
+                        const float pe = ev[j] - a * wv[j]; // translation.py:281
+                        const float val = proj ? pe : (tail ? pe + rv[j] : pe - rv[j]);
+                        q0[k] = val;
+                        if (wq) wq[k] = wv[j];
+                        if (qh) emit_hi(qh, k, val);
+                    }
+                }
+                break;
+            }
             float a = 0.f;
             for (int k = lane; k < dr; k += 64) a = fmaf(e[k], w[k], a);
             a = wave_sum(a);
-            float *wq = p.Wq ? p.Wq + i * dr : nullptr;
             for (int k = lane; k < dr; k += 64) {
                 const float pe = e[k] - a * w[k]; // translation.py:281
                 const float val = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
@@ -149,10 +179,37 @@ __global__ __launch_bounds__(WPB * 64) void lp_prep_kernel(const PrepParams p)
         case KGE_TRANSD: {
             const float *e = p.t0 + ei * de, *ep = p.t2 + ei * de;
             const float *r = p.t1 + ri * dr, *rp = p.t3 + ri * dr;
+            float *wq = p.Wq ? p.Wq + i * dr : nullptr;
+            if (de <= 256 && dr <= de && p.inflight) {
+                // (r06: as TransH -- every load of the query in flight at once, same operations in the same order)
+                float ev[4], pv[4], rv[4], rpv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    ev[j] = k < de ? e[k] : 0.f; pv[j] = k < de ? ep[k] : 0.f;
+                    rv[j] = k < dr ? r[k] : 0.f; rpv[j] = k < dr ? rp[k] : 0.f;
+                }
+                float sc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (lane + 64 * j < de) sc = fmaf(pv[j], ev[j], sc);
+                sc = wave_sum(sc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < dr) {
+                        const float pe = sc * rpv[j] + ev[j]; // translation.py:646
+                        const float val = proj ? pe : (tail ? pe + rv[j] : pe - rv[j]);
+                        q0[k] = val;
+                        if (wq) wq[k] = rpv[j];
+                        if (qh) emit_hi(qh, k, val);
+                    }
+                }
+                break;
+            }
             float sc = 0.f;
             for (int k = lane; k < de; k += 64) sc = fmaf(ep[k], e[k], sc);
             sc = wave_sum(sc);
-            float *wq = p.Wq ? p.Wq + i * dr : nullptr;
             for (int k = lane; k < dr; k += 64) {
                 const float pe = sc * rp[k] + e[k]; // translation.py:646
                 const float val = proj ? pe : (tail ? pe + r[k] : pe - r[k]);
@@ -445,17 +502,36 @@ __global__ __launch_bounds__(64 * NW) void proj_query_stats_kernel(const float *
     for (int64_t grp = (int64_t)blockIdx.x * NW + wv; grp < ngroups; grp += (int64_t)gridDim.x * NW) {
         const int64_t row0 = grp * RPW;
         float acc = 0.f;
+        // (r06) the next chunk's row pieces are in flight while this chunk's chains run (RPW x 8 pieces of 16 bytes per
+        // operand: two per lane) -- the kernel was one load latency per 32 columns
+        static_assert(RPW * (KGE_PS_KC / 4) <= 128, "two pieces per lane and operand");
+        // (NAMED registers: as arrays carried around the chunk loop hipcc leaves them in scratch memory)
+        float4 px0 = make_float4(0.f, 0.f, 0.f, 0.f), px1 = px0, py0 = px0, py1 = px0;
+#define KGE_QS_FETCH(IT, KK)                                                                                  \
+    {                                                                                                         \
+        const int pieces_ = min(KGE_PS_KC, K - (KK)) >> 2, idx_ = lane + 64 * IT;                             \
+        if (idx_ < RPW * pieces_) {                                                                           \
+            const int rr_ = idx_ / pieces_, pc_ = idx_ - rr_ * pieces_;                                       \
+            const int64_t r_ = min(row0 + rr_, rows - 1);                                                     \
+            px##IT = *reinterpret_cast<const float4 *>(Q + r_ * ldq + (KK) + pc_ * 4);                        \
+            py##IT = *reinterpret_cast<const float4 *>(W + r_idx[r_] * ldw + (KK) + pc_ * 4);                 \
+        }                                                                                                     \
+    }
+#define KGE_QS_STORE(IT, PIECES)                                                                              \
+    {                                                                                                         \
+        const int idx_ = lane + 64 * IT;                                                                      \
+        if (idx_ < RPW * (PIECES)) {                                                                          \
+            const int rr_ = idx_ / (PIECES), pc_ = idx_ - rr_ * (PIECES);                                     \
+            *reinterpret_cast<float4 *>(xs + rr_ * KGE_PS_LD + pc_ * 4) = px##IT;                             \
+            *reinterpret_cast<float4 *>(ys + rr_ * KGE_PS_LD + pc_ * 4) = py##IT;                             \
+        }                                                                                                     \
+    }
+        KGE_QS_FETCH(0, 0) KGE_QS_FETCH(1, 0)
         for (int k0 = 0; k0 < K; k0 += KGE_PS_KC) {   // K % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned (host-checked)
             const int kc = min(KGE_PS_KC, K - k0);
             const int pieces = kc >> 2;
-            for (int idx = lane; idx < RPW * pieces; idx += 64) {
-                const int rr = idx / pieces, pc = idx - rr * pieces;
-                const int64_t r = min(row0 + rr, rows - 1);
-                *reinterpret_cast<float4 *>(xs + rr * KGE_PS_LD + pc * 4) =
-                    *reinterpret_cast<const float4 *>(Q + r * ldq + k0 + pc * 4);
-                *reinterpret_cast<float4 *>(ys + rr * KGE_PS_LD + pc * 4) =
-                    *reinterpret_cast<const float4 *>(W + r_idx[r] * ldw + k0 + pc * 4);
-            }
+            KGE_QS_STORE(0, pieces) KGE_QS_STORE(1, pieces)
+            if (k0 + KGE_PS_KC < K) { KGE_QS_FETCH(0, k0 + KGE_PS_KC) KGE_QS_FETCH(1, k0 + KGE_PS_KC) }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (chain < 3) {
                 const float *x = (chain == 2 ? ys : xs) + row_l * KGE_PS_LD;
@@ -478,6 +554,8 @@ __global__ __launch_bounds__(64 * NW) void proj_query_stats_kernel(const float *
             big = __uint_as_float(max(__float_as_uint(big), __float_as_uint(acc)));
         }
     }
+#undef KGE_QS_STORE
+#undef KGE_QS_FETCH
     if (qmax_io) {      // one atomic per block (same-address atomics serialise in the L2)
         unsigned m = __float_as_uint(big);
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
@@ -689,7 +767,7 @@ extern "C" int kge_lp_prep_hi(int kind, int side, const float *t0, const float *
         if ((kind != KGE_TRANSH && kind != KGE_TRANSD) || ent_n >= 0 || hi_units_p * 16 < d_rel + 2 || Bp < nq) return KGE_EINVAL;
     }
     PrepParams p{kind, side, t0, t1, t2, t3, d_ent, d_rel, h, t, r, B, Q0, Q1, Wq, ent_lo, ent_n,
-                 reinterpret_cast<_Float16 *>(Qh), hi_units_p, Bp, q_dn2};
+                 reinterpret_cast<_Float16 *>(Qh), hi_units_p, Bp, q_dn2, kge_env_int("KGE_PREP_INFLIGHT", 1)};
     hipLaunchKernelGGL(lp_prep_kernel, dim3(grid_rows(Qh ? Bp : nq)), dim3(WPB * 64), 0, kge_s(stream), p);
     KGE_CHECK_LAUNCH();
     if (qn) return kge_row_sqnorm(Q0, d_rel, nq, d_rel, qn, nullptr, stream);
