@@ -243,7 +243,9 @@ int kge_relation_scores_proj(int kind, const float *E, const float *R, const flo
  * kge_row_sqnorm / kge_row_dot (same bits as the six launches it replaces); *qmax_io = max(*qmax_io, max qn).
  * KGE_EUNSUPPORTED unless K % 4 == 0, ldq % 4 == 0, ldw % 4 == 0 and Q, W are 16-byte aligned. */
 int kge_proj_query_stats(const float *Q, int64_t ldq, const float *W, int64_t ldw, const int64_t *r_idx, int64_t rows,
-                         int K, float scale, float z_add, float *qn, float *pz, float *qmax_io, kge_stream_t stream);
+                         int K, float scale, float z_add, float *qn, float *pz, float *qmax_io,
+                         int32_t *zero_i32 /* optional (ABI 32): zero_n int32 zeroed by this launch -- the batch's rank
+                         counters, as kge_lp_query_pipeline does */, int64_t zero_n, kge_stream_t stream);
 /* out = op(a, b[, c, d]) elementwise over n floats (separate mul / add roundings,
  * as the reference's (re_h * re_r - im_h * im_r) etc., bilinear.py:514-522). */
 int kge_ewise(int op, const float *a, const float *b, const float *c, const float *d, int64_t n,

@@ -79,7 +79,7 @@ _SIGNATURES = {
                        _vp, _vp, _vp, _int, _i64, _vp, _vp],
     'kge_relation_scores_proj': [_int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     'kge_ewise': [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
-    'kge_proj_query_stats': [_vp, _i64, _vp, _i64, _vp, _i64, _int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp],
+    'kge_proj_query_stats': [_vp, _i64, _vp, _i64, _vp, _i64, _int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _vp],
     'kge_row_sqnorm': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     'kge_row_sqnorm_any_order': [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     'kge_row_dot': [_vp, _vp, _i64, _i64, _int, ctypes.c_float, _vp, _vp],
@@ -150,7 +150,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['kge_corrupt_ws_elems', 'kge_abi_
                                                'kge_column_plan_ws_bytes'])
 
 _lib = None
-ABI_VERSION = 31        # kge_abi_version() of the library this binding was written against
+ABI_VERSION = 32        # kge_abi_version() of the library this binding was written against
 
 
 def load_library():
@@ -402,7 +402,7 @@ def lp_prep(kind, side, tables, d_ent, d_rel, h, t, r, want_qn=False, want_w=Fal
     return Q0, Q1, qn, Wq
 
 
-def proj_query_stats(Q, W, r_idx, scale, z_add, qmax_io=None):
+def proj_query_stats(Q, W, r_idx, scale, z_add, qmax_io=None, zero=None):
     """kge_proj_query_stats: (qn, pz) of a projection-mode problem in one launch -- ||Q_i||^2 and (scale * Q_i . W[r_i],
     ||W[r_i]||^2 + z_add), the chains of row_sqnorm / row_dot (same bits).  None when shapes / alignment need the
     separate kernels."""
@@ -414,7 +414,8 @@ def proj_query_stats(Q, W, r_idx, scale, z_add, qmax_io=None):
     pz = torch.empty(rows, 2, dtype=torch.float32, device=Q.device)
     with _on(Q.device):
         rc = int(lib.kge_proj_query_stats(_p(Q), Q.stride(0), _p(W), W.stride(0), _p(r_idx), rows, K, float(scale), float(z_add),
-                                          _p(qn), _p(pz), _p(qmax_io), _stream()))
+                                          _p(qn), _p(pz), _p(qmax_io), _p(zero), 0 if zero is None else zero.numel(),
+                                          _stream()))
     if rc == KGE_EUNSUPPORTED:
         return None
     _check(rc, 'kge_proj_query_stats')

@@ -488,8 +488,10 @@ __global__ __launch_bounds__(64 * NW) void proj_query_stats_kernel(const float *
                                                                    const float *__restrict__ W, int64_t ldw,
                                                                    const int64_t *__restrict__ r_idx, int64_t rows, int K,
                                                                    float scale, float z_add, float *qn, float *pz,
-                                                                   float *qmax_io)
+                                                                   float *qmax_io, int32_t *zero_i32, int64_t zero_n)
 {
+    // (r06) the batch's rank counters zeroed by this launch (as the fused query pipelines do): no fill node of their own
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < zero_n; j += (int64_t)gridDim.x * blockDim.x) zero_i32[j] = 0;
     constexpr int RPW = 16;
     __shared__ __attribute__((aligned(16))) float xs_all[NW * RPW * KGE_PS_LD];
     __shared__ __attribute__((aligned(16))) float ys_all[NW * RPW * KGE_PS_LD];
@@ -684,15 +686,15 @@ extern "C" int kge_row_dot(const float *X, const float *Y, int64_t ld, int64_t r
  * KGE_EUNSUPPORTED unless K % 4 == 0, ldq % 4 == 0, ldw % 4 == 0 and both matrices are 16-byte aligned. */
 extern "C" int kge_proj_query_stats(const float *Q, int64_t ldq, const float *W, int64_t ldw, const int64_t *r_idx,
                                     int64_t rows, int K, float scale, float z_add, float *qn, float *pz, float *qmax_io,
-                                    kge_stream_t stream)
+                                    int32_t *zero_i32, int64_t zero_n, kge_stream_t stream)
 {
-    if (rows < 0 || K <= 0 || ldq < K || ldw < K) return KGE_EINVAL;
+    if (rows < 0 || K <= 0 || ldq < K || ldw < K || zero_n < 0 || (zero_n > 0 && !zero_i32)) return KGE_EINVAL;
     if (rows == 0) return 0;
     if (!Q || !W || !r_idx || !qn || !pz) return KGE_EINVAL;
     if (K % 4 || ldq % 4 || ldw % 4 || !kge_aligned16(Q) || !kge_aligned16(W)) return KGE_EUNSUPPORTED;
     const int64_t blocks = (rows + 63) / 64;        // 4 wavefronts x 16 rows
     hipLaunchKernelGGL(proj_query_stats_kernel<4>, dim3((int)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, kge_s(stream), Q, ldq,
-                       W, ldw, r_idx, rows, K, scale, z_add, qn, pz, qmax_io);
+                       W, ldw, r_idx, rows, K, scale, z_add, qn, pz, qmax_io, zero_i32, zero_n);
     KGE_CHECK_LAUNCH();
     return 0;
 }

@@ -1218,7 +1218,7 @@ extern "C" int kge_topk(const float *scores, int64_t ld, int64_t B, int64_t N, i
     return 0;
 }
 
-extern "C" int kge_abi_version(void) { return 31; }
+extern "C" int kge_abi_version(void) { return 32; }
 
 __global__ __launch_bounds__(256) void copy_i64_indirect_kernel(const int64_t *__restrict__ src, int64_t n, int64_t *const *dst_ind)
 {

@@ -159,6 +159,11 @@ class HipRankEngine(object):
         all-candidates count and its exact recheck on the current stream (fork / join by events: captured into the
         hipGraph of evaluate() as two parallel branches)."""
         pre_counts = prob.pre.pop('counts', None) if getattr(prob, 'pre', None) is not None else None
+        if pre_counts is None and getattr(prob, 'zero_counts', None) is not None:
+            # TransH / TransD: zeroed by kge_proj_query_stats' launch -- unless this sweep wants region counters zeroed too
+            zc, prob.zero_counts = prob.zero_counts, None
+            if pad == 0 and not (prob.wants_regions() if hasattr(prob, 'wants_regions') else 0):
+                pre_counts = zc
         if pre_counts is not None and pad == 0 and tuple(pre_counts.shape) == (3, prob.B):
             out = pre_counts        # zeroed by the fused query pipeline's launch: no fill node
         else:

@@ -633,7 +633,9 @@ class TranslationModel(Model):
         hi_too = frag and (self._row_shard is None or qtabs is not None)
         out = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, **({'want_hi': True} if hi_too else {}))
         Q0 = out[0]
-        st = _hip.proj_query_stats(Q0, Wt, r_both, scale, z_add, qmax_io=g[0:1])
+        # (r06: the launch also zeroes the batch's (3, 2B) rank counters -- the evaluator's partial_counts takes them)
+        zc = torch.empty(3, Q0.shape[0], dtype=torch.int32, device=Q0.device) if Q0.is_cuda else None
+        st = _hip.proj_query_stats(Q0, Wt, r_both, scale, z_add, qmax_io=g[0:1], zero=zc)
         if side is not None:
             main.wait_stream(side)
             for x in cand[0] or ():
@@ -662,6 +664,7 @@ class TranslationModel(Model):
         prob.split = split
         if hi_too:
             prob.pre_q = (out[4], out[5])
+        prob.zero_counts = zc
         return prob
 
     def _proj_fast_ok(self):
