@@ -133,6 +133,8 @@ def _table_of(cand):
 
 # the DOT models' query side of a batch in one launch (kge_lp_dot_query_pipeline); KGE_DOT_FUSED=0: the separate kernels
 DOT_FUSED = os.environ.get('KGE_DOT_FUSED', '1') == '1'
+# TransH / TransD with the evaluator's second stream: which side of the preparation runs there (KGE_PREP_SIDE_SWAP=0: the candidate side; r06 same-box 0.565 -> 0.559 / 0.602 -> 0.597 ms with the query side there)
+PREP_SIDE_SWAP = os.environ.get('KGE_PREP_SIDE_SWAP', '1') == '1'
 # ... and their candidate table in one pass from the second evaluation on (kge_lp_dot_table_prep_fused); KGE_DOT_PREP_ONE_PASS=0: two
 DOT_PREP_ONE_PASS = os.environ.get('KGE_DOT_PREP_ONE_PASS', '1') != '0'
 
@@ -624,26 +626,42 @@ class TranslationModel(Model):
         # beside the query side's two (LinkPredictionEvaluator hands the stream over for the session: fork / join by
         # events, two parallel branches of the captured graph).  They write different guard scalars.
         side = getattr(self, '_lp_side_stream', None) if table.is_cuda else None
+        # (one-product level on unsharded tables / replicas: the query rows' planar hi operand rides the same launch)
+        hi_too = frag and (self._row_shard is None or qtabs is not None)
+
+        def query_side():
+            out_ = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, **({'want_hi': True} if hi_too else {}))
+            # (r06: the launch also zeroes the batch's (3, 2B) rank counters -- the evaluator's partial_counts takes them)
+            zc_ = torch.empty(3, out_[0].shape[0], dtype=torch.int32, device=out_[0].device) if out_[0].is_cuda else None
+            return out_, zc_, _hip.proj_query_stats(out_[0], Wt, r_both, scale, z_add, qmax_io=g[0:1], zero=zc_)
+
+        def keep(xs):       # allocated on the side stream, consumed on the main one
+            for x in xs:
+                if torch.is_tensor(x):
+                    x.record_stream(main)
+                elif isinstance(x, (tuple, list)):
+                    keep(x)
         if side is not None:
             main = torch.cuda.current_stream(table.device)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            if PREP_SIDE_SWAP:
+                # the QUERY side on the second stream: what follows the join -- true scores, thresholds, sweep -- then stays on
+                # the queue of the candidate side's branch (the graph executor continues a joined chain there: the other
+                # way round the critical chain changed queues twice, ~11 us per change)
+                with torch.cuda.stream(side):
+                    out, zc, st = query_side()
                 cand = cand_side()
-        # (one-product level on unsharded tables / replicas: the query rows' planar hi operand rides the same launch)
-        hi_too = frag and (self._row_shard is None or qtabs is not None)
-        out = self._lp_prep(sd, h_idx, t_idx, r_idx, exchange, qtabs=qtabs, **({'want_hi': True} if hi_too else {}))
+                main.wait_stream(side)
+                keep([out, zc, st])
+            else:
+                with torch.cuda.stream(side):
+                    cand = cand_side()
+                out, zc, st = query_side()
+                main.wait_stream(side)
+                keep(cand)
+        else:
+            out, zc, st = query_side()
         Q0 = out[0]
-        # (r06: the launch also zeroes the batch's (3, 2B) rank counters -- the evaluator's partial_counts takes them)
-        zc = torch.empty(3, Q0.shape[0], dtype=torch.int32, device=Q0.device) if Q0.is_cuda else None
-        st = _hip.proj_query_stats(Q0, Wt, r_both, scale, z_add, qmax_io=g[0:1], zero=zc)
-        if side is not None:
-            main.wait_stream(side)
-            for x in cand[0] or ():
-                if torch.is_tensor(x):
-                    x.record_stream(main)       # allocated on the side stream, consumed on this one
-            for x in cand[1:]:
-                if torch.is_tensor(x):
-                    x.record_stream(main)
         if st is None:
             return None
         qn, pz = st
