@@ -594,6 +594,43 @@ def test_mfma_kernels_hold_no_lane_crossing_packed_f32_operand():
     assert r.returncode != 0 and 'KGE_BUILD_NO_SLP' in r.stderr
 
 
+def test_region_policy_and_lazy_rank_rows_of_the_evaluator():
+    """Host logic of r06 (no GPU): (1) the sweep's uncertain pairs go to regions from REGION_MIN_LEVEL0 re-scored pairs per query
+    seen on the three-product level -- and, once the one-product level has been measured, only from REGION_MIN_LEVEL1 there;
+    never on several ranks, never on level 0.  (2) The four rank vectors are rows of the packed host tensor of the last
+    steady-state evaluation, handed out on access; an assigned tensor wins.  (3) The level thresholds scale with the number of
+    candidates."""
+    from torchkge_amd import evaluation as evm
+    m = tk.TransEModel(8, 20, 3, 'L2')
+    h = torch.randint(0, 20, (30,)); t = torch.randint(0, 20, (30,)); r = torch.randint(0, 3, (30,))
+    kg = tk.KnowledgeGraph(kg={'heads': h, 'tails': t, 'relations': r}, ent2ix={j: j for j in range(20)},
+                           rel2ix={j: j for j in range(3)})
+    ev = tk.LinkPredictionEvaluator(m, kg, share_state=False)
+    assert ev._regions_for(1, False) is False                       # nothing seen yet
+    ev._level0_seen = evm.REGION_MIN_LEVEL0 + 0.1
+    assert ev._regions_for(1, False) and not ev._regions_for(0, False) and not ev._regions_for(1, True)
+    ev._level1_seen = evm.REGION_MIN_LEVEL1 - 0.5                   # measured on the level the regions serve: too few pairs
+    assert ev._regions_for(1, False) is False
+    ev._level1_seen = evm.REGION_MIN_LEVEL1 + 0.5
+    assert ev._regions_for(1, False) is True
+    ev._level0_seen = evm.REGION_MIN_LEVEL0 - 0.1
+    assert ev._regions_for(1, False) is False
+    # (2)
+    n = 7
+    packed = torch.arange(4 * n + 2, dtype=torch.int64)
+    ev.__dict__['_rank_rows'] = packed.as_strided((4, n), (n, 1))
+    ev.__dict__['_rank_set'] = {}
+    assert torch.equal(ev.rank_true_heads, packed[:n]) and torch.equal(ev.filt_rank_true_tails, packed[3 * n:4 * n])
+    assert ev.rank_true_tails is ev.rank_true_tails                 # built once per evaluation
+    ev.rank_true_tails = torch.zeros(n, dtype=torch.int64)
+    assert int(ev.rank_true_tails.sum()) == 0 and torch.equal(ev.filt_rank_true_heads, packed[2 * n:3 * n])
+    # (3)
+    e1, l1 = evm.level1_thresholds(14541)
+    e5, l5 = evm.level1_thresholds(4594485)
+    assert (e1, l1) == (evm.LEVEL1_ENTER, evm.LEVEL1_LEAVE) and e5 == pytest.approx(e1 * 4594485 / 14541) and l5 > e5
+    assert evm.level1_thresholds(100) == (e1, l1)                   # never below the FB15k-237 figures
+
+
 def test_evaluator_state_cache_is_bounded_weak_and_clearable():
     """What evaluators learn about (model, kg, options) is shared at module level (evaluation._EvalState): at most
     MAX_STATES_PER_MODEL states per model (least recently used first out), none once the model is gone, and
